@@ -1,0 +1,424 @@
+"""
+ORACLE -- TEST INFRASTRUCTURE ONLY.  Not part of the product path.
+
+NumPy/SciPy restatement of the mogp_emulator (v0.7.2) CPU ``GaussianProcess``
+hot path: kernel-matrix build -> jittered Cholesky -> triangular solves ->
+negative log-posterior (+ gradient) -> predictive mean / variance.  Every
+function cites the reference file:line whose arithmetic it follows.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s
+``cpu_baseline`` leg may import this module, and only as the checker / the
+reported CPU baseline.  The product (``mogp_emulator_amd``) never imports it.
+
+Pinning: ``tests/test_oracle_golden.py`` checks every function here against
+``tests/golden/*.npz`` which were produced by importing the real reference in
+the build container (``tests/golden/make_golden.py``), and against the
+known-answer values held by the reference's own tests.
+
+Scope: zero / fixed mean function (``mean=None``), SquaredExponential and
+Matern52 kernels, nugget types adaptive / fit / fixed.  With ``mean=None`` the
+reference's design matrix is n x 0, ``Ainv`` is 0 x 0 and every ``H``/``A`` term
+in GaussianProcess.py:657-685, 745-778, 896-920 vanishes identically; that is
+the branch restated here.
+"""
+
+import numpy as np
+from scipy import linalg
+from scipy.linalg import lapack, cho_solve
+from scipy.special import gammaln
+
+SQEXP = "SquaredExponential"
+MAT52 = "Matern52"
+
+
+# ----------------------------------------------------------------------------
+# Kernel.py
+# ----------------------------------------------------------------------------
+
+def calc_r2(x1, x2, corr_raw):
+    """Scaled squared distance, Kernel.py:444-485 (StationaryKernel.calc_r2).
+
+    r2_ij = sum_d exp(theta_d) (x1_id - x2_jd)^2, built with the same
+    (n1, n2, D) broadcast temporary and ``np.sum(axis=-1)`` as the reference.
+    """
+    x1 = np.asarray(x1, dtype=np.float64)
+    x2 = np.asarray(x2, dtype=np.float64)
+    scale = np.exp(np.asarray(corr_raw, dtype=np.float64))
+    diff = x1[:, np.newaxis, :] - x2[np.newaxis, :, :]
+    r2 = np.sum(scale * diff ** 2, axis=-1)
+    if np.any(np.isinf(r2)):
+        raise FloatingPointError("Inf enountered in kernel distance computation")
+    return r2
+
+
+def calc_r2_chunked(x1, x2, corr_raw, rows=512):
+    """Same arithmetic as :func:`calc_r2` but over row blocks of ``x1`` so the
+    (n1, n2, D) temporary stays bounded (SURVEY.md section 8d memory guard).
+    Per-entry operations and summation order are unchanged."""
+    out = np.empty((x1.shape[0], x2.shape[0]))
+    for s in range(0, x1.shape[0], rows):
+        out[s:s + rows] = calc_r2(x1[s:s + rows], x2, corr_raw)
+    return out
+
+
+def calc_dr2dtheta(x1, x2, corr_raw):
+    """d r2 / d theta_p = exp(theta_p) (x1_p - x2_p)^2, shape (D, n1, n2).
+    Kernel.py:487-530."""
+    scale = np.exp(np.asarray(corr_raw, dtype=np.float64))
+    diff = x1[:, np.newaxis, :] - x2[np.newaxis, :, :]
+    return np.transpose(scale * diff ** 2, (2, 0, 1))
+
+
+def calc_K(r2, kernel=SQEXP):
+    """k(r2).  SqExp: Kernel.py:772-791; Matern-5/2: Kernel.py:861-882."""
+    r2 = np.asarray(r2)
+    assert np.all(r2 >= 0.), "kernel distances must be positive"
+    if kernel == SQEXP:
+        return np.exp(-0.5 * r2)
+    elif kernel == MAT52:
+        return (1. + np.sqrt(5. * r2) + 5. / 3. * r2) * np.exp(-np.sqrt(5. * r2))
+    raise ValueError("unknown kernel " + str(kernel))
+
+
+def calc_dKdr2(r2, kernel=SQEXP):
+    """dk/d(r2).  SqExp: Kernel.py:793-814; Matern-5/2: Kernel.py:884-906."""
+    r2 = np.asarray(r2)
+    assert np.all(r2 >= 0.), "kernel distances must be positive"
+    if kernel == SQEXP:
+        return -0.5 * np.exp(-0.5 * r2)
+    elif kernel == MAT52:
+        return -5. / 6. * (1. + np.sqrt(5. * r2)) * np.exp(-np.sqrt(5 * r2))
+    raise ValueError("unknown kernel " + str(kernel))
+
+
+def kernel_f(x1, x2, corr_raw, kernel=SQEXP):
+    """Kernel.py:99-131 (kernel_f = calc_K(calc_r2))."""
+    return calc_K(calc_r2(x1, x2, corr_raw), kernel)
+
+
+def kernel_deriv(x1, x2, corr_raw, kernel=SQEXP):
+    """Kernel.py:133-173: dK/dtheta = dK/dr2 * dr2/dtheta, shape (D, n1, n2)."""
+    return calc_dKdr2(calc_r2(x1, x2, corr_raw), kernel) * calc_dr2dtheta(x1, x2, corr_raw)
+
+
+def kernel_inputderiv(x1, x2, corr_raw, kernel=SQEXP):
+    """d k(x1_i, x2_j) / d x1_id, shape (D, n1, n2).
+
+    Not in the CPU reference (deriv deprecated, GaussianProcess.py:922-925);
+    this is the quantity the reference GPU kernels ``*_cov_deriv_x_batch``
+    (mogp_gpu/src/kernel.cu:69-100, 264-302) compute:
+    dk/dr2 * dr2/dx with dr2/dx1_d = 2 exp(theta_d) (x1_d - x2_d).
+    The reference tests check it by finite differences
+    (tests/test_GaussianProcess.py:1010-1015); so does tests/test_oracle_golden.py.
+    """
+    scale = np.exp(np.asarray(corr_raw, dtype=np.float64))
+    diff = x1[:, np.newaxis, :] - x2[np.newaxis, :, :]
+    dr2dx = np.transpose(2. * scale * diff, (2, 0, 1))
+    return calc_dKdr2(calc_r2(x1, x2, corr_raw), kernel) * dr2dx
+
+
+# ----------------------------------------------------------------------------
+# linalg/cholesky.py
+# ----------------------------------------------------------------------------
+
+def _check_cholesky_inputs(A):
+    """linalg/cholesky.py:196-222."""
+    A = np.array(A)
+    assert A.ndim == 2 and A.shape[0] == A.shape[1], "A must have shape (n,n)"
+    np.testing.assert_allclose(A.T, A)
+    if np.any(np.diag(A) <= 0.0):
+        raise linalg.LinAlgError("not pd: non-positive diagonal elements")
+    return A
+
+
+def fixed_cholesky(A):
+    """linalg/cholesky.py:225-231."""
+    A = _check_cholesky_inputs(A)
+    return linalg.cholesky(A, lower=True)
+
+
+def jit_cholesky(A, maxtries=5):
+    """linalg/cholesky.py:234-281.  Plain dpotrf first; on failure add
+    jitter = 1e-6 * mean(diag A) * 10^k, k = 0 .. maxtries-1."""
+    A = _check_cholesky_inputs(A)
+    assert int(maxtries) > 0
+    A = np.ascontiguousarray(A)
+    L, info = lapack.dpotrf(A, lower=1)
+    if info == 0:
+        return L, 0.0
+    jitter = np.diag(A).mean() * 1e-6
+    num_tries = 1
+    while num_tries <= maxtries and np.isfinite(jitter):
+        try:
+            L = linalg.cholesky(A + np.eye(A.shape[0]) * jitter, lower=True)
+            return L, jitter
+        except Exception:
+            jitter *= 10
+        finally:
+            num_tries += 1
+    raise linalg.LinAlgError("not positive definite, even with jitter.")
+
+
+def cholesky_factor(A, nugget, nugget_type):
+    """linalg/cholesky.py:168-193 (without the "pivot" branch - out of scope)."""
+    if nugget_type == "adaptive":
+        L, nugget = jit_cholesky(A)
+    elif nugget_type in ("fit", "fixed"):
+        A = A + nugget * np.eye(A.shape[0])
+        L = fixed_cholesky(A)
+    else:
+        raise ValueError("Bad value for nugget_type in cholesky_factor")
+    return L, nugget
+
+
+def cho_solve_L(L, b):
+    """ChoInv.solve, linalg/cholesky.py:22-42."""
+    if L.shape == (1, 1):
+        return b / L[0, 0] ** 2
+    return cho_solve((L, True), b)
+
+
+def logdet_L(L):
+    """ChoInv.logdet, linalg/cholesky.py:67-79."""
+    return 2.0 * np.sum(np.log(np.diag(L)))
+
+
+def logdet_deriv(L, dKdtheta):
+    """linalg/linalg_utils.py:170-198: tr(K^-1 dK_p) for each p, computed as the
+    trace of cho_solve on the (n, n, P) stacked right-hand side."""
+    dK = np.transpose(dKdtheta, (1, 2, 0))
+    n, _, P = dK.shape
+    sol = cho_solve_L(L, dK.reshape(n, n * P)).reshape(n, n, P)
+    return np.trace(sol, axis1=0, axis2=1)
+
+
+# ----------------------------------------------------------------------------
+# Priors.py (log-density pieces entering the posterior)
+# ----------------------------------------------------------------------------
+
+class Prior(object):
+    """(kind, shape, scale) prior on a *scaled* hyper-parameter.
+
+    kind in {"weak", "invgamma", "gamma", "lognormal"}:
+    WeakPrior Priors.py:578-649; LogNormalPrior :842-901; GammaPrior :903-971;
+    InvGammaPrior :973-1128.
+    """
+
+    def __init__(self, kind="weak", shape=0., scale=0.):
+        self.kind, self.shape, self.scale = kind.lower(), float(shape), float(scale)
+
+    def logp(self, x):
+        a, b = self.shape, self.scale
+        if self.kind == "weak":
+            return 0.
+        if self.kind == "invgamma":
+            return a * np.log(b) - gammaln(a) - (a + 1.) * np.log(x) - b / x
+        if self.kind == "gamma":
+            return -a * np.log(b) - gammaln(a) + (a - 1.) * np.log(x) - x / b
+        if self.kind == "lognormal":
+            return (-0.5 * (np.log(x / b) / a) ** 2 - 0.5 * np.log(2. * np.pi)
+                    - np.log(x) - np.log(a))
+        raise ValueError(self.kind)
+
+    def dlogpdx(self, x):
+        a, b = self.shape, self.scale
+        if self.kind == "weak":
+            return 0.
+        if self.kind == "invgamma":
+            return -(a + 1.) / x + b / x ** 2
+        if self.kind == "gamma":
+            return (a - 1.) / x - 1. / b
+        if self.kind == "lognormal":
+            return -np.log(x / b) / a ** 2 / x - 1. / x
+        raise ValueError(self.kind)
+
+
+class GPPriorsRef(object):
+    """GPPriors.logp / dlogpdtheta, Priors.py:291-354.
+
+    ``corr`` acts on l_d = exp(-theta_d/2) with dl/dtheta = -l/2
+    (GPParams.py:35-67); ``cov`` and ``nugget`` act on exp(theta) with
+    d/dtheta = exp(theta) (GPParams.py:115-147)."""
+
+    def __init__(self, n_corr, nugget_type, corr=None, cov=None, nugget=None):
+        self.n_corr = n_corr
+        self.nugget_type = nugget_type
+        self.corr = list(corr) if corr is not None else [Prior() for _ in range(n_corr)]
+        self.cov = cov if cov is not None else Prior()
+        self.nugget = nugget if nugget is not None else Prior()
+
+    def logp(self, theta):
+        D = self.n_corr
+        lp = 0.
+        for p, th in zip(self.corr, theta[:D]):
+            lp += p.logp(np.exp(-0.5 * th))
+        lp += self.cov.logp(np.exp(theta[D]))
+        if self.nugget_type == "fit":
+            lp += self.nugget.logp(np.exp(theta[D + 1]))
+        return lp
+
+    def dlogpdtheta(self, theta):
+        D = self.n_corr
+        out = []
+        for p, th in zip(self.corr, theta[:D]):
+            l = np.exp(-0.5 * th)
+            out.append(float(p.dlogpdx(l) * (-0.5 * l)))
+        s2 = np.exp(theta[D])
+        out.append(float(self.cov.dlogpdx(s2) * s2))
+        if self.nugget_type == "fit":
+            eta = np.exp(theta[D + 1])
+            out.append(float(self.nugget.dlogpdx(eta) * eta))
+        return np.array(out)
+
+
+# ----------------------------------------------------------------------------
+# GaussianProcess.py (mean=None branch)
+# ----------------------------------------------------------------------------
+
+class GPRef(object):
+    """Zero-mean restatement of ``GaussianProcess``.
+
+    nugget: "adaptive", "fit" or a non-negative float (GPParams.py:165-199).
+    theta layout: [corr_raw (D) | log sigma^2 | log nugget (fit only)]
+    (GPParams.py:215-545)."""
+
+    def __init__(self, inputs, targets, kernel=SQEXP, nugget="adaptive", priors=None,
+                 chunk_rows=None):
+        self.X = np.ascontiguousarray(np.asarray(inputs, dtype=np.float64))
+        if self.X.ndim == 1:
+            self.X = self.X.reshape(-1, 1)
+        self.t = np.asarray(targets, dtype=np.float64)
+        assert self.t.ndim == 1 and self.t.shape[0] == self.X.shape[0]
+        self.n, self.D = self.X.shape
+        self.kernel = kernel
+        if isinstance(nugget, str):
+            assert nugget in ("adaptive", "fit")
+            self.nugget_type, self.nugget = nugget, None
+        else:
+            assert float(nugget) >= 0.
+            self.nugget_type, self.nugget = "fixed", float(nugget)
+        self.n_params = self.D + 1 + int(self.nugget_type == "fit")
+        self.priors = priors if priors is not None else GPPriorsRef(self.D, self.nugget_type)
+        self.theta = None
+        self.chunk_rows = chunk_rows
+        self.L = self.Kinv_t = self.current_logpost = None
+
+    # -- helpers ------------------------------------------------------------
+    def _r2(self, a, b, corr_raw):
+        if self.chunk_rows:
+            return calc_r2_chunked(a, b, corr_raw, self.chunk_rows)
+        return calc_r2(a, b, corr_raw)
+
+    def get_cov_matrix(self, other):
+        """GaussianProcess.py:517-543: sigma^2 k(X, other), shape (n, m)."""
+        D = self.D
+        return np.exp(self.theta[D]) * calc_K(self._r2(self.X, other, self.theta[:D]), self.kernel)
+
+    def get_K_matrix(self):
+        """GaussianProcess.py:545-558 (no nugget)."""
+        return self.get_cov_matrix(self.X)
+
+    def _refit(self, theta):
+        """GaussianProcess.py:606-627."""
+        return self.theta is None or not np.allclose(theta, self.theta, rtol=1.e-10, atol=1.e-15)
+
+    # -- fit / objective ----------------------------------------------------
+    def fit(self, theta):
+        """GaussianProcess.py:629-685 with H = (n x 0)."""
+        theta = np.array(theta, dtype=np.float64)
+        assert theta.shape == (self.n_params,), "bad shape for hyperparameters"
+        self.theta = theta
+        if self.nugget_type == "fit":
+            self.nugget = float(np.exp(theta[-1]))
+        K = self.get_K_matrix()
+        self.L, newnugget = cholesky_factor(K, self.nugget, self.nugget_type)
+        if self.nugget_type == "adaptive":
+            self.nugget = float(newnugget)
+        self.Kinv_t = cho_solve_L(self.L, self.t)
+        self.current_logpost = 0.5 * (np.dot(self.t, self.Kinv_t) + logdet_L(self.L)
+                                      + self.n * np.log(2. * np.pi))
+        self.current_logpost -= self.priors.logp(theta)
+        return self.current_logpost
+
+    def logposterior(self, theta):
+        """GaussianProcess.py:688-709."""
+        if self._refit(theta):
+            self.fit(theta)
+        return self.current_logpost
+
+    def logpost_deriv(self, theta):
+        """GaussianProcess.py:711-782 with w = 0, A = 0x0."""
+        if self._refit(theta):
+            self.fit(theta)
+        D = self.D
+        partials = np.zeros(self.n_params)
+        dKdtheta = np.exp(self.theta[D]) * kernel_deriv(self.X, self.X, self.theta[:D], self.kernel)
+        a = self.Kinv_t
+        partials[:D] = 0.5 * (-np.dot(a, np.dot(dKdtheta, a).T) + logdet_deriv(self.L, dKdtheta))
+        dKdcov = self.get_K_matrix().reshape(1, self.n, self.n)
+        partials[D] = 0.5 * (-np.dot(a, np.dot(dKdcov[0], a)) + logdet_deriv(self.L, dKdcov)[0])
+        if self.nugget_type == "fit":
+            eye = np.eye(self.n).reshape(1, self.n, self.n)
+            partials[-1] = 0.5 * self.nugget * (-np.dot(a, a) + logdet_deriv(self.L, eye)[0])
+        partials -= self.priors.dlogpdtheta(self.theta)
+        return partials
+
+    # -- predict ------------------------------------------------------------
+    def predict(self, testing, unc=True, deriv=False, include_nugget=True):
+        """GaussianProcess.py:818-927 (full_cov=False, R = 0).  ``deriv=True``
+        returns the analytic input-derivative of the mean, which is what
+        DenseGP_GPU::predict_deriv (densegp_gpu.hpp:411-448) returns."""
+        if self.theta is None:
+            raise ValueError("hyperparameters have not been fit for this Gaussian Process")
+        testing = np.asarray(testing, dtype=np.float64)
+        if testing.ndim == 1:
+            testing = testing.reshape(-1, 1) if self.D == 1 else testing.reshape(1, -1)
+        assert testing.shape[1] == self.D
+        Ktest = self.get_cov_matrix(testing)
+        mu = np.dot(Ktest.T, self.Kinv_t)
+        var = None
+        if unc:
+            Kinv_Ktest = cho_solve_L(self.L, Ktest)
+            sigma_2 = np.exp(self.theta[self.D])
+            if include_nugget:
+                sigma_2 = sigma_2 + self.nugget
+            var = np.maximum(sigma_2 - np.sum(Ktest * Kinv_Ktest, axis=0), 0.)
+        d = None
+        if deriv:
+            dk = np.exp(self.theta[self.D]) * kernel_inputderiv(testing, self.X, self.theta[:self.D],
+                                                                self.kernel)
+            d = np.einsum("dmj,j->md", dk, self.Kinv_t)
+        return mu, var, d
+
+
+# ----------------------------------------------------------------------------
+# fitting.py
+# ----------------------------------------------------------------------------
+
+def fit_GP_MAP_ref(gp, n_tries=15, theta0=None, method="L-BFGS-B", sampler=None, **kwargs):
+    """fitting.py:219-266 (_fit_single_GP_MAP): multi-start minimisation of
+    the negative log-posterior, keep the best.  ``sampler()`` returns a start
+    point (the reference draws it from the priors, Priors.py:394-418)."""
+    from scipy.optimize import minimize
+    if sampler is None:
+        rng = np.random.default_rng(0)
+        sampler = lambda: 5. * (rng.random(gp.n_params) - 0.5)  # WeakPrior.sample, Priors.py:636-649
+    old = np.seterr(divide="raise", over="raise", invalid="raise")
+    vals, thetas = [], []
+    try:
+        for i in range(int(n_tries)):
+            theta = np.array(theta0) if (i == 0 and theta0 is not None) else sampler()
+            try:
+                res = minimize(gp.logposterior, theta, method=method, jac=gp.logpost_deriv,
+                               options=kwargs)
+                vals.append(res["fun"])
+                thetas.append(res["x"])
+            except (linalg.LinAlgError, FloatingPointError):
+                pass
+    finally:
+        np.seterr(**old)
+    if not vals:
+        gp.theta = None
+        return gp
+    gp.fit(thetas[int(np.argmin(vals))])
+    return gp

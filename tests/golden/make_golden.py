@@ -1,0 +1,220 @@
+"""
+Generate the golden vectors under tests/golden/ by IMPORTING THE REAL REFERENCE.
+
+Runs only in the build container (never on the GPU box, never from tests):
+
+    mkdir -p /tmp/ref_oracle && cp -r /root/reference/mogp_emulator /tmp/ref_oracle/
+    echo "version = '0.7.2'" > /tmp/ref_oracle/mogp_emulator/version.py   # setup.py:23-34 generates this
+    cd /root/repo && PYTHONPATH=/tmp/ref_oracle /opt/conda/bin/python3.9 -W ignore tests/golden/make_golden.py
+
+(/opt/conda/bin/python3.9 has patsy, which mogp_emulator/GaussianProcess.py:10-13
+hard-requires; the system python3 does not.)
+
+The outputs are data only: inputs + the reference's outputs on them.
+"""
+import os
+import sys
+import numpy as np
+
+import mogp_emulator
+from mogp_emulator import GaussianProcess, MultiOutputGP, fit_GP_MAP
+from mogp_emulator.Kernel import SquaredExponential, Matern52
+from mogp_emulator.Priors import (GPPriors, InvGammaPrior, GammaPrior, LogNormalPrior, WeakPrior,
+                                  min_spacing, max_spacing)
+from mogp_emulator.GPParams import GPParams
+from mogp_emulator.linalg.cholesky import jit_cholesky, fixed_cholesky
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+KERNELS = {"SquaredExponential": SquaredExponential, "Matern52": Matern52}
+
+
+def synth(config_id, n, d, n_out, m):
+    """SURVEY.md section 8d synthetic generator."""
+    rng = np.random.default_rng(20240607 + config_id)
+    X = rng.uniform(0, 1, (n, d))
+    T = np.empty((n_out, n))
+    for k in range(n_out):
+        w = rng.normal(size=d)
+        T[k] = np.sin(2 * np.pi * X @ w / np.sqrt(d)) + 0.1 * (X ** 2) @ np.abs(w) + 0.01 * rng.normal(size=n)
+    Xs = rng.uniform(0, 1, (m, d))
+    return X, T, Xs
+
+
+def weak(n_corr, nugget_type):
+    return GPPriors(n_corr=n_corr, nugget_type=nugget_type)
+
+
+def run_gp(X, t, kernel, nugget, theta, Xs, priors="weak"):
+    nugget_type = nugget if isinstance(nugget, str) else "fixed"
+    pri = weak(X.shape[1], nugget_type) if priors == "weak" else None
+    gp = GaussianProcess(X, t, kernel=KERNELS[kernel](), nugget=nugget, priors=pri)
+    gp.fit(np.array(theta))
+    out = dict(logpost=gp.current_logpost, nugget=gp.nugget, L=gp.Kinv.L, alpha=gp.Kinv_t,
+               grad=gp.logpost_deriv(np.array(theta)), K=gp.get_K_matrix())
+    if Xs is not None:
+        mean, var, _ = gp.predict(Xs)
+        mean2, var_nonug, _ = gp.predict(Xs, include_nugget=False)
+        out.update(mean=mean, var=var, var_nonug=var_nonug)
+    return gp, out
+
+
+def main():
+    # ---- 1. the 2x3 fixture of tests/test_GaussianProcess.py:16-22, 556 ------------------------
+    X = np.array([[1., 2., 3.], [4., 5., 6.]])
+    t = np.array([2., 4.])
+    Xs = np.array([[2., 3., 4.]])
+    d = dict(X=X, t=t, Xs=Xs)
+    for kern in KERNELS:
+        for name, theta in (("ones", np.ones(4)), ("zeros", np.zeros(4))):
+            _, o = run_gp(X, t, kern, 0., theta, Xs)
+            for k, v in o.items():
+                d["%s_%s_%s" % (kern, name, k)] = v
+    np.savez(os.path.join(HERE, "fixture_2x3.npz"), **d)
+
+    # ---- 2. 11x11 grid of tests/test_GaussianProcess.py:632-650 ---------------------------------
+    xg, yg = np.meshgrid(np.linspace(0., 4., 11), np.linspace(0., 4., 11))
+    X = np.stack([xg.ravel(), yg.ravel()], axis=1)
+    t = np.exp(-0.5 * ((X[:, 0] - 2.) ** 2 + (X[:, 1] - 3.) ** 2))
+    rng = np.random.default_rng(7)
+    Xs = rng.uniform(0., 4., (32, 2))
+    d = dict(X=X, t=t, Xs=Xs)
+    for kern in KERNELS:
+        for mode, nugget, theta in (("fixed", 1.e-6, [-1., -1., -2.]),
+                                    ("fit", "fit", [-1., -1., -2., np.log(1.e-6)]),
+                                    ("adaptive", "adaptive", [-1., -1., -2.])):
+            _, o = run_gp(X, t, kern, nugget, theta, Xs)
+            d["%s_%s_theta" % (kern, mode)] = np.array(theta)
+            for k, v in o.items():
+                if k == "K":
+                    continue
+                d["%s_%s_%s" % (kern, mode, k)] = v
+    np.savez_compressed(os.path.join(HERE, "grid11.npz"), **d)
+
+    # ---- 3. kernel known answers / derivative tensors --------------------------------------------
+    rng = np.random.default_rng(3)
+    x1 = rng.normal(size=(7, 3))
+    x2 = rng.normal(size=(5, 3))
+    th = np.array([0.3, -0.7, 1.1])  # reference kernels take D correlation params (Kernel.py:63-74)
+    d = dict(x1=x1, x2=x2, theta=th)
+    for kern, cls in KERNELS.items():
+        k = cls()
+        d[kern + "_r2"] = k.calc_r2(x1, x2, th)
+        d[kern + "_K"] = k.kernel_f(x1, x2, th)
+        d[kern + "_dKdtheta"] = k.kernel_deriv(x1, x2, th)
+    # closed forms from tests/test_Kernel.py:721-754, 1021-1061
+    d["closed_x"] = np.array([[1.], [2.]])
+    d["closed_y"] = np.array([[2.], [3.]])
+    d["closed_theta"] = np.zeros(1)
+    for kern, cls in KERNELS.items():
+        d[kern + "_closed_K"] = cls().kernel_f(d["closed_x"], d["closed_y"], d["closed_theta"])
+    np.savez(os.path.join(HERE, "kernels.npz"), **d)
+
+    # ---- 4. Cholesky known answers, tests/test_linalg.py:103-154 ---------------------------------
+    wiki = np.array([[4., 12., -16.], [12., 37., -43.], [-16., -43., 98.]])
+    Lw, jw = jit_cholesky(wiki)
+    sing = np.array([[1., 1.], [1., 1.]])
+    Ls, js = jit_cholesky(sing)
+    np.savez(os.path.join(HERE, "cholesky.npz"), wiki=wiki, wiki_L=Lw, wiki_jitter=jw,
+             sing=sing, sing_L=Ls, sing_jitter=js, wiki_fixed_L=fixed_cholesky(wiki))
+
+    # ---- 5. priors: log densities, gradients, defaults ------------------------------------------
+    xs = np.array([0.05, 0.3, 1.0, 3.0, 12.5])
+    d = dict(x=xs)
+    for nm, cls in (("invgamma", InvGammaPrior), ("gamma", GammaPrior), ("lognormal", LogNormalPrior)):
+        p = cls(2., 2.)
+        d[nm + "_2_2_logp"] = np.array([p.logp(x) for x in xs])
+        d[nm + "_2_2_dlogpdx"] = np.array([p.dlogpdx(x) for x in xs])
+        p = cls(0.84, 0.0017)
+        d[nm + "_b_logp"] = np.array([p.logp(x) for x in xs])
+    # default priors, Priors.py:85-152 (pinning I/O: SURVEY.md section 8b)
+    Xd = np.random.default_rng(0).uniform(0, 1, (2000, 10))
+    dp = GPPriors.default_priors(Xd, 10, "fit")
+    d["default_X_seed"] = np.array(0)
+    d["default_corr_shape"] = np.array([p.shape for p in dp.corr])
+    d["default_corr_scale"] = np.array([p.scale for p in dp.corr])
+    d["default_nugget"] = np.array([float(dp.nugget.shape), float(dp.nugget.scale)])
+    d["default_min_spacing"] = np.array([min_spacing(c) for c in Xd.T])
+    d["default_max_spacing"] = np.array([max_spacing(c) for c in Xd.T])
+    # GPPriors.logp / dlogpdtheta on a 3-corr "fit" parameter vector
+    pri = GPPriors(corr=[InvGammaPrior(2., 1.), GammaPrior(3., 0.5), LogNormalPrior(0.7, 1.3)],
+                   cov=GammaPrior(2., 3.), nugget=InvGammaPrior(3.3, 4.3e-7), nugget_type="fit")
+    gpp = GPParams(n_mean=0, n_corr=3, nugget="fit")
+    thp = np.array([0.4, -1.2, 2.0, 0.7, np.log(2.e-7)])
+    gpp.set_data(thp)
+    d["gppriors_theta"] = thp
+    d["gppriors_logp"] = np.array(pri.logp(gpp))
+    d["gppriors_dlogp"] = pri.dlogpdtheta(gpp)
+    np.savez(os.path.join(HERE, "priors.npz"), **d)
+
+    # ---- 6. variance-stability regression, tests/test_GaussianProcess.py:1144-1161 --------------
+    x = np.linspace(0., 5., 21)
+    y = x ** 2
+    xt = np.linspace(0., 5., 101)
+    gp = GaussianProcess(x, y, nugget=1.e-8, priors=weak(1, "fixed"))  # predictions are prior-independent
+    th = np.array([-7.352408190715323, 15.041447753599755])
+    gp.fit(th)
+    mean, var, _ = gp.predict(xt)
+    np.savez(os.path.join(HERE, "var_stability.npz"), x=x, y=y, xt=xt, theta=th, mean=mean, var=var,
+             logpost=gp.current_logpost)
+
+    # ---- 7. medium synthetic configs (C1 and a d=10 case), SURVEY.md section 8c item 7 ----------
+    for tag, cid, n, dd in (("c1_n200_d4", 1, 200, 4), ("n500_d10", 6, 500, 10)):
+        X, T, Xs = synth(cid, n, dd, 2, 256)
+        out = dict(X=X, T=T, Xs=Xs)
+        corr = -2. * np.log(0.3 * np.sqrt(dd))
+        for kern in KERNELS:
+            for mode, nugget in (("fixed", 1.e-6), ("fit", "fit"), ("adaptive", "adaptive")):
+                theta = [corr] * dd + [0.]
+                if mode == "fit":
+                    theta = theta + [np.log(1.e-4)]
+                _, o = run_gp(X, T[0], kern, nugget, theta, Xs)
+                pre = "%s_%s_" % (kern, mode)
+                out[pre + "theta"] = np.array(theta)
+                K = o.pop("K")
+                L = o.pop("L")
+                out[pre + "K_sum"] = np.array(K.sum())
+                out[pre + "K_rows"] = K[::37, ::41]
+                out[pre + "L_diag"] = np.diag(L)
+                out[pre + "L_rows"] = L[::37, ::41]
+                for k, v in o.items():
+                    out[pre + k] = v
+        # default (non-weak) priors: logpost + grad with the prior terms
+        gp = GaussianProcess(X, T[1], nugget="fit")
+        theta = np.array([corr] * dd + [0.1, np.log(3.e-7)])
+        gp.fit(theta)
+        out["defprior_theta"] = theta
+        out["defprior_logpost"] = np.array(gp.current_logpost)
+        out["defprior_grad"] = gp.logpost_deriv(theta)
+        out["defprior_corr_shape"] = np.array([p.shape for p in gp.priors.corr])
+        out["defprior_corr_scale"] = np.array([p.scale for p in gp.priors.corr])
+        out["defprior_nugget"] = np.array([float(gp.priors.nugget.shape), float(gp.priors.nugget.scale)])
+        np.savez_compressed(os.path.join(HERE, tag + ".npz"), **out)
+
+    # ---- 8. multi-output: 4 emulators sharing X --------------------------------------------------
+    X, T, Xs = synth(8, 60, 3, 4, 40)
+    thetas = np.array([[0.5, 0.2, -0.3, 0.1], [1.0, 1.0, 1.0, -0.5], [-0.2, 0.4, 0.9, 0.3], [0., 0., 0., 0.]])
+    out = dict(X=X, T=T, Xs=Xs, thetas=thetas)
+    means, vs, lps, grads = [], [], [], []
+    for k in range(4):
+        _, o = run_gp(X, T[k], "SquaredExponential", 1.e-6, thetas[k], Xs)
+        means.append(o["mean"]); vs.append(o["var"]); lps.append(o["logpost"]); grads.append(o["grad"])
+    out.update(mean=np.array(means), var=np.array(vs), logpost=np.array(lps), grad=np.array(grads))
+    np.savez_compressed(os.path.join(HERE, "mogp4.npz"), **out)
+
+    # ---- 9. fit_GP_MAP end point on C1 (objective value only; trajectory parity is unpinned) ----
+    X, T, Xs = synth(1, 200, 4, 2, 256)
+    np.random.seed(1234)
+    gp = GaussianProcess(X, T[0], nugget=1.e-6)
+    theta0 = np.array([-2. * np.log(0.3 * 2.)] * 4 + [0.])
+    gp = fit_GP_MAP(gp, n_tries=1, theta0=theta0)
+    mean, var, _ = gp.predict(Xs)
+    np.savez_compressed(os.path.join(HERE, "fitmap_c1.npz"), X=X, t=T[0], Xs=Xs, theta0=theta0,
+                        theta_hat=gp.theta.get_data(), logpost_hat=np.array(gp.current_logpost),
+                        mean=mean, var=var,
+                        corr_shape=np.array([p.shape for p in gp.priors.corr]),
+                        corr_scale=np.array([p.scale for p in gp.priors.corr]))
+    print("golden vectors written to", HERE)
+
+
+if __name__ == "__main__":
+    main()

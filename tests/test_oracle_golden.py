@@ -1,0 +1,215 @@
+"""Pin the oracle (oracle/cpu_ref.py) against vectors produced by the real
+reference (tests/golden/make_golden.py) and against the known answers the
+reference's own tests hold.  CPU only."""
+import numpy as np
+import pytest
+from numpy.testing import assert_allclose
+
+from oracle import cpu_ref as R
+from conftest import load_golden
+
+KERNELS = ["SquaredExponential", "Matern52"]
+MODES = {"fixed": 1.e-6, "fit": "fit", "adaptive": "adaptive"}
+
+
+def test_known_answers_2x3():
+    # literals from the reference's tests/test_GaussianProcess.py fixture
+    X = np.array([[1., 2., 3.], [4., 5., 6.]]); t = np.array([2., 4.])
+    gp = R.GPRef(X, t, nugget=0.)
+    assert_allclose(gp.fit(np.ones(4)), 6.516671478123768, rtol=1e-14)
+    assert_allclose(gp.Kinv_t, [0.7357588823428844, 1.471517764685769], rtol=1e-14)
+    assert_allclose(gp.logposterior(np.zeros(4)), 11.83786609875451, rtol=1e-14)
+    gp.fit(np.ones(4))
+    mu, var, _ = gp.predict(np.array([[2., 3., 4.]]))
+    assert_allclose(mu, [0.03390252374096476], rtol=1e-13)
+    assert_allclose(var, [2.717500758226203], rtol=1e-13)
+    gm = R.GPRef(X, t, kernel=R.MAT52, nugget=0.)
+    assert_allclose(gm.fit(np.ones(4)), 6.516669468923918, rtol=1e-14)
+    assert_allclose(gm.logpost_deriv(np.ones(4))[-1], -2.6787924025148055, rtol=1e-12)
+
+
+@pytest.mark.parametrize("kern", KERNELS)
+def test_fixture_2x3_vs_reference(kern):
+    g = load_golden("fixture_2x3.npz")
+    for name, theta in (("ones", np.ones(4)), ("zeros", np.zeros(4))):
+        gp = R.GPRef(g["X"], g["t"], kernel=kern, nugget=0.)
+        pre = "%s_%s_" % (kern, name)
+        assert_allclose(gp.fit(theta), g[pre + "logpost"], rtol=1e-14)
+        assert_allclose(gp.L, g[pre + "L"], rtol=1e-13, atol=1e-15)
+        assert_allclose(gp.Kinv_t, g[pre + "alpha"], rtol=1e-13)
+        assert_allclose(gp.logpost_deriv(theta), g[pre + "grad"], rtol=1e-10, atol=1e-13)
+        mu, var, _ = gp.predict(g["Xs"])
+        assert_allclose(mu, g[pre + "mean"], rtol=1e-13)
+        assert_allclose(var, g[pre + "var"], rtol=1e-13)
+
+
+@pytest.mark.parametrize("kern", KERNELS)
+@pytest.mark.parametrize("mode", list(MODES))
+def test_grid11_vs_reference(kern, mode):
+    g = load_golden("grid11.npz")
+    pre = "%s_%s_" % (kern, mode)
+    gp = R.GPRef(g["X"], g["t"], kernel=kern, nugget=MODES[mode])
+    theta = g[pre + "theta"]
+    assert_allclose(gp.fit(theta), g[pre + "logpost"], rtol=1e-10)  # cond(K)~1e8: LAPACK builds differ at 1e-12
+    assert_allclose(gp.nugget, g[pre + "nugget"], rtol=1e-14)
+    assert_allclose(gp.logpost_deriv(theta), g[pre + "grad"], rtol=1e-9)
+    mu, var, _ = gp.predict(g["Xs"])
+    assert_allclose(mu, g[pre + "mean"], rtol=1e-9, atol=1e-12)
+    assert_allclose(var, g[pre + "var"], rtol=1e-8, atol=1e-12)
+    _, var2, _ = gp.predict(g["Xs"], include_nugget=False)
+    assert_allclose(var2, g[pre + "var_nonug"], rtol=1e-8, atol=1e-12)
+
+
+def test_grid11_known_answers():
+    # literals recorded in SURVEY.md 8c item 2 (adaptive jitter fires for SqExp, not for Matern)
+    g = load_golden("grid11.npz")
+    gp = R.GPRef(g["X"], g["t"], nugget="adaptive")
+    assert_allclose(gp.fit([-1., -1., -2.]), -544.6415369237842, rtol=1e-11)
+    assert_allclose(gp.nugget, 1.3533528323661265e-07, rtol=1e-14)
+    gm = R.GPRef(g["X"], g["t"], kernel=R.MAT52, nugget="adaptive")
+    assert_allclose(gm.fit([-1., -1., -2.]), -296.4071272139189, rtol=1e-11)
+    assert gm.nugget == 0.0
+    gf = R.GPRef(g["X"], g["t"], nugget=1.e-6)
+    assert_allclose(gf.fit([-1., -1., -2.]), -499.7247964919526, rtol=1e-11)
+    assert_allclose(gf.logpost_deriv([-1., -1., -2.]),
+                    [-176.26704767253534, -159.4375217639966, -37.07969446011822], rtol=1e-8)
+
+
+@pytest.mark.parametrize("kern", KERNELS)
+def test_kernels_vs_reference(kern):
+    g = load_golden("kernels.npz")
+    assert_allclose(R.calc_r2(g["x1"], g["x2"], g["theta"]), g[kern + "_r2"], rtol=1e-15)
+    assert_allclose(R.kernel_f(g["x1"], g["x2"], g["theta"], kern), g[kern + "_K"], rtol=1e-15)
+    assert_allclose(R.kernel_deriv(g["x1"], g["x2"], g["theta"], kern), g[kern + "_dKdtheta"], rtol=1e-14)
+    assert_allclose(R.kernel_f(g["closed_x"], g["closed_y"], g["closed_theta"], kern),
+                    g[kern + "_closed_K"], rtol=1e-15)
+    # closed form (reference tests/test_Kernel.py): sqexp k(r2)=exp(-r2/2)
+    if kern == R.SQEXP:
+        assert_allclose(g[kern + "_closed_K"], np.exp(-0.5 * np.array([[1., 4.], [0., 1.]])), rtol=1e-15)
+
+
+@pytest.mark.parametrize("kern", KERNELS)
+def test_kernel_inputderiv_fd(kern):
+    rng = np.random.default_rng(5)
+    x1 = rng.normal(size=(4, 3)); x2 = rng.normal(size=(6, 3)); th = np.array([0.2, -0.4, 0.9])
+    an = R.kernel_inputderiv(x1, x2, th, kern)
+    h = 1e-6
+    for d in range(3):
+        e = np.zeros(3); e[d] = h
+        fd = (R.kernel_f(x1 + e, x2, th, kern) - R.kernel_f(x1 - e, x2, th, kern)) / (2 * h)
+        assert_allclose(an[d], fd, rtol=1e-6, atol=1e-9)
+
+
+def test_cholesky_known_answers():
+    g = load_golden("cholesky.npz")
+    L, j = R.jit_cholesky(g["wiki"])
+    assert_allclose(L, [[2., 0., 0.], [6., 1., 0.], [-8., 5., 3.]], atol=1e-14)
+    assert j == 0.
+    assert_allclose(np.tril(L), np.tril(g["wiki_L"]), atol=1e-15)
+    L, j = R.jit_cholesky(g["sing"])
+    assert_allclose(j, g["sing_jitter"], rtol=1e-15)
+    assert_allclose(np.tril(L), np.tril(g["sing_L"]), rtol=1e-10)  # sqrt(1e-6-ish cancellation)
+    assert_allclose(j, 1e-6, rtol=1e-15)  # tests/test_linalg.py:128-154: jitter 1e-6
+    with pytest.raises(np.linalg.LinAlgError):
+        R.jit_cholesky(np.array([[1., 2.], [2., 1.]]))
+    with pytest.raises(np.linalg.LinAlgError):
+        R.fixed_cholesky(np.array([[-1., 0.], [0., 1.]]))
+
+
+def test_priors_vs_reference():
+    g = load_golden("priors.npz")
+    for nm in ("invgamma", "gamma", "lognormal"):
+        p = R.Prior(nm, 2., 2.)
+        assert_allclose([p.logp(x) for x in g["x"]], g[nm + "_2_2_logp"], rtol=1e-14)
+        assert_allclose([p.dlogpdx(x) for x in g["x"]], g[nm + "_2_2_dlogpdx"], rtol=1e-14)
+        p = R.Prior(nm, 0.84, 0.0017)
+        assert_allclose([p.logp(x) for x in g["x"]], g[nm + "_b_logp"], rtol=1e-13)
+    pri = R.GPPriorsRef(3, "fit", corr=[R.Prior("invgamma", 2., 1.), R.Prior("gamma", 3., 0.5),
+                                       R.Prior("lognormal", 0.7, 1.3)],
+                        cov=R.Prior("gamma", 2., 3.), nugget=R.Prior("invgamma", 3.3, 4.3e-7))
+    assert_allclose(pri.logp(g["gppriors_theta"]), g["gppriors_logp"], rtol=1e-14)
+    assert_allclose(pri.dlogpdtheta(g["gppriors_theta"]), g["gppriors_dlogp"], rtol=1e-13)
+    # C++ spot values, mogp_gpu/test/test_gppriors.cu:22-62 (x=3, shape=scale=2), tolerance 1e-3 there
+    assert abs(R.Prior("invgamma", 2., 2.).logp(3.) - (2 * np.log(2.) - 3 * np.log(3.) - 2. / 3.)) < 1e-12
+
+
+def test_variance_stability_regression():
+    g = load_golden("var_stability.npz")
+    gp = R.GPRef(g["x"], g["y"], nugget=1.e-8)
+    gp.fit(g["theta"])   # sigma^2=e^15, nugget 1e-8: cond(K)>1e14, logdet is not reproducible between LAPACK builds
+    mu, var, _ = gp.predict(g["xt"])
+    assert_allclose(mu, g["mean"], rtol=1e-6, atol=1e-6)
+    assert_allclose(var, g["var"], atol=1e-3)          # the reference's own bar (test_GaussianProcess.py:1161)
+    assert_allclose(var, 0., atol=1e-3)
+
+
+@pytest.mark.parametrize("tag", ["c1_n200_d4", "n500_d10"])
+@pytest.mark.parametrize("kern", KERNELS)
+@pytest.mark.parametrize("mode", list(MODES))
+def test_medium_vs_reference(tag, kern, mode):
+    g = load_golden(tag + ".npz")
+    pre = "%s_%s_" % (kern, mode)
+    nug = 1.e-6 if mode == "fixed" else mode
+    gp = R.GPRef(g["X"], g["T"][0], kernel=kern, nugget=nug)
+    theta = g[pre + "theta"]
+    # adaptive with zero jitter factorises K with cond ~ 1/eps: only ~6 digits of logdet are
+    # reproducible between LAPACK builds (conda OpenBLAS vs system) -- tolerance reflects that
+    assert_allclose(gp.fit(theta), g[pre + "logpost"], rtol=1e-5 if mode == "adaptive" else 1e-10)
+    assert_allclose(gp.nugget, g[pre + "nugget"], rtol=1e-14)
+    K = gp.get_K_matrix()
+    assert_allclose(K.sum(), g[pre + "K_sum"], rtol=1e-13)
+    assert_allclose(K[::37, ::41], g[pre + "K_rows"], rtol=1e-14)
+    assert_allclose(np.diag(gp.L), g[pre + "L_diag"], rtol=1e-9)
+    assert_allclose(gp.Kinv_t, g[pre + "alpha"], rtol=1e-6, atol=1e-6)
+    assert_allclose(gp.logpost_deriv(theta), g[pre + "grad"], rtol=1e-8, atol=1e-8)
+    mu, var, _ = gp.predict(g["Xs"])
+    assert_allclose(mu, g[pre + "mean"], rtol=1e-8, atol=1e-9)
+    assert_allclose(var, g[pre + "var"], rtol=1e-7, atol=1e-9)
+
+
+@pytest.mark.parametrize("tag", ["c1_n200_d4", "n500_d10"])
+def test_default_prior_posterior_vs_reference(tag):
+    g = load_golden(tag + ".npz")
+    D = g["X"].shape[1]
+    pri = R.GPPriorsRef(D, "fit",
+                        corr=[R.Prior("invgamma", a, b) for a, b in zip(g["defprior_corr_shape"], g["defprior_corr_scale"])],
+                        nugget=R.Prior("invgamma", *g["defprior_nugget"]))
+    gp = R.GPRef(g["X"], g["T"][1], nugget="fit", priors=pri)
+    assert_allclose(gp.fit(g["defprior_theta"]), g["defprior_logpost"], rtol=1e-8)
+    assert_allclose(gp.logpost_deriv(g["defprior_theta"]), g["defprior_grad"], rtol=1e-8, atol=1e-8)
+
+
+def test_mogp4_vs_reference():
+    g = load_golden("mogp4.npz")
+    for k in range(4):
+        gp = R.GPRef(g["X"], g["T"][k], nugget=1.e-6)
+        assert_allclose(gp.fit(g["thetas"][k]), g["logpost"][k], rtol=1e-9)
+        assert_allclose(gp.logpost_deriv(g["thetas"][k]), g["grad"][k], rtol=1e-8, atol=1e-9)
+        mu, var, _ = gp.predict(g["Xs"])
+        assert_allclose(mu, g["mean"][k], rtol=1e-8, atol=1e-10)
+        assert_allclose(var, g["var"][k], rtol=1e-7, atol=1e-10)
+
+
+def test_fit_map_endpoint_vs_reference():
+    # optimiser trajectory parity is unpinned; the end-point objective is compared
+    g = load_golden("fitmap_c1.npz")
+    D = g["X"].shape[1]
+    pri = R.GPPriorsRef(D, "fixed", corr=[R.Prior("invgamma", a, b) for a, b in zip(g["corr_shape"], g["corr_scale"])])
+    gp = R.GPRef(g["X"], g["t"], nugget=1.e-6, priors=pri)
+    R.fit_GP_MAP_ref(gp, n_tries=1, theta0=g["theta0"])
+    assert_allclose(gp.current_logpost, g["logpost_hat"], rtol=1e-6)
+    assert_allclose(gp.fit(g["theta_hat"]), g["logpost_hat"], rtol=1e-10)
+
+
+def test_gradient_fd():
+    # FD check in the style of tests/test_GaussianProcess.py:626-661
+    g = load_golden("grid11.npz")
+    for kern in KERNELS:
+        gp = R.GPRef(g["X"], g["t"], kernel=kern, nugget="fit")
+        th = np.array([-1., -1., -2., np.log(1e-6)])
+        an = gp.logpost_deriv(th)
+        h = 1e-6
+        for p in range(4):
+            e = np.zeros(4); e[p] = h
+            fd = (gp.logposterior(th + e) - gp.logposterior(th - e)) / (2 * h)
+            assert_allclose(an[p], fd, rtol=1e-4, atol=1e-4)
