@@ -1,0 +1,148 @@
+"""
+ctypes binding of the C ABI declared in include/mogp_hip.h (libmogp_hip.so).
+
+This is the only place the shared library is touched.  There is NO CPU fallback:
+if the library cannot be loaded, ``load()`` raises, and every higher layer
+(``libgpgpu``) fails loudly instead of silently computing somewhere else.
+"""
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_double, c_int, c_longlong, c_uint, c_ulonglong, c_void_p
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmogp_hip.so")
+
+_lib = None
+
+c_double_p = POINTER(c_double)
+c_int_p = POINTER(c_int)
+
+
+def dptr(a):
+    """double* of a C-contiguous float64 ndarray (or NULL for None)."""
+    if a is None:
+        return None
+    assert a.dtype == np.float64 and a.flags["C_CONTIGUOUS"], "need a C-contiguous float64 array"
+    return a.ctypes.data_as(c_double_p)
+
+
+def iptr(a):
+    if a is None:
+        return None
+    assert a.dtype == np.int32 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(c_int_p)
+
+
+# name -> (restype, argtypes); every symbol of include/mogp_hip.h
+SIGNATURES = {
+    "mogp_last_error": (c_char_p, []),
+    "mogp_have_compatible_device": (c_int, []),
+    "mogp_device_count": (c_int, []),
+    "mogp_set_device": (c_int, [c_int]),
+    "mogp_version": (c_char_p, []),
+    "mogp_meanfunc_zero": (c_void_p, []),
+    "mogp_meanfunc_fixed": (c_void_p, [c_double]),
+    "mogp_meanfunc_const": (c_void_p, []),
+    "mogp_meanfunc_poly": (c_void_p, [c_int_p, c_int_p, c_int]),
+    "mogp_meanfunc_destroy": (None, [c_void_p]),
+    "mogp_meanfunc_n_params": (c_int, [c_void_p]),
+    "mogp_meanfunc_mean_f": (c_int, [c_void_p, c_double_p, c_int, c_int, c_double_p, c_int, c_double_p]),
+    "mogp_meanfunc_mean_deriv": (c_int, [c_void_p, c_double_p, c_int, c_int, c_double_p, c_int, c_double_p]),
+    "mogp_meanfunc_mean_inputderiv": (c_int, [c_void_p, c_double_p, c_int, c_int, c_double_p, c_int, c_double_p]),
+    "mogp_densegp_create": (c_void_p, [c_double_p, c_int, c_int, c_double_p, c_uint, c_void_p, c_int, c_int, c_double]),
+    "mogp_densegp_destroy": (None, [c_void_p]),
+    "mogp_densegp_n": (c_int, [c_void_p]),
+    "mogp_densegp_D": (c_int, [c_void_p]),
+    "mogp_densegp_n_corr": (c_int, [c_void_p]),
+    "mogp_densegp_n_params": (c_int, [c_void_p]),
+    "mogp_densegp_n_mean": (c_int, [c_void_p]),
+    "mogp_densegp_n_data": (c_int, [c_void_p]),
+    "mogp_densegp_inputs": (c_int, [c_void_p, c_double_p]),
+    "mogp_densegp_targets": (c_int, [c_void_p, c_double_p]),
+    "mogp_densegp_theta_fit_status": (c_int, [c_void_p]),
+    "mogp_densegp_reset_theta_fit_status": (c_int, [c_void_p]),
+    "mogp_densegp_get_theta": (c_int, [c_void_p, c_double_p, c_double_p]),
+    "mogp_densegp_create_gppriors": (c_int, [c_void_p, c_int, c_int_p, c_double_p, c_int, c_double_p, c_int, c_double_p]),
+    "mogp_densegp_priors_logp": (c_int, [c_void_p, c_double_p, c_int, c_double_p]),
+    "mogp_densegp_priors_dlogpdtheta": (c_int, [c_void_p, c_double_p, c_int, c_double_p]),
+    "mogp_densegp_priors_sample": (c_int, [c_void_p, c_double_p]),
+    "mogp_densegp_fit": (c_int, [c_void_p, c_double_p, c_int]),
+    "mogp_densegp_get_logpost": (c_int, [c_void_p, c_double_p, c_int, c_double_p]),
+    "mogp_densegp_logpost_deriv": (c_int, [c_void_p, c_double_p, c_int]),
+    "mogp_densegp_predict": (c_int, [c_void_p, c_double_p, c_int, c_double_p]),
+    "mogp_densegp_predict_variance": (c_int, [c_void_p, c_double_p, c_int, c_double_p, c_double_p]),
+    "mogp_densegp_predict_batch": (c_int, [c_void_p, c_double_p, c_int, c_int, c_double_p, c_int]),
+    "mogp_densegp_predict_variance_batch": (c_int, [c_void_p, c_double_p, c_int, c_int, c_double_p, c_double_p, c_int]),
+    "mogp_densegp_predict_deriv": (c_int, [c_void_p, c_double_p, c_int, c_int, c_double_p, c_int, c_int]),
+    "mogp_densegp_get_K": (c_int, [c_void_p, c_double_p]),
+    "mogp_densegp_get_invQ": (c_int, [c_void_p, c_double_p]),
+    "mogp_densegp_get_invQt": (c_int, [c_void_p, c_double_p]),
+    "mogp_densegp_get_cholesky_lower": (c_int, [c_void_p, c_double_p]),
+    "mogp_densegp_get_nugget_size": (c_double, [c_void_p]),
+    "mogp_densegp_set_nugget_size": (c_int, [c_void_p, c_double]),
+    "mogp_densegp_get_nugget_type": (c_int, [c_void_p]),
+    "mogp_densegp_set_nugget_type": (c_int, [c_void_p, c_int]),
+    "mogp_densegp_get_kernel_type": (c_int, [c_void_p]),
+    "mogp_fit_single_GP_MAP": (c_int, [c_void_p, c_int, c_double_p, c_int]),
+    "mogp_mogp_create": (c_void_p, [c_double_p, c_int, c_int, c_double_p, c_int, c_uint, c_void_p, c_int, c_int, c_double]),
+    "mogp_mogp_destroy": (None, [c_void_p]),
+    "mogp_mogp_n": (c_int, [c_void_p]),
+    "mogp_mogp_D": (c_int, [c_void_p]),
+    "mogp_mogp_n_emulators": (c_int, [c_void_p]),
+    "mogp_mogp_inputs": (c_int, [c_void_p, c_double_p]),
+    "mogp_mogp_targets": (c_int, [c_void_p, c_double_p]),
+    "mogp_mogp_emulator": (c_void_p, [c_void_p, c_int]),
+    "mogp_mogp_get_nugget_type": (c_int, [c_void_p]),
+    "mogp_mogp_get_nugget_size": (c_double, [c_void_p]),
+    "mogp_mogp_get_fitted_indices": (c_int, [c_void_p, c_int_p]),
+    "mogp_mogp_get_unfitted_indices": (c_int, [c_void_p, c_int_p]),
+    "mogp_mogp_reset_fit_status": (c_int, [c_void_p]),
+    "mogp_mogp_create_priors_for_emulator": (c_int, [c_void_p, c_int, c_int, c_int_p, c_double_p, c_int, c_double_p, c_int, c_double_p]),
+    "mogp_mogp_fit": (c_int, [c_void_p, c_double_p, c_int, c_int]),
+    "mogp_mogp_fit_emulator": (c_int, [c_void_p, c_int, c_double_p, c_int]),
+    "mogp_mogp_eval": (c_int, [c_void_p, c_double_p, c_int, c_int, c_double_p, c_double_p, c_int_p]),
+    "mogp_mogp_predict_batch": (c_int, [c_void_p, c_double_p, c_int, c_int, c_double_p]),
+    "mogp_mogp_predict_variance_batch": (c_int, [c_void_p, c_double_p, c_int, c_int, c_double_p, c_double_p]),
+    "mogp_mogp_predict_deriv": (c_int, [c_void_p, c_double_p, c_int, c_int, c_double_p]),
+    "mogp_mogp_predict_variance_batch_dev": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "mogp_fit_GP_MAP": (c_int, [c_void_p, c_int, c_double_p, c_int]),
+    "mogp_set_fit_options": (c_int, [c_int, c_double, c_double, c_ulonglong]),
+    "mogp_profile_enable": (c_int, [c_int]),
+    "mogp_profile_reset": (c_int, []),
+    "mogp_profile_get": (c_int, [c_char_p, c_double_p, POINTER(c_longlong), c_double_p, c_double_p]),
+    "mogp_dev_malloc": (c_void_p, [c_ulonglong]),
+    "mogp_dev_free": (c_int, [c_void_p]),
+    "mogp_dev_upload": (c_int, [c_void_p, c_void_p, c_ulonglong]),
+    "mogp_dev_download": (c_int, [c_void_p, c_void_p, c_ulonglong]),
+    "mogp_dev_synchronize": (c_int, []),
+}
+
+
+def load():
+    """Load libmogp_hip.so (once) and attach the prototypes.  Raises OSError /
+    AttributeError if the library or one of its symbols is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise OSError("libmogp_hip.so not found at %s -- run `python -c 'import __graft_entry__ as g; g.build()'` "
+                      "or `make -C mogp_emulator_amd/csrc`" % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def last_error():
+    return load().mogp_last_error().decode("utf-8", "replace")
+
+
+def check(status):
+    """Non-zero status -> RuntimeError(message), as pybind11 maps std::runtime_error."""
+    if status != 0:
+        raise RuntimeError(last_error())

@@ -1,0 +1,105 @@
+// Engine: B independent zero/parametric-mean GPs that share one input matrix X, resident on one
+// MI355X.  It is the device-side state behind both DenseGP_GPU (B = 1, densegp_gpu.hpp:36-123) and
+// MultiOutputGP_GPU (B = n_emulators, multioutputgp_gpu.hpp:35-287).  Where the reference loops
+// over emulators with OpenMP and serialises them on the default stream, every operation here is
+// ONE batched launch sequence over an index list of emulators.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <random>
+#include <string>
+#include <vector>
+
+#include "hostmath.h"
+#include "launch.h"
+
+namespace mogp {
+
+struct GPState {
+  std::vector<double> data;      // n_data: corr_raw (D), log sigma^2, [log nugget]
+  std::vector<double> meanp;     // n_mean
+  bool has_data = false;
+  int nug_type = NUG_ADAPTIVE;
+  double nug_size = 0.;          // adaptive: jitter found by the last fit; fixed: the constant
+  Priors pri;
+  double logpost = 0.;
+  bool factored = false;         // A holds L (and y) for `data`
+  bool linv = false, kinv = false;
+  double nugget_used = 0.;       // value actually added to the diagonal in the last factorisation
+};
+
+class Engine {
+ public:
+  Engine(const double* X, int n, int D, const double* targets, int B, unsigned testing_size, const MeanFunc& mean,
+         int kernel_type, int nug_type, double nug_size);
+  ~Engine();
+  Engine(const Engine&) = delete;
+
+  int n, D, NP, PS, B, kernel_type;
+  unsigned testing_size;
+  MeanFunc mean;
+  std::vector<GPState> gp;
+  std::vector<double> hX, hT;    // host copies (inputs()/targets())
+
+  int n_mean() const { return mean.n_params(); }
+  int n_data(int i) const { return D + 1 + (gp[i].nug_type == NUG_FIT ? 1 : 0); }
+  int n_theta(int i) const { return n_mean() + n_data(i); }
+  double nugget_size(int i) const;
+
+  // Batched objective (+ gradient) at per-emulator thetas (full vectors [mean | data]).
+  // ok[k] = 1 when the factorisation succeeded.  Never throws for numerical failure.
+  void eval(const std::vector<int>& ids, const std::vector<const double*>& thetas, bool want_grad, double* f, double* grad,
+            int grad_ld, int* ok);
+  // fit(theta) for one emulator: throws std::runtime_error on failure (densegp_gpu.hpp:556-570)
+  void fit_one(int i, const double* theta, int len);
+  void grad_current(const std::vector<int>& ids, double* grad, int grad_ld);
+
+  // predictions for emulators `ids` (must be fitted). Xs host (m, D) unless xs_on_device.
+  // means/vars: (ids.size(), m) row-major with leading dimension out_ld; host unless out_on_device.
+  void predict(const std::vector<int>& ids, const double* Xs, int m, bool xs_on_device, double* means, double* vars,
+               long out_ld, bool out_on_device, double* derivs /* host (ids, m, D) or null */);
+
+  void get_K(int i, double* out);
+  void get_invQ(int i, double* out);
+  void get_invQt(int i, double* out);
+  void get_chol(int i, double* out);
+
+  // multi-start MAP fit of emulators `ids` in lock-step (fitting.hpp:61-128)
+  void fit_map(const std::vector<int>& ids, int n_tries, const double* theta0, int theta0_len);
+
+  hipStream_t stream = nullptr;
+
+ private:
+  void upload_params(const std::vector<int>& ids);
+  void upload_idx(const std::vector<int>& ids);
+  void factorize(const std::vector<int>& ids, std::vector<int>& info);
+  void ensure_linv(const std::vector<int>& ids);
+  void ensure_kinv(const std::vector<int>& ids);
+  BatchView view(int nb) const;
+  void set_theta(int i, const double* theta);
+  void ensure_predict_scratch(int nb, int MC);
+
+  double *dX = nullptr, *dP = nullptr, *dT = nullptr, *dA = nullptr, *dLinv = nullptr, *dKinv = nullptr, *dAlpha = nullptr;
+  double *dLogdet = nullptr, *dYty = nullptr, *dGradOut = nullptr, *dGradPartial = nullptr;
+  int *dInfo = nullptr, *dIdx = nullptr;
+  std::vector<double> hP;
+  // predict scratch
+  double *dXs = nullptr, *dKs = nullptr, *dMean = nullptr, *dVar = nullptr, *dVarPartial = nullptr, *dDeriv = nullptr;
+  size_t capXs = 0, capKs = 0, capMean = 0, capVarPartial = 0, capDeriv = 0;
+  std::mt19937_64 rng;
+};
+
+// optimiser options (mogp_set_fit_options)
+struct FitOptions {
+  int max_iter = 200;
+  double ftol = 1e-9;   // |f_k - f_{k+1}| <= ftol * max(1, |f|)   (dlib objective_delta_stop_strategy(1e-9), fitting.hpp:92)
+  double gtol = 1e-6;
+  unsigned long long seed = 0;
+};
+FitOptions& fit_options();
+
+void hip_check(hipError_t e, const char* what);
+void prof_enable(bool on);
+void prof_reset();
+bool prof_get(const char* tag, double* ms, long long* launches, double* flops, double* bytes);
+
+}  // namespace mogp

@@ -1,0 +1,717 @@
+#include "engine.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <map>
+#include <mutex>
+
+namespace mogp {
+
+void hip_check(hipError_t e, const char* what) {
+  if (e != hipSuccess) throw std::runtime_error(std::string("HIP error in ") + what + ": " + hipGetErrorString(e));
+}
+#define HIPCK(x) hip_check((x), #x)
+
+FitOptions& fit_options() {
+  static FitOptions o;
+  return o;
+}
+
+// ---------------------------------------------------------------------------------------------
+// profiling registry (bench.py): HIP events on the launch stream around tagged kernels
+// ---------------------------------------------------------------------------------------------
+namespace {
+struct ProfRec {
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
+  double flops = 0., bytes = 0., ms_done = 0.;
+  long long launches = 0;
+  hipEvent_t pending = nullptr;
+};
+bool g_prof_on = false;
+std::map<std::string, ProfRec> g_prof;
+std::mutex g_prof_mu;
+}  // namespace
+
+void prof_begin(const char* tag, hipStream_t s) {
+  if (!g_prof_on) return;
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  ProfRec& r = g_prof[tag];
+  hipEvent_t e;
+  if (hipEventCreate(&e) != hipSuccess) return;
+  hipEventRecord(e, s);
+  r.pending = e;
+}
+void prof_end(const char* tag, hipStream_t s, double flops, double bytes) {
+  if (!g_prof_on) return;
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  ProfRec& r = g_prof[tag];
+  if (!r.pending) return;
+  hipEvent_t e;
+  if (hipEventCreate(&e) != hipSuccess) return;
+  hipEventRecord(e, s);
+  r.ev.emplace_back(r.pending, e);
+  r.pending = nullptr;
+  r.flops += flops;
+  r.bytes += bytes;
+  r.launches += 1;
+}
+void prof_enable(bool on) { g_prof_on = on; }
+void prof_reset() {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  for (auto& kv : g_prof) {
+    for (auto& p : kv.second.ev) {
+      hipEventDestroy(p.first);
+      hipEventDestroy(p.second);
+    }
+  }
+  g_prof.clear();
+}
+bool prof_get(const char* tag, double* ms, long long* launches, double* flops, double* bytes) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  auto it = g_prof.find(tag);
+  if (it == g_prof.end()) return false;
+  ProfRec& r = it->second;
+  for (auto& p : r.ev) {
+    hipEventSynchronize(p.second);
+    float t = 0.f;
+    hipEventElapsedTime(&t, p.first, p.second);
+    r.ms_done += t;
+    hipEventDestroy(p.first);
+    hipEventDestroy(p.second);
+  }
+  r.ev.clear();
+  *ms = r.ms_done;
+  *launches = r.launches;
+  *flops = r.flops;
+  *bytes = r.bytes;
+  return true;
+}
+
+// ---------------------------------------------------------------------------------------------
+static int roundup(int x, int m) { return (x + m - 1) / m * m; }
+
+template <class T>
+static T* dalloc(size_t count) {
+  T* p = nullptr;
+  HIPCK(hipMalloc(reinterpret_cast<void**>(&p), std::max<size_t>(count, 1) * sizeof(T)));
+  return p;
+}
+template <class T>
+static void grow(T*& p, size_t& cap, size_t need) {
+  if (need <= cap) return;
+  if (p) HIPCK(hipFree(p));
+  p = dalloc<T>(need);
+  cap = need;
+}
+
+Engine::Engine(const double* X, int n_, int D_, const double* targets, int B_, unsigned testing_size_, const MeanFunc& mean_,
+               int kernel_type_, int nug_type, double nug_size)
+    : n(n_), D(D_), B(B_), kernel_type(kernel_type_), testing_size(testing_size_), mean(mean_) {
+  if (n < 1 || D < 1 || B < 1) throw std::runtime_error("inputs must have shape (n, D) with n, D >= 1");
+  if (kernel_type != 0 && kernel_type != 1) throw std::runtime_error("Unrecognized kernel type\n");
+  if (nug_type < 0 || nug_type > 2) throw std::runtime_error("Unrecognized nugget_type");
+  for (int d : mean.dims)
+    if (d >= D) throw std::runtime_error("Dimension index must be less than " + std::to_string(D));
+  NP = roundup(n + 1, TILE);
+  PS = D + 2;
+  hX.assign(X, X + (size_t)n * D);
+  hT.assign(targets, targets + (size_t)B * n);
+  gp.resize(B);
+  for (auto& g : gp) {
+    g.nug_type = nug_type;
+    g.nug_size = nug_size;
+    g.data.assign(D + 1 + (nug_type == NUG_FIT ? 1 : 0), 0.);
+    g.meanp.assign(mean.n_params(), 0.);
+  }
+  HIPCK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+  dX = dalloc<double>((size_t)n * D);
+  dP = dalloc<double>((size_t)B * PS);
+  dT = dalloc<double>((size_t)B * n);
+  dA = dalloc<double>((size_t)B * NP * NP);
+  dAlpha = dalloc<double>((size_t)B * NP);
+  dLogdet = dalloc<double>(B);
+  dYty = dalloc<double>(B);
+  dInfo = dalloc<int>(B);
+  dIdx = dalloc<int>(B);
+  hP.assign((size_t)B * PS, 0.);
+  HIPCK(hipMemcpy(dX, hX.data(), hX.size() * sizeof(double), hipMemcpyHostToDevice));
+  // residual targets for parameter-free means are fixed once
+  std::vector<double> res(hT);
+  if (mean.n_params() == 0 && mean.kind == 1)
+    for (auto& x : res) x -= mean.value;
+  HIPCK(hipMemcpy(dT, res.data(), res.size() * sizeof(double), hipMemcpyHostToDevice));
+  rng.seed(fit_options().seed ? fit_options().seed : std::random_device{}());
+}
+
+Engine::~Engine() {
+  for (void* p : {(void*)dX, (void*)dP, (void*)dT, (void*)dA, (void*)dLinv, (void*)dKinv, (void*)dAlpha, (void*)dLogdet, (void*)dYty,
+                  (void*)dGradOut, (void*)dGradPartial, (void*)dInfo, (void*)dIdx, (void*)dXs, (void*)dKs, (void*)dMean, (void*)dVar,
+                  (void*)dVarPartial, (void*)dDeriv})
+    if (p) hipFree(p);
+  if (stream) hipStreamDestroy(stream);
+}
+
+double Engine::nugget_size(int i) const {
+  const GPState& g = gp[i];
+  if (g.nug_type == NUG_FIT) return g.has_data ? std::exp(g.data[D + 1]) : g.nug_size;   // gpparams.hpp:176-182
+  return g.nug_size;
+}
+
+BatchView Engine::view(int nb) const {
+  BatchView v;
+  v.n = n; v.D = D; v.NP = NP; v.PS = PS; v.kernel_type = kernel_type;
+  v.X = dX; v.P = dP; v.T = dT; v.A = dA; v.Linv = dLinv; v.Kinv = dKinv; v.alpha = dAlpha;
+  v.idx = dIdx; v.nb = nb;
+  return v;
+}
+
+void Engine::upload_idx(const std::vector<int>& ids) {
+  HIPCK(hipMemcpyAsync(dIdx, ids.data(), ids.size() * sizeof(int), hipMemcpyHostToDevice, stream));
+  HIPCK(hipStreamSynchronize(stream));   // ids may be a temporary
+}
+
+void Engine::set_theta(int i, const double* theta) {
+  GPState& g = gp[i];
+  const int nm = n_mean(), nd = n_data(i);
+  g.meanp.assign(theta, theta + nm);
+  g.data.assign(theta + nm, theta + nm + nd);
+  g.has_data = false;
+  g.factored = g.linv = g.kinv = false;
+  if (g.nug_type == NUG_ADAPTIVE) g.nug_size = 0.;   // gpparams.hpp:118-126
+  if (nm > 0) {
+    std::vector<double> m(n), r(n);
+    mean.mean_f(hX.data(), n, D, g.meanp.data(), nm, m.data());
+    for (int k = 0; k < n; ++k) r[k] = hT[(size_t)i * n + k] - m[k];
+    HIPCK(hipMemcpyAsync(dT + (size_t)i * n, r.data(), n * sizeof(double), hipMemcpyHostToDevice, stream));
+    HIPCK(hipStreamSynchronize(stream));
+  }
+}
+
+void Engine::upload_params(const std::vector<int>& ids) {
+  for (int i : ids) {
+    const GPState& g = gp[i];
+    double* p = hP.data() + (size_t)i * PS;
+    for (int d = 0; d < D; ++d) p[d] = std::exp(g.data[d]);
+    p[D] = std::exp(g.data[D]);
+    p[D + 1] = g.nugget_used;
+  }
+  HIPCK(hipMemcpyAsync(dP, hP.data(), hP.size() * sizeof(double), hipMemcpyHostToDevice, stream));
+}
+
+// Blocked right-looking Cholesky of K + nugget I for the emulators in `ids` (one batched sequence).
+//   outer block 128 = two 64-wide panels; per outer block:
+//   potf2 -> trsm -> narrow update of the second panel -> potf2 -> trsm -> MFMA trailing update (K = 128)
+void Engine::factorize(const std::vector<int>& ids, std::vector<int>& info) {
+  const int nb = (int)ids.size();
+  upload_idx(ids);
+  upload_params(ids);
+  BatchView v = view(nb);
+  HIPCK(hipMemsetAsync(dInfo, 0, B * sizeof(int), stream));
+  launch_cov_build(v, stream);
+  for (int o = 0; o < n + 1; o += TILE) {
+    launch_potf2(v, o, dInfo, stream);
+    launch_trsm(v, o, o + NBI, stream);
+    launch_update_narrow(v, o + NBI, o, o + NBI, stream);
+    launch_potf2(v, o + NBI, dInfo, stream);
+    launch_trsm(v, o + NBI, o + TILE, stream);
+    launch_update_trailing(v, o + TILE, o, o + TILE, stream);
+  }
+  info.assign(B, 0);
+  HIPCK(hipMemcpyAsync(info.data(), dInfo, B * sizeof(int), hipMemcpyDeviceToHost, stream));
+  HIPCK(hipStreamSynchronize(stream));
+  HIPCK(hipGetLastError());
+}
+
+void Engine::eval(const std::vector<int>& ids, const std::vector<const double*>& thetas, bool want_grad, double* f, double* grad,
+                  int grad_ld, int* ok) {
+  const int nb = (int)ids.size();
+  if (nb == 0) return;
+  for (int k = 0; k < nb; ++k) {
+    set_theta(ids[k], thetas[k]);
+    GPState& g = gp[ids[k]];
+    g.nugget_used = (g.nug_type == NUG_FIXED) ? g.nug_size : (g.nug_type == NUG_FIT ? std::exp(g.data[D + 1]) : 0.0);
+  }
+  std::vector<int> info;
+  factorize(ids, info);
+  std::vector<char> good(B, 0);
+  std::vector<int> failed;
+  for (int i : ids) {
+    if (info[i] == 0) good[i] = 1;
+    else failed.push_back(i);
+  }
+  // adaptive jitter ladder: linalg/cholesky.py:268-279 -- jitter = mean(diag K) * 1e-6, x10 per try, 5 tries.
+  // diag K = sigma^2 k(0) = sigma^2 exactly, so mean(diag K) = sigma^2.
+  std::vector<double> jitter(B, 0.);
+  {
+    std::vector<int> retry;
+    for (int i : failed)
+      if (gp[i].nug_type == NUG_ADAPTIVE) {
+        jitter[i] = std::exp(gp[i].data[D]) * 1e-6;
+        retry.push_back(i);
+      }
+    for (int attempt = 0; attempt < 5 && !retry.empty(); ++attempt) {
+      std::vector<int> todo;
+      for (int i : retry)
+        if (std::isfinite(jitter[i])) {
+          gp[i].nugget_used = jitter[i];
+          todo.push_back(i);
+        }
+      if (todo.empty()) break;
+      factorize(todo, info);
+      std::vector<int> still;
+      for (int i : todo) {
+        if (info[i] == 0) {
+          good[i] = 1;
+          gp[i].nug_size = jitter[i];
+        } else {
+          jitter[i] *= 10;
+          still.push_back(i);
+        }
+      }
+      retry.swap(still);
+    }
+  }
+  std::vector<int> okids;
+  for (int i : ids)
+    if (good[i]) okids.push_back(i);
+  std::vector<double> logdet(B, 0.), yty(B, 0.);
+  if (!okids.empty()) {
+    upload_idx(okids);
+    BatchView v = view((int)okids.size());
+    launch_logdet(v, dLogdet, dYty, stream);
+    launch_backsolve(v, stream);
+    HIPCK(hipMemcpyAsync(logdet.data(), dLogdet, B * sizeof(double), hipMemcpyDeviceToHost, stream));
+    HIPCK(hipMemcpyAsync(yty.data(), dYty, B * sizeof(double), hipMemcpyDeviceToHost, stream));
+    HIPCK(hipStreamSynchronize(stream));
+  }
+  for (int k = 0; k < nb; ++k) {
+    const int i = ids[k];
+    GPState& g = gp[i];
+    double val = std::numeric_limits<double>::quiet_NaN();
+    bool fine = good[i];
+    if (fine) {
+      // GaussianProcess.py:679-685 with mean = None; densegp_gpu.hpp:604-611
+      val = 0.5 * (yty[i] + logdet[i] + n * std::log(2.0 * M_PI)) - g.pri.logp(g.data, D, g.nug_type);
+      if (!std::isfinite(val)) fine = false;
+    }
+    g.has_data = fine;
+    g.factored = fine;
+    g.logpost = val;
+    if (f) f[k] = val;
+    if (ok) ok[k] = fine ? 1 : 0;
+    if (!fine) good[i] = 0;
+  }
+  if (want_grad && grad) {
+    std::vector<int> gids;
+    std::vector<int> pos;
+    for (int k = 0; k < nb; ++k)
+      if (good[ids[k]]) {
+        gids.push_back(ids[k]);
+        pos.push_back(k);
+      }
+    if (!gids.empty()) {
+      std::vector<double> tmp((size_t)gids.size() * grad_ld);
+      grad_current(gids, tmp.data(), grad_ld);
+      for (size_t q = 0; q < gids.size(); ++q)
+        std::memcpy(grad + (size_t)pos[q] * grad_ld, tmp.data() + q * grad_ld, sizeof(double) * n_theta(gids[q]));
+    }
+  }
+}
+
+void Engine::fit_one(int i, const double* theta, int len) {
+  if (len != n_theta(i)) throw std::runtime_error("Shape of new GPParams object does not match existing one");
+  double f;
+  int ok;
+  std::vector<int> ids{i};
+  std::vector<const double*> th{theta};
+  eval(ids, th, false, &f, nullptr, 0, &ok);
+  if (!ok) {
+    if (gp[i].nug_type == NUG_ADAPTIVE) throw std::runtime_error("All attempts at factorization failed. Last return code 1");
+    throw std::runtime_error("Unable to factorize matrix using selected nugget type");
+  }
+}
+
+void Engine::ensure_linv(const std::vector<int>& ids) {
+  std::vector<int> need;
+  for (int i : ids) {
+    if (!gp[i].factored) throw std::runtime_error("emulator has not been fit");
+    if (!gp[i].linv) need.push_back(i);
+  }
+  if (need.empty()) return;
+  if (!dLinv) {
+    dLinv = dalloc<double>((size_t)B * NP * NP);
+    dKinv = dalloc<double>((size_t)B * NP * NP);
+    dGradOut = dalloc<double>((size_t)B * (D + 3));
+    dGradPartial = dalloc<double>((size_t)B * grad_num_tiles(n) * (D + 3));
+  }
+  upload_idx(need);
+  BatchView v = view((int)need.size());
+  launch_trtri(v, stream);
+  for (int i : need) {
+    gp[i].linv = true;
+    gp[i].kinv = false;   // trtri used Kinv as scratch
+  }
+}
+
+void Engine::ensure_kinv(const std::vector<int>& ids) {
+  ensure_linv(ids);
+  std::vector<int> need;
+  for (int i : ids)
+    if (!gp[i].kinv) need.push_back(i);
+  if (need.empty()) return;
+  upload_idx(need);
+  BatchView v = view((int)need.size());
+  launch_kinv(v, stream);
+  for (int i : need) gp[i].kinv = true;
+}
+
+void Engine::grad_current(const std::vector<int>& ids, double* grad, int grad_ld) {
+  if (ids.empty()) return;
+  ensure_kinv(ids);
+  upload_idx(ids);
+  BatchView v = view((int)ids.size());
+  launch_grad(v, dGradPartial, dGradOut, stream);
+  const int NQ = D + 3;
+  std::vector<double> out((size_t)B * NQ);
+  HIPCK(hipMemcpyAsync(out.data(), dGradOut, out.size() * sizeof(double), hipMemcpyDeviceToHost, stream));
+  HIPCK(hipStreamSynchronize(stream));
+  HIPCK(hipGetLastError());
+  const int nm = n_mean();
+  std::vector<double> dpr(D + 2);
+  for (size_t q = 0; q < ids.size(); ++q) {
+    const int i = ids[q];
+    const GPState& g = gp[i];
+    double* gr = grad + q * grad_ld;
+    const double* o = out.data() + (size_t)i * NQ;
+    g.pri.dlogpdtheta(g.data, D, g.nug_type, dpr.data());
+    // GaussianProcess.py:751-780: 0.5 sum W dK/dtheta_p  -  d log prior / d theta_p
+    for (int p = 0; p <= D; ++p) gr[nm + p] = o[p] - dpr[p];
+    if (g.nug_type == NUG_FIT) gr[nm + D + 1] = 0.5 * std::exp(g.data[D + 1]) * (o[D + 1] - o[D + 2]) - dpr[D + 1];
+    if (nm > 0) {
+      // densegp_gpu.hpp:734-747: -(d mean / d beta)^T alpha
+      std::vector<double> a(n), md((size_t)nm * n);
+      HIPCK(hipMemcpy(a.data(), dAlpha + (size_t)i * NP, n * sizeof(double), hipMemcpyDeviceToHost));
+      mean.mean_deriv(hX.data(), n, D, g.meanp.data(), nm, md.data());
+      for (int p = 0; p < nm; ++p) {
+        double s = 0.;
+        for (int k = 0; k < n; ++k) s += md[(size_t)p * n + k] * a[k];
+        gr[p] = -s;
+      }
+    }
+  }
+}
+
+void Engine::ensure_predict_scratch(int nb, int MC) {
+  grow(dKs, capKs, (size_t)nb * MC * NP);
+  grow(dVarPartial, capVarPartial, (size_t)nb * ((n + 127) / 128) * MC);
+}
+
+void Engine::predict(const std::vector<int>& ids, const double* Xs, int m, bool xs_on_device, double* means, double* vars, long out_ld,
+                     bool out_on_device, double* derivs) {
+  const int nb = (int)ids.size();
+  if (nb == 0 || m == 0) return;
+  for (int i : ids)
+    if (!gp[i].factored) throw std::runtime_error("emulator has not been fit");
+  if (vars) ensure_linv(ids);
+  upload_idx(ids);
+  BatchView v = view(nb);
+  const double* dXsrc = Xs;
+  if (!xs_on_device) {
+    grow(dXs, capXs, (size_t)m * D);
+    HIPCK(hipMemcpyAsync(dXs, Xs, (size_t)m * D * sizeof(double), hipMemcpyHostToDevice, stream));
+    dXsrc = dXs;
+  }
+  double* dm = means;
+  double* dv = vars;
+  long ld = out_ld;
+  if (!out_on_device) {
+    grow(dMean, capMean, (size_t)2 * nb * m);
+    dm = dMean;
+    dv = dMean + (size_t)nb * m;
+    ld = m;
+  }
+  const int MPtot = roundup(m, 128);
+  long MC = (long)(6.0e9 / ((double)nb * NP * 8.0)) / 128 * 128;
+  MC = std::max<long>(128, std::min<long>(MC, MPtot));
+  if (vars) ensure_predict_scratch(nb, (int)MC);
+  for (int c0 = 0; c0 < m; c0 += (int)MC) {
+    const int mc = std::min<int>((int)MC, m - c0);
+    const int MPc = roundup(mc, 128);
+    launch_cross_cov_mean(v, dXsrc + (size_t)c0 * D, mc, MPc, vars ? dKs : nullptr, dm + c0, (int)ld, stream);
+    if (vars) launch_predict_var(v, dKs, mc, MPc, dVarPartial, dv + c0, (int)ld, stream);
+  }
+  if (derivs) {
+    grow(dDeriv, capDeriv, (size_t)nb * m * D);
+    launch_predict_deriv(v, dXsrc, m, dDeriv, (long)m * D, stream);
+    HIPCK(hipMemcpyAsync(derivs, dDeriv, (size_t)nb * m * D * sizeof(double), hipMemcpyDeviceToHost, stream));
+  }
+  if (!out_on_device) {
+    for (int k = 0; k < nb; ++k) {
+      HIPCK(hipMemcpyAsync(means + (size_t)k * out_ld, dm + (size_t)k * m, m * sizeof(double), hipMemcpyDeviceToHost, stream));
+      if (vars) HIPCK(hipMemcpyAsync(vars + (size_t)k * out_ld, dv + (size_t)k * m, m * sizeof(double), hipMemcpyDeviceToHost, stream));
+    }
+  }
+  HIPCK(hipStreamSynchronize(stream));
+  HIPCK(hipGetLastError());
+  // mean function contribution (host, O(m)): densegp_gpu.hpp:334-337, 402-405, 443-447
+  if (mean.kind != 0 && !out_on_device) {
+    std::vector<double> hx;
+    const double* xs_h = Xs;
+    if (xs_on_device) {
+      hx.resize((size_t)m * D);
+      HIPCK(hipMemcpy(hx.data(), Xs, hx.size() * sizeof(double), hipMemcpyDeviceToHost));
+      xs_h = hx.data();
+    }
+    std::vector<double> mv(m), mid((size_t)D * m);
+    for (int k = 0; k < nb; ++k) {
+      const GPState& g = gp[ids[k]];
+      mean.mean_f(xs_h, m, D, g.meanp.data(), n_mean(), mv.data());
+      for (int j = 0; j < m; ++j) means[(size_t)k * out_ld + j] += mv[j];
+      if (derivs) {
+        mean.mean_inputderiv(xs_h, m, D, g.meanp.data(), n_mean(), mid.data());
+        for (int j = 0; j < m; ++j)
+          for (int d = 0; d < D; ++d) derivs[((size_t)k * m + j) * D + d] += mid[(size_t)d * m + j];
+      }
+    }
+  }
+}
+
+void Engine::get_K(int i, double* out) {
+  if (!gp[i].has_data) throw std::runtime_error("emulator has not been fit");
+  double* tmp = dalloc<double>((size_t)n * n);
+  std::vector<int> ids{i};
+  upload_params(ids);
+  launch_cov_full(view(1), i, tmp, stream);
+  HIPCK(hipMemcpyAsync(out, tmp, (size_t)n * n * sizeof(double), hipMemcpyDeviceToHost, stream));
+  HIPCK(hipStreamSynchronize(stream));
+  hipFree(tmp);
+}
+
+void Engine::get_invQ(int i, double* out) {
+  std::vector<int> ids{i};
+  ensure_kinv(ids);
+  double* tmp = dalloc<double>((size_t)n * n);
+  launch_extract(dKinv + (size_t)i * NP * NP, NP, n, tmp, 2, stream);
+  HIPCK(hipMemcpyAsync(out, tmp, (size_t)n * n * sizeof(double), hipMemcpyDeviceToHost, stream));
+  HIPCK(hipStreamSynchronize(stream));
+  hipFree(tmp);
+}
+
+void Engine::get_invQt(int i, double* out) {
+  if (!gp[i].factored) throw std::runtime_error("emulator has not been fit");
+  HIPCK(hipMemcpy(out, dAlpha + (size_t)i * NP, n * sizeof(double), hipMemcpyDeviceToHost));
+}
+
+void Engine::get_chol(int i, double* out) {
+  if (!gp[i].factored) throw std::runtime_error("emulator has not been fit");
+  double* tmp = dalloc<double>((size_t)n * n);
+  launch_extract(dA + (size_t)i * NP * NP, NP, n, tmp, 1, stream);
+  HIPCK(hipMemcpyAsync(out, tmp, (size_t)n * n * sizeof(double), hipMemcpyDeviceToHost, stream));
+  HIPCK(hipStreamSynchronize(stream));
+  hipFree(tmp);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Multi-start MAP fit, all emulators in lock-step (fitting.hpp:61-128, fitting.py:219-266).
+// Each optimiser "round" is ONE batched device evaluation (objective + gradient) of every
+// emulator that still needs one; every emulator runs its own L-BFGS (memory 10) with an
+// Armijo/curvature line search.  Optimiser trajectory parity with dlib / scipy is unpinned
+// (SURVEY.md section 8c); the end-point objective is what the tests compare.
+// ---------------------------------------------------------------------------------------------
+namespace {
+struct Lbfgs {
+  int np = 0;
+  std::vector<double> x, g, d, xt, gt;   // current point/gradient, direction, trial point/gradient
+  double f = 0., ft = 0., step = 1., slope = 0.;
+  std::vector<std::vector<double>> S, Y;
+  std::vector<double> rho;
+  int iter = 0, ls_iter = 0;
+  enum { NEED_F0, LINESEARCH, DONE, FAILED } state = NEED_F0;
+  double step_lo = 0., step_hi = 0.;      // bracketing for the curvature condition
+
+  void direction() {
+    d = g;
+    const int h = (int)S.size();
+    std::vector<double> al(h);
+    for (int i = h - 1; i >= 0; --i) {
+      double a = 0.;
+      for (int k = 0; k < np; ++k) a += S[i][k] * d[k];
+      a *= rho[i];
+      al[i] = a;
+      for (int k = 0; k < np; ++k) d[k] -= a * Y[i][k];
+    }
+    if (h > 0) {
+      double yy = 0., sy = 0.;
+      for (int k = 0; k < np; ++k) { yy += Y[h - 1][k] * Y[h - 1][k]; sy += S[h - 1][k] * Y[h - 1][k]; }
+      const double gam = sy / yy;
+      for (int k = 0; k < np; ++k) d[k] *= gam;
+    }
+    for (int i = 0; i < h; ++i) {
+      double b = 0.;
+      for (int k = 0; k < np; ++k) b += Y[i][k] * d[k];
+      b *= rho[i];
+      for (int k = 0; k < np; ++k) d[k] += S[i][k] * (al[i] - b);
+    }
+    for (int k = 0; k < np; ++k) d[k] = -d[k];
+    slope = 0.;
+    for (int k = 0; k < np; ++k) slope += g[k] * d[k];
+    if (!(slope < 0.)) {   // not a descent direction: restart from steepest descent
+      S.clear(); Y.clear(); rho.clear();
+      for (int k = 0; k < np; ++k) d[k] = -g[k];
+      slope = 0.;
+      for (int k = 0; k < np; ++k) slope -= g[k] * g[k];
+    }
+  }
+  void trial() {
+    for (int k = 0; k < np; ++k) xt[k] = x[k] + step * d[k];
+  }
+};
+}  // namespace
+
+void Engine::fit_map(const std::vector<int>& ids_in, int n_tries, const double* theta0, int theta0_len) {
+  const FitOptions& opt = fit_options();
+  std::vector<int> ids(ids_in);
+  if (ids.empty()) return;
+  if (n_tries < 1) throw std::runtime_error("number of attempts must be positive");
+  for (int i : ids)
+    if (theta0_len > 0 && theta0_len != n_theta(i)) throw std::runtime_error("length of theta0 must equal n_params of GP.");
+  const int ne = (int)ids.size();
+  std::vector<double> best_f(ne, std::numeric_limits<double>::infinity());
+  std::vector<std::vector<double>> best_x(ne);
+
+  for (int start = 0; start < n_tries; ++start) {
+    std::vector<Lbfgs> st(ne);
+    for (int e = 0; e < ne; ++e) {
+      Lbfgs& s = st[e];
+      s.np = n_theta(ids[e]);
+      s.x.resize(s.np); s.g.resize(s.np); s.d.resize(s.np); s.xt.resize(s.np); s.gt.resize(s.np);
+      if (start == 0 && theta0_len > 0) s.x.assign(theta0, theta0 + theta0_len);
+      else {
+        const int nm = n_mean();
+        for (int k = 0; k < nm; ++k) s.x[k] = 0.;
+        gp[ids[e]].pri.sample(rng, D, gp[ids[e]].nug_type, s.x.data() + nm);
+      }
+      s.xt = s.x;
+    }
+    for (int round = 0; round < opt.max_iter * 25; ++round) {
+      std::vector<int> act, actid;
+      std::vector<const double*> th;
+      for (int e = 0; e < ne; ++e)
+        if (st[e].state == Lbfgs::NEED_F0 || st[e].state == Lbfgs::LINESEARCH) {
+          act.push_back(e);
+          actid.push_back(ids[e]);
+          th.push_back(st[e].xt.data());
+        }
+      if (act.empty()) break;
+      int maxnp = 0;
+      for (int e : act) maxnp = std::max(maxnp, st[e].np);
+      std::vector<double> fv(act.size()), gv(act.size() * (size_t)maxnp);
+      std::vector<int> okv(act.size());
+      eval(actid, th, true, fv.data(), gv.data(), maxnp, okv.data());
+      for (size_t q = 0; q < act.size(); ++q) {
+        Lbfgs& s = st[act[q]];
+        const bool ok = okv[q] != 0;
+        const double* gq = gv.data() + q * maxnp;
+        bool gfinite = ok;
+        if (ok) for (int k = 0; k < s.np; ++k) gfinite = gfinite && std::isfinite(gq[k]);
+        if (s.state == Lbfgs::NEED_F0) {
+          if (!gfinite) { s.state = Lbfgs::FAILED; continue; }
+          s.f = fv[q];
+          s.g.assign(gq, gq + s.np);
+          s.direction();
+          double gn = 0.;
+          for (int k = 0; k < s.np; ++k) gn += s.g[k] * s.g[k];
+          gn = std::sqrt(gn);
+          if (gn <= opt.gtol) { s.state = Lbfgs::DONE; continue; }
+          s.step = std::min(1.0, 1.0 / gn);
+          s.step_lo = 0.; s.step_hi = 0.; s.ls_iter = 0;
+          s.trial();
+          s.state = Lbfgs::LINESEARCH;
+          continue;
+        }
+        // line search step: Armijo (1e-4) + weak curvature (0.9) by bisection/expansion
+        const double c1 = 1e-4, c2 = 0.9;
+        bool accept = false;
+        if (!gfinite || !(fv[q] <= s.f + c1 * s.step * s.slope)) {
+          s.step_hi = s.step;
+          s.step = 0.5 * (s.step_lo + s.step_hi);
+        } else {
+          double st_slope = 0.;
+          for (int k = 0; k < s.np; ++k) st_slope += gq[k] * s.d[k];
+          if (st_slope < c2 * s.slope && s.ls_iter < 10) {
+            s.step_lo = s.step;
+            s.step = (s.step_hi > 0.) ? 0.5 * (s.step_lo + s.step_hi) : 2.0 * s.step;
+          } else {
+            accept = true;
+          }
+        }
+        s.ls_iter++;
+        if (!accept) {
+          if (s.ls_iter > 40 || s.step < 1e-20) {
+            // could not make progress along d: take what we have
+            s.state = Lbfgs::DONE;
+            continue;
+          }
+          s.trial();
+          continue;
+        }
+        // accept xt
+        std::vector<double> sv(s.np), yv(s.np);
+        double sy = 0., yy = 0.;
+        for (int k = 0; k < s.np; ++k) {
+          sv[k] = s.xt[k] - s.x[k];
+          yv[k] = gq[k] - s.g[k];
+          sy += sv[k] * yv[k];
+          yy += yv[k] * yv[k];
+        }
+        const double fold = s.f;
+        s.x = s.xt;
+        s.f = fv[q];
+        s.g.assign(gq, gq + s.np);
+        if (sy > 1e-10 * yy && yy > 0.) {
+          s.S.push_back(sv); s.Y.push_back(yv); s.rho.push_back(1.0 / sy);
+          if (s.S.size() > 10) { s.S.erase(s.S.begin()); s.Y.erase(s.Y.begin()); s.rho.erase(s.rho.begin()); }
+        }
+        s.iter++;
+        double gmax = 0.;
+        for (int k = 0; k < s.np; ++k) gmax = std::max(gmax, std::fabs(s.g[k]));
+        if (std::fabs(fold - s.f) <= opt.ftol * std::max(1.0, std::fabs(s.f)) || gmax <= opt.gtol || s.iter >= opt.max_iter) {
+          s.state = Lbfgs::DONE;
+          continue;
+        }
+        s.direction();
+        s.step = 1.0; s.step_lo = 0.; s.step_hi = 0.; s.ls_iter = 0;
+        s.trial();
+      }
+    }
+    for (int e = 0; e < ne; ++e) {
+      const Lbfgs& s = st[e];
+      if (s.state == Lbfgs::FAILED || s.state == Lbfgs::NEED_F0) continue;
+      if (std::isfinite(s.f) && s.f < best_f[e]) {
+        best_f[e] = s.f;
+        best_x[e] = s.x;
+      }
+    }
+  }
+  // refit at the best point of every emulator (fitting.hpp:115-117); failures -> "not fit" (:111-113)
+  std::vector<int> fin;
+  std::vector<const double*> th;
+  for (int e = 0; e < ne; ++e) {
+    if (best_x[e].empty()) {
+      gp[ids[e]].has_data = false;
+      gp[ids[e]].factored = false;
+    } else {
+      fin.push_back(ids[e]);
+      th.push_back(best_x[e].data());
+    }
+  }
+  if (!fin.empty()) {
+    std::vector<double> fv(fin.size());
+    std::vector<int> okv(fin.size());
+    eval(fin, th, false, fv.data(), nullptr, 0, okv.data());
+  }
+}
+
+}  // namespace mogp

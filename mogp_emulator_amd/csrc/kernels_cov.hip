@@ -1,0 +1,436 @@
+// Distance + covariance kernels (HBM-bound): K build, cross-covariance with fused predictive
+// mean, input-derivative of the mean, and the fused log-posterior-gradient reduction.
+//
+// They replace the reference's thread-per-entry CUDA kernels and its materialised derivative
+// planes:  *_cov_batch_kernel (kernel.cu:55-65, 251-261), *_cov_deriv_x_batch_kernel
+// (kernel.cu:69-100, 264-302), *_cov_deriv_theta_batch_kernel + 3 gemv (kernel.cu:106-141,
+// 305-348; densegp_gpu.hpp:679-730); arithmetic follows the CPU oracle, Kernel.py:444-485,
+// 772-814, 861-906 (sigma^2 multiplies the kernel value outside the exponential,
+// GaussianProcess.py:542).
+//
+// Tiling: a 64x64 output tile per 256-thread workgroup; the two 64-row blocks of X are staged
+// once in LDS as [D][64] (coalesced global reads of contiguous row blocks, conflict-free LDS
+// reads because consecutive lanes touch consecutive rows); each thread owns a 4x4 micro tile so
+// every staged coordinate is reused 4 times from registers and K rows are written as 32-byte
+// pieces of full 512-byte row segments.  exp(theta_d) is precomputed once per emulator on the
+// host (parameter block P), not per pair as in the reference.
+#include "launch.h"
+
+namespace mogp {
+
+__device__ __forceinline__ int slot_emu2(const int* idx, int z) { return idx ? idx[z] : z; }
+
+template <int KT>
+__device__ __forceinline__ double kern_val(double r2) {
+  if (KT == 0) return exp(-0.5 * r2);
+  const double s = sqrt(5.0 * r2);
+  return (1.0 + s + (5.0 / 3.0) * r2) * exp(-s);
+}
+// dk/d(r2)
+template <int KT>
+__device__ __forceinline__ double kern_dr2(double r2) {
+  if (KT == 0) return -0.5 * exp(-0.5 * r2);
+  const double s = sqrt(5.0 * r2);
+  return -(5.0 / 6.0) * (1.0 + s) * exp(-s);
+}
+
+// stage rows [r0, r0+64) of Xg (nrows, D) into sx[d*64 + r]; rows >= nrows are zero filled
+__device__ __forceinline__ void stage_rows(const double* __restrict__ Xg, int nrows, int D, int r0, double* sx) {
+  const int cnt = 64 * D;
+  const int avail = max(0, min(64, nrows - r0)) * D;
+  const double* src = Xg + (size_t)r0 * D;
+  for (int e = threadIdx.x; e < cnt; e += 256) {
+    const int r = e / D, d = e - r * D;
+    sx[d * 64 + r] = (e < avail) ? src[e] : 0.0;
+  }
+}
+
+// r2 for the thread's 4x4 micro tile (rows 4*ty.., cols 4*tx..)
+__device__ __forceinline__ void micro_r2(const double* si, const double* sj, const double* __restrict__ P, int D, int ty, int tx,
+                                         double (&r2)[4][4]) {
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) r2[a][b] = 0.0;
+  for (int d = 0; d < D; ++d) {
+    const double e = P[d];
+    double xi[4], xj[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) xi[a] = si[d * 64 + 4 * ty + a];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) xj[b] = sj[d * 64 + 4 * tx + b];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const double df = xi[a] - xj[b];
+        r2[a][b] = __builtin_fma(e * df, df, r2[a][b]);
+      }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K build into the factor buffer A (lower tiles only, diagonal tiles in full), with the nugget
+// fused on the diagonal, the targets laid into row n and identity padding beyond.
+// ---------------------------------------------------------------------------------------------
+template <int KT>
+__global__ __launch_bounds__(256) void cov_build_kernel(BatchView v, int nt) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  const int z = blockIdx.y;
+  const int emu = slot_emu2(v.idx, z);
+  int tile = blockIdx.x;
+  int ti = (int)((sqrt(8.0 * tile + 1.0) - 1.0) * 0.5);
+  while (ti * (ti + 1) / 2 > tile) --ti;
+  while ((ti + 1) * (ti + 2) / 2 <= tile) ++ti;
+  const int tj = tile - ti * (ti + 1) / 2;
+  const int i0 = ti * 64, j0 = tj * 64;
+  const int n = v.n, D = v.D, ld = v.NP;
+  const double* P = v.P + (size_t)emu * v.PS;
+  double* A = v.A + (size_t)emu * ld * ld;
+  const double* T = v.T + (size_t)emu * n;
+  double* si = sm;
+  double* sj = sm + 64 * D;
+  stage_rows(v.X, n, D, i0, si);
+  stage_rows(v.X, n, D, j0, sj);
+  __syncthreads();
+  const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
+  double r2[4][4];
+  micro_r2(si, sj, P, D, ty, tx, r2);
+  const double sig2 = P[D], nug = P[D + 1];
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    const int i = i0 + 4 * ty + a;
+    double out[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int j = j0 + 4 * tx + b;
+      const int hi = max(i, j), lo = min(i, j);
+      double x;
+      if (hi < n) {
+        x = sig2 * kern_val<KT>(r2[a][b]);
+        if (i == j) x += nug;
+      } else if (hi == n) {
+        x = (lo < n) ? T[lo] : PAD_BIG;
+      } else {
+        x = (i == j) ? 1.0 : 0.0;
+      }
+      out[b] = x;
+    }
+    double* p = A + (size_t)i * ld + j0 + 4 * tx;
+    *reinterpret_cast<double2*>(p) = make_double2(out[0], out[1]);
+    *reinterpret_cast<double2*>(p + 2) = make_double2(out[2], out[3]);
+  }
+}
+
+// full (n,n) sigma^2 k(X,X) without nugget for get_K (GaussianProcessGPU.py:504-513)
+template <int KT>
+__global__ __launch_bounds__(256) void cov_full_kernel(BatchView v, int emu, double* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  const int i0 = blockIdx.y * 64, j0 = blockIdx.x * 64;
+  const int n = v.n, D = v.D;
+  const double* P = v.P + (size_t)emu * v.PS;
+  double* si = sm;
+  double* sj = sm + 64 * D;
+  stage_rows(v.X, n, D, i0, si);
+  stage_rows(v.X, n, D, j0, sj);
+  __syncthreads();
+  const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
+  double r2[4][4];
+  micro_r2(si, sj, P, D, ty, tx, r2);
+  const double sig2 = P[D];
+  for (int a = 0; a < 4; ++a)
+    for (int b = 0; b < 4; ++b) {
+      const int i = i0 + 4 * ty + a, j = j0 + 4 * tx + b;
+      if (i < n && j < n) out[(size_t)i * n + j] = sig2 * kern_val<KT>(r2[a][b]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Cross covariance Ks[z][m][j] = sigma^2 k(x*_m, x_j) (zero for j >= n, m >= mtot) with the
+// predictive mean fused: mean[z][m] = sum_j Ks[m][j] alpha_j.  One workgroup per 64 test points,
+// sweeping all training-point tiles, so the mean needs no atomics and is deterministic.
+// ---------------------------------------------------------------------------------------------
+template <int KT>
+__global__ __launch_bounds__(256) void cross_cov_mean_kernel(BatchView v, const double* __restrict__ Xs, int m, int MP,
+                                                           double* __restrict__ Ks, double* __restrict__ mean, int mean_ld) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  const int z = blockIdx.y;
+  const int emu = slot_emu2(v.idx, z);
+  const int n = v.n, D = v.D, ld = v.NP;
+  const int i0 = blockIdx.x * 64;
+  const double* P = v.P + (size_t)emu * v.PS;
+  const double* alpha = v.alpha + (size_t)emu * ld;
+  double* si = sm;
+  double* sj = sm + 64 * D;
+  double* sa = sm + 128 * D;          // alpha tile (64)
+  double* red = sa + 64;              // 64 x 17
+  stage_rows(Xs, m, D, i0, si);
+  const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
+  const double sig2 = P[D];
+  double macc[4] = {0., 0., 0., 0.};
+  double* Kz = Ks ? Ks + (size_t)z * MP * ld : nullptr;
+  const int ntj = ld / 64;
+  for (int tj = 0; tj < ntj; ++tj) {
+    const int j0 = tj * 64;
+    __syncthreads();
+    if (j0 < n) {
+      stage_rows(v.X, n, D, j0, sj);
+      if (threadIdx.x < 64) sa[threadIdx.x] = (j0 + threadIdx.x < n) ? alpha[j0 + threadIdx.x] : 0.0;
+    }
+    __syncthreads();
+    double r2[4][4];
+    if (j0 < n) micro_r2(si, sj, P, D, ty, tx, r2);
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const int i = i0 + 4 * ty + a;
+      double out[4];
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const int j = j0 + 4 * tx + b;
+        double x = 0.0;
+        if (j < n && i < m) x = sig2 * kern_val<KT>(r2[a][b]);
+        out[b] = x;
+        if (j0 < n) macc[a] = __builtin_fma(x, sa[4 * tx + b], macc[a]);
+      }
+      if (Kz) {
+        double* p = Kz + (size_t)i * ld + j0 + 4 * tx;
+        *reinterpret_cast<double2*>(p) = make_double2(out[0], out[1]);
+        *reinterpret_cast<double2*>(p + 2) = make_double2(out[2], out[3]);
+      }
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int a = 0; a < 4; ++a) red[(4 * ty + a) * 17 + tx] = macc[a];
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    double s = 0.;
+    for (int q = 0; q < 16; ++q) s += red[threadIdx.x * 17 + q];
+    const int i = i0 + threadIdx.x;
+    if (i < m) mean[(size_t)z * mean_ld + i] = s;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// d mean / d x*:  deriv[z][m][d] = sum_j sigma^2 dk/dr2(r2_mj) * 2 e_d (x*_md - x_jd) alpha_j
+// ---------------------------------------------------------------------------------------------
+template <int KT>
+__global__ __launch_bounds__(256) void predict_deriv_kernel(BatchView v, const double* __restrict__ Xs, int m,
+                                                          double* __restrict__ deriv, long deriv_stride) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  const int z = blockIdx.y;
+  const int emu = slot_emu2(v.idx, z);
+  const int n = v.n, D = v.D, ld = v.NP;
+  const int i0 = blockIdx.x * 64;
+  const double* P = v.P + (size_t)emu * v.PS;
+  const double* alpha = v.alpha + (size_t)emu * ld;
+  double* si = sm;                    // [D][64] test points
+  double* sj = sm + 64 * D;           // [D][64] training points
+  double* G = sm + 128 * D;           // [64][65]  G[m][j] = sig2 * dk/dr2 * 2 * alpha_j
+  double* dacc = G + 64 * 65;         // [64][D]
+  stage_rows(Xs, m, D, i0, si);
+  for (int e = threadIdx.x; e < 64 * D; e += 256) dacc[e] = 0.0;
+  const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
+  const double sig2 = P[D];
+  const int row = threadIdx.x >> 2, part = threadIdx.x & 3;     // phase 2 mapping
+  for (int j0 = 0; j0 < n; j0 += 64) {
+    __syncthreads();
+    stage_rows(v.X, n, D, j0, sj);
+    __syncthreads();
+    double r2[4][4];
+    micro_r2(si, sj, P, D, ty, tx, r2);
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const int j = j0 + 4 * tx + b;
+        G[(4 * ty + a) * 65 + 4 * tx + b] = (j < n) ? 2.0 * sig2 * kern_dr2<KT>(r2[a][b]) * alpha[j] : 0.0;
+      }
+    __syncthreads();
+    for (int d = 0; d < D; ++d) {
+      const double xm = si[d * 64 + row];
+      double s = 0.;
+#pragma unroll 4
+      for (int q = 0; q < 16; ++q) {
+        const int j = part * 16 + q;
+        s = __builtin_fma(G[row * 65 + j], xm - sj[d * 64 + j], s);
+      }
+      s += __shfl_xor(s, 1);
+      s += __shfl_xor(s, 2);
+      if (part == 0) dacc[row * D + d] += P[d] * s;
+    }
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < 64 * D; e += 256) {
+    const int r = e / D;
+    if (i0 + r < m) deriv[(size_t)z * deriv_stride + (size_t)(i0 + r) * D + (e - r * D)] = dacc[e];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Fused gradient reduction.  For every lower tile of W = Kinv - alpha alpha^T:
+//   s_p   = sum_ij w_ij W_ij sigma^2 dk/dr2(r2_ij) e_p (x_ip - x_jp)^2     p < D
+//   s_D   = sum_ij w_ij W_ij K_ij                                           (covariance scale)
+//   s_D+1 = sum_i Kinv_ii ,  s_D+2 = sum_i alpha_i^2                         (nugget)
+// with w_ij = 2 below the diagonal, 1 on it.  K and dK/dtheta are recomputed from LDS-staged X,
+// never materialised (the reference writes and re-reads (D+1) n x n planes).
+// partial[(z*ntiles + tile)*(D+3) + p]
+// ---------------------------------------------------------------------------------------------
+template <int KT>
+__global__ __launch_bounds__(256) void grad_kernel(BatchView v, int ntiles, double* __restrict__ partial) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  const int z = blockIdx.y;
+  const int emu = slot_emu2(v.idx, z);
+  int tile = blockIdx.x;
+  int ti = (int)((sqrt(8.0 * tile + 1.0) - 1.0) * 0.5);
+  while (ti * (ti + 1) / 2 > tile) --ti;
+  while ((ti + 1) * (ti + 2) / 2 <= tile) ++ti;
+  const int tj = tile - ti * (ti + 1) / 2;
+  const int i0 = ti * 64, j0 = tj * 64;
+  const int n = v.n, D = v.D, ld = v.NP;
+  const double* P = v.P + (size_t)emu * v.PS;
+  const double* Ki = v.Kinv + (size_t)emu * ld * ld;
+  const double* alpha = v.alpha + (size_t)emu * ld;
+  double* si = sm;
+  double* sj = sm + 64 * D;
+  double* wsum = sm + 128 * D;        // [4 waves][D+3]
+  stage_rows(v.X, n, D, i0, si);
+  stage_rows(v.X, n, D, j0, sj);
+  __syncthreads();
+  const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double r2[4][4];
+  micro_r2(si, sj, P, D, ty, tx, r2);
+  const double sig2 = P[D];
+  double G[4][4];                     // w * W * sigma^2 * dk/dr2
+  double scov = 0., strace = 0., saa = 0.;
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    const int i = i0 + 4 * ty + a;
+    const double ai = (i < n) ? alpha[i] : 0.0;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int j = j0 + 4 * tx + b;
+      double w = 0.0;
+      if (i < n && j < n) w = (j < i) ? 2.0 : ((j == i) ? 1.0 : 0.0);
+      double g = 0.0;
+      if (w != 0.0) {
+        const double kin = Ki[(size_t)i * ld + j];
+        const double W = kin - ai * alpha[j];
+        scov += w * W * sig2 * kern_val<KT>(r2[a][b]);
+        g = w * W * sig2 * kern_dr2<KT>(r2[a][b]);
+        if (i == j) {
+          strace += kin;
+          saa += ai * ai;
+        }
+      }
+      G[a][b] = g;
+    }
+  }
+  const int NQ = D + 3;
+  for (int p = 0; p < NQ; ++p) {
+    double s;
+    if (p < D) {
+      s = 0.;
+      double xi[4], xj[4];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) xi[a] = si[p * 64 + 4 * ty + a];
+#pragma unroll
+      for (int b = 0; b < 4; ++b) xj[b] = sj[p * 64 + 4 * tx + b];
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          const double df = xi[a] - xj[b];
+          s = __builtin_fma(G[a][b], df * df, s);
+        }
+      s *= P[p];
+    } else if (p == D) s = scov;
+    else if (p == D + 1) s = strace;
+    else s = saa;
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    if (lane == 0) wsum[wave * NQ + p] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < NQ) {
+    const int p = threadIdx.x;
+    partial[((size_t)z * ntiles + tile) * NQ + p] = wsum[p] + wsum[NQ + p] + wsum[2 * NQ + p] + wsum[3 * NQ + p];
+  }
+}
+
+// out[emu][p] = 0.5 * sum_tiles partial  (p <= D);  raw sums for p = D+1, D+2
+__global__ __launch_bounds__(256) void grad_finish_kernel(BatchView v, int ntiles, const double* __restrict__ partial, double* __restrict__ out) {
+  __shared__ double red[256];
+  const int z = blockIdx.y, p = blockIdx.x;
+  const int emu = slot_emu2(v.idx, z);
+  const int NQ = v.D + 3;
+  double s = 0.;
+  for (int t = threadIdx.x; t < ntiles; t += 256) s += partial[((size_t)z * ntiles + t) * NQ + p];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if (threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[(size_t)emu * NQ + p] = (p <= v.D) ? 0.5 * red[0] : red[0];
+}
+
+// =============================================================================================
+#define KT_DISPATCH(kt, CALL)            \
+  do {                                   \
+    if ((kt) == 0) { CALL(0); } else { CALL(1); } \
+  } while (0)
+
+void launch_cov_build(const BatchView& v, hipStream_t s) {
+  const int nt = v.NP / 64;
+  const int ntiles = nt * (nt + 1) / 2;
+  const size_t sm = (size_t)128 * v.D * sizeof(double);
+  prof_begin("cov_build", s);
+#define CALL(K) hipLaunchKernelGGL((cov_build_kernel<K>), dim3(ntiles, v.nb), dim3(256), sm, s, v, nt)
+  KT_DISPATCH(v.kernel_type, CALL);
+#undef CALL
+  // algorithmic bytes: lower triangle written once (4 n^2) + X read once per emulator
+  prof_end("cov_build", s, 0., (double)v.nb * (4.0 * v.NP * (double)v.NP + 8.0 * v.n * v.D));
+}
+
+void launch_cov_full(const BatchView& v, int emu, double* out, hipStream_t s) {
+  const int nt = (v.n + 63) / 64;
+  const size_t sm = (size_t)128 * v.D * sizeof(double);
+#define CALL(K) hipLaunchKernelGGL((cov_full_kernel<K>), dim3(nt, nt), dim3(256), sm, s, v, emu, out)
+  KT_DISPATCH(v.kernel_type, CALL);
+#undef CALL
+}
+
+void launch_cross_cov_mean(const BatchView& v, const double* Xs, int m, int MP, double* Ks, double* mean, int mean_ld, hipStream_t s) {
+  const size_t sm = (size_t)(128 * v.D + 64 + 64 * 17) * sizeof(double);
+  prof_begin("cross_cov", s);
+#define CALL(K) hipLaunchKernelGGL((cross_cov_mean_kernel<K>), dim3(MP / 64, v.nb), dim3(256), sm, s, v, Xs, m, MP, Ks, mean, mean_ld)
+  KT_DISPATCH(v.kernel_type, CALL);
+#undef CALL
+  prof_end("cross_cov", s, 0., (double)v.nb * (8.0 * MP * (double)v.NP + 8.0 * ((double)m + v.n) * v.D));
+}
+
+void launch_predict_deriv(const BatchView& v, const double* Xs, int m, double* deriv, long deriv_stride, hipStream_t s) {
+  const size_t sm = (size_t)(128 * v.D + 64 * 65 + 64 * v.D) * sizeof(double);
+#define CALL(K) hipLaunchKernelGGL((predict_deriv_kernel<K>), dim3((m + 63) / 64, v.nb), dim3(256), sm, s, v, Xs, m, deriv, deriv_stride)
+  KT_DISPATCH(v.kernel_type, CALL);
+#undef CALL
+}
+
+int grad_num_tiles(int n) {
+  const int nt = (n + 63) / 64;
+  return nt * (nt + 1) / 2;
+}
+
+void launch_grad(const BatchView& v, double* partial, double* out, hipStream_t s) {
+  const int ntiles = grad_num_tiles(v.n);
+  const size_t sm = (size_t)(128 * v.D + 4 * (v.D + 3)) * sizeof(double);
+  prof_begin("grad_reduce", s);
+#define CALL(K) hipLaunchKernelGGL((grad_kernel<K>), dim3(ntiles, v.nb), dim3(256), sm, s, v, ntiles, partial)
+  KT_DISPATCH(v.kernel_type, CALL);
+#undef CALL
+  prof_end("grad_reduce", s, 0., (double)v.nb * 4.0 * v.n * (double)v.n);
+  hipLaunchKernelGGL(grad_finish_kernel, dim3(v.D + 3, v.nb), dim3(256), 0, s, v, ntiles, partial, out);
+}
+
+}  // namespace mogp

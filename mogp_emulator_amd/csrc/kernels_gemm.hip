@@ -1,0 +1,367 @@
+// fp64 MFMA tile kernels for gfx950 (v_mfma_f64_16x16x4_f64).
+//
+// One device main loop, gemm_mainloop<WT, A_KMAJ, B_KMAJ>, computes for a workgroup tile
+//     acc(i, j) = sum_k opA(i, k) * opB(j, k)
+// where each operand is either "K-major" (stored [row][k], k contiguous) or "M-major"
+// (stored [k][row], row contiguous).  Both natural global layouts are kept unchanged in LDS:
+//   K-major LDS tile  [BM][16+2]   : fragment read (row = lane&15, k = lane>>4) hits 32 distinct
+//                                    8-byte bank pairs per 32-lane half (row stride 18 doubles)
+//   M-major LDS tile  [16][BM+16]  : same, because the k stride is == 16 (mod 32) doubles
+// so there is no transposing copy anywhere and every ds_read_b64 is conflict free.
+// Workgroup = 256 threads = 4 waves in a 2x2 grid; each wave owns WT x WT MFMA tiles of 16x16
+// (WT=4: 128x128 block tile, 128 accumulator VGPRs; WT=2: 64x64 block tile).
+// The K loop is double buffered in LDS with a register-staged global prefetch (one barrier per
+// 16-deep step; 64 MFMAs per wave per step at WT=4).
+//
+// fp64 C/D fragment map (verified on hardware by tools/mfma_probe.hip):
+//   row = (lane>>4) + 4*reg, col = lane&15;  A: A[lane&15][lane>>4];  B: B[lane>>4][lane&15].
+//
+// Reference operations these kernels replace (as a group): cusolverDnDpotrf's trailing updates
+// (densegp_gpu.hpp:451-474), the explicit inverse via potrs (densegp_gpu.hpp:576-582) and the
+// predictive-variance gemm + batched dot (densegp_gpu.hpp:374-396).
+#include "launch.h"
+
+namespace mogp {
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+typedef double v2d __attribute__((ext_vector_type(2)));
+
+constexpr int BK = 16;
+constexpr int LDK = BK + 2;
+
+template <int WT>
+struct Cfg {
+  static constexpr int BM = 32 * WT;            // block tile edge
+  static constexpr int WM = 16 * WT;            // wave tile edge
+  static constexpr int LDM = BM + 16;
+  static constexpr int CH = BM * 8 / 256;       // 16-byte chunks per thread per operand tile
+  static constexpr int OPSZ = (BM * LDK > BK * LDM) ? BM * LDK : BK * LDM;
+  static constexpr int SMEM_DOUBLES = 4 * OPSZ; // 2 buffers x (A, B)
+};
+
+template <int WT, bool KMAJ>
+__device__ __forceinline__ void g2r(const double* __restrict__ g, int ld, v2d (&r)[Cfg<WT>::CH]) {
+  const int t = threadIdx.x;
+#pragma unroll
+  for (int q = 0; q < Cfg<WT>::CH; ++q) {
+    const int c = t + 256 * q;
+    if (KMAJ) {
+      const int row = c >> 3, kc = (c & 7) * 2;
+      r[q] = *reinterpret_cast<const v2d*>(g + (size_t)row * ld + kc);
+    } else {
+      const int krow = c / (Cfg<WT>::BM / 2), mc = (c % (Cfg<WT>::BM / 2)) * 2;
+      r[q] = *reinterpret_cast<const v2d*>(g + (size_t)krow * ld + mc);
+    }
+  }
+}
+
+template <int WT, bool KMAJ>
+__device__ __forceinline__ void r2s(double* s, const v2d (&r)[Cfg<WT>::CH]) {
+  const int t = threadIdx.x;
+#pragma unroll
+  for (int q = 0; q < Cfg<WT>::CH; ++q) {
+    const int c = t + 256 * q;
+    if (KMAJ) {
+      const int row = c >> 3, kc = (c & 7) * 2;
+      *reinterpret_cast<v2d*>(s + row * LDK + kc) = r[q];
+    } else {
+      const int krow = c / (Cfg<WT>::BM / 2), mc = (c % (Cfg<WT>::BM / 2)) * 2;
+      *reinterpret_cast<v2d*>(s + krow * Cfg<WT>::LDM + mc) = r[q];
+    }
+  }
+}
+
+template <int WT, bool KMAJ>
+__device__ __forceinline__ double frag(const double* s, int row, int k) {
+  return KMAJ ? s[row * LDK + k] : s[k * Cfg<WT>::LDM + row];
+}
+
+// Ag: K-major -> &A[i0*lda + k0] ; M-major -> &A[k0*lda + i0].  nk = number of 16-deep steps.
+template <int WT, bool AK, bool BKM>
+__device__ __forceinline__ void gemm_mainloop(const double* __restrict__ Ag, int lda, const double* __restrict__ Bg,
+                                              int ldb, int nk, v4d (&acc)[WT][WT], double* smem) {
+  using C = Cfg<WT>;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int fr = lane & 15, fk = lane >> 4;
+#pragma unroll
+  for (int i = 0; i < WT; ++i)
+#pragma unroll
+    for (int j = 0; j < WT; ++j) acc[i][j] = (v4d){0., 0., 0., 0.};
+  if (nk <= 0) return;
+
+  const size_t stepA = AK ? (size_t)BK : (size_t)BK * lda;
+  const size_t stepB = BKM ? (size_t)BK : (size_t)BK * ldb;
+  v2d ra[C::CH], rb[C::CH];
+  g2r<WT, AK>(Ag, lda, ra);
+  g2r<WT, BKM>(Bg, ldb, rb);
+  r2s<WT, AK>(smem, ra);
+  r2s<WT, BKM>(smem + C::OPSZ, rb);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const double* sA = smem + (kt & 1) * 2 * C::OPSZ;
+    const double* sB = sA + C::OPSZ;
+    const bool more = (kt + 1 < nk);
+    if (more) {
+      Ag += stepA;
+      Bg += stepB;
+      g2r<WT, AK>(Ag, lda, ra);
+      g2r<WT, BKM>(Bg, ldb, rb);
+    }
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      double a[WT], b[WT];
+      const int k = kk * 4 + fk;
+#pragma unroll
+      for (int i = 0; i < WT; ++i) a[i] = frag<WT, AK>(sA, wr * C::WM + i * 16 + fr, k);
+#pragma unroll
+      for (int j = 0; j < WT; ++j) b[j] = frag<WT, BKM>(sB, wc * C::WM + j * 16 + fr, k);
+#pragma unroll
+      for (int i = 0; i < WT; ++i)
+#pragma unroll
+        for (int j = 0; j < WT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    if (more) {
+      double* dA = smem + ((kt + 1) & 1) * 2 * C::OPSZ;
+      r2s<WT, AK>(dA, ra);
+      r2s<WT, BKM>(dA + C::OPSZ, rb);
+    }
+    __syncthreads();
+  }
+}
+
+// iterate the accumulator fragment: f(row_in_tile, col_in_tile, value&)
+template <int WT, typename F>
+__device__ __forceinline__ void for_each_acc(v4d (&acc)[WT][WT], F f) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+#pragma unroll
+  for (int i = 0; i < WT; ++i)
+#pragma unroll
+    for (int j = 0; j < WT; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        f(wr * Cfg<WT>::WM + i * 16 + (lane >> 4) + 4 * r, wc * Cfg<WT>::WM + j * 16 + (lane & 15), acc[i][j][r]);
+}
+
+__device__ __forceinline__ int slot_to_emu(const int* idx, int z) { return idx ? idx[z] : z; }
+
+// Decode a 1-D grid into (batch slot z, tile id).  When the slot count is a multiple of 8 each
+// XCD (block id % 8) works through whole emulators one after another, so an emulator's panels
+// and trailing matrix stay inside one 4 MiB L2 instead of being spread over all eight.
+__device__ __forceinline__ void decode_block(int nb, int ntiles, int& z, int& tile) {
+  const int L = blockIdx.x;
+  if ((nb & 7) == 0) {
+    const int xcd = L & 7, w = L >> 3;
+    z = (w / ntiles) * 8 + xcd;
+    tile = w % ntiles;
+  } else {
+    z = L / ntiles;
+    tile = L % ntiles;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Trailing / narrow symmetric update on A:  C[i,j] -= sum_{k in [k0,k1)} A[i,k] A[j,k]
+//   TRI = true : lower-triangular tile set over rows/cols [c0, NP)  (WT = 4)
+//   TRI = false: single tile column [c0, c0+BM), rows [c0, NP)     (WT = 2, "narrow" update)
+// ---------------------------------------------------------------------------------------------
+template <int WT, bool TRI>
+__global__ __launch_bounds__(256, 2) void update_kernel(BatchView v, int c0, int k0, int k1, int nt, int ntiles) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  using C = Cfg<WT>;
+  int z, tile;
+  decode_block(v.nb, ntiles, z, tile);
+  if (z >= v.nb) return;
+  int ti, tj;
+  if (TRI) {
+    // tile = ti*(ti+1)/2 + tj, tj <= ti
+    ti = (int)((sqrt(8.0 * tile + 1.0) - 1.0) * 0.5);
+    while (ti * (ti + 1) / 2 > tile) --ti;
+    while ((ti + 1) * (ti + 2) / 2 <= tile) ++ti;
+    tj = tile - ti * (ti + 1) / 2;
+  } else {
+    ti = tile;
+    tj = 0;
+  }
+  const int emu = slot_to_emu(v.idx, z);
+  double* A = v.A + (size_t)emu * v.NP * v.NP;
+  const int ld = v.NP;
+  const int i0 = c0 + ti * C::BM, j0 = c0 + tj * C::BM;
+  v4d acc[WT][WT];
+  gemm_mainloop<WT, true, true>(A + (size_t)i0 * ld + k0, ld, A + (size_t)j0 * ld + k0, ld, (k1 - k0) / BK, acc, smem);
+  for_each_acc<WT>(acc, [&](int r, int c, double x) {
+    double* p = A + (size_t)(i0 + r) * ld + (j0 + c);
+    *p = *p - x;
+  });
+}
+
+// ---------------------------------------------------------------------------------------------
+// trtri merge, level h:  node q covers [base, base+2h), base = q*2h
+//   STEP 0:  T     = L21 * Linv11          (T kept in scratch at the position of block 21)
+//   STEP 1:  Linv21 = -Linv22 * T
+// ---------------------------------------------------------------------------------------------
+template <int WT, int STEP>
+__global__ __launch_bounds__(256, 2) void trtri_merge_kernel(BatchView v, int h, int tiles_per_dim) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  using C = Cfg<WT>;
+  const int z = blockIdx.z;
+  const int emu = slot_to_emu(v.idx, z);
+  const int ld = v.NP;
+  const int base = blockIdx.y * 2 * h;
+  if (base + h >= v.NP) return;
+  const int m2 = min(h, v.NP - base - h);
+  const int ti = blockIdx.x / tiles_per_dim, tj = blockIdx.x % tiles_per_dim;
+  const int i0 = ti * C::BM, j0 = tj * C::BM;          // node-local
+  if (i0 >= m2) return;
+  const double* L = v.A + (size_t)emu * ld * ld;
+  double* Li = v.Linv + (size_t)emu * ld * ld;
+  double* S = v.Kinv + (size_t)emu * ld * ld;
+  v4d acc[WT][WT];
+  if (STEP == 0) {
+    // T[i,j] = sum_{k >= j0} L21[i,k] Linv11[k,j]
+    const double* Ag = L + (size_t)(base + h + i0) * ld + base + j0;       // K-major, k from j0
+    const double* Bg = Li + (size_t)(base + j0) * ld + base + j0;          // M-major: [k][j], k from j0
+    gemm_mainloop<WT, true, false>(Ag, ld, Bg, ld, (h - j0) / BK, acc, smem);
+    for_each_acc<WT>(acc, [&](int r, int c, double x) { S[(size_t)(base + h + i0 + r) * ld + base + j0 + c] = x; });
+  } else {
+    // Linv21[i,j] = - sum_{k < i0+BM} Linv22[i,k] T[k,j]
+    const double* Ag = Li + (size_t)(base + h + i0) * ld + base + h;       // K-major, k from 0
+    const double* Bg = S + (size_t)(base + h) * ld + base + j0;            // M-major: T[k][j]
+    const int kend = min(i0 + C::BM, m2);
+    gemm_mainloop<WT, true, false>(Ag, ld, Bg, ld, kend / BK, acc, smem);
+    for_each_acc<WT>(acc, [&](int r, int c, double x) { Li[(size_t)(base + h + i0 + r) * ld + base + j0 + c] = -x; });
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Kinv = Linv^T Linv (lower tiles):  Kinv[i,j] = sum_{k >= i0} Linv[k,i] Linv[k,j]
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void kinv_kernel(BatchView v, int ntiles, int kend) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  using C = Cfg<4>;
+  int z, tile;
+  decode_block(v.nb, ntiles, z, tile);
+  if (z >= v.nb) return;
+  int ti = (int)((sqrt(8.0 * tile + 1.0) - 1.0) * 0.5);
+  while (ti * (ti + 1) / 2 > tile) --ti;
+  while ((ti + 1) * (ti + 2) / 2 <= tile) ++ti;
+  const int tj = tile - ti * (ti + 1) / 2;
+  const int emu = slot_to_emu(v.idx, z);
+  const int ld = v.NP;
+  const double* Li = v.Linv + (size_t)emu * ld * ld;
+  double* Ki = v.Kinv + (size_t)emu * ld * ld;
+  const int i0 = ti * C::BM, j0 = tj * C::BM;
+  v4d acc[4][4];
+  gemm_mainloop<4, false, false>(Li + (size_t)i0 * ld + i0, ld, Li + (size_t)i0 * ld + j0, ld, (kend - i0) / BK, acc, smem);
+  for_each_acc<4>(acc, [&](int r, int c, double x) { Ki[(size_t)(i0 + r) * ld + j0 + c] = x; });
+}
+
+// ---------------------------------------------------------------------------------------------
+// predictive variance partials: V = Linv * Ks^T (never stored);  partial[z][ti][m] = sum_{i in tile ti} V[i,m]^2
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void predict_var_kernel(BatchView v, const double* __restrict__ Ks, int MP, int nti, int ntj,
+                                                           double* __restrict__ partial) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  using C = Cfg<4>;
+  int z, tile;
+  decode_block(v.nb, nti * ntj, z, tile);
+  if (z >= v.nb) return;
+  // tj fastest: neighbouring blocks share the Linv row panel
+  const int ti = tile / ntj, tj = tile % ntj;
+  const int emu = slot_to_emu(v.idx, z);
+  const int ld = v.NP;
+  const double* Li = v.Linv + (size_t)emu * ld * ld;
+  const double* K = Ks + (size_t)z * MP * ld;
+  const int i0 = ti * C::BM, j0 = tj * C::BM;
+  v4d acc[4][4];
+  gemm_mainloop<4, true, true>(Li + (size_t)i0 * ld, ld, K + (size_t)j0 * ld, ld, (i0 + C::BM) / BK, acc, smem);
+  // column sums of squares over the tile's 128 rows
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  __syncthreads();
+  double* red = smem;  // [2 (wr)][128]
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    double s = 0.;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) s += acc[i][j][r] * acc[i][j][r];
+    s += __shfl_xor(s, 16);
+    s += __shfl_xor(s, 32);
+    if (lane < 16) red[wr * 128 + wc * 64 + j * 16 + lane] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < 128) partial[((size_t)z * nti + ti) * MP + j0 + threadIdx.x] = red[threadIdx.x] + red[128 + threadIdx.x];
+}
+
+__global__ void predict_var_finish_kernel(BatchView v, const double* __restrict__ partial, int m, int MP, int nti, double* var, int var_ld) {
+  const int z = blockIdx.y;
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= m) return;
+  const int emu = slot_to_emu(v.idx, z);
+  double s = 0.;
+  for (int t = 0; t < nti; ++t) s += partial[((size_t)z * nti + t) * MP + j];
+  var[(size_t)z * var_ld + j] = v.P[(size_t)emu * v.PS + v.D] - s;
+}
+
+// =============================================================================================
+// launchers
+// =============================================================================================
+template <int WT>
+static constexpr size_t smem_bytes() { return Cfg<WT>::SMEM_DOUBLES * sizeof(double); }
+
+static int padded_grid(int nb, int ntiles) { return ((nb & 7) == 0) ? nb * ntiles : nb * ntiles; }
+
+void launch_update_narrow(const BatchView& v, int c0, int k0, int k1, hipStream_t s) {
+  const int nt = (v.NP - c0) / 64;
+  if (nt <= 0) return;
+  hipLaunchKernelGGL((update_kernel<2, false>), dim3(padded_grid(v.nb, nt)), dim3(256), smem_bytes<2>(), s, v, c0, k0, k1, nt, nt);
+}
+
+void launch_update_trailing(const BatchView& v, int c0, int k0, int k1, hipStream_t s) {
+  const int nt = (v.NP - c0) / 128;
+  if (nt <= 0) return;
+  const int ntiles = nt * (nt + 1) / 2;
+  const double m = (double)(v.NP - c0);
+  prof_begin("syrk_trailing", s);
+  hipLaunchKernelGGL((update_kernel<4, true>), dim3(padded_grid(v.nb, ntiles)), dim3(256), smem_bytes<4>(), s, v, c0, k0, k1, nt, ntiles);
+  // algorithmic: lower half of an m x m rank-(k1-k0) update = m^2 (k1-k0) flops; bytes: read+write C lower half + panel
+  prof_end("syrk_trailing", s, (double)v.nb * m * m * (k1 - k0), (double)v.nb * (8.0 * m * m + 8.0 * m * (k1 - k0)));
+}
+
+void launch_trtri_merges(const BatchView& v, hipStream_t s) {
+  for (int h = 64; h < v.NP; h *= 2) {
+    const int nodes = (v.NP + 2 * h - 1) / (2 * h);
+    if (h == 64) {
+      hipLaunchKernelGGL((trtri_merge_kernel<2, 0>), dim3(1, nodes, v.nb), dim3(256), smem_bytes<2>(), s, v, h, 1);
+      hipLaunchKernelGGL((trtri_merge_kernel<2, 1>), dim3(1, nodes, v.nb), dim3(256), smem_bytes<2>(), s, v, h, 1);
+    } else {
+      const int tpd = h / 128;
+      prof_begin("trtri_merge", s);
+      hipLaunchKernelGGL((trtri_merge_kernel<4, 0>), dim3(tpd * tpd, nodes, v.nb), dim3(256), smem_bytes<4>(), s, v, h, tpd);
+      hipLaunchKernelGGL((trtri_merge_kernel<4, 1>), dim3(tpd * tpd, nodes, v.nb), dim3(256), smem_bytes<4>(), s, v, h, tpd);
+      prof_end("trtri_merge", s, (double)v.nb * nodes * 2.0 * h * h * h, 0.);
+    }
+  }
+}
+
+void launch_kinv(const BatchView& v, hipStream_t s) {
+  const int nt = (v.n + 127) / 128;      // tiles that contain real rows
+  const int ntiles = nt * (nt + 1) / 2;
+  const int kend = ((v.n + 15) / 16) * 16;
+  prof_begin("kinv", s);
+  hipLaunchKernelGGL(kinv_kernel, dim3(padded_grid(v.nb, ntiles)), dim3(256), smem_bytes<4>(), s, v, ntiles, kend);
+  prof_end("kinv", s, (double)v.nb * (double)v.n * v.n * v.n / 3.0, 0.);
+}
+
+void launch_predict_var(const BatchView& v, const double* Ks, int m, int MP, double* partial, double* var, int var_ld, hipStream_t s) {
+  const int nti = (v.n + 127) / 128, ntj = MP / 128;
+  prof_begin("predict_var", s);
+  hipLaunchKernelGGL(predict_var_kernel, dim3(padded_grid(v.nb, nti * ntj)), dim3(256), smem_bytes<4>(), s, v, Ks, MP, nti, ntj, partial);
+  prof_end("predict_var", s, (double)v.nb * (double)m * v.n * v.n, 0.);
+  hipLaunchKernelGGL(predict_var_finish_kernel, dim3((m + 255) / 256, v.nb), dim3(256), 0, s, v, partial, m, MP, nti, var, var_ld);
+}
+
+}  // namespace mogp

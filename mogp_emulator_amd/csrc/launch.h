@@ -1,0 +1,84 @@
+// Host-side launchers for the gfx950 kernels.  All launches are asynchronous on `stream`.
+//
+// Data layout in HBM:
+//   X      (n, D) row-major, shared by every emulator of an engine
+//   P      per emulator parameter block of PS doubles: [e_0..e_{D-1} = exp(theta_d), sigma^2, nugget]
+//   T      per emulator residual targets (n)
+//   A      per emulator NP x NP row-major "factor" matrix, NP = roundup(n+1, 128).
+//          rows/cols < n : K + nugget I -> overwritten in place by L (lower triangle)
+//          row n         : the targets t -> overwritten by y^T = (L^-1 t)^T   (free forward solve)
+//          rows > n      : identity padding
+//   Linv   per emulator NP x NP row-major, lower triangular L^-1
+//   Kinv   per emulator NP x NP row-major, K^-1 (lower tiles valid); doubles as scratch for trtri
+//   batch slot z -> emulator index: idx ? idx[z] : z
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+namespace mogp {
+
+constexpr int TILE = 128;       // outer Cholesky block / MFMA macro tile
+constexpr int NBI = 64;         // inner panel width (potf2 / trsm / trtri leaf)
+constexpr double PAD_BIG = 1e300;
+
+struct BatchView {
+  int n, D, NP, PS;             // PS = parameter block stride (doubles)
+  int kernel_type;
+  const double* X;              // n*D
+  const double* P;              // B*PS
+  const double* T;              // B*n
+  double* A;                    // B*NP*NP
+  double* Linv;                 // B*NP*NP (may be null)
+  double* Kinv;                 // B*NP*NP (may be null)
+  double* alpha;                // B*NP
+  const int* idx;               // device: nb entries or null
+  int nb;                       // number of batch slots in this launch
+};
+
+// --- covariance build ---------------------------------------------------------------------
+void launch_cov_build(const BatchView& v, hipStream_t s);
+// full symmetric K (no nugget) for get_K: out (n,n) for one emulator
+void launch_cov_full(const BatchView& v, int emu, double* out, hipStream_t s);
+
+// --- blocked Cholesky ---------------------------------------------------------------------
+// potf2 of the 64x64 diagonal block at c0; info[emu] = first failing (1-based) column or 0
+void launch_potf2(const BatchView& v, int c0, int* info, hipStream_t s);
+// rows [r0, NP) of column block [c0, c0+64): X L_kk^T = A
+void launch_trsm(const BatchView& v, int c0, int r0, hipStream_t s);
+// C[i,j] -= sum_{k in [k0,k1)} A[i,k] A[j,k] for the 64-wide column block [c0,c0+64), rows [c0, NP)
+void launch_update_narrow(const BatchView& v, int c0, int k0, int k1, hipStream_t s);
+// trailing lower-triangular update, rows/cols [c0, NP), k in [k0,k1) (c0 multiple of 128)
+void launch_update_trailing(const BatchView& v, int c0, int k0, int k1, hipStream_t s);
+// logdet[emu] = 2 sum_{i<n} log L_ii ; yty[emu] = sum_{c<n} L[n,c]^2
+void launch_logdet(const BatchView& v, double* logdet, double* yty, hipStream_t s);
+// alpha = L^-T y (y = row n of A)
+void launch_backsolve(const BatchView& v, hipStream_t s);
+
+// --- L^-1, K^-1 ----------------------------------------------------------------------------
+void launch_trtri(const BatchView& v, hipStream_t s);        // A(L) -> Linv   (uses Kinv as scratch)
+void launch_kinv(const BatchView& v, hipStream_t s);         // Linv -> Kinv (lower tiles)
+void launch_alpha_from_linv(const BatchView& v, hipStream_t s);   // alpha = Linv^T y
+
+// --- gradient ------------------------------------------------------------------------------
+// partial: nb * ntiles * (D+3) doubles scratch; out: per emulator (D+3): [g_0..g_{D-1}, g_cov, tr(Kinv), alpha.alpha]
+int grad_num_tiles(int n);
+void launch_grad(const BatchView& v, double* partial, double* out, hipStream_t s);
+
+// --- predict -------------------------------------------------------------------------------
+// Ks: nb * MP * NP (MP = roundup(m,128)) cross-covariance sigma^2 k(x*_m, x_j); mean (nb, m) written;
+// if Ks == null only the mean is computed.
+void launch_cross_cov_mean(const BatchView& v, const double* Xs, int m, int MP, double* Ks, double* mean, int mean_ld, hipStream_t s);
+// var[z][m] = sigma^2 - sum_i (Linv Ks^T)[i][m]^2 ; partial: nb * (NP/128) * MP scratch
+void launch_predict_var(const BatchView& v, const double* Ks, int m, int MP, double* partial, double* var, int var_ld, hipStream_t s);
+// deriv[z][m][d]
+void launch_predict_deriv(const BatchView& v, const double* Xs, int m, double* deriv, long deriv_stride, hipStream_t s);
+
+// --- utilities -------------------------------------------------------------------------------
+// out (n,n) <- tile of src (NP,NP): mode 0 copy, mode 1 transpose, mode 2 symmetrise from lower
+void launch_extract(const double* src, int NP, int n, double* out, int mode, hipStream_t s);
+
+// --- profiling hooks (bench only) -------------------------------------------------------------
+void prof_begin(const char* tag, hipStream_t s);
+void prof_end(const char* tag, hipStream_t s, double flops, double bytes);
+
+}  // namespace mogp
