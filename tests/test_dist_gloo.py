@@ -1,0 +1,78 @@
+"""World-size-2 gloo test (CPU) of the emulator sharding + single gather used for N > 1 GPUs.
+The per-rank model is a stand-in defined HERE (tests only): the product's per-rank model is
+MultiOutputGP_GPU and needs a GPU; what is being tested is the partition / gather logic."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from mogp_emulator_amd.dist import ShardedMultiOutputGP, gather_rows, shard_bounds, shard_sizes
+
+
+class _LocalStub(object):
+    """Deterministic stand-in: 'prediction' of emulator k at x is (sum(targets_k) + sum(x), sum(x)^2)."""
+    def __init__(self, inputs, targets, **kw):
+        self.t = np.asarray(targets)
+        self.fitted = None
+
+    def fit(self, thetas):
+        self.fitted = np.asarray(thetas)
+
+    def predict(self, testing, deriv=False, **kw):
+        s = np.asarray(testing).sum(axis=1)
+        mean = self.t.sum(axis=1)[:, None] + s[None, :]
+        if self.fitted is not None:
+            mean = mean + self.fitted.sum(axis=1)[:, None]
+        return mean, np.tile(s ** 2, (self.t.shape[0], 1)), None
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, n_out, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rng = np.random.default_rng(0)
+    X = rng.normal(size=(6, 2)); T = rng.normal(size=(n_out, 6)); Xs = rng.normal(size=(5, 2))
+    thetas = rng.normal(size=(n_out, 3))
+    gp = ShardedMultiOutputGP(X, T, factory=_LocalStub)
+    gp.fit(thetas)
+    mean, unc = gp.predict(Xs)
+    ref = _LocalStub(X, T); ref.fit(thetas)
+    rm, ru, _ = ref.predict(Xs)
+    ok = np.allclose(mean, rm) and np.allclose(unc, ru) and mean.shape == (n_out, 5)
+    lo, hi = shard_bounds(n_out, world, rank)
+    g = gather_rows(np.arange(lo, hi, dtype=np.float64).reshape(-1, 1), n_out).numpy().ravel()
+    ok = ok and np.array_equal(g, np.arange(n_out))
+    q.put((rank, bool(ok), (gp.lo, gp.hi)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_out", [8, 5, 1])
+def test_sharded_predict_gather_world2(n_out):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_out, q)) for r in range(2)]
+    for p in procs: p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs: p.join(timeout=60)
+    assert all(r[1] for r in res), res
+    bounds = dict((r[0], r[2]) for r in res)
+    assert bounds[0][0] == 0 and bounds[0][1] == bounds[1][0] and bounds[1][1] == n_out
+
+
+def test_shard_bounds_cover_everything():
+    for n in (1, 7, 16, 64, 65):
+        for w in (1, 2, 4, 8):
+            b = [shard_bounds(n, w, r) for r in range(w)]
+            assert b[0][0] == 0 and b[-1][1] == n
+            assert all(b[i][1] == b[i + 1][0] for i in range(w - 1))
+            assert sum(shard_sizes(n, w)) == n
+    assert shard_sizes(64, 8) == [8] * 8          # C3: 8 emulators per GPU

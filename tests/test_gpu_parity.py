@@ -1,0 +1,450 @@
+"""GPU parity tests (run with -m gpu on an MI355X).  Every call goes through the C ABI
+(libmogp_hip.so) via the host-side mirror of the reference interface and is compared with
+  * the golden vectors produced by the real reference (tests/golden/*.npz),
+  * the oracle (oracle/cpu_ref.py) on the same seeded inputs,
+  * size-independent identities at the BASELINE sizes.
+Stated fp64 tolerances: K rtol 1e-13; L, alpha rtol 1e-8 on well-conditioned
+fixtures; logpost rtol 1e-10 (1e-9 where cond(K) > 1e8); gradient rtol 1e-7 / atol 1e-8;
+predictive mean rtol 1e-7; variance atol 1e-7 * sigma^2 (the reference's own GPU-vs-CPU bar,
+tests/test_GaussianProcess.py:1017-1018, 1113-1118)."""
+import pickle
+
+import numpy as np
+import pytest
+from numpy.testing import assert_allclose
+
+import mogp_emulator_amd as M
+from mogp_emulator_amd import LibGPGPU
+from mogp_emulator_amd.Priors import GPPriors, InvGammaPrior
+from oracle import cpu_ref as R
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+KERNELS = ["SquaredExponential", "Matern52"]
+MODES = {"fixed": 1.e-6, "fit": "fit", "adaptive": "adaptive"}
+
+
+def weak(D, nugget):
+    return GPPriors(n_corr=D, nugget_type=nugget if isinstance(nugget, str) else "fixed")
+
+
+def make_gp(X, t, kern="SquaredExponential", nugget=1e-6, priors="weak", **kw):
+    X = np.asarray(X)
+    D = 1 if X.ndim == 1 else X.shape[1]
+    pri = weak(D, nugget) if priors == "weak" else priors
+    return M.GaussianProcessGPU(X, t, kernel=kern, nugget=nugget, priors=pri, **kw)
+
+
+def synth(seed, n, d, n_out, m):
+    rng = np.random.default_rng(seed)
+    X = rng.uniform(0, 1, (n, d))
+    T = np.empty((n_out, n))
+    for k in range(n_out):
+        w = rng.normal(size=d)
+        T[k] = np.sin(2 * np.pi * X @ w / np.sqrt(d)) + 0.1 * (X ** 2) @ np.abs(w) + 0.01 * rng.normal(size=n)
+    return X, T, rng.uniform(0, 1, (m, d))
+
+
+def test_device_is_gfx950_and_library_is_native():
+    assert LibGPGPU.gpu_usable()
+    assert LibGPGPU.have_compatible_device()
+
+
+# ------------------------------------------------------------------------------------------------
+# golden vectors of the reference
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("kern", KERNELS)
+def test_fixture_2x3_known_answers(kern):
+    g = load_golden("fixture_2x3.npz")
+    for name, theta in (("ones", np.ones(4)), ("zeros", np.zeros(4))):
+        pre = "%s_%s_" % (kern, name)
+        gp = make_gp(g["X"], g["t"], kern, 0.)
+        gp.fit(theta)
+        assert_allclose(gp.current_logpost, g[pre + "logpost"], rtol=1e-13)
+        assert_allclose(gp.L, g[pre + "L"], rtol=1e-12, atol=1e-15)
+        assert_allclose(gp.Kinv_t, g[pre + "alpha"], rtol=1e-12)
+        assert_allclose(gp.logpost_deriv(theta), g[pre + "grad"], rtol=1e-9, atol=1e-13)
+        assert_allclose(gp.get_K_matrix(), g[pre + "K"], rtol=1e-14)
+        mean, unc, deriv = gp.predict(g["Xs"])
+        assert_allclose(mean, g[pre + "mean"], rtol=1e-12)
+        assert_allclose(unc, g[pre + "var"], rtol=1e-12)
+    # literals held by the reference's own tests
+    if kern == "SquaredExponential":
+        gp = make_gp(g["X"], g["t"], kern, 0.)
+        assert_allclose(gp.logposterior(np.ones(4)), 6.516671478123768, rtol=1e-13)
+        assert_allclose(gp.predict(np.array([2., 3., 4.]))[0], [0.03390252374096476], rtol=1e-12)
+
+
+@pytest.mark.parametrize("kern", KERNELS)
+@pytest.mark.parametrize("mode", list(MODES))
+def test_grid11_all_nugget_modes(kern, mode):
+    g = load_golden("grid11.npz")
+    pre = "%s_%s_" % (kern, mode)
+    theta = g[pre + "theta"]
+    gp = make_gp(g["X"], g["t"], kern, MODES[mode])
+    gp.fit(theta)
+    assert_allclose(gp.nugget, g[pre + "nugget"], rtol=1e-13, atol=0)      # incl. adaptive jitter 1.3533528323661265e-07
+    assert_allclose(gp.current_logpost, g[pre + "logpost"], rtol=1e-9)
+    assert_allclose(gp.logpost_deriv(theta), g[pre + "grad"], rtol=1e-7, atol=1e-8)
+    mean, unc, _ = gp.predict(g["Xs"])
+    sig2 = np.exp(theta[2])
+    assert_allclose(mean, g[pre + "mean"], rtol=1e-7, atol=1e-10)
+    assert_allclose(unc, g[pre + "var"], atol=1e-7 * sig2)
+    assert_allclose(gp.predict(g["Xs"], include_nugget=False)[1], g[pre + "var_nonug"], atol=1e-7 * sig2)
+
+
+@pytest.mark.parametrize("tag", ["c1_n200_d4", "n500_d10"])
+@pytest.mark.parametrize("kern", KERNELS)
+@pytest.mark.parametrize("mode", ["fixed", "fit"])
+def test_medium_configs_vs_reference(tag, kern, mode):
+    g = load_golden(tag + ".npz")
+    pre = "%s_%s_" % (kern, mode)
+    theta = g[pre + "theta"]
+    gp = make_gp(g["X"], g["T"][0], kern, MODES[mode])
+    gp.fit(theta)
+    K = gp.get_K_matrix()
+    assert_allclose(K.sum(), g[pre + "K_sum"], rtol=1e-13)
+    assert_allclose(K[::37, ::41], g[pre + "K_rows"], rtol=1e-13)
+    assert_allclose(np.diag(gp.L), g[pre + "L_diag"], rtol=1e-8)
+    assert_allclose(gp.L[::37, ::41], g[pre + "L_rows"], rtol=1e-7, atol=1e-10)
+    assert_allclose(gp.Kinv_t, g[pre + "alpha"], rtol=1e-6, atol=1e-6 * np.abs(g[pre + "alpha"]).max())
+    assert_allclose(gp.current_logpost, g[pre + "logpost"], rtol=1e-9)
+    assert_allclose(gp.logpost_deriv(theta), g[pre + "grad"], rtol=1e-7, atol=1e-7)
+    mean, unc, _ = gp.predict(g["Xs"])
+    assert_allclose(mean, g[pre + "mean"], rtol=1e-7, atol=1e-8)
+    assert_allclose(unc, g[pre + "var"], atol=1e-7)
+
+
+@pytest.mark.parametrize("tag", ["c1_n200_d4", "n500_d10"])
+def test_default_priors_enter_posterior(tag):
+    g = load_golden(tag + ".npz")
+    gp = M.GaussianProcessGPU(g["X"], g["T"][1], nugget="fit")          # default priors computed on the host
+    theta = g["defprior_theta"]
+    assert_allclose(gp.logposterior(theta), g["defprior_logpost"], rtol=1e-8)
+    assert_allclose(gp.logpost_deriv(theta), g["defprior_grad"], rtol=1e-7, atol=1e-7)
+    pri = gp.priors
+    assert np.isfinite(pri.get_logp(theta))
+    assert len(pri.sample()) == gp.n_params
+
+
+def test_variance_stability_regression():
+    g = load_golden("var_stability.npz")
+    gp = make_gp(g["x"], g["y"], nugget=1.e-8)
+    gp.fit(g["theta"])
+    mean, unc, _ = gp.predict(g["xt"])
+    assert_allclose(unc, 0., atol=1e-3)            # tests/test_GaussianProcess.py:1144-1161
+    assert np.all(unc >= 0.)
+    assert_allclose(mean, g["mean"], rtol=1e-4, atol=1e-3)
+
+
+def test_multioutput_vs_reference():
+    g = load_golden("mogp4.npz")
+    D = g["X"].shape[1]
+    gp = M.MultiOutputGP_GPU(g["X"], g["T"], nugget=1e-6, priors=weak(D, 1e-6))
+    assert gp.n_emulators == 4 and gp.get_indices_fit() == [] and gp.get_indices_not_fit() == [0, 1, 2, 3]
+    with pytest.raises(ValueError):
+        gp.predict(g["Xs"])
+    gp.fit(g["thetas"])
+    assert gp.get_indices_fit() == [0, 1, 2, 3]
+    mean, unc, deriv = gp.predict(g["Xs"])
+    assert mean.shape == (4, 40) and deriv.shape == (4, 40, 3)
+    assert_allclose(mean, g["mean"], rtol=1e-7, atol=1e-9)
+    assert_allclose(unc, g["var"], atol=1e-7)
+    f, grad, ok = gp._mogp_gpu.eval(g["thetas"], grad=True)
+    assert ok.all()
+    assert_allclose(f, g["logpost"], rtol=1e-9)
+    assert_allclose(grad, g["grad"], rtol=1e-7, atol=1e-8)
+    # allow_not_fit: NaN rows (MultiOutputGP_GPU.py:292-296)
+    gp.reset_fit_status()
+    gp.fit_emulator(2, g["thetas"][2])
+    mean, unc, deriv = gp.predict(g["Xs"], allow_not_fit=True)
+    assert np.isnan(mean[0]).all() and np.isnan(unc[3]).all() and np.isnan(deriv[1]).all()
+    assert_allclose(mean[2], g["mean"][2], rtol=1e-7, atol=1e-9)
+    # the same emulator reached through emulator(i)
+    em = gp.emulators[2]
+    assert_allclose(em.predict(g["Xs"])[0], g["mean"][2], rtol=1e-7, atol=1e-9)
+
+
+# ------------------------------------------------------------------------------------------------
+# oracle on seeded inputs
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("kern", KERNELS)
+def test_predict_deriv_vs_fd_and_oracle(kern):
+    X, T, Xs = synth(11, 150, 3, 1, 20)
+    theta = np.array([1.0, 0.5, 1.5, 0.3])
+    gp = make_gp(X, T[0], kern, 1e-5)
+    gp.fit(theta)
+    mean, unc, deriv = gp.predict(Xs)
+    ref = R.GPRef(X, T[0], kernel=kern, nugget=1e-5)
+    ref.fit(theta)
+    _, _, rd = ref.predict(Xs, deriv=True)
+    assert_allclose(deriv, rd, rtol=1e-7, atol=1e-8)
+    h = 1e-6                                         # reference style FD check, tests/test_GaussianProcess.py:1010-1015
+    for d in range(3):
+        e = np.zeros(3); e[d] = h
+        fd = (gp.predict(Xs + e, unc=False, deriv=False)[0] - gp.predict(Xs - e, unc=False, deriv=False)[0]) / (2 * h)
+        assert_allclose(deriv[:, d], fd, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("kern", KERNELS)
+def test_gradient_vs_finite_differences(kern):
+    g = load_golden("grid11.npz")
+    gp = make_gp(g["X"], g["t"], kern, "fit")
+    th = np.array([-1., -1., -2., np.log(1e-6)])
+    an = gp.logpost_deriv(th)
+    h = 1e-6
+    for p in range(4):
+        e = np.zeros(4); e[p] = h
+        fd = (gp.logposterior(th + e) - gp.logposterior(th - e)) / (2 * h)
+        assert_allclose(an[p], fd, rtol=1e-4, atol=1e-4)      # the reference's bar, tests/test_GaussianProcess.py:626-661
+
+
+def test_matern_nugget_fit_d20_vs_oracle():
+    # C4-shaped (Matern-5/2, fitted nugget, d=20), at a size the oracle finishes in seconds
+    X, T, Xs = synth(4, 700, 20, 1, 100)
+    theta = np.array([-2. * np.log(0.3 * np.sqrt(20))] * 20 + [0.2, np.log(1e-4)])
+    gp = make_gp(X, T[0], "Matern52", "fit")
+    ref = R.GPRef(X, T[0], kernel=R.MAT52, nugget="fit")
+    assert_allclose(gp.logposterior(theta), ref.fit(theta), rtol=1e-10)
+    assert_allclose(gp.logpost_deriv(theta), ref.logpost_deriv(theta), rtol=1e-7, atol=1e-8)
+    mean, unc, _ = gp.predict(Xs, deriv=False)
+    mu, var, _ = ref.predict(Xs)
+    assert_allclose(mean, mu, rtol=1e-7, atol=1e-9)
+    assert_allclose(unc, var, atol=1e-7 * np.exp(0.2))
+
+
+def test_adaptive_jitter_ladder_on_duplicated_inputs():
+    # exactly singular K (duplicated rows): both sides must walk the same ladder (linalg/cholesky.py:268-279)
+    rng = np.random.default_rng(3)
+    X = rng.uniform(0, 1, (40, 2)); X = np.vstack([X, X[:5]])
+    t = np.sin(X.sum(axis=1))
+    theta = np.array([0.5, 0.5, 1.0])
+    gp = make_gp(X, t, nugget="adaptive")
+    gp.fit(theta)
+    ref = R.GPRef(X, t, nugget="adaptive")
+    ref.fit(theta)
+    assert gp.nugget > 0.
+    assert_allclose(gp.nugget, ref.nugget, rtol=1e-13)
+    assert_allclose(gp.current_logpost, ref.current_logpost, rtol=1e-6)
+    # fixed zero nugget on the same matrix cannot be factorised -> RuntimeError (densegp_gpu.hpp:568-570)
+    bad = make_gp(X, t, nugget=0.)
+    with pytest.raises(RuntimeError, match="Unable to factorize"):
+        bad.fit(theta)
+    assert not bad.theta.data_has_been_set()
+
+
+def test_error_behaviour_matches_reference():
+    X, T, Xs = synth(5, 30, 2, 1, 4)
+    gp = make_gp(X, T[0], nugget="fit")
+    assert gp.n_params == 4 and gp.n == 30 and gp.D == 2 and gp.n_corr == 2 and gp.nugget_type == "fit"
+    assert gp.Kinv_t is None and gp.current_logpost is None
+    with pytest.raises(ValueError):
+        gp.predict(Xs)                                   # GaussianProcessGPU.py:589-590
+    with pytest.raises(RuntimeError):
+        gp.fit(np.ones(3))                               # bad theta length, tests/test_GaussianProcess.py:346-347
+    with pytest.raises(AssertionError):
+        gp.logpost_deriv(np.ones(7))
+    with pytest.raises(RuntimeError):
+        gp.fit(np.array([800., 800., 800., 0.]))         # exp overflow -> factorisation fails
+    gp.fit(np.zeros(4))
+    with pytest.raises(AssertionError):
+        gp.predict(np.zeros((3, 5)))
+    small = make_gp(X, T[0], nugget=1e-6, max_batch_size=8)
+    small.fit(np.zeros(3))
+    out = np.zeros(20)
+    with pytest.raises(RuntimeError, match="More test points"):      # densegp_gpu.hpp:312-315
+        small._densegp_gpu.predict_batch(np.zeros((20, 2)), out)
+    with pytest.raises(RuntimeError, match="too small"):             # densegp_gpu.hpp:307-310
+        small._densegp_gpu.predict_batch(np.zeros((4, 2)), np.zeros(2))
+    gp.theta = None
+    assert not gp.theta.data_has_been_set()
+    with pytest.raises(ValueError):
+        M.GaussianProcessGPU(X, T[0], kernel="UniformSqExp")
+    with pytest.raises(ValueError):
+        M.GaussianProcessGPU(X, T[0], nugget="pivot")
+
+
+def test_predict_chunking_ragged_and_single_point():
+    X, T, Xs = synth(6, 120, 4, 1, 301)
+    theta = np.array([0.5] * 4 + [0.1])
+    gp = make_gp(X, T[0], nugget=1e-6, max_batch_size=64)     # 301 points -> 5 chunks, last ragged
+    gp.fit(theta)
+    ref = R.GPRef(X, T[0], nugget=1e-6); ref.fit(theta)
+    mu, var, rd = ref.predict(Xs, deriv=True)
+    mean, unc, deriv = gp.predict(Xs)
+    assert_allclose(mean, mu, rtol=1e-8, atol=1e-10); assert_allclose(unc, var, atol=1e-8); assert_allclose(deriv, rd, rtol=1e-7, atol=1e-8)
+    one = gp.predict(Xs[7])
+    assert one.mean.shape == (1,) and one.deriv.shape == (1, 4)
+    assert_allclose(one.mean, mu[7:8], rtol=1e-8)
+    assert_allclose(gp(Xs[:3]), mu[:3], rtol=1e-8)
+    assert gp.predict(Xs[:2], unc=False, deriv=False).unc is None
+    # native single-point entry points (bindings.cu:71-95)
+    v = np.zeros(1)
+    assert_allclose(gp._densegp_gpu.predict(Xs[3]), mu[3], rtol=1e-8)
+    assert_allclose(gp._densegp_gpu.predict_variance(Xs[3], v), mu[3], rtol=1e-8)
+    assert_allclose(v[0] + 1e-6, var[3], atol=1e-8)
+    # 1-D inputs
+    g1 = make_gp(X[:, 0], T[0], nugget=1e-4); g1.fit(np.array([1., 0.]))
+    r1 = R.GPRef(X[:, 0], T[0], nugget=1e-4); r1.fit(np.array([1., 0.]))
+    assert_allclose(g1.predict(np.linspace(0, 1, 7))[0], r1.predict(np.linspace(0, 1, 7))[0], rtol=1e-8, atol=1e-10)
+
+
+def test_getters_invq_cholesky_layout():
+    X, T, _ = synth(7, 90, 3, 1, 1)
+    theta = np.array([0.2, 0.4, 0.6, 0.5])
+    gp = make_gp(X, T[0], nugget=1e-3); gp.fit(theta)
+    K = gp.get_K_matrix() + 1e-3 * np.eye(90)
+    L = gp.L
+    assert_allclose(L @ L.T, K, rtol=1e-12, atol=1e-13)
+    assert np.all(np.triu(L, 1) == 0.)
+    raw = np.zeros((90, 90)); gp._densegp_gpu.get_cholesky_lower(raw)
+    assert_allclose(np.tril(raw.T), L)                          # GaussianProcessGPU.py:476-478 convention
+    Q = np.zeros((90, 90)); gp._densegp_gpu.get_invQ(Q)
+    assert_allclose(Q @ K, np.eye(90), atol=1e-8)
+    assert_allclose(Q, Q.T, atol=0)
+    assert_allclose(gp.Kinv_t, np.linalg.solve(K, T[0]), rtol=1e-8)
+    th = gp.theta
+    assert_allclose(th.get_data(), theta); assert_allclose(th.get_cov(), np.exp(0.5)); assert th.get_nugget_size() == 1e-3
+
+
+def test_mean_functions_follow_gpu_reference_semantics():
+    # mean parameters are part of theta (densegp_gpu.hpp:497-508); oracle = zero-mean GP on t - m(X)
+    X, T, Xs = synth(8, 80, 2, 1, 9)
+    theta_k = np.array([0.3, 0.7, 0.2])
+    gp = M.GaussianProcessGPU(X, T[0], mean="1.5", nugget=1e-5, priors=weak(2, 1e-5))
+    gp.fit(theta_k)
+    ref = R.GPRef(X, T[0] - 1.5, nugget=1e-5); ref.fit(theta_k)
+    assert_allclose(gp.current_logpost, ref.current_logpost, rtol=1e-10)
+    assert_allclose(gp.predict(Xs)[0], ref.predict(Xs)[0] + 1.5, rtol=1e-8)
+    gp = M.GaussianProcessGPU(X, T[0], mean="c+c*x[0]+c*x[1]^2", nugget=1e-5, priors=weak(2, 1e-5))
+    beta = np.array([0.4, -0.3, 0.8])
+    assert gp.n_params == 6
+    full = np.concatenate([beta, theta_k])
+    mX = beta[0] + beta[1] * X[:, 0] + beta[2] * X[:, 1] ** 2
+    ref = R.GPRef(X, T[0] - mX, nugget=1e-5)
+    assert_allclose(gp.logposterior(full), ref.fit(theta_k), rtol=1e-10)
+    grad = gp.logpost_deriv(full)
+    assert_allclose(grad[3:], ref.logpost_deriv(theta_k), rtol=1e-7, atol=1e-8)
+    h = 1e-6
+    for p in range(3):
+        e = np.zeros(6); e[p] = h
+        fd = (gp.logposterior(full + e) - gp.logposterior(full - e)) / (2 * h)
+        assert_allclose(grad[p], fd, rtol=1e-5, atol=1e-5)
+    gp.fit(full)
+    mXs = beta[0] + beta[1] * Xs[:, 0] + beta[2] * Xs[:, 1] ** 2
+    mean, _, deriv = gp.predict(Xs)
+    assert_allclose(mean, ref.predict(Xs)[0] + mXs, rtol=1e-8)
+    _, _, rd = ref.predict(Xs, deriv=True)
+    rd = rd + np.stack([np.full(9, beta[1]), 2 * beta[2] * Xs[:, 1]], axis=1)
+    assert_allclose(deriv, rd, rtol=1e-7, atol=1e-8)
+
+
+def test_pickle_roundtrip_refits():
+    X, T, Xs = synth(9, 60, 2, 1, 5)
+    gp = make_gp(X, T[0], "Matern52", 1e-5); gp.fit(np.array([0.1, 0.2, 0.3]))
+    clone = pickle.loads(pickle.dumps(gp))
+    assert_allclose(clone.predict(Xs)[0], gp.predict(Xs)[0], rtol=0, atol=0)
+    assert clone.kernel == gp.kernel and clone.nugget == gp.nugget
+
+
+# ------------------------------------------------------------------------------------------------
+# fit_GP_MAP
+# ------------------------------------------------------------------------------------------------
+def test_fit_GP_MAP_single_reaches_reference_optimum():
+    g = load_golden("fitmap_c1.npz")
+    LibGPGPU.set_fit_options(max_iter=500, ftol=1e-12, gtol=1e-8, seed=7)
+    gp = M.GaussianProcessGPU(g["X"], g["t"], nugget=1e-6)         # default priors, as in the golden run
+    gp = M.fit_GP_MAP(gp, n_tries=1, theta0=g["theta0"])
+    assert gp.theta.data_has_been_set()
+    # trajectory parity is unpinned; the MAP objective must be at least as good as scipy's end point
+    assert gp.current_logpost <= g["logpost_hat"] + 1e-5 * abs(g["logpost_hat"])
+    assert_allclose(gp.logposterior(g["theta_hat"]), g["logpost_hat"], rtol=1e-8)
+    gp.fit(g["theta_hat"])
+    assert_allclose(gp.predict(g["Xs"])[0], g["mean"], rtol=1e-6, atol=1e-7)
+    LibGPGPU.set_fit_options(max_iter=200, ftol=1e-9, gtol=1e-6, seed=0)
+
+
+def test_fit_GP_MAP_multioutput_and_failures():
+    X, T, Xs = synth(10, 100, 3, 6, 12)
+    LibGPGPU.set_fit_options(seed=11)
+    gp = M.fit_GP_MAP(X, T, nugget=1e-6, n_tries=2)
+    assert isinstance(gp, M.MultiOutputGP_GPU) and gp.get_indices_not_fit() == []      # tests/test_fitting.py:45-65
+    mean, unc, _ = gp.predict(Xs)
+    assert mean.shape == (6, 12) and np.all(np.isfinite(mean)) and np.all(unc >= 0.)
+    # each emulator's optimum must beat its own starting objective
+    th0 = np.zeros(4)
+    gp2 = M.MultiOutputGP_GPU(X, T, nugget=1e-6)
+    f0, _, _ = gp2._mogp_gpu.eval(np.tile(th0, (6, 1)), grad=False)
+    gp2 = M.fit_GP_MAP(gp2, n_tries=1, theta0=th0)
+    f1 = np.array([em.current_logpost for em in gp2.emulators])
+    assert np.all(f1 < f0)
+    with pytest.raises(NotImplementedError):
+        M.fit_GP_MAP(gp2, method="CG", refit=True)
+    # a hopeless start (theta0 = 800: overflow) with a single try leaves every emulator unfit
+    gp3 = M.MultiOutputGP_GPU(X, T[:2], nugget=1e-6)
+    gp3 = M.fit_GP_MAP(gp3, n_tries=1, theta0=np.full(4, 800.))
+    assert gp3.get_indices_not_fit() == [0, 1]
+    with pytest.raises(RuntimeError):
+        M.fit_GP_MAP(gp3, n_tries=1, theta0=np.full(4, 800.), skip_failures=False)
+    single = M.GaussianProcessGPU(X, T[0], nugget=1e-6)
+    with pytest.raises(RuntimeError):
+        M.fit_GP_MAP(single, n_tries=1, theta0=np.full(4, 800.))
+    with pytest.raises(RuntimeError):
+        M.fit_GP_MAP(single, n_tries=1, theta0=np.zeros(9))      # wrong theta0 length, tests/test_fitting.py:135-136
+
+
+# ------------------------------------------------------------------------------------------------
+# BASELINE sizes: oracle where it finishes in seconds + size-independent identities
+# ------------------------------------------------------------------------------------------------
+def test_c2_full_size_vs_oracle_and_identities():
+    n, d = 2000, 10
+    X, T, Xs = synth(20240607 + 2, n, d, 8, 700)
+    theta = np.array([-2. * np.log(0.3 * np.sqrt(d))] * d + [0.])
+    eta = 1e-6
+    mo = M.MultiOutputGP_GPU(X, T, nugget=eta, priors=weak(d, eta))
+    f, g, ok = mo._mogp_gpu.eval(np.tile(theta, (8, 1)), grad=True)
+    assert ok.all()
+    ref = R.GPRef(X, T[0], nugget=eta)
+    assert_allclose(f[0], ref.fit(theta), rtol=1e-10)
+    assert_allclose(g[0], ref.logpost_deriv(theta), rtol=1e-7, atol=1e-7)
+    mean, unc, _ = mo.predict(Xs, deriv=False)
+    mu, var, _ = ref.predict(Xs)
+    assert_allclose(mean[0], mu, rtol=1e-7, atol=1e-8)
+    assert_allclose(unc[0], var, atol=1e-7)
+    # identities, all 8 emulators: at a training point x_i the predictive mean is t_i - eta*alpha_i and the
+    # (nugget-free) variance is eta - eta^2 [ (K+eta I)^-1 ]_ii
+    tm, tv, _ = mo.predict(X[:256], deriv=False, include_nugget=False)
+    for k in range(8):
+        em = mo.emulators[k]
+        a = em.Kinv_t
+        assert_allclose(tm[k], T[k, :256] - eta * a[:256], rtol=1e-7, atol=1e-8)
+    Q = np.zeros((n, n)); mo._mogp_gpu.emulator(3).get_invQ(Q)
+    assert_allclose(tv[3], np.maximum(eta - eta ** 2 * np.diag(Q)[:256], 0.), atol=1e-9)
+    L = mo.emulators[5].L
+    K = mo.emulators[5].get_K_matrix()
+    resid = np.abs(L @ L.T - K - eta * np.eye(n)).max()
+    assert resid < 1e-12
+    assert np.abs(K @ mo.emulators[5].Kinv_t + eta * mo.emulators[5].Kinv_t - T[5]).max() < 1e-8
+    # batching is invisible: an emulator inside the batch equals the same emulator alone, bit for bit
+    solo = make_gp(X, T[2], nugget=eta); solo.fit(theta)
+    assert solo.current_logpost == mo.emulators[2].current_logpost
+    assert np.array_equal(solo.Kinv_t, mo.emulators[2].Kinv_t)
+
+
+def test_c5_shaped_single_large_identities():
+    # n = 4000, d = 8 (C5 family at a quarter size): no oracle, identities only
+    n, d = 4000, 8
+    X, T, Xs = synth(20240607 + 5, n, d, 1, 300)
+    theta = np.array([-2. * np.log(0.3 * np.sqrt(d))] * d + [0.])
+    eta = 1e-6
+    gp = make_gp(X, T[0], nugget=eta)
+    gp.fit(theta)
+    a = gp.Kinv_t
+    K = gp.get_K_matrix()
+    assert np.abs(K @ a + eta * a - T[0]).max() < 1e-7
+    tm, tv, _ = gp.predict(X[:128], deriv=False, include_nugget=False)
+    assert_allclose(tm, T[0, :128] - eta * a[:128], rtol=1e-7, atol=1e-8)
+    assert np.all(tv >= 0.) and np.all(tv < 2 * eta)
+    L = gp.L
+    assert_allclose(2 * np.log(np.diag(L)).sum(), np.linalg.slogdet(K + eta * np.eye(n))[1], rtol=1e-9)

@@ -1,0 +1,220 @@
+"""CPU-only tests: the C-ABI library loads and exports every symbol include/mogp_hip.h declares,
+and the host-side mirror of the reference's GPU-facing interface behaves like the reference's
+(names, argument coercion, error types).  No compute calls are made without a GPU."""
+import os
+import pickle
+import re
+
+import numpy as np
+import pytest
+from numpy.testing import assert_allclose
+
+import mogp_emulator_amd as M
+from mogp_emulator_amd import LibGPGPU, _capi, libgpgpu
+from mogp_emulator_amd.GaussianProcessGPU import (PredictResult, create_prior_params, interpret_nugget,
+                                                   ndarray_coerce_type_and_flags, parse_meanfunc_formula)
+from mogp_emulator_amd.Priors import GammaPrior, GPPriors, InvGammaPrior, LogNormalPrior, WeakPrior, input_spacing
+from conftest import ROOT, load_golden
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    lib = _capi.load()
+    header = open(os.path.join(ROOT, "include", "mogp_hip.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = set(re.findall(r"\b(mogp_[a-zA-Z0-9_]+)\s*\(", header))
+    assert len(declared) > 70
+    for name in declared:
+        assert hasattr(lib, name), "libmogp_hip.so does not export " + name
+        assert name in _capi.SIGNATURES, "no ctypes prototype for " + name
+    assert set(_capi.SIGNATURES) == declared
+    assert b"gfx950" in lib.mogp_version()
+
+
+def test_no_gpu_here_means_loud_failure():
+    if LibGPGPU.gpu_usable():
+        pytest.skip("a GPU is visible")
+    assert LibGPGPU.HAVE_LIBGPGPU
+    with pytest.raises(RuntimeError):
+        M.GaussianProcessGPU(np.zeros((3, 2)), np.zeros(3))
+    with pytest.raises(RuntimeError):
+        M.MultiOutputGP_GPU(np.zeros((3, 2)), np.zeros((2, 3)))
+
+
+def test_module_surface_matches_reference_bindings():
+    # exported names of bindings.cu:13-621 that the Python layer uses
+    for name in ["have_compatible_device", "fit_GP_MAP", "kernel_type", "nugget_type", "prior_type", "ZeroMeanFunc",
+                 "FixedMeanFunc", "ConstMeanFunc", "PolyMeanFunc", "GPParameters", "DenseGP_GPU", "MultiOutputGP_GPU",
+                 "SquaredExponentialKernel", "Matern52Kernel", "WeakPrior", "InvGammaPrior", "GammaPrior", "CovTransform",
+                 "CorrTransform", "GPPriors"]:
+        assert hasattr(LibGPGPU, name), name
+    for meth in ["n", "D", "n_corr", "inputs", "targets", "n_params", "theta_fit_status", "reset_theta_fit_status", "get_theta",
+                 "get_gppriors", "create_gppriors", "predict", "predict_variance", "predict_batch", "predict_variance_batch",
+                 "predict_deriv", "fit", "get_K", "get_invQ", "get_invQt", "get_logpost", "get_nugget_size", "set_nugget_size",
+                 "get_nugget_type", "set_nugget_type", "get_kernel_type", "get_meanfunc", "get_cholesky_lower", "logpost_deriv"]:
+        assert hasattr(libgpgpu.DenseGP_GPU, meth), meth
+    for meth in ["inputs", "targets", "targets_at_index", "emulator", "n", "D", "n_emulators", "n_data_params", "n_corr_params",
+                 "get_nugget_type", "get_nugget_size", "get_fitted_indices", "get_unfitted_indices", "create_priors_for_emulator",
+                 "reset_fit_status", "fit_emulator", "fit", "predict", "predict_batch", "predict_variance_batch", "predict_deriv"]:
+        assert hasattr(libgpgpu.MultiOutputGP_GPU, meth), meth
+
+
+def test_enums_behave_like_pybind_enums():
+    nt = LibGPGPU.nugget_type
+    assert str(nt.adaptive) == "nugget_type.adaptive" and str(nt.fit).split(".")[1] == "fit"
+    assert nt(0) == nt.adaptive and nt(1) == nt.fit and nt(2) == nt.fixed          # types.hpp:29
+    assert int(LibGPGPU.kernel_type.SquaredExponential) == 0 and int(LibGPGPU.kernel_type.Matern52) == 1
+    pt = LibGPGPU.prior_type
+    assert [int(pt.InvGamma), int(pt.Gamma), int(pt.LogNormal), int(pt.Weak)] == [0, 1, 2, 3]
+    with pytest.raises(ValueError):
+        nt(7)
+
+
+def test_mean_functions_and_error_messages():
+    # tests/test_GPUMeanFunction.py:87-109 of the reference
+    x = np.array([[1., 2.], [3., 4.]])
+    assert_allclose(LibGPGPU.ZeroMeanFunc().mean_f(x, np.zeros(0)), [0., 0.])
+    assert_allclose(LibGPGPU.FixedMeanFunc(2.5).mean_f(x, np.zeros(0)), [2.5, 2.5])
+    assert_allclose(LibGPGPU.ConstMeanFunc().mean_f(x, np.array([4.4])), [4.4, 4.4])
+    poly = LibGPGPU.PolyMeanFunc([[0, 1], [1, 2]])
+    assert poly.get_n_params() == 3
+    assert_allclose(poly.mean_f(x, np.array([1., 2., 3.])), [1 + 2 * 1 + 3 * 4, 1 + 2 * 3 + 3 * 16])
+    assert_allclose(poly.mean_deriv(x, np.array([1., 2., 3.])), [[1., 1.], [1., 3.], [4., 16.]])
+    assert_allclose(poly.mean_inputderiv(x, np.array([1., 2., 3.])), [[2., 2.], [3 * 2 * 2., 3 * 2 * 4.]])
+    with pytest.raises(RuntimeError, match="Expected params list of length 3"):
+        poly.mean_f(x, np.array([1.]))
+    with pytest.raises(RuntimeError, match="Expected params list of length 1"):
+        LibGPGPU.ConstMeanFunc().mean_f(x, np.zeros(0))
+    with pytest.raises(RuntimeError, match="Dimension index must be less than"):
+        LibGPGPU.PolyMeanFunc([[5, 1]]).mean_f(x, np.array([1., 2.]))
+
+
+def test_parse_meanfunc_formula():
+    assert isinstance(parse_meanfunc_formula("c"), LibGPGPU.ConstMeanFunc)
+    assert isinstance(parse_meanfunc_formula("3.5"), LibGPGPU.FixedMeanFunc)
+    p = parse_meanfunc_formula("c+c*x[0]+c*x[1]^2")
+    assert isinstance(p, LibGPGPU.PolyMeanFunc) and p.get_n_params() == 3
+    assert_allclose(p.mean_f(np.array([[2., 3.]]), np.array([1., 1., 1.])), [1 + 2 + 9])
+    assert parse_meanfunc_formula("c+c*x[0]*x[0]").mean_f(np.array([[3.]]), np.array([0., 1.]))[0] == 9.
+    with pytest.raises(NotImplementedError):
+        parse_meanfunc_formula("c*x[0]*x[1]")
+    assert parse_meanfunc_formula("hello") is None
+
+
+def test_gpparameters_host_object():
+    p = LibGPGPU.GPParameters(0, 3, LibGPGPU.nugget_type.fit)
+    assert p.get_n_data() == 5 and not p.data_has_been_set()
+    p.set_data(np.array([0., 2., -2., 1., np.log(1e-6)]))
+    assert p.data_has_been_set()
+    assert_allclose(p.get_corr(), np.exp(-0.5 * np.array([0., 2., -2.])))       # CorrTransform, GPParams.py:35-45
+    assert_allclose(p.get_cov(), np.e)
+    assert_allclose(p.get_nugget_size(), 1e-6)
+    assert p.test_same_shape(np.zeros(5)) and not p.test_same_shape(np.zeros(4))
+    with pytest.raises(RuntimeError):
+        p.set_data(np.zeros(3))
+    p.unset_data()
+    assert not p.data_has_been_set() and p.get_cov() == 0.
+    q = LibGPGPU.GPParameters(0, 3, LibGPGPU.nugget_type.fixed, 1e-3)
+    assert q.get_n_data() == 4 and q.get_nugget_size() == 1e-3
+
+
+def test_transforms():
+    c = LibGPGPU.CorrTransform()
+    assert_allclose(c.raw_to_scaled(2.), np.exp(-1.)); assert_allclose(c.scaled_to_raw(np.exp(-1.)), 2.)
+    assert_allclose(c.dscaled_draw(3.), -1.5); assert_allclose(c.d2scaled_draw2(2.), 0.5)   # CPU sign, GPParams.py:69-80
+    v = LibGPGPU.CovTransform()
+    assert_allclose(v.raw_to_scaled(1.), np.e); assert_allclose(v.dscaled_draw(3.), 3.)
+
+
+def test_interpret_nugget_and_coercion():
+    assert interpret_nugget("adaptive") == (LibGPGPU.nugget_type.adaptive, 0.)
+    assert interpret_nugget("fit") == (LibGPGPU.nugget_type.fit, 0.)
+    assert interpret_nugget(1e-4) == (LibGPGPU.nugget_type.fixed, 1e-4)
+    assert interpret_nugget(1) == (LibGPGPU.nugget_type.fixed, 1.)
+    with pytest.raises(ValueError):
+        interpret_nugget("pivot")
+    with pytest.raises(ValueError):
+        interpret_nugget(-1.)
+    with pytest.raises(TypeError):
+        interpret_nugget([1, 2])
+    a = ndarray_coerce_type_and_flags(np.arange(6).reshape(2, 3)[:, ::2])
+    assert a.dtype == np.float64 and a.flags["C_CONTIGUOUS"] and a.flags["WRITEABLE"]
+
+
+def test_priors_match_reference_values():
+    g = load_golden("priors.npz")
+    for nm, cls in (("invgamma", InvGammaPrior), ("gamma", GammaPrior), ("lognormal", LogNormalPrior)):
+        p = cls(2., 2.)
+        assert_allclose([p.logp(x) for x in g["x"]], g[nm + "_2_2_logp"], rtol=1e-13)
+        assert_allclose([p.dlogpdx(x) for x in g["x"]], g[nm + "_2_2_dlogpdx"], rtol=1e-13)
+    assert WeakPrior().logp(1.) == 0.
+
+
+def test_default_priors_match_reference():
+    g = load_golden("priors.npz")
+    X = np.random.default_rng(int(g["default_X_seed"])).uniform(0, 1, (2000, 10))
+    lo_hi = np.array([input_spacing(c) for c in X.T])
+    assert_allclose(lo_hi[:, 0], g["default_min_spacing"], rtol=1e-14)
+    assert_allclose(lo_hi[:, 1], g["default_max_spacing"], rtol=1e-14)
+    pri = GPPriors.default_priors(X, 10, "fit")
+    assert_allclose([p.shape for p in pri.corr], g["default_corr_shape"], rtol=1e-9)
+    assert_allclose([p.scale for p in pri.corr], g["default_corr_scale"], rtol=1e-9)
+    assert_allclose([pri.nugget.shape, pri.nugget.scale], g["default_nugget"], rtol=1e-9)
+    # SURVEY 8b pinning I/O
+    assert_allclose(pri.corr[0].shape, 0.8408705121074469, rtol=1e-9)
+    assert_allclose(pri.corr[0].scale, 0.0017112471182106296, rtol=1e-9)
+    assert isinstance(pri.cov, WeakPrior) and not isinstance(pri.cov, InvGammaPrior)
+    assert GPPriors.default_priors(X, 10, "adaptive").nugget is None
+    # too few unique inputs -> weak (Priors.py:746-779)
+    flat = GPPriors.default_priors(np.ones((5, 2)), 2, "fixed")
+    assert all(type(p) is WeakPrior for p in flat.corr)
+
+
+def test_create_prior_params_layout():
+    X = np.random.default_rng(1).uniform(0, 1, (50, 3))
+    n_corr, corr, cov, nug = create_prior_params(inputs=X, n_corr=3, nugget_type="fit")
+    assert n_corr == 3 and len(corr) == 3
+    assert corr[0][0] == LibGPGPU.prior_type.InvGamma and len(corr[0][1]) == 2
+    assert cov == (LibGPGPU.prior_type.Weak, [0., 0.])
+    assert nug[0] == LibGPGPU.prior_type.InvGamma
+    n_corr, corr, cov, nug = create_prior_params(newpriors=GPPriors(n_corr=2, nugget_type="fixed", cov=GammaPrior(2., 3.)))
+    assert [c[0] for c in corr] == [LibGPGPU.prior_type.Weak] * 2 and cov == (LibGPGPU.prior_type.Gamma, [2., 3.])
+    n_corr, corr, cov, nug = create_prior_params(newpriors=dict(n_corr=1, nugget_type="fit", nugget=LogNormalPrior(1., 2.)))
+    assert nug == (LibGPGPU.prior_type.LogNormal, [1., 2.])
+    with pytest.raises(TypeError):
+        create_prior_params(foo=1)
+    with pytest.raises(TypeError):
+        create_prior_params(newpriors=dict(bogus=3))
+
+
+def test_gppriors_validation():
+    with pytest.raises(ValueError):
+        GPPriors()
+    with pytest.raises(AssertionError):
+        GPPriors(n_corr=1, nugget_type="blah")
+    with pytest.raises(TypeError):
+        GPPriors(corr=[1., 2.])
+    with pytest.raises(TypeError):
+        GPPriors(n_corr=1, cov=3.)
+    p = GPPriors(n_corr=2, nugget_type="adaptive", nugget=InvGammaPrior(1., 1.))
+    assert p.nugget is None and p.n_corr == 2
+
+
+def test_predict_result_container():
+    r = PredictResult(mean=np.ones(2), unc=None, deriv=np.zeros((2, 1)))
+    mean, unc, deriv = r
+    assert unc is None and r[0] is r.mean and r["deriv"] is r[2]
+    with pytest.raises(KeyError):
+        r[3]
+    with pytest.raises(AttributeError):
+        r.nothing
+    assert pickle.loads(pickle.dumps(dict(r)))["unc"] is None
+
+
+def test_fit_gp_map_argument_checks():
+    from mogp_emulator_amd.fitting import fit_GP_MAP, _check_common
+    with pytest.raises(TypeError):
+        fit_GP_MAP()
+    with pytest.raises(NotImplementedError):
+        _check_common(3, "Nelder-Mead")
+    with pytest.raises(AssertionError):
+        _check_common(0, "L-BFGS-B")
