@@ -1,0 +1,207 @@
+#!/usr/bin/env python
+"""
+bench.py -- headline benchmark of the hot path (BASELINE.json):
+GP fits/sec + predict pts/sec, 64 outputs x n=2000 x d=10, fp64, synthetic data.
+
+One process per GPU (launched by torch.distributed.run for N > 1).  Every rank owns 64 independent
+emulators ("scaling": "weak": per-GPU work is fixed) that share X; the only exchange
+is ONE RCCL all_gather of the predictive means/variances at the end of every step.
+
+A "step" is one pass of the hot path over the rank's batch:
+    phase fit      : objective of all emulators at theta  (K build + Cholesky + alpha + logdet + logpost)
+    phase fit+grad : objective + gradient (adds L^-1, K^-1, fused gradient reduction)
+    phase predict  : mean + variance at m = 10 000 points per emulator (inputs + outputs HBM resident)
+`value` = fits/s over the whole job = emulators x steps / time spent in the fit phase;
+fit+grad/s and predict pts/s are reported next to it from the same timed steps.
+
+roofline: for the kernel with the largest share of device time; `achieved` = algorithmic flops
+(n^3/3 per Cholesky, m n^2 per predictive variance, ...) of all its launches in the
+timed steps / their total duration measured with HIP events recorded on the launch stream inside
+libmogp_hip.so (mogp_profile_*).  cpu_baseline: the oracle (NumPy/LAPACK restatement of the reference
+CPU path) timed on this host on a bounded sample of the same workload.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP64_MFMA_PEAK_TF = 78.6      # AMD MI355X FP64 matrix spec; tools/mfma_probe.hip measures 78.2 on this part
+HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def synth(config_id, n, d, n_out, m):
+    """SURVEY.md section 8d deterministic synthetic inputs."""
+    rng = np.random.default_rng(20240607 + config_id)
+    X = rng.uniform(0, 1, (n, d))
+    T = np.empty((n_out, n))
+    for k in range(n_out):
+        w = rng.normal(size=d)
+        T[k] = np.sin(2 * np.pi * X @ w / np.sqrt(d)) + 0.1 * (X ** 2) @ np.abs(w) + 0.01 * rng.normal(size=n)
+    Xs = rng.uniform(0, 1, (m, d))
+    return X, T, Xs
+
+
+def cpu_baseline(X, T, Xs, theta, nugget, budget_s=25.0):
+    """Oracle timed on the host cores: 1 emulator fit, 1 gradient, predict on a 1000-point sample."""
+    from oracle import cpu_ref as R
+    try:
+        from threadpoolctl import threadpool_info
+        threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+    except Exception:
+        threads = os.cpu_count() or 1
+    gp = R.GPRef(X, T[0], nugget=nugget)
+    t0 = time.perf_counter(); gp.fit(theta); t_fit = time.perf_counter() - t0
+    t0 = time.perf_counter(); gp.logpost_deriv(theta); t_grad = time.perf_counter() - t0
+    ms = min(1000, Xs.shape[0])
+    t0 = time.perf_counter(); gp.predict(Xs[:ms]); t_pred = time.perf_counter() - t0
+    return {
+        "value": 1.0 / t_fit, "unit": "fits/s", "cores": int(threads), "kind": "port",
+        "sample": "1 emulator n=%d d=%d: fit %.2fs, gradient %.2fs, predict %d pts %.2fs (NumPy/LAPACK oracle)" % (
+            X.shape[0], X.shape[1], t_fit, t_grad, ms, t_pred),
+        "fit_grad_per_s": 1.0 / (t_fit + t_grad), "predict_pts_per_s": ms / t_pred,
+        "host_cpus": os.cpu_count(), "affinity": len(os.sched_getaffinity(0)),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--n", type=int, default=2000)
+    ap.add_argument("--d", type=int, default=10)
+    ap.add_argument("--outputs", type=int, default=64, help="emulators per GPU")
+    ap.add_argument("--m", type=int, default=10000, help="prediction points per emulator")
+    ap.add_argument("--kernel", default="SquaredExponential")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    import mogp_emulator_amd as M
+    from mogp_emulator_amd import _capi, libgpgpu
+    from mogp_emulator_amd.Priors import GPPriors
+    lib = _capi.load()
+    libgpgpu.set_device(local_rank)
+    assert M.gpu_usable(), "no gfx950 device / library"
+
+    n, d, B, m = args.n, args.d, args.outputs, args.m
+    nugget = 1e-6
+    # every rank gets its own 64 outputs (different seeds) on the same kind of data
+    X, T, Xs = synth(2 + 1000 * rank, n, d, B, m)
+    theta = np.array([-2. * np.log(0.3 * np.sqrt(d))] * d + [0.])
+    thetas = np.tile(theta, (B, 1))
+
+    gp = M.MultiOutputGP_GPU(X, T, kernel=args.kernel, nugget=nugget, priors=GPPriors(n_corr=d, nugget_type="fixed"))
+    mo = gp._mogp_gpu
+    d_Xs = torch.from_numpy(Xs).to(dev)
+    d_mean = torch.empty((B, m), dtype=torch.float64, device=dev)
+    d_var = torch.empty((B, m), dtype=torch.float64, device=dev)
+    gathered = torch.empty((world, 2, B, m), dtype=torch.float64, device=dev) if world > 1 else None
+    torch.cuda.synchronize()
+
+    phase = {"fit": 0.0, "fitgrad": 0.0, "predict": 0.0, "gather": 0.0}
+
+    def step(it, timed):
+        th = thetas + 1e-3 * np.sin(it + np.arange(B))[:, None]      # new theta every step: nothing can be cached
+        t0 = time.perf_counter()
+        f, _, ok = mo.eval(th, grad=False)
+        t1 = time.perf_counter()
+        f2, g, ok2 = mo.eval(th, grad=True)
+        t2 = time.perf_counter()
+        mo.predict_variance_batch_dev(d_Xs.data_ptr(), m, d_mean.data_ptr(), d_var.data_ptr())
+        t3 = time.perf_counter()
+        if world > 1:
+            dist.all_gather_into_tensor(gathered.view(world, -1), torch.stack([d_mean, d_var]).view(-1))
+            torch.cuda.synchronize()
+        t4 = time.perf_counter()
+        assert ok.all() and ok2.all() and np.all(np.isfinite(g))
+        if timed:
+            phase["fit"] += t1 - t0; phase["fitgrad"] += t2 - t1; phase["predict"] += t3 - t2; phase["gather"] += t4 - t3
+        return f
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        lib.mogp_dev_synchronize()
+
+    for it in range(args.warmup):
+        step(it, False)
+    lib.mogp_profile_reset()
+    lib.mogp_profile_enable(1)
+    barrier()
+    t_start = time.perf_counter()
+    for it in range(args.steps):
+        f_last = step(args.warmup + it, True)
+    barrier()
+    elapsed = time.perf_counter() - t_start
+    lib.mogp_profile_enable(0)
+
+    # per-kernel device times from HIP events on the launch stream
+    kern = {}
+    for tag, bound in (("syrk_trailing", "mfma"), ("trtri_merge", "mfma"), ("kinv", "mfma"), ("predict_var", "mfma"),
+                       ("cov_build", "hbm"), ("cross_cov", "hbm"), ("grad_reduce", "hbm")):
+        ms, cnt, fl, by = ctypes.c_double(), ctypes.c_longlong(), ctypes.c_double(), ctypes.c_double()
+        if lib.mogp_profile_get(tag.encode(), ctypes.byref(ms), ctypes.byref(cnt), ctypes.byref(fl), ctypes.byref(by)) == 0 and cnt.value:
+            sec = ms.value * 1e-3
+            kern[tag] = {"bound": bound, "launches": cnt.value, "ms_total": ms.value, "avg_ms": ms.value / cnt.value,
+                         "achieved": (fl.value / sec * 1e-12) if bound == "mfma" else (by.value / sec * 1e-9),
+                         "unit": "TFLOP/s" if bound == "mfma" else "GB/s"}
+
+    # max over ranks of every time
+    times = torch.tensor([elapsed, phase["fit"], phase["fitgrad"], phase["predict"], phase["gather"]], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(times, op=dist.ReduceOp.MAX)
+    elapsed, t_fit, t_fg, t_pr, t_ga = [float(x) for x in times.cpu()]
+
+    if rank == 0:
+        K = args.steps
+        total_emus = B * world
+        dom = max(kern, key=lambda k: kern[k]["ms_total"]) if kern else None
+        roofline = None
+        if dom:
+            kd = kern[dom]
+            peak = FP64_MFMA_PEAK_TF if kd["bound"] == "mfma" else HBM_PEAK_GBS
+            roofline = {"kernel": dom, "bound": kd["bound"], "achieved": kd["achieved"], "peak": peak, "unit": kd["unit"],
+                        "frac": kd["achieved"] / peak, "traffic": None, "avg_launch_ms": kd["avg_ms"], "launches": kd["launches"]}
+        out = {
+            "metric": "GP fits/sec (+ fit+grad/s, predict pts/s), %d-output n=%d d=%d per GPU, fp64" % (B, n, d),
+            "value": total_emus * K / t_fit, "unit": "fits/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
+            "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "MultiOutputGP %d outputs/GPU x n=%d x d=%d, %s kernel, fixed nugget 1e-6, predict m=%d (unc=True)" % (
+                B, n, d, args.kernel, m), "outputs_per_gpu": B, "n": n, "d": d, "m_predict": m, "parallelism": "emulator-shard x%d" % world},
+            "fit_grad_per_s": total_emus * K / t_fg,
+            "predict_pts_per_s": total_emus * m * K / (t_pr + t_ga),
+            "phase_ms_per_step": {"fit": t_fit / K * 1e3, "fit_grad": t_fg / K * 1e3, "predict": t_pr / K * 1e3, "gather": t_ga / K * 1e3},
+            "roofline": roofline, "kernels": kern,
+            "logpost_checksum": float(np.sum(f_last)),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(X, T, Xs, theta, nugget)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
