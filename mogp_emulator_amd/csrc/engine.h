@@ -66,12 +66,15 @@ class Engine {
   // multi-start MAP fit of emulators `ids` in lock-step (fitting.hpp:61-128)
   void fit_map(const std::vector<int>& ids, int n_tries, const double* theta0, int theta0_len);
 
-  hipStream_t stream = nullptr;
+  hipStream_t stream = nullptr;      // main stream: covariance build, trailing updates, everything else
+  hipStream_t pstream = nullptr;     // look-ahead stream: panel factorisations
+  std::vector<hipEvent_t> evPanel, evUpd;
 
  private:
   void upload_params(const std::vector<int>& ids);
   void upload_idx(const std::vector<int>& ids);
   void factorize(const std::vector<int>& ids, std::vector<int>& info);
+  void panel(const BatchView& v, int o, int w, hipStream_t st);
   void ensure_linv(const std::vector<int>& ids);
   void ensure_kinv(const std::vector<int>& ids);
   BatchView view(int nb) const;
@@ -81,6 +84,7 @@ class Engine {
   double *dX = nullptr, *dP = nullptr, *dT = nullptr, *dA = nullptr, *dLinv = nullptr, *dKinv = nullptr, *dAlpha = nullptr;
   double *dLogdet = nullptr, *dYty = nullptr, *dGradOut = nullptr, *dGradPartial = nullptr;
   int *dInfo = nullptr, *dIdx = nullptr;
+  double* dLpack = nullptr;      // packed transposed diagonal block + reciprocal diagonal (potf2 -> trsm)
   std::vector<double> hP;
   // predict scratch
   double *dXs = nullptr, *dKs = nullptr, *dMean = nullptr, *dVar = nullptr, *dVarPartial = nullptr, *dDeriv = nullptr;

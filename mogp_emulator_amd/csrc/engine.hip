@@ -126,6 +126,7 @@ Engine::Engine(const double* X, int n_, int D_, const double* targets, int B_, u
     g.meanp.assign(mean.n_params(), 0.);
   }
   HIPCK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+  HIPCK(hipStreamCreateWithFlags(&pstream, hipStreamNonBlocking));
   dX = dalloc<double>((size_t)n * D);
   dP = dalloc<double>((size_t)B * PS);
   dT = dalloc<double>((size_t)B * n);
@@ -135,6 +136,7 @@ Engine::Engine(const double* X, int n_, int D_, const double* targets, int B_, u
   dYty = dalloc<double>(B);
   dInfo = dalloc<int>(B);
   dIdx = dalloc<int>(B);
+  dLpack = dalloc<double>((size_t)B * lpack_doubles_per_emulator());
   hP.assign((size_t)B * PS, 0.);
   HIPCK(hipMemcpy(dX, hX.data(), hX.size() * sizeof(double), hipMemcpyHostToDevice));
   // residual targets for parameter-free means are fixed once
@@ -148,8 +150,11 @@ Engine::Engine(const double* X, int n_, int D_, const double* targets, int B_, u
 Engine::~Engine() {
   for (void* p : {(void*)dX, (void*)dP, (void*)dT, (void*)dA, (void*)dLinv, (void*)dKinv, (void*)dAlpha, (void*)dLogdet, (void*)dYty,
                   (void*)dGradOut, (void*)dGradPartial, (void*)dInfo, (void*)dIdx, (void*)dXs, (void*)dKs, (void*)dMean, (void*)dVar,
-                  (void*)dVarPartial, (void*)dDeriv})
+                  (void*)dVarPartial, (void*)dDeriv, (void*)dLpack})
     if (p) hipFree(p);
+  for (auto e : evPanel) hipEventDestroy(e);
+  for (auto e : evUpd) hipEventDestroy(e);
+  if (pstream) hipStreamDestroy(pstream);
   if (stream) hipStreamDestroy(stream);
 }
 
@@ -201,8 +206,28 @@ void Engine::upload_params(const std::vector<int>& ids) {
 }
 
 // Blocked right-looking Cholesky of K + nugget I for the emulators in `ids` (one batched sequence).
-//   outer block 128 = two 64-wide panels; per outer block:
-//   potf2 -> trsm -> narrow update of the second panel -> potf2 -> trsm -> MFMA trailing update (K = 128)
+// Recursive panel: a block column of width w is factored as [left half] -> update of the right half
+// (K = w/2, MFMA) -> [right half], down to 64-wide leaves (potf2 + trsm).  The outer block is 256
+// wide so the big trailing update runs with K = 256: per 128x128 tile the MFMA work (64k cycles)
+// then outweighs the read-modify-write of C (256 KB at ~10 B/clk/CU), which it does not at K = 128.
+void Engine::panel(const BatchView& v, int o, int w, hipStream_t st) {
+  if (w == NBI) {
+    launch_potf2(v, o, dInfo, dLpack, st);
+    launch_trsm(v, o, o + NBI, dLpack, st);
+    return;
+  }
+  const int h = w / 2;
+  panel(v, o, h, st);
+  if (h == NBI) launch_update_narrow(v, o + h, o, o + h, st);
+  else launch_update_wide(v, o + h, o, o + h, st);
+  panel(v, o + h, h, st);
+}
+
+// Look-ahead schedule on two HIP streams: as soon as the columns of the NEXT outer block have
+// received the update from panel k (U_a, main stream), panel k+1 is factored on the panel stream
+// while the main stream applies panel k to the rest of the trailing matrix (U_b).  The
+// latency-bound panel kernels (potf2 / trsm, few workgroups) thereby run underneath the MFMA
+// trailing update instead of in front of it.
 void Engine::factorize(const std::vector<int>& ids, std::vector<int>& info) {
   const int nb = (int)ids.size();
   upload_idx(ids);
@@ -210,13 +235,35 @@ void Engine::factorize(const std::vector<int>& ids, std::vector<int>& info) {
   BatchView v = view(nb);
   HIPCK(hipMemsetAsync(dInfo, 0, B * sizeof(int), stream));
   launch_cov_build(v, stream);
-  for (int o = 0; o < n + 1; o += TILE) {
-    launch_potf2(v, o, dInfo, stream);
-    launch_trsm(v, o, o + NBI, stream);
-    launch_update_narrow(v, o + NBI, o, o + NBI, stream);
-    launch_potf2(v, o + NBI, dInfo, stream);
-    launch_trsm(v, o + NBI, o + TILE, stream);
-    launch_update_trailing(v, o + TILE, o, o + TILE, stream);
+  std::vector<int> starts;
+  for (int o = 0; o < n + 1; o += OUTER) starts.push_back(o);
+  const int K = (int)starts.size();
+  while ((int)evPanel.size() < K + 1) {
+    hipEvent_t a, b;
+    HIPCK(hipEventCreateWithFlags(&a, hipEventDisableTiming));
+    HIPCK(hipEventCreateWithFlags(&b, hipEventDisableTiming));
+    evPanel.push_back(a);
+    evUpd.push_back(b);
+  }
+  auto width = [&](int k) { return std::min(OUTER, NP - starts[k]); };
+  HIPCK(hipEventRecord(evUpd[K], stream));                 // K build done
+  HIPCK(hipStreamWaitEvent(pstream, evUpd[K], 0));
+  panel(v, starts[0], width(0), pstream);
+  HIPCK(hipEventRecord(evPanel[0], pstream));
+  for (int k = 0; k < K; ++k) {
+    const int o = starts[k], w = width(k);
+    HIPCK(hipStreamWaitEvent(stream, evPanel[k], 0));
+    if (k + 1 < K) {
+      const int on = starts[k + 1], wn = width(k + 1);
+      for (int c = on; c < on + wn; c += TILE) launch_update_wide(v, c, o, o + w, stream);     // U_a
+      HIPCK(hipEventRecord(evUpd[k], stream));
+      HIPCK(hipStreamWaitEvent(pstream, evUpd[k], 0));
+      panel(v, on, wn, pstream);
+      HIPCK(hipEventRecord(evPanel[k + 1], pstream));
+      launch_update_trailing(v, on + wn, o, o + w, stream);                                     // U_b
+    } else {
+      launch_update_trailing(v, o + w, o, o + w, stream);   // (empty unless padding rows remain)
+    }
   }
   info.assign(B, 0);
   HIPCK(hipMemcpyAsync(info.data(), dInfo, B * sizeof(int), hipMemcpyDeviceToHost, stream));
@@ -277,11 +324,20 @@ void Engine::eval(const std::vector<int>& ids, const std::vector<const double*>&
   for (int i : ids)
     if (good[i]) okids.push_back(i);
   std::vector<double> logdet(B, 0.), yty(B, 0.);
+  for (int i : ids) gp[i].factored = good[i] != 0;
   if (!okids.empty()) {
     upload_idx(okids);
     BatchView v = view((int)okids.size());
     launch_logdet(v, dLogdet, dYty, stream);
-    launch_backsolve(v, stream);
+    if (want_grad) {
+      // gradient path: L^-1 is needed anyway, so alpha = L^-T y is one fully parallel gemv with it
+      ensure_linv(okids);
+      upload_idx(okids);
+      v = view((int)okids.size());
+      launch_alpha_from_linv(v, stream);
+    } else {
+      launch_backsolve(v, stream);
+    }
     HIPCK(hipMemcpyAsync(logdet.data(), dLogdet, B * sizeof(double), hipMemcpyDeviceToHost, stream));
     HIPCK(hipMemcpyAsync(yty.data(), dYty, B * sizeof(double), hipMemcpyDeviceToHost, stream));
     HIPCK(hipStreamSynchronize(stream));

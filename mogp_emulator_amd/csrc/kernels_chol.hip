@@ -15,76 +15,101 @@ typedef double v2d __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ int slot_emu(const int* idx, int z) { return idx ? idx[z] : z; }
 
 // ---------------------------------------------------------------------------------------------
-// potf2: unblocked Cholesky of the 64x64 diagonal block at (c0, c0), one workgroup per emulator.
+// potf2: unblocked Cholesky of the 64x64 diagonal block at (c0, c0): ONE wave per emulator, lane i
+// owns row i in registers (fully unrolled, compile-time register indices).  Per column j the pivot
+// is broadcast with v_readlane, the scaled column goes through a 512-byte LDS line and is re-read
+// by every lane as broadcast operands of the rank-1 update (63-j independent FMAs per lane).
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void potf2_kernel(BatchView v, int c0, int* __restrict__ info) {
-  __shared__ double S[64][65];
-  __shared__ int fail;
+__device__ __forceinline__ double readlane_f64(double x, int srclane) {
+  int lo = __double2loint(x), hi = __double2hiint(x);
+  lo = __builtin_amdgcn_readlane(lo, srclane);
+  hi = __builtin_amdgcn_readlane(hi, srclane);
+  return __hiloint2double(hi, lo);
+}
+
+// 1/sqrt(d) and sqrt(d) by v_rsq_f64 + two coupled Goldschmidt steps (about six dependent FMAs)
+// instead of a correctly rounded sqrt followed by a divide (two long dependent sequences) on the
+// critical path of every column.  Result error <= ~2 ulp, i.e. backward-stable like LAPACK's.
+__device__ __forceinline__ void rsqrt_sqrt(double d, double& rs, double& sq) {
+  const double r0 = __builtin_amdgcn_rsq(d);
+  double g = d * r0, h = 0.5 * r0;
+  double e = __builtin_fma(-g, h, 0.5);
+  g = __builtin_fma(g, e, g);
+  h = __builtin_fma(h, e, h);
+  e = __builtin_fma(-g, h, 0.5);
+  g = __builtin_fma(g, e, g);
+  h = __builtin_fma(h, e, h);
+  rs = h + h;
+  sq = g;
+}
+
+// Lpack (per emulator, PACK_STRIDE doubles): [c*64 + q] = L_kk[q][c] (q >= c), [4096 + c] = 1/L_kk[c][c].
+// Written by potf2, read by the panel TRSM through wave-uniform SCALAR loads (s_load_*), so the
+// TRSM's 2016 broadcast operands per row come through the scalar cache into SGPRs and cost no LDS
+// or vector-memory bandwidth at all.
+constexpr int PACK_STRIDE = 64 * 64 + 64;
+
+__global__ __launch_bounds__(64) void potf2_kernel(BatchView v, int c0, int* __restrict__ info, double* __restrict__ Lpack) {
   const int emu = slot_emu(v.idx, blockIdx.x);
-  double* A = v.A + (size_t)emu * v.NP * v.NP + (size_t)c0 * v.NP + c0;
   const int ld = v.NP;
-  const int t = threadIdx.x;
-  for (int e = t; e < 64 * 64; e += 256) {
-    const int r = e >> 6, c = e & 63;
-    S[r][c] = A[(size_t)r * ld + c];
+  double* A = v.A + (size_t)emu * ld * ld + (size_t)c0 * ld + c0;
+  double* pack = Lpack + (size_t)emu * PACK_STRIDE;
+  const int lane = threadIdx.x;
+  double* arow = A + (size_t)lane * ld;
+  double a[64];
+#pragma unroll
+  for (int q = 0; q < 32; ++q) {
+    const v2d w = *reinterpret_cast<const v2d*>(arow + 2 * q);
+    a[2 * q] = w[0];
+    a[2 * q + 1] = w[1];
   }
-  if (t == 0) fail = 0;
-  __syncthreads();
+  int fail = 0;
+  double myrs = 1.0;
+#pragma unroll
   for (int j = 0; j < 64; ++j) {
-    double d = S[j][j];
-    if (!(d > 0.0)) {           // also catches NaN
-      if (t == 0 && fail == 0) fail = j + 1;
+    double d = readlane_f64(a[j], j);
+    if (!(d > 0.0) || !(d < 1e308)) {   // wave-uniform; catches <= 0, NaN and Inf
+      if (fail == 0) fail = j + 1;
       d = 1.0;
     }
-    const double dj = sqrt(d);
-    __syncthreads();            // everyone has read S[j][j]
-    if (t > j && t < 64) S[t][j] = S[t][j] / dj;
-    if (t == j) S[j][j] = dj;
-    __syncthreads();
-    // rank-1 update of the trailing lower triangle: (r, c) with r >= c > j
-    const int m = 63 - j;       // trailing size
-    for (int e = t; e < m * m; e += 256) {
-      const int r = j + 1 + e / m, c = j + 1 + e % m;
-      if (c <= r) S[r][c] -= S[r][j] * S[c][j];
+    double rs, dj;
+    rsqrt_sqrt(d, rs, dj);
+    const double l = (lane == j) ? dj : a[j] * rs;
+    a[j] = l;
+    if (lane == j) myrs = rs;
+    // rank-1 update; l_c is broadcast from lane c with v_readlane (SGPR operand of the FMA)
+#pragma unroll
+    for (int c = j + 1; c < 64; ++c) a[c] = __builtin_fma(-l, readlane_f64(l, c), a[c]);
+  }
+#pragma unroll
+  for (int c = 0; c < 64; ++c)
+    if (c <= lane) {
+      arow[c] = a[c];
+      pack[c * 64 + lane] = a[c];       // column c of L, coalesced across lanes
     }
-    __syncthreads();
-  }
-  for (int e = t; e < 64 * 64; e += 256) {
-    const int r = e >> 6, c = e & 63;
-    if (c <= r) A[(size_t)r * ld + c] = S[r][c];
-  }
-  if (t == 0 && fail != 0 && info[emu] == 0) info[emu] = c0 + fail;
+  pack[4096 + lane] = myrs;
+  if (lane == 0 && fail != 0 && info[emu] == 0) info[emu] = c0 + fail;
 }
 
 // ---------------------------------------------------------------------------------------------
-// Forward substitution with a 64x64 lower-triangular block held in LDS (row-major, ld 64):
-//   solve  Lb * x = rhs  with x, rhs in registers (fully unrolled, broadcast LDS reads).
-// Used per matrix row by the panel TRSM (x L^T = a  <=>  L x^T = a^T) and per unit vector by the
-// triangular-inverse leaf.
+// Panel TRSM: rows [r0, NP) of the column block [c0, c0+64):  X * L_kk^T = A_panel, one thread per
+// row, right-looking (column oriented) substitution so the 63-c updates of step c are independent
+// FMAs; L_kk^T and the reciprocal diagonal (as optimised BLAS trsm kernels use) arrive as scalar
+// operands from Lpack.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void forward_subst_64(const double* __restrict__ Lb, double (&x)[64]) {
-#pragma unroll
-  for (int c = 0; c < 64; ++c) {
-    double s = x[c];
-#pragma unroll
-    for (int p = 0; p < c; ++p) s = __builtin_fma(-x[p], Lb[c * 64 + p], s);
-    x[c] = s / Lb[c * 64 + c];
-  }
-}
-
-// rows [r0, NP) of the column block [c0, c0+64):  X * L_kk^T = A_panel, one thread per row.
-__global__ __launch_bounds__(256) void trsm_kernel(BatchView v, int c0, int r0) {
-  __shared__ __attribute__((aligned(16))) double Lb[64 * 64];
+// The 2016 broadcast operands per row come from an LDS copy of Lpack and are read as 16-byte
+// aligned pairs (ds_read_b128: half the LDS cycles of ds_read2_b64, which is what bounds this
+// kernel: 8 waves per CU each re-read the whole block).  SMEM operands were tried and lost: scalar
+// loads return out of order, so every batch waits lgkmcnt(0) and exposes a full L2 round trip.
+__global__ __launch_bounds__(256) void trsm_kernel(BatchView v, int c0, int r0, const double* __restrict__ Lpack) {
+  __shared__ __attribute__((aligned(16))) double LT[PACK_STRIDE];
   const int emu = slot_emu(v.idx, blockIdx.y);
   const int ld = v.NP;
   double* A = v.A + (size_t)emu * ld * ld;
-  const int t = threadIdx.x;
-  for (int e = t; e < 64 * 64; e += 256) {
-    const int r = e >> 6, c = e & 63;
-    Lb[e] = (c <= r) ? A[(size_t)(c0 + r) * ld + c0 + c] : 0.0;
-  }
+  const v2d* src = reinterpret_cast<const v2d*>(Lpack + (size_t)emu * PACK_STRIDE);
+  for (int e = threadIdx.x; e < PACK_STRIDE / 2; e += 256) reinterpret_cast<v2d*>(LT)[e] = src[e];
   __syncthreads();
-  const int row = r0 + blockIdx.x * 256 + t;
+  const int row = r0 + blockIdx.x * 256 + threadIdx.x;
   if (row >= v.NP) return;
   double* arow = A + (size_t)row * ld + c0;
   double x[64];
@@ -94,7 +119,17 @@ __global__ __launch_bounds__(256) void trsm_kernel(BatchView v, int c0, int r0) 
     x[2 * q] = w[0];
     x[2 * q + 1] = w[1];
   }
-  forward_subst_64(Lb, x);
+#pragma unroll
+  for (int c = 0; c < 64; ++c) {
+    x[c] *= LT[4096 + c];
+    const double xc = x[c];
+#pragma unroll
+    for (int q0 = (c + 1) & ~1; q0 < 64; q0 += 2) {
+      const v2d lv = *reinterpret_cast<const v2d*>(LT + c * 64 + q0);
+      if (q0 > c) x[q0] = __builtin_fma(-xc, lv[0], x[q0]);
+      x[q0 + 1] = __builtin_fma(-xc, lv[1], x[q0 + 1]);
+    }
+  }
 #pragma unroll
   for (int q = 0; q < 32; ++q) {
     v2d w;
@@ -135,65 +170,82 @@ __global__ __launch_bounds__(256) void logdet_kernel(BatchView v, double* __rest
 }
 
 // ---------------------------------------------------------------------------------------------
-// alpha = L^-T y, blocked right-looking back substitution, one workgroup per emulator.
+// alpha = L^-T y, blocked right-looking back substitution, one 512-thread workgroup per emulator.
 //   for kb = last .. 0:  alpha_kb = L_kk^-T w_kb ;  w[0:k0] -= L[kb rows, 0:k0]^T alpha_kb
+// The 64x64 transposed solve runs in wave 0 with lane i holding column i of L_kk in registers
+// (= row i of U = L_kk^T): per step one multiply by the reciprocal diagonal, one v_readlane
+// broadcast and one FMA per lane, no LDS and no division on the dependent chain.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void backsolve_kernel(BatchView v) {
-  __shared__ double Lb[64][65];
+constexpr int BS_THREADS = 512;
+
+__global__ __launch_bounds__(BS_THREADS) void backsolve_kernel(BatchView v) {
   __shared__ double ab[64];
   const int emu = slot_emu(v.idx, blockIdx.x);
   const int ld = v.NP, n = v.n;
   const double* A = v.A + (size_t)emu * ld * ld;
   double* w = v.alpha + (size_t)emu * ld;
   const int t = threadIdx.x;
-  for (int i = t; i < ld; i += 256) w[i] = (i < n) ? A[(size_t)n * ld + i] : 0.0;
+  for (int i = t; i < ld; i += BS_THREADS) w[i] = (i < n) ? A[(size_t)n * ld + i] : 0.0;
   __syncthreads();
   const int nblk = (n + 63) / 64;
   for (int kb = nblk - 1; kb >= 0; --kb) {
     const int k0 = kb * 64;
-    for (int e = t; e < 64 * 64; e += 256) {
-      const int r = e >> 6, c = e & 63;
-      Lb[r][c] = A[(size_t)(k0 + r) * ld + k0 + c];
-    }
-    if (t < 64) ab[t] = w[k0 + t];
-    __syncthreads();
-    // transposed triangular solve inside the block (rows >= n of the block are identity padding,
-    // except row n which holds y: it must not take part)
     if (t < 64) {
+      double u[64];
+#pragma unroll
+      for (int j = 0; j < 64; ++j) u[j] = A[(size_t)(k0 + j) * ld + k0 + t];     // u[j] = L[k0+j][k0+t], coalesced in t
+      const double rdg = 1.0 / A[(size_t)(k0 + t) * ld + k0 + t];
+      double b = w[k0 + t];
+      double xout = 0.0;
+#pragma unroll
       for (int j = 63; j >= 0; --j) {
-        // lane j finalises, the others subtract
-        double aj = ab[j] / Lb[j][j];
-        if (k0 + j >= n) aj = 0.0;
-        if (t == j) ab[j] = aj;
-        if (t < j) ab[t] -= Lb[j][t] * aj;      // L^T[t][j] = L[j][t]
-        __builtin_amdgcn_wave_barrier();
+        double xj = readlane_f64(b * rdg, j);
+        if (k0 + j >= n) xj = 0.0;            // identity padding and the y row take no part
+        if (t == j) xout = xj;
+        b = __builtin_fma(-u[j], xj, b);      // only lanes < j use it afterwards
       }
+      ab[t] = xout;
+      w[k0 + t] = xout;
     }
     __syncthreads();
-    if (t < 64) w[k0 + t] = ab[t];
-    // w[c] -= sum_r L[k0+r][c] alpha[k0+r], c < k0 : each thread owns columns, rows are contiguous
-    for (int c = t; c < k0; c += 256) {
-      double s = 0.;
-#pragma unroll 8
-      for (int r = 0; r < 64; ++r) s = __builtin_fma(A[(size_t)(k0 + r) * ld + c], ab[r], s);
-      w[c] -= s;
+    // w[c] -= sum_r L[k0+r][c] alpha[k0+r], c < k0: threads own column pairs, rows are contiguous
+    for (int c = 2 * t; c < k0; c += 2 * BS_THREADS) {
+      v2d s = {0., 0.};
+      const double* p = A + (size_t)k0 * ld + c;
+#pragma unroll 16
+      for (int r = 0; r < 64; ++r) {
+        const v2d x = *reinterpret_cast<const v2d*>(p + (size_t)r * ld);
+        const double ar = ab[r];
+        s[0] = __builtin_fma(x[0], ar, s[0]);
+        s[1] = __builtin_fma(x[1], ar, s[1]);
+      }
+      v2d cur = *reinterpret_cast<v2d*>(w + c);
+      cur[0] -= s[0];
+      cur[1] -= s[1];
+      *reinterpret_cast<v2d*>(w + c) = cur;
     }
     __syncthreads();
   }
 }
 
-// alpha = Linv^T y  (used when Linv is already available): alpha_i = sum_{k>=i, k<n} Linv[k][i] y_k
+// alpha = Linv^T y (fit+gradient path, Linv already available): alpha_i = sum_{i<=k<n} Linv[k][i] y_k.
+// One workgroup per 64-column strip; the 4 waves split the k range, rows are 512-byte coalesced reads.
 __global__ __launch_bounds__(256) void alpha_linv_kernel(BatchView v) {
+  __shared__ double red[4][64];
   const int emu = slot_emu(v.idx, blockIdx.y);
   const int ld = v.NP, n = v.n;
   const double* Li = v.Linv + (size_t)emu * ld * ld;
   const double* y = v.A + (size_t)emu * ld * ld + (size_t)n * ld;
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= ld) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i0 = blockIdx.x * 64, i = i0 + lane;
   double s = 0.;
-  if (i < n)
-    for (int k = i; k < n; ++k) s = __builtin_fma(Li[(size_t)k * ld + i], y[k], s);
-  v.alpha[(size_t)emu * ld + i] = s;
+  if (i0 < n) {
+#pragma unroll 8
+    for (int k = i0 + wave; k < n; k += 4) s = __builtin_fma(Li[(size_t)k * ld + i], y[k], s);   // Linv[k][i] = 0 for k < i
+  }
+  red[wave][lane] = s;
+  __syncthreads();
+  if (wave == 0) v.alpha[(size_t)emu * ld + i] = (i < n) ? red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane] : 0.0;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -201,23 +253,28 @@ __global__ __launch_bounds__(256) void alpha_linv_kernel(BatchView v) {
 // Also zeroes the block to the right inside the same 128-tile so that 128-granular consumers can
 // treat diagonal tiles of Linv as dense.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void trtri_leaf_kernel(BatchView v) {
-  __shared__ __attribute__((aligned(16))) double Lb[64 * 64];
-  const int emu = slot_emu(v.idx, blockIdx.y);
+__global__ __launch_bounds__(64) void trtri_leaf_kernel(BatchView v, const double* __restrict__ Lmat) {
+  const int emu = __builtin_amdgcn_readfirstlane(slot_emu(v.idx, blockIdx.y));
   const int ld = v.NP;
   const int d0 = blockIdx.x * 64;
-  const double* L = v.A + (size_t)emu * ld * ld;
+  const double* __restrict__ L = Lmat + (size_t)emu * ld * ld + (size_t)d0 * ld + d0;   // wave-uniform: scalar loads
   double* Li = v.Linv + (size_t)emu * ld * ld;
   const int t = threadIdx.x;
-  for (int e = t; e < 64 * 64; e += 64) {
-    const int r = e >> 6, c = e & 63;
-    Lb[e] = (c <= r) ? L[(size_t)(d0 + r) * ld + d0 + c] : 0.0;
-  }
-  __syncthreads();
+  // lane t computes column t of the inverse: L z = e_t, row-oriented with 4 partial sums
   double x[64];
 #pragma unroll
-  for (int i = 0; i < 64; ++i) x[i] = (i == t) ? 1.0 : 0.0;
-  forward_subst_64(Lb, x);
+  for (int c = 0; c < 64; ++c) {
+    double s0 = (c == t) ? 1.0 : 0.0, s1 = 0., s2 = 0., s3 = 0.;
+#pragma unroll
+    for (int p = 0; p < c; ++p) {
+      const double lv = L[(size_t)c * ld + p];
+      if ((p & 3) == 0) s0 = __builtin_fma(-x[p], lv, s0);
+      else if ((p & 3) == 1) s1 = __builtin_fma(-x[p], lv, s1);
+      else if ((p & 3) == 2) s2 = __builtin_fma(-x[p], lv, s2);
+      else s3 = __builtin_fma(-x[p], lv, s3);
+    }
+    x[c] = ((s0 + s1) + (s2 + s3)) / L[(size_t)c * ld + c];
+  }
 #pragma unroll
   for (int i = 0; i < 64; ++i) Li[(size_t)(d0 + i) * ld + d0 + t] = x[i];
   if ((blockIdx.x & 1) == 0 && d0 + 64 < ld) {
@@ -239,32 +296,34 @@ __global__ void extract_kernel(const double* __restrict__ src, int NP, int n, do
 }
 
 // =============================================================================================
-void launch_potf2(const BatchView& v, int c0, int* info, hipStream_t s) {
-  hipLaunchKernelGGL(potf2_kernel, dim3(v.nb), dim3(256), 0, s, v, c0, info);
+void launch_potf2(const BatchView& v, int c0, int* info, double* Lpack, hipStream_t s) {
+  hipLaunchKernelGGL(potf2_kernel, dim3(v.nb), dim3(64), 0, s, v, c0, info, Lpack);
 }
 
-void launch_trsm(const BatchView& v, int c0, int r0, hipStream_t s) {
+void launch_trsm(const BatchView& v, int c0, int r0, const double* Lpack, hipStream_t s) {
   const int rows = v.NP - r0;
   if (rows <= 0) return;
-  hipLaunchKernelGGL(trsm_kernel, dim3((rows + 255) / 256, v.nb), dim3(256), 0, s, v, c0, r0);
+  hipLaunchKernelGGL(trsm_kernel, dim3((rows + 255) / 256, v.nb), dim3(256), 0, s, v, c0, r0, Lpack);
 }
+
+size_t lpack_doubles_per_emulator() { return PACK_STRIDE; }
 
 void launch_logdet(const BatchView& v, double* logdet, double* yty, hipStream_t s) {
   hipLaunchKernelGGL(logdet_kernel, dim3(v.nb), dim3(256), 0, s, v, logdet, yty);
 }
 
 void launch_backsolve(const BatchView& v, hipStream_t s) {
-  hipLaunchKernelGGL(backsolve_kernel, dim3(v.nb), dim3(256), 0, s, v);
+  hipLaunchKernelGGL(backsolve_kernel, dim3(v.nb), dim3(BS_THREADS), 0, s, v);
 }
 
 void launch_alpha_from_linv(const BatchView& v, hipStream_t s) {
-  hipLaunchKernelGGL(alpha_linv_kernel, dim3((v.NP + 255) / 256, v.nb), dim3(256), 0, s, v);
+  hipLaunchKernelGGL(alpha_linv_kernel, dim3(v.NP / 64, v.nb), dim3(256), 0, s, v);
 }
 
 void launch_trtri_merges(const BatchView& v, hipStream_t s);   // kernels_gemm.hip
 
 void launch_trtri(const BatchView& v, hipStream_t s) {
-  hipLaunchKernelGGL(trtri_leaf_kernel, dim3(v.NP / 64, v.nb), dim3(64), 0, s, v);
+  hipLaunchKernelGGL(trtri_leaf_kernel, dim3(v.NP / 64, v.nb), dim3(64), 0, s, v, (const double*)v.A);
   launch_trtri_merges(v, s);
 }
 

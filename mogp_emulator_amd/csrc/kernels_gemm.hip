@@ -320,6 +320,13 @@ void launch_update_narrow(const BatchView& v, int c0, int k0, int k1, hipStream_
   hipLaunchKernelGGL((update_kernel<2, false>), dim3(padded_grid(v.nb, nt)), dim3(256), smem_bytes<2>(), s, v, c0, k0, k1, nt, nt);
 }
 
+// one 128-wide block column [c0, c0+128), rows [c0, NP) (inner update of the recursive panel)
+void launch_update_wide(const BatchView& v, int c0, int k0, int k1, hipStream_t s) {
+  const int nt = (v.NP - c0) / 128;
+  if (nt <= 0) return;
+  hipLaunchKernelGGL((update_kernel<4, false>), dim3(padded_grid(v.nb, nt)), dim3(256), smem_bytes<4>(), s, v, c0, k0, k1, nt, nt);
+}
+
 void launch_update_trailing(const BatchView& v, int c0, int k0, int k1, hipStream_t s) {
   const int nt = (v.NP - c0) / 128;
   if (nt <= 0) return;

@@ -17,7 +17,8 @@
 
 namespace mogp {
 
-constexpr int TILE = 128;       // outer Cholesky block / MFMA macro tile
+constexpr int TILE = 128;       // MFMA macro tile / padding granule
+constexpr int OUTER = 256;      // outer Cholesky block = K depth of the trailing update
 constexpr int NBI = 64;         // inner panel width (potf2 / trsm / trtri leaf)
 constexpr double PAD_BIG = 1e300;
 
@@ -42,11 +43,14 @@ void launch_cov_full(const BatchView& v, int emu, double* out, hipStream_t s);
 
 // --- blocked Cholesky ---------------------------------------------------------------------
 // potf2 of the 64x64 diagonal block at c0; info[emu] = first failing (1-based) column or 0
-void launch_potf2(const BatchView& v, int c0, int* info, hipStream_t s);
+void launch_potf2(const BatchView& v, int c0, int* info, double* Lpack, hipStream_t s);
+size_t lpack_doubles_per_emulator();   // scratch written by potf2, read by trsm
 // rows [r0, NP) of column block [c0, c0+64): X L_kk^T = A
-void launch_trsm(const BatchView& v, int c0, int r0, hipStream_t s);
+void launch_trsm(const BatchView& v, int c0, int r0, const double* Lpack, hipStream_t s);
 // C[i,j] -= sum_{k in [k0,k1)} A[i,k] A[j,k] for the 64-wide column block [c0,c0+64), rows [c0, NP)
 void launch_update_narrow(const BatchView& v, int c0, int k0, int k1, hipStream_t s);
+// same for a 128-wide column block (MFMA 128x128 tiles)
+void launch_update_wide(const BatchView& v, int c0, int k0, int k1, hipStream_t s);
 // trailing lower-triangular update, rows/cols [c0, NP), k in [k0,k1) (c0 multiple of 128)
 void launch_update_trailing(const BatchView& v, int c0, int k0, int k1, hipStream_t s);
 // logdet[emu] = 2 sum_{i<n} log L_ii ; yty[emu] = sum_{c<n} L[n,c]^2

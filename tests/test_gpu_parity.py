@@ -427,6 +427,7 @@ def test_c2_full_size_vs_oracle_and_identities():
     assert resid < 1e-12
     assert np.abs(K @ mo.emulators[5].Kinv_t + eta * mo.emulators[5].Kinv_t - T[5]).max() < 1e-8
     # batching is invisible: an emulator inside the batch equals the same emulator alone, bit for bit
+    mo.fit(np.tile(theta, (8, 1)))               # same code path (fit: alpha by back substitution) on both sides
     solo = make_gp(X, T[2], nugget=eta); solo.fit(theta)
     assert solo.current_logpost == mo.emulators[2].current_logpost
     assert np.array_equal(solo.Kinv_t, mo.emulators[2].Kinv_t)
