@@ -157,7 +157,7 @@ def main():
 
     # per-kernel device times from HIP events on the launch stream
     kern = {}
-    for tag, bound in (("syrk_trailing", "mfma"), ("trtri_merge", "mfma"), ("kinv", "mfma"), ("predict_var", "mfma"),
+    for tag, bound in (("update_wide", "mfma"), ("syrk_trailing", "mfma"), ("trtri_merge", "mfma"), ("kinv", "mfma"), ("predict_var", "mfma"),
                        ("cov_build", "hbm"), ("cross_cov", "hbm"), ("grad_reduce", "hbm")):
         ms, cnt, fl, by = ctypes.c_double(), ctypes.c_longlong(), ctypes.c_double(), ctypes.c_double()
         if lib.mogp_profile_get(tag.encode(), ctypes.byref(ms), ctypes.byref(cnt), ctypes.byref(fl), ctypes.byref(by)) == 0 and cnt.value:

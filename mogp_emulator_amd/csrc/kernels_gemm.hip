@@ -324,7 +324,11 @@ void launch_update_narrow(const BatchView& v, int c0, int k0, int k1, hipStream_
 void launch_update_wide(const BatchView& v, int c0, int k0, int k1, hipStream_t s) {
   const int nt = (v.NP - c0) / 128;
   if (nt <= 0) return;
+  const double m = (double)(v.NP - c0);
+  prof_begin("update_wide", s);
   hipLaunchKernelGGL((update_kernel<4, false>), dim3(padded_grid(v.nb, nt)), dim3(256), smem_bytes<4>(), s, v, c0, k0, k1, nt, nt);
+  // algorithmic flops of the block-column update (lower part): (m*128 - 128*128/2) * 2 * K / 2 ... count m*128*K*2 minus the upper half of the diagonal tile
+  prof_end("update_wide", s, (double)v.nb * (m * 128.0 - 128.0 * 128.0 / 2.0) * 2.0 * (k1 - k0), (double)v.nb * (16.0 * m * 128.0 + 8.0 * (m + 128.0) * (k1 - k0)));
 }
 
 void launch_update_trailing(const BatchView& v, int c0, int k0, int k1, hipStream_t s) {
