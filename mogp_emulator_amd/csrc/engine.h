@@ -69,6 +69,9 @@ class Engine {
   hipStream_t stream = nullptr;      // main stream: covariance build, trailing updates, everything else
   hipStream_t pstream = nullptr;     // look-ahead stream: panel factorisations
   std::vector<hipEvent_t> evPanel, evUpd;
+  std::vector<hipStream_t> gstreams;  // extra streams for independent emulator groups
+  hipEvent_t evReady = nullptr;
+  hipEvent_t evGroup[15] = {};
 
  private:
   void upload_params(const std::vector<int>& ids);

@@ -50,44 +50,86 @@ __device__ __forceinline__ void rsqrt_sqrt(double d, double& rs, double& sq) {
 constexpr int PACK_STRIDE = 64 * 64 + 64;
 
 __global__ __launch_bounds__(64) void potf2_kernel(BatchView v, int c0, int* __restrict__ info, double* __restrict__ Lpack) {
+  __shared__ __attribute__((aligned(16))) double colbuf[16][64];
   const int emu = slot_emu(v.idx, blockIdx.x);
   const int ld = v.NP;
   double* A = v.A + (size_t)emu * ld * ld + (size_t)c0 * ld + c0;
   double* pack = Lpack + (size_t)emu * PACK_STRIDE;
   const int lane = threadIdx.x;
-  double* arow = A + (size_t)lane * ld;
+  // coalesced block I/O: 2 full 512-byte rows per load instruction into an LDS image (row stride 65
+  // doubles), from which every lane takes its own row; a lane-per-row global access would touch 64
+  // different cache lines per instruction (and 64 partial lines per 8-byte store on the way out).
+  __shared__ double blk[64 * 65];
+  {
+    const int half = lane >> 5, part = lane & 31;
+#pragma unroll 8
+    for (int q = 0; q < 32; ++q) {
+      const int r = 2 * q + half;
+      const v2d w = *reinterpret_cast<const v2d*>(A + (size_t)r * ld + 2 * part);
+      blk[r * 65 + 2 * part] = w[0];
+      blk[r * 65 + 2 * part + 1] = w[1];
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
   double a[64];
 #pragma unroll
-  for (int q = 0; q < 32; ++q) {
-    const v2d w = *reinterpret_cast<const v2d*>(arow + 2 * q);
-    a[2 * q] = w[0];
-    a[2 * q + 1] = w[1];
-  }
+  for (int c = 0; c < 64; ++c) a[c] = blk[lane * 65 + c];
+  __builtin_amdgcn_wave_barrier();
   int fail = 0;
   double myrs = 1.0;
+  // 4 block steps of 16 columns: inside a block the pivots / multipliers travel by v_readlane
+  // (at most 15 per column); the rank-16 update of all later columns takes its broadcast operands
+  // from an 8 KB LDS image of the 16 finished columns as aligned ds_read_b128 pairs.
 #pragma unroll
-  for (int j = 0; j < 64; ++j) {
-    double d = readlane_f64(a[j], j);
-    if (!(d > 0.0) || !(d < 1e308)) {   // wave-uniform; catches <= 0, NaN and Inf
-      if (fail == 0) fail = j + 1;
-      d = 1.0;
+  for (int jb = 0; jb < 4; ++jb) {
+#pragma unroll
+    for (int jl = 0; jl < 16; ++jl) {
+      const int j = jb * 16 + jl;
+      double d = readlane_f64(a[j], j);
+      if (!(d > 0.0) || !(d < 1e308)) {   // wave-uniform; catches <= 0, NaN and Inf
+        if (fail == 0) fail = j + 1;
+        d = 1.0;
+      }
+      double rs, dj;
+      rsqrt_sqrt(d, rs, dj);
+      const double l = (lane == j) ? dj : a[j] * rs;
+      a[j] = l;
+      if (lane == j) myrs = rs;
+      colbuf[jl][lane] = l;
+#pragma unroll
+      for (int c = j + 1; c < jb * 16 + 16; ++c) a[c] = __builtin_fma(-l, readlane_f64(l, c), a[c]);
     }
-    double rs, dj;
-    rsqrt_sqrt(d, rs, dj);
-    const double l = (lane == j) ? dj : a[j] * rs;
-    a[j] = l;
-    if (lane == j) myrs = rs;
-    // rank-1 update; l_c is broadcast from lane c with v_readlane (SGPR operand of the FMA)
+    __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int c = j + 1; c < 64; ++c) a[c] = __builtin_fma(-l, readlane_f64(l, c), a[c]);
+    for (int c = jb * 16 + 16; c < 64; c += 2) {
+#pragma unroll
+      for (int jl = 0; jl < 16; ++jl) {
+        const v2d lc = *reinterpret_cast<const v2d*>(&colbuf[jl][c]);
+        a[c] = __builtin_fma(-a[jb * 16 + jl], lc[0], a[c]);
+        a[c + 1] = __builtin_fma(-a[jb * 16 + jl], lc[1], a[c + 1]);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
   }
 #pragma unroll
-  for (int c = 0; c < 64; ++c)
-    if (c <= lane) {
-      arow[c] = a[c];
-      pack[c * 64 + lane] = a[c];       // column c of L, coalesced across lanes
-    }
+  for (int c = 0; c < 64; ++c) {
+    const double x = (c <= lane) ? a[c] : 0.0;      // upper triangle of the block is written as zeros
+    blk[lane * 65 + c] = x;
+    if (c <= lane) pack[c * 64 + lane] = x;           // column c of L, coalesced across lanes
+  }
   pack[4096 + lane] = myrs;
+  __builtin_amdgcn_wave_barrier();
+  {
+    const int half = lane >> 5, part = lane & 31;
+#pragma unroll 8
+    for (int q = 0; q < 32; ++q) {
+      const int r = 2 * q + half;
+      v2d w;
+      w[0] = blk[r * 65 + 2 * part];
+      w[1] = blk[r * 65 + 2 * part + 1];
+      *reinterpret_cast<v2d*>(A + (size_t)r * ld + 2 * part) = w;
+    }
+  }
   if (lane == 0 && fail != 0 && info[emu] == 0) info[emu] = c0 + fail;
 }
 
@@ -101,15 +143,18 @@ __global__ __launch_bounds__(64) void potf2_kernel(BatchView v, int c0, int* __r
 // aligned pairs (ds_read_b128: half the LDS cycles of ds_read2_b64, which is what bounds this
 // kernel: 8 waves per CU each re-read the whole block).  SMEM operands were tried and lost: scalar
 // loads return out of order, so every batch waits lgkmcnt(0) and exposes a full L2 round trip.
-__global__ __launch_bounds__(256) void trsm_kernel(BatchView v, int c0, int r0, const double* __restrict__ Lpack) {
+constexpr int TRSM_THREADS = 256;   // one row per thread (two rows per thread spill: 2 x 64 doubles + operands > 256 VGPRs)
+constexpr int TRSM_ROWS = TRSM_THREADS;
+
+__global__ __launch_bounds__(TRSM_THREADS) void trsm_kernel(BatchView v, int c0, int r0, const double* __restrict__ Lpack) {
   __shared__ __attribute__((aligned(16))) double LT[PACK_STRIDE];
   const int emu = slot_emu(v.idx, blockIdx.y);
   const int ld = v.NP;
   double* A = v.A + (size_t)emu * ld * ld;
   const v2d* src = reinterpret_cast<const v2d*>(Lpack + (size_t)emu * PACK_STRIDE);
-  for (int e = threadIdx.x; e < PACK_STRIDE / 2; e += 256) reinterpret_cast<v2d*>(LT)[e] = src[e];
+  for (int e = threadIdx.x; e < PACK_STRIDE / 2; e += TRSM_THREADS) reinterpret_cast<v2d*>(LT)[e] = src[e];
   __syncthreads();
-  const int row = r0 + blockIdx.x * 256 + threadIdx.x;
+  const int row = r0 + blockIdx.x * TRSM_ROWS + threadIdx.x;
   if (row >= v.NP) return;
   double* arow = A + (size_t)row * ld + c0;
   double x[64];
@@ -176,7 +221,7 @@ __global__ __launch_bounds__(256) void logdet_kernel(BatchView v, double* __rest
 // (= row i of U = L_kk^T): per step one multiply by the reciprocal diagonal, one v_readlane
 // broadcast and one FMA per lane, no LDS and no division on the dependent chain.
 // ---------------------------------------------------------------------------------------------
-constexpr int BS_THREADS = 512;
+constexpr int BS_THREADS = 512;   // 1024 threads measured 2x slower: the kernel is bound by one CU's ~25 GB/s streaming rate
 
 __global__ __launch_bounds__(BS_THREADS) void backsolve_kernel(BatchView v) {
   __shared__ double ab[64];
@@ -303,7 +348,7 @@ void launch_potf2(const BatchView& v, int c0, int* info, double* Lpack, hipStrea
 void launch_trsm(const BatchView& v, int c0, int r0, const double* Lpack, hipStream_t s) {
   const int rows = v.NP - r0;
   if (rows <= 0) return;
-  hipLaunchKernelGGL(trsm_kernel, dim3((rows + 255) / 256, v.nb), dim3(256), 0, s, v, c0, r0, Lpack);
+  hipLaunchKernelGGL(trsm_kernel, dim3((rows + TRSM_ROWS - 1) / TRSM_ROWS, v.nb), dim3(TRSM_THREADS), 0, s, v, c0, r0, Lpack);
 }
 
 size_t lpack_doubles_per_emulator() { return PACK_STRIDE; }
