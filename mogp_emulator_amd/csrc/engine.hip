@@ -257,6 +257,7 @@ void Engine::factorize(const std::vector<int>& ids, std::vector<int>& info) {
     // ROCm 7.2: kernels of different streams do not overlap usefully here (2 groups -6 %, 4 groups
     // 2.7x slower), so the default is ONE in-order launch sequence and overlap is sought inside kernels.
     static const long tail_threshold = [] { const char* e = getenv("MOGP_TAIL"); return e ? atol(e) : 1100L; }();
+    static const bool fuse_potf2 = [] { const char* e = getenv("MOGP_FUSE_POTF2"); return e && e[0] == '1'; }();
     static const int want_groups = [] { const char* e = getenv("MOGP_GROUPS"); return e ? std::max(1, atoi(e)) : 1; }();
     int G = std::min(want_groups, std::max(1, nb / 8));
     while ((int)gstreams.size() < G - 1) {
@@ -284,6 +285,17 @@ void Engine::factorize(const std::vector<int>& ids, std::vector<int>& info) {
           const long tiles128 = (long)gv[g].nb * ((NP - o) / TILE);
           if (tiles128 >= tail_threshold) launch_update_wide(gv[g], o, 0, o, gs[g]);
           else {
+            if (fuse_potf2) {
+              // experiment (MOGP_FUSE_POTF2=1): the diagonal tile's workgroup factors D1 / D2 itself.  Measured
+              // SLOWER (7.5 -> 8.0..8.5 ms): the potf2 wave's 128+ live VGPRs set the register allocation of the
+              // whole update kernel (86 -> 168/255), costing a resident workgroup per CU or spilling.
+              launch_update_narrow_potf2(gv[g], o, 0, o, dInfo, dLpack, gs[g]);          // + potf2(o)
+              launch_update_narrow(gv[g], o + NBI, 0, o, gs[g]);
+              launch_trsm(gv[g], o, o + NBI, dLpack, gs[g]);
+              launch_update_narrow_potf2(gv[g], o + NBI, o, o + NBI, dInfo, dLpack, gs[g]);   // + potf2(o+64)
+              launch_trsm(gv[g], o + NBI, o + TILE, dLpack, gs[g]);
+              continue;
+            }
             launch_update_narrow(gv[g], o, 0, o, gs[g]);
             launch_update_narrow(gv[g], o + NBI, 0, o, gs[g]);
           }

@@ -7,6 +7,7 @@
 // dtrsm.  A pivot that is not > 0 (or is NaN) marks the emulator as failed (info = 1-based
 // column), which is what drives the adaptive-nugget ladder (linalg/cholesky.py:234-281).
 #include "launch.h"
+#include "potf2_dev.h"
 
 namespace mogp {
 
@@ -20,117 +21,25 @@ __device__ __forceinline__ int slot_emu(const int* idx, int z) { return idx ? id
 // is broadcast with v_readlane, the scaled column goes through a 512-byte LDS line and is re-read
 // by every lane as broadcast operands of the rank-1 update (63-j independent FMAs per lane).
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ double readlane_f64(double x, int srclane) {
-  int lo = __double2loint(x), hi = __double2hiint(x);
-  lo = __builtin_amdgcn_readlane(lo, srclane);
-  hi = __builtin_amdgcn_readlane(hi, srclane);
-  return __hiloint2double(hi, lo);
-}
-
-// 1/sqrt(d) and sqrt(d) by v_rsq_f64 + two coupled Goldschmidt steps (about six dependent FMAs)
-// instead of a correctly rounded sqrt followed by a divide (two long dependent sequences) on the
-// critical path of every column.  Result error <= ~2 ulp, i.e. backward-stable like LAPACK's.
-__device__ __forceinline__ void rsqrt_sqrt(double d, double& rs, double& sq) {
-  const double r0 = __builtin_amdgcn_rsq(d);
-  double g = d * r0, h = 0.5 * r0;
-  double e = __builtin_fma(-g, h, 0.5);
-  g = __builtin_fma(g, e, g);
-  h = __builtin_fma(h, e, h);
-  e = __builtin_fma(-g, h, 0.5);
-  g = __builtin_fma(g, e, g);
-  h = __builtin_fma(h, e, h);
-  rs = h + h;
-  sq = g;
-}
-
-// Lpack (per emulator, PACK_STRIDE doubles): [c*64 + q] = L_kk[q][c] (q >= c), [4096 + c] = 1/L_kk[c][c].
-// Written by potf2, read by the panel TRSM through wave-uniform SCALAR loads (s_load_*), so the
-// TRSM's 2016 broadcast operands per row come through the scalar cache into SGPRs and cost no LDS
-// or vector-memory bandwidth at all.
-constexpr int PACK_STRIDE = 64 * 64 + 64;
-
 __global__ __launch_bounds__(64) void potf2_kernel(BatchView v, int c0, int* __restrict__ info, double* __restrict__ Lpack) {
-  __shared__ __attribute__((aligned(16))) double colbuf[16][64];
+  __shared__ __attribute__((aligned(16))) double lds[POTF2_LDS_DOUBLES];
   const int emu = slot_emu(v.idx, blockIdx.x);
   const int ld = v.NP;
   double* A = v.A + (size_t)emu * ld * ld + (size_t)c0 * ld + c0;
-  double* pack = Lpack + (size_t)emu * PACK_STRIDE;
   const int lane = threadIdx.x;
-  // coalesced block I/O: 2 full 512-byte rows per load instruction into an LDS image (row stride 65
-  // doubles), from which every lane takes its own row; a lane-per-row global access would touch 64
-  // different cache lines per instruction (and 64 partial lines per 8-byte store on the way out).
-  __shared__ double blk[64 * 65];
+  // coalesced block load: 2 full 512-byte rows per load instruction into the LDS image
   {
     const int half = lane >> 5, part = lane & 31;
 #pragma unroll 8
     for (int q = 0; q < 32; ++q) {
       const int r = 2 * q + half;
       const v2d w = *reinterpret_cast<const v2d*>(A + (size_t)r * ld + 2 * part);
-      blk[r * 65 + 2 * part] = w[0];
-      blk[r * 65 + 2 * part + 1] = w[1];
+      lds[r * 65 + 2 * part] = w[0];
+      lds[r * 65 + 2 * part + 1] = w[1];
     }
   }
   __builtin_amdgcn_wave_barrier();
-  double a[64];
-#pragma unroll
-  for (int c = 0; c < 64; ++c) a[c] = blk[lane * 65 + c];
-  __builtin_amdgcn_wave_barrier();
-  int fail = 0;
-  double myrs = 1.0;
-  // 4 block steps of 16 columns: inside a block the pivots / multipliers travel by v_readlane
-  // (at most 15 per column); the rank-16 update of all later columns takes its broadcast operands
-  // from an 8 KB LDS image of the 16 finished columns as aligned ds_read_b128 pairs.
-#pragma unroll
-  for (int jb = 0; jb < 4; ++jb) {
-#pragma unroll
-    for (int jl = 0; jl < 16; ++jl) {
-      const int j = jb * 16 + jl;
-      double d = readlane_f64(a[j], j);
-      if (!(d > 0.0) || !(d < 1e308)) {   // wave-uniform; catches <= 0, NaN and Inf
-        if (fail == 0) fail = j + 1;
-        d = 1.0;
-      }
-      double rs, dj;
-      rsqrt_sqrt(d, rs, dj);
-      const double l = (lane == j) ? dj : a[j] * rs;
-      a[j] = l;
-      if (lane == j) myrs = rs;
-      colbuf[jl][lane] = l;
-#pragma unroll
-      for (int c = j + 1; c < jb * 16 + 16; ++c) a[c] = __builtin_fma(-l, readlane_f64(l, c), a[c]);
-    }
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int c = jb * 16 + 16; c < 64; c += 2) {
-#pragma unroll
-      for (int jl = 0; jl < 16; ++jl) {
-        const v2d lc = *reinterpret_cast<const v2d*>(&colbuf[jl][c]);
-        a[c] = __builtin_fma(-a[jb * 16 + jl], lc[0], a[c]);
-        a[c + 1] = __builtin_fma(-a[jb * 16 + jl], lc[1], a[c + 1]);
-      }
-    }
-    __builtin_amdgcn_wave_barrier();
-  }
-#pragma unroll
-  for (int c = 0; c < 64; ++c) {
-    const double x = (c <= lane) ? a[c] : 0.0;      // upper triangle of the block is written as zeros
-    blk[lane * 65 + c] = x;
-    if (c <= lane) pack[c * 64 + lane] = x;           // column c of L, coalesced across lanes
-  }
-  pack[4096 + lane] = myrs;
-  __builtin_amdgcn_wave_barrier();
-  {
-    const int half = lane >> 5, part = lane & 31;
-#pragma unroll 8
-    for (int q = 0; q < 32; ++q) {
-      const int r = 2 * q + half;
-      v2d w;
-      w[0] = blk[r * 65 + 2 * part];
-      w[1] = blk[r * 65 + 2 * part + 1];
-      *reinterpret_cast<v2d*>(A + (size_t)r * ld + 2 * part) = w;
-    }
-  }
-  if (lane == 0 && fail != 0 && info[emu] == 0) info[emu] = c0 + fail;
+  potf2_wave(lds, lds + 64 * 65, A, ld, Lpack + (size_t)emu * PACK_STRIDE, info + emu, c0);
 }
 
 // ---------------------------------------------------------------------------------------------

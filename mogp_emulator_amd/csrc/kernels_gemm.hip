@@ -19,7 +19,10 @@
 // Reference operations these kernels replace (as a group): cusolverDnDpotrf's trailing updates
 // (densegp_gpu.hpp:451-474), the explicit inverse via potrs (densegp_gpu.hpp:576-582) and the
 // predictive-variance gemm + batched dot (densegp_gpu.hpp:374-396).
+#include <algorithm>
+#include <cstdlib>
 #include "launch.h"
+#include "potf2_dev.h"
 
 namespace mogp {
 
@@ -166,8 +169,9 @@ __device__ __forceinline__ void decode_block(int nb, int ntiles, int& z, int& ti
 //   TRI = true : lower-triangular tile set over rows/cols [c0, NP)  (WT = 4)
 //   TRI = false: single tile column [c0, c0+BM), rows [c0, NP)     (WT = 2, "narrow" update)
 // ---------------------------------------------------------------------------------------------
-template <int WT, bool TRI>
-__global__ __launch_bounds__(256, 2) void update_kernel(BatchView v, int c0, int k0, int k1, int nt, int ntiles) {
+template <int WT, bool TRI, bool FUSE>
+__global__ __launch_bounds__(256, (FUSE ? 3 : 2)) void update_kernel(BatchView v, int c0, int k0, int k1, int nt, int ntiles, int* __restrict__ info,
+                                                        double* __restrict__ Lpack) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   using C = Cfg<WT>;
   int z, tile;
@@ -190,10 +194,20 @@ __global__ __launch_bounds__(256, 2) void update_kernel(BatchView v, int c0, int
   const int i0 = c0 + ti * C::BM, j0 = c0 + tj * C::BM;
   v4d acc[WT][WT];
   gemm_mainloop<WT, true, true>(A + (size_t)i0 * ld + k0, ld, A + (size_t)j0 * ld + k0, ld, (k1 - k0) / BK, acc, smem);
+  // FUSE (64x64 tiles only): the workgroup that owns the diagonal tile keeps its updated block in LDS
+  // and one of its waves factors it right away (potf2), hidden under the rest of this launch.
+  const bool fuse_tile = FUSE && WT == 2 && tile == 0;
   for_each_acc<WT>(acc, [&](int r, int c, double x) {
     double* p = A + (size_t)(i0 + r) * ld + (j0 + c);
-    *p = *p - x;
+    const double nv = *p - x;
+    *p = nv;
+    if (fuse_tile) smem[r * 65 + c] = nv;
   });
+  if (fuse_tile) {
+    __syncthreads();
+    if (threadIdx.x < 64)
+      potf2_wave(smem, smem + 64 * 65, A + (size_t)i0 * ld + j0, ld, Lpack + (size_t)emu * PACK_STRIDE, info + emu, c0);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -211,7 +225,16 @@ __global__ __launch_bounds__(256, 2) void trtri_merge_kernel(BatchView v, int h,
   const int base = blockIdx.y * 2 * h;
   if (base + h >= v.NP) return;
   const int m2 = min(h, v.NP - base - h);
-  const int ti = blockIdx.x / tiles_per_dim, tj = blockIdx.x % tiles_per_dim;
+  // longest-K tiles are dispatched first (STEP 0: K = h - j0 -> small tj first; STEP 1: K = i0 + BM ->
+  // large ti first) so the tail of the launch is made of short tiles
+  int ti, tj;
+  if (STEP == 0) {
+    tj = blockIdx.x / tiles_per_dim;
+    ti = blockIdx.x % tiles_per_dim;
+  } else {
+    ti = tiles_per_dim - 1 - (int)(blockIdx.x / tiles_per_dim);
+    tj = blockIdx.x % tiles_per_dim;
+  }
   const int i0 = ti * C::BM, j0 = tj * C::BM;          // node-local
   if (i0 >= m2) return;
   const double* L = v.A + (size_t)emu * ld * ld;
@@ -317,7 +340,19 @@ static int padded_grid(int nb, int ntiles) { return ((nb & 7) == 0) ? nb * ntile
 void launch_update_narrow(const BatchView& v, int c0, int k0, int k1, hipStream_t s) {
   const int nt = (v.NP - c0) / 64;
   if (nt <= 0) return;
-  hipLaunchKernelGGL((update_kernel<2, false>), dim3(padded_grid(v.nb, nt)), dim3(256), smem_bytes<2>(), s, v, c0, k0, k1, nt, nt);
+  hipLaunchKernelGGL((update_kernel<2, false, false>), dim3(padded_grid(v.nb, nt)), dim3(256), smem_bytes<2>(), s, v, c0, k0, k1, nt, nt, (int*)nullptr,
+                     (double*)nullptr);
+}
+
+// 64-wide block-column update whose diagonal-tile workgroup also factors the 64x64 block at (c0, c0)
+void launch_update_narrow_potf2(const BatchView& v, int c0, int k0, int k1, int* info, double* Lpack, hipStream_t s) {
+  const int nt = (v.NP - c0) / 64;
+  if (nt <= 0) return;
+  const size_t sm = std::max(smem_bytes<2>(), (size_t)POTF2_LDS_DOUBLES * sizeof(double));
+  const double m = (double)(v.NP - c0);
+  prof_begin("update_wide", s);
+  hipLaunchKernelGGL((update_kernel<2, false, true>), dim3(padded_grid(v.nb, nt)), dim3(256), sm, s, v, c0, k0, k1, nt, nt, info, Lpack);
+  prof_end("update_wide", s, (double)v.nb * (m * 64.0 - 64.0 * 64.0 / 2.0) * 2.0 * (k1 - k0), 0.);
 }
 
 // one 128-wide block column [c0, c0+128), rows [c0, NP) (inner update of the recursive panel)
@@ -326,7 +361,8 @@ void launch_update_wide(const BatchView& v, int c0, int k0, int k1, hipStream_t 
   if (nt <= 0) return;
   const double m = (double)(v.NP - c0);
   prof_begin("update_wide", s);
-  hipLaunchKernelGGL((update_kernel<4, false>), dim3(padded_grid(v.nb, nt)), dim3(256), smem_bytes<4>(), s, v, c0, k0, k1, nt, nt);
+  hipLaunchKernelGGL((update_kernel<4, false, false>), dim3(padded_grid(v.nb, nt)), dim3(256), smem_bytes<4>(), s, v, c0, k0, k1, nt, nt, (int*)nullptr,
+                     (double*)nullptr);
   // algorithmic flops of the block-column update (lower part): (m*128 - 128*128/2) * 2 * K / 2 ... count m*128*K*2 minus the upper half of the diagonal tile
   prof_end("update_wide", s, (double)v.nb * (m * 128.0 - 128.0 * 128.0 / 2.0) * 2.0 * (k1 - k0), (double)v.nb * (16.0 * m * 128.0 + 8.0 * (m + 128.0) * (k1 - k0)));
 }
@@ -337,23 +373,29 @@ void launch_update_trailing(const BatchView& v, int c0, int k0, int k1, hipStrea
   const int ntiles = nt * (nt + 1) / 2;
   const double m = (double)(v.NP - c0);
   prof_begin("syrk_trailing", s);
-  hipLaunchKernelGGL((update_kernel<4, true>), dim3(padded_grid(v.nb, ntiles)), dim3(256), smem_bytes<4>(), s, v, c0, k0, k1, nt, ntiles);
+  hipLaunchKernelGGL((update_kernel<4, true, false>), dim3(padded_grid(v.nb, ntiles)), dim3(256), smem_bytes<4>(), s, v, c0, k0, k1, nt, ntiles,
+                     (int*)nullptr, (double*)nullptr);
   // algorithmic: lower half of an m x m rank-(k1-k0) update = m^2 (k1-k0) flops; bytes: read+write C lower half + panel
   prof_end("syrk_trailing", s, (double)v.nb * m * m * (k1 - k0), (double)v.nb * (8.0 * m * m + 8.0 * m * (k1 - k0)));
 }
 
 void launch_trtri_merges(const BatchView& v, hipStream_t s) {
+  static const int wt = [] { const char* e = getenv("MOGP_TRTRI_WT"); return e ? atoi(e) : 2; }();
   for (int h = 64; h < v.NP; h *= 2) {
     const int nodes = (v.NP + 2 * h - 1) / (2 * h);
-    if (h == 64) {
-      hipLaunchKernelGGL((trtri_merge_kernel<2, 0>), dim3(1, nodes, v.nb), dim3(256), smem_bytes<2>(), s, v, h, 1);
-      hipLaunchKernelGGL((trtri_merge_kernel<2, 1>), dim3(1, nodes, v.nb), dim3(256), smem_bytes<2>(), s, v, h, 1);
+    if (h == 64 || wt == 2) {
+      const int tpd = h / 64;
+      if (h > 64) prof_begin("trtri_merge", s);
+      hipLaunchKernelGGL((trtri_merge_kernel<2, 0>), dim3(tpd * tpd, nodes, v.nb), dim3(256), smem_bytes<2>(), s, v, h, tpd);
+      hipLaunchKernelGGL((trtri_merge_kernel<2, 1>), dim3(tpd * tpd, nodes, v.nb), dim3(256), smem_bytes<2>(), s, v, h, tpd);
+      if (h > 64) prof_end("trtri_merge", s, (double)v.nb * nodes * 2.0 * h * h * h / 2.0, 0.);
     } else {
       const int tpd = h / 128;
       prof_begin("trtri_merge", s);
       hipLaunchKernelGGL((trtri_merge_kernel<4, 0>), dim3(tpd * tpd, nodes, v.nb), dim3(256), smem_bytes<4>(), s, v, h, tpd);
       hipLaunchKernelGGL((trtri_merge_kernel<4, 1>), dim3(tpd * tpd, nodes, v.nb), dim3(256), smem_bytes<4>(), s, v, h, tpd);
-      prof_end("trtri_merge", s, (double)v.nb * nodes * 2.0 * h * h * h, 0.);
+      // algorithmic flops: two triangular-times-square products of size h per node = 2 * h^3 / 2 * 2 flops... = 2 h^3
+      prof_end("trtri_merge", s, (double)v.nb * nodes * 2.0 * h * h * h / 2.0, 0.);
     }
   }
 }

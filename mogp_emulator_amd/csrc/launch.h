@@ -49,6 +49,8 @@ size_t lpack_doubles_per_emulator();   // scratch written by potf2, read by trsm
 void launch_trsm(const BatchView& v, int c0, int r0, const double* Lpack, hipStream_t s);
 // C[i,j] -= sum_{k in [k0,k1)} A[i,k] A[j,k] for the 64-wide column block [c0,c0+64), rows [c0, NP)
 void launch_update_narrow(const BatchView& v, int c0, int k0, int k1, hipStream_t s);
+// same, and the diagonal-tile workgroup then factors the 64x64 block at (c0,c0) (fused potf2)
+void launch_update_narrow_potf2(const BatchView& v, int c0, int k0, int k1, int* info, double* Lpack, hipStream_t s);
 // same for a 128-wide column block (MFMA 128x128 tiles)
 void launch_update_wide(const BatchView& v, int c0, int k0, int k1, hipStream_t s);
 // trailing lower-triangular update, rows/cols [c0, NP), k in [k0,k1) (c0 multiple of 128)
