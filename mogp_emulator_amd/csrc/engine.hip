@@ -246,12 +246,15 @@ void Engine::factorize(const std::vector<int>& ids, std::vector<int>& info) {
   HIPCK(hipMemsetAsync(dInfo, 0, B * sizeof(int), stream));
   launch_cov_build(v, stream);
   // schedule: 0 = left-looking (default), 2 = left-looking + two-stream look-ahead split, 1 = right-looking + look-ahead
-  static const int schedule = [] {
+  static const int forced = [] {
     const char* e = getenv("MOGP_CHOL");
-    if (!e) return 0;
+    if (!e) return -1;
     if (e[0] == 'r') return 1;
     return (std::string(e) == "leftla") ? 2 : 0;
   }();
+  // Left-looking needs enough tiles per block column to fill 256 CUs (many emulators, C2/C3/C4);
+  // a single large matrix (C5) has thousands of trailing tiles per step instead -> right-looking.
+  const int schedule = forced >= 0 ? forced : (((long)nb * (NP / TILE) >= 512) ? 0 : 1);
   if (schedule == 0) {
     // Optional independent emulator groups on separate streams (MOGP_GROUPS).  Measured on MI355X /
     // ROCm 7.2: kernels of different streams do not overlap usefully here (2 groups -6 %, 4 groups

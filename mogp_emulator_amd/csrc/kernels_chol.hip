@@ -6,6 +6,7 @@
 // (no inverted diagonal blocks), i.e. the same backward-stable recurrence as LAPACK dpotrf /
 // dtrsm.  A pivot that is not > 0 (or is NaN) marks the emulator as failed (info = 1-based
 // column), which is what drives the adaptive-nugget ladder (linalg/cholesky.py:234-281).
+#include <cstdlib>
 #include "launch.h"
 #include "potf2_dev.h"
 
@@ -52,9 +53,9 @@ __global__ __launch_bounds__(64) void potf2_kernel(BatchView v, int c0, int* __r
 // aligned pairs (ds_read_b128: half the LDS cycles of ds_read2_b64, which is what bounds this
 // kernel: 8 waves per CU each re-read the whole block).  SMEM operands were tried and lost: scalar
 // loads return out of order, so every batch waits lgkmcnt(0) and exposes a full L2 round trip.
-constexpr int TRSM_THREADS = 256;   // one row per thread (two rows per thread spill: 2 x 64 doubles + operands > 256 VGPRs)
-constexpr int TRSM_ROWS = TRSM_THREADS;
-
+// one row per thread (two rows per thread spill: 2 x 64 doubles + operands > 256 VGPRs);
+// TRSM_THREADS = 256 for big batches, 64 when a launch would otherwise have < 256 workgroups (single large matrix)
+template <int TRSM_THREADS>
 __global__ __launch_bounds__(TRSM_THREADS) void trsm_kernel(BatchView v, int c0, int r0, const double* __restrict__ Lpack) {
   __shared__ __attribute__((aligned(16))) double LT[PACK_STRIDE];
   const int emu = slot_emu(v.idx, blockIdx.y);
@@ -63,7 +64,7 @@ __global__ __launch_bounds__(TRSM_THREADS) void trsm_kernel(BatchView v, int c0,
   const v2d* src = reinterpret_cast<const v2d*>(Lpack + (size_t)emu * PACK_STRIDE);
   for (int e = threadIdx.x; e < PACK_STRIDE / 2; e += TRSM_THREADS) reinterpret_cast<v2d*>(LT)[e] = src[e];
   __syncthreads();
-  const int row = r0 + blockIdx.x * TRSM_ROWS + threadIdx.x;
+  const int row = r0 + blockIdx.x * TRSM_THREADS + threadIdx.x;
   if (row >= v.NP) return;
   double* arow = A + (size_t)row * ld + c0;
   double x[64];
@@ -182,6 +183,66 @@ __global__ __launch_bounds__(BS_THREADS) void backsolve_kernel(BatchView v) {
   }
 }
 
+// Multi-launch variant of the back substitution: per 64-row block one tiny diagonal-solve launch
+// (one wave per emulator) and one gemv launch spread over as many workgroups as there are column
+// chunks.  The single-workgroup kernel above is bound by ONE CU's streaming rate (~25 GB/s: 0.7 ms at
+// n=2000, 40 ms at n=16000); here all CUs stream L.
+__global__ __launch_bounds__(256) void backsolve_init_kernel(BatchView v) {
+  const int emu = slot_emu(v.idx, blockIdx.y);
+  const int ld = v.NP, n = v.n;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < ld) v.alpha[(size_t)emu * ld + i] = (i < n) ? v.A[(size_t)emu * ld * ld + (size_t)n * ld + i] : 0.0;
+}
+
+__global__ __launch_bounds__(64) void backsolve_diag_kernel(BatchView v, int k0) {
+  const int emu = slot_emu(v.idx, blockIdx.x);
+  const int ld = v.NP, n = v.n;
+  const double* A = v.A + (size_t)emu * ld * ld;
+  double* w = v.alpha + (size_t)emu * ld;
+  const int t = threadIdx.x;
+  double u[64];
+#pragma unroll
+  for (int j = 0; j < 64; ++j) u[j] = A[(size_t)(k0 + j) * ld + k0 + t];
+  const double rdg = 1.0 / A[(size_t)(k0 + t) * ld + k0 + t];
+  double b = w[k0 + t];
+  double xout = 0.0;
+#pragma unroll
+  for (int j = 63; j >= 0; --j) {
+    double xj = readlane_f64(b * rdg, j);
+    if (k0 + j >= n) xj = 0.0;
+    if (t == j) xout = xj;
+    b = __builtin_fma(-u[j], xj, b);
+  }
+  w[k0 + t] = xout;
+}
+
+// w[c] -= sum_r L[k0+r][c] alpha[k0+r] for c < k0; one column pair per thread
+constexpr int BSG_THREADS = 64;     // small workgroups: at n=16000, B=1 a 256-thread version has only 32 workgroups in flight
+__global__ __launch_bounds__(BSG_THREADS) void backsolve_gemv_kernel(BatchView v, int k0) {
+  __shared__ double ab[64];
+  const int emu = slot_emu(v.idx, blockIdx.y);
+  const int ld = v.NP;
+  const double* A = v.A + (size_t)emu * ld * ld;
+  double* w = v.alpha + (size_t)emu * ld;
+  if (threadIdx.x < 64) ab[threadIdx.x] = w[k0 + threadIdx.x];
+  __syncthreads();
+  const int c = 2 * (blockIdx.x * BSG_THREADS + threadIdx.x);
+  if (c >= k0) return;
+  v2d s = {0., 0.};
+  const double* p = A + (size_t)k0 * ld + c;
+#pragma unroll 32
+  for (int r = 0; r < 64; ++r) {
+    const v2d x = *reinterpret_cast<const v2d*>(p + (size_t)r * ld);
+    const double ar = ab[r];
+    s[0] = __builtin_fma(x[0], ar, s[0]);
+    s[1] = __builtin_fma(x[1], ar, s[1]);
+  }
+  v2d cur = *reinterpret_cast<v2d*>(w + c);
+  cur[0] -= s[0];
+  cur[1] -= s[1];
+  *reinterpret_cast<v2d*>(w + c) = cur;
+}
+
 // alpha = Linv^T y (fit+gradient path, Linv already available): alpha_i = sum_{i<=k<n} Linv[k][i] y_k.
 // One workgroup per 64-column strip; the 4 waves split the k range, rows are 512-byte coalesced reads.
 __global__ __launch_bounds__(256) void alpha_linv_kernel(BatchView v) {
@@ -257,7 +318,10 @@ void launch_potf2(const BatchView& v, int c0, int* info, double* Lpack, hipStrea
 void launch_trsm(const BatchView& v, int c0, int r0, const double* Lpack, hipStream_t s) {
   const int rows = v.NP - r0;
   if (rows <= 0) return;
-  hipLaunchKernelGGL(trsm_kernel, dim3((rows + TRSM_ROWS - 1) / TRSM_ROWS, v.nb), dim3(TRSM_THREADS), 0, s, v, c0, r0, Lpack);
+  if ((long)v.nb * ((rows + 255) / 256) >= 256)
+    hipLaunchKernelGGL(trsm_kernel<256>, dim3((rows + 255) / 256, v.nb), dim3(256), 0, s, v, c0, r0, Lpack);
+  else
+    hipLaunchKernelGGL(trsm_kernel<64>, dim3((rows + 63) / 64, v.nb), dim3(64), 0, s, v, c0, r0, Lpack);
 }
 
 size_t lpack_doubles_per_emulator() { return PACK_STRIDE; }
@@ -267,7 +331,18 @@ void launch_logdet(const BatchView& v, double* logdet, double* yty, hipStream_t 
 }
 
 void launch_backsolve(const BatchView& v, hipStream_t s) {
-  hipLaunchKernelGGL(backsolve_kernel, dim3(v.nb), dim3(BS_THREADS), 0, s, v);
+  static const int mode = [] { const char* e = getenv("MOGP_BACKSOLVE"); return e ? atoi(e) : 1; }();   // 0: one workgroup per emulator
+  if (mode == 0) {
+    hipLaunchKernelGGL(backsolve_kernel, dim3(v.nb), dim3(BS_THREADS), 0, s, v);
+    return;
+  }
+  hipLaunchKernelGGL(backsolve_init_kernel, dim3((v.NP + 255) / 256, v.nb), dim3(256), 0, s, v);
+  const int nblk = (v.n + 63) / 64;
+  for (int kb = nblk - 1; kb >= 0; --kb) {
+    const int k0 = kb * 64;
+    hipLaunchKernelGGL(backsolve_diag_kernel, dim3(v.nb), dim3(64), 0, s, v, k0);
+    if (k0 > 0) hipLaunchKernelGGL(backsolve_gemv_kernel, dim3((k0 / 2 + BSG_THREADS - 1) / BSG_THREADS, v.nb), dim3(BSG_THREADS), 0, s, v, k0);
+  }
 }
 
 void launch_alpha_from_linv(const BatchView& v, hipStream_t s) {

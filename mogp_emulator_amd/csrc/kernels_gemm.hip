@@ -287,11 +287,17 @@ __global__ __launch_bounds__(256, 2) void predict_var_kernel(BatchView v, const 
                                                            double* __restrict__ partial) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   using C = Cfg<4>;
+  // L2 blocking: the tiles of an emulator are walked in 8x8 super-tiles (64 workgroups = one XCD's
+  // resident set), so the 8 Linv row panels and the 8 K* panels of a super-tile are each fetched from
+  // HBM once and re-used 8 times out of the 4 MiB L2 while the 64 workgroups sweep k together.
+  // (Row-major tile order streamed every K* panel from HBM once per row tile: ~47 GB per launch.)
+  const int nsj = (ntj + 7) / 8, nsi = (nti + 7) / 8;
   int z, tile;
-  decode_block(v.nb, nti * ntj, z, tile);
+  decode_block(v.nb, nsi * nsj * 64, z, tile);
   if (z >= v.nb) return;
-  // tj fastest: neighbouring blocks share the Linv row panel
-  const int ti = tile / ntj, tj = tile % ntj;
+  const int st = tile >> 6, w = tile & 63;
+  const int ti = (st / nsj) * 8 + (w >> 3), tj = (st % nsj) * 8 + (w & 7);
+  if (ti >= nti || tj >= ntj) return;
   const int emu = slot_to_emu(v.idx, z);
   const int ld = v.NP;
   const double* Li = v.Linv + (size_t)emu * ld * ld;
@@ -412,7 +418,8 @@ void launch_kinv(const BatchView& v, hipStream_t s) {
 void launch_predict_var(const BatchView& v, const double* Ks, int m, int MP, double* partial, double* var, int var_ld, hipStream_t s) {
   const int nti = (v.n + 127) / 128, ntj = MP / 128;
   prof_begin("predict_var", s);
-  hipLaunchKernelGGL(predict_var_kernel, dim3(padded_grid(v.nb, nti * ntj)), dim3(256), smem_bytes<4>(), s, v, Ks, MP, nti, ntj, partial);
+  const int nsup = ((nti + 7) / 8) * ((ntj + 7) / 8) * 64;
+  hipLaunchKernelGGL(predict_var_kernel, dim3(padded_grid(v.nb, nsup)), dim3(256), smem_bytes<4>(), s, v, Ks, MP, nti, ntj, partial);
   prof_end("predict_var", s, (double)v.nb * (double)m * v.n * v.n, 0.);
   hipLaunchKernelGGL(predict_var_finish_kernel, dim3((m + 255) / 256, v.nb), dim3(256), 0, s, v, partial, m, MP, nti, var, var_ld);
 }
