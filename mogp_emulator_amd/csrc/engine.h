@@ -34,7 +34,8 @@ class Engine {
   ~Engine();
   Engine(const Engine&) = delete;
 
-  int n, D, NP, PS, B, kernel_type;
+  int n, D, NP, LD, PS, B, kernel_type;
+  size_t MS;
   unsigned testing_size;
   MeanFunc mean;
   std::vector<GPState> gp;

@@ -116,6 +116,14 @@ Engine::Engine(const double* X, int n_, int D_, const double* targets, int B_, u
   for (int d : mean.dims)
     if (d >= D) throw std::runtime_error("Dimension index must be less than " + std::to_string(D));
   NP = roundup(n + 1, TILE);
+  // Row stride.  A non-power-of-two stride (NP + 16) was tried against L2 set aliasing of the
+  // 16 KiB-strided tile rows and measured SLOWER on MI355X (fit 7.5 -> 8.2 ms, fit+grad 15.3 -> 16.2 ms),
+  // so the default pad is 0; MOGP_LDPAD (even) re-enables it for experiments.
+  {
+    const char* e = getenv("MOGP_LDPAD");
+    LD = NP + (e ? (atoi(e) & ~1) : 0);
+  }
+  MS = (size_t)NP * LD;
   PS = D + 2;
   hX.assign(X, X + (size_t)n * D);
   hT.assign(targets, targets + (size_t)B * n);
@@ -137,8 +145,8 @@ Engine::Engine(const double* X, int n_, int D_, const double* targets, int B_, u
   dX = dalloc<double>((size_t)n * D);
   dP = dalloc<double>((size_t)B * PS);
   dT = dalloc<double>((size_t)B * n);
-  dA = dalloc<double>((size_t)B * NP * NP);
-  dAlpha = dalloc<double>((size_t)B * NP);
+  dA = dalloc<double>((size_t)B * MS);
+  dAlpha = dalloc<double>((size_t)B * LD);
   dLogdet = dalloc<double>(B);
   dYty = dalloc<double>(B);
   dInfo = dalloc<int>(B);
@@ -176,7 +184,7 @@ double Engine::nugget_size(int i) const {
 
 BatchView Engine::view(int nb) const {
   BatchView v;
-  v.n = n; v.D = D; v.NP = NP; v.PS = PS; v.kernel_type = kernel_type;
+  v.n = n; v.D = D; v.NP = NP; v.LD = LD; v.MS = MS; v.PS = PS; v.kernel_type = kernel_type;
   v.X = dX; v.P = dP; v.T = dT; v.A = dA; v.Linv = dLinv; v.Kinv = dKinv; v.alpha = dAlpha;
   v.idx = dIdx; v.nb = nb;
   return v;
@@ -514,8 +522,8 @@ void Engine::ensure_linv(const std::vector<int>& ids) {
   }
   if (need.empty()) return;
   if (!dLinv) {
-    dLinv = dalloc<double>((size_t)B * NP * NP);
-    dKinv = dalloc<double>((size_t)B * NP * NP);
+    dLinv = dalloc<double>((size_t)B * MS);
+    dKinv = dalloc<double>((size_t)B * MS);
     dGradOut = dalloc<double>((size_t)B * (D + 3));
     dGradPartial = dalloc<double>((size_t)B * grad_num_tiles(n) * (D + 3));
   }
@@ -565,7 +573,7 @@ void Engine::grad_current(const std::vector<int>& ids, double* grad, int grad_ld
     if (nm > 0) {
       // densegp_gpu.hpp:734-747: -(d mean / d beta)^T alpha
       std::vector<double> a(n), md((size_t)nm * n);
-      HIPCK(hipMemcpy(a.data(), dAlpha + (size_t)i * NP, n * sizeof(double), hipMemcpyDeviceToHost));
+      HIPCK(hipMemcpy(a.data(), dAlpha + (size_t)i * LD, n * sizeof(double), hipMemcpyDeviceToHost));
       mean.mean_deriv(hX.data(), n, D, g.meanp.data(), nm, md.data());
       for (int p = 0; p < nm; ++p) {
         double s = 0.;
@@ -577,7 +585,7 @@ void Engine::grad_current(const std::vector<int>& ids, double* grad, int grad_ld
 }
 
 void Engine::ensure_predict_scratch(int nb, int MC) {
-  grow(dKs, capKs, (size_t)nb * MC * NP);
+  grow(dKs, capKs, (size_t)nb * MC * LD);
   grow(dVarPartial, capVarPartial, (size_t)nb * ((n + 127) / 128) * MC);
 }
 
@@ -606,7 +614,7 @@ void Engine::predict(const std::vector<int>& ids, const double* Xs, int m, bool 
     ld = m;
   }
   const int MPtot = roundup(m, 128);
-  long MC = (long)(6.0e9 / ((double)nb * NP * 8.0)) / 128 * 128;
+  long MC = (long)(6.0e9 / ((double)nb * LD * 8.0)) / 128 * 128;
   MC = std::max<long>(128, std::min<long>(MC, MPtot));
   if (vars) ensure_predict_scratch(nb, (int)MC);
   for (int c0 = 0; c0 < m; c0 += (int)MC) {
@@ -666,7 +674,7 @@ void Engine::get_invQ(int i, double* out) {
   std::vector<int> ids{i};
   ensure_kinv(ids);
   double* tmp = dalloc<double>((size_t)n * n);
-  launch_extract(dKinv + (size_t)i * NP * NP, NP, n, tmp, 2, stream);
+  launch_extract(dKinv + (size_t)i * MS, LD, n, tmp, 2, stream);
   HIPCK(hipMemcpyAsync(out, tmp, (size_t)n * n * sizeof(double), hipMemcpyDeviceToHost, stream));
   HIPCK(hipStreamSynchronize(stream));
   hipFree(tmp);
@@ -674,13 +682,13 @@ void Engine::get_invQ(int i, double* out) {
 
 void Engine::get_invQt(int i, double* out) {
   if (!gp[i].factored) throw std::runtime_error("emulator has not been fit");
-  HIPCK(hipMemcpy(out, dAlpha + (size_t)i * NP, n * sizeof(double), hipMemcpyDeviceToHost));
+  HIPCK(hipMemcpy(out, dAlpha + (size_t)i * LD, n * sizeof(double), hipMemcpyDeviceToHost));
 }
 
 void Engine::get_chol(int i, double* out) {
   if (!gp[i].factored) throw std::runtime_error("emulator has not been fit");
   double* tmp = dalloc<double>((size_t)n * n);
-  launch_extract(dA + (size_t)i * NP * NP, NP, n, tmp, 1, stream);
+  launch_extract(dA + (size_t)i * MS, LD, n, tmp, 1, stream);
   HIPCK(hipMemcpyAsync(out, tmp, (size_t)n * n * sizeof(double), hipMemcpyDeviceToHost, stream));
   HIPCK(hipStreamSynchronize(stream));
   hipFree(tmp);

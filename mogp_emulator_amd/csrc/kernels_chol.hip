@@ -25,8 +25,8 @@ __device__ __forceinline__ int slot_emu(const int* idx, int z) { return idx ? id
 __global__ __launch_bounds__(64) void potf2_kernel(BatchView v, int c0, int* __restrict__ info, double* __restrict__ Lpack) {
   __shared__ __attribute__((aligned(16))) double lds[POTF2_LDS_DOUBLES];
   const int emu = slot_emu(v.idx, blockIdx.x);
-  const int ld = v.NP;
-  double* A = v.A + (size_t)emu * ld * ld + (size_t)c0 * ld + c0;
+  const int ld = v.LD;
+  double* A = v.A + (size_t)emu * v.MS + (size_t)c0 * ld + c0;
   const int lane = threadIdx.x;
   // coalesced block load: 2 full 512-byte rows per load instruction into the LDS image
   {
@@ -59,8 +59,8 @@ template <int TRSM_THREADS>
 __global__ __launch_bounds__(TRSM_THREADS) void trsm_kernel(BatchView v, int c0, int r0, const double* __restrict__ Lpack) {
   __shared__ __attribute__((aligned(16))) double LT[PACK_STRIDE];
   const int emu = slot_emu(v.idx, blockIdx.y);
-  const int ld = v.NP;
-  double* A = v.A + (size_t)emu * ld * ld;
+  const int ld = v.LD;
+  double* A = v.A + (size_t)emu * v.MS;
   const v2d* src = reinterpret_cast<const v2d*>(Lpack + (size_t)emu * PACK_STRIDE);
   for (int e = threadIdx.x; e < PACK_STRIDE / 2; e += TRSM_THREADS) reinterpret_cast<v2d*>(LT)[e] = src[e];
   __syncthreads();
@@ -100,8 +100,8 @@ __global__ __launch_bounds__(TRSM_THREADS) void trsm_kernel(BatchView v, int c0,
 __global__ __launch_bounds__(256) void logdet_kernel(BatchView v, double* __restrict__ logdet, double* __restrict__ yty) {
   __shared__ double red[2][256];
   const int emu = slot_emu(v.idx, blockIdx.x);
-  const int ld = v.NP;
-  const double* A = v.A + (size_t)emu * ld * ld;
+  const int ld = v.LD;
+  const double* A = v.A + (size_t)emu * v.MS;
   double s = 0., q = 0.;
   for (int i = threadIdx.x; i < v.n; i += 256) {
     s += log(A[(size_t)i * ld + i]);
@@ -136,8 +136,8 @@ constexpr int BS_THREADS = 512;   // 1024 threads measured 2x slower: the kernel
 __global__ __launch_bounds__(BS_THREADS) void backsolve_kernel(BatchView v) {
   __shared__ double ab[64];
   const int emu = slot_emu(v.idx, blockIdx.x);
-  const int ld = v.NP, n = v.n;
-  const double* A = v.A + (size_t)emu * ld * ld;
+  const int ld = v.LD, n = v.n;
+  const double* A = v.A + (size_t)emu * v.MS;
   double* w = v.alpha + (size_t)emu * ld;
   const int t = threadIdx.x;
   for (int i = t; i < ld; i += BS_THREADS) w[i] = (i < n) ? A[(size_t)n * ld + i] : 0.0;
@@ -189,15 +189,15 @@ __global__ __launch_bounds__(BS_THREADS) void backsolve_kernel(BatchView v) {
 // n=2000, 40 ms at n=16000); here all CUs stream L.
 __global__ __launch_bounds__(256) void backsolve_init_kernel(BatchView v) {
   const int emu = slot_emu(v.idx, blockIdx.y);
-  const int ld = v.NP, n = v.n;
+  const int ld = v.LD, n = v.n;
   const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i < ld) v.alpha[(size_t)emu * ld + i] = (i < n) ? v.A[(size_t)emu * ld * ld + (size_t)n * ld + i] : 0.0;
+  if (i < ld) v.alpha[(size_t)emu * ld + i] = (i < n) ? v.A[(size_t)emu * v.MS + (size_t)n * ld + i] : 0.0;
 }
 
 __global__ __launch_bounds__(64) void backsolve_diag_kernel(BatchView v, int k0) {
   const int emu = slot_emu(v.idx, blockIdx.x);
-  const int ld = v.NP, n = v.n;
-  const double* A = v.A + (size_t)emu * ld * ld;
+  const int ld = v.LD, n = v.n;
+  const double* A = v.A + (size_t)emu * v.MS;
   double* w = v.alpha + (size_t)emu * ld;
   const int t = threadIdx.x;
   double u[64];
@@ -221,8 +221,8 @@ constexpr int BSG_THREADS = 64;     // small workgroups: at n=16000, B=1 a 256-t
 __global__ __launch_bounds__(BSG_THREADS) void backsolve_gemv_kernel(BatchView v, int k0) {
   __shared__ double ab[64];
   const int emu = slot_emu(v.idx, blockIdx.y);
-  const int ld = v.NP;
-  const double* A = v.A + (size_t)emu * ld * ld;
+  const int ld = v.LD;
+  const double* A = v.A + (size_t)emu * v.MS;
   double* w = v.alpha + (size_t)emu * ld;
   if (threadIdx.x < 64) ab[threadIdx.x] = w[k0 + threadIdx.x];
   __syncthreads();
@@ -248,9 +248,9 @@ __global__ __launch_bounds__(BSG_THREADS) void backsolve_gemv_kernel(BatchView v
 __global__ __launch_bounds__(256) void alpha_linv_kernel(BatchView v) {
   __shared__ double red[4][64];
   const int emu = slot_emu(v.idx, blockIdx.y);
-  const int ld = v.NP, n = v.n;
-  const double* Li = v.Linv + (size_t)emu * ld * ld;
-  const double* y = v.A + (size_t)emu * ld * ld + (size_t)n * ld;
+  const int ld = v.LD, n = v.n;
+  const double* Li = v.Linv + (size_t)emu * v.MS;
+  const double* y = v.A + (size_t)emu * v.MS + (size_t)n * ld;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i0 = blockIdx.x * 64, i = i0 + lane;
   double s = 0.;
@@ -270,10 +270,10 @@ __global__ __launch_bounds__(256) void alpha_linv_kernel(BatchView v) {
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void trtri_leaf_kernel(BatchView v, const double* __restrict__ Lmat) {
   const int emu = __builtin_amdgcn_readfirstlane(slot_emu(v.idx, blockIdx.y));
-  const int ld = v.NP;
+  const int ld = v.LD;
   const int d0 = blockIdx.x * 64;
-  const double* __restrict__ L = Lmat + (size_t)emu * ld * ld + (size_t)d0 * ld + d0;   // wave-uniform: scalar loads
-  double* Li = v.Linv + (size_t)emu * ld * ld;
+  const double* __restrict__ L = Lmat + (size_t)emu * v.MS + (size_t)d0 * ld + d0;   // wave-uniform: scalar loads
+  double* Li = v.Linv + (size_t)emu * v.MS;
   const int t = threadIdx.x;
   // lane t computes column t of the inverse: L z = e_t, row-oriented with 4 partial sums
   double x[64];

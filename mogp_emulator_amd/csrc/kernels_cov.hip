@@ -84,9 +84,9 @@ __global__ __launch_bounds__(256) void cov_build_kernel(BatchView v, int nt) {
   while ((ti + 1) * (ti + 2) / 2 <= tile) ++ti;
   const int tj = tile - ti * (ti + 1) / 2;
   const int i0 = ti * 64, j0 = tj * 64;
-  const int n = v.n, D = v.D, ld = v.NP;
+  const int n = v.n, D = v.D, ld = v.LD;
   const double* P = v.P + (size_t)emu * v.PS;
-  double* A = v.A + (size_t)emu * ld * ld;
+  double* A = v.A + (size_t)emu * v.MS;
   const double* T = v.T + (size_t)emu * n;
   double* si = sm;
   double* sj = sm + 64 * D;
@@ -156,7 +156,7 @@ __global__ __launch_bounds__(256) void cross_cov_mean_kernel(BatchView v, const 
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int z = blockIdx.y;
   const int emu = slot_emu2(v.idx, z);
-  const int n = v.n, D = v.D, ld = v.NP;
+  const int n = v.n, D = v.D, ld = v.LD;
   const int i0 = blockIdx.x * 64;
   const double* P = v.P + (size_t)emu * v.PS;
   const double* alpha = v.alpha + (size_t)emu * ld;
@@ -169,7 +169,7 @@ __global__ __launch_bounds__(256) void cross_cov_mean_kernel(BatchView v, const 
   const double sig2 = P[D];
   double macc[4] = {0., 0., 0., 0.};
   double* Kz = Ks ? Ks + (size_t)z * MP * ld : nullptr;
-  const int ntj = ld / 64;
+  const int ntj = v.NP / 64;
   for (int tj = 0; tj < ntj; ++tj) {
     const int j0 = tj * 64;
     __syncthreads();
@@ -220,7 +220,7 @@ __global__ __launch_bounds__(256) void predict_deriv_kernel(BatchView v, const d
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int z = blockIdx.y;
   const int emu = slot_emu2(v.idx, z);
-  const int n = v.n, D = v.D, ld = v.NP;
+  const int n = v.n, D = v.D, ld = v.LD;
   const int i0 = blockIdx.x * 64;
   const double* P = v.P + (size_t)emu * v.PS;
   const double* alpha = v.alpha + (size_t)emu * ld;
@@ -287,9 +287,9 @@ __global__ __launch_bounds__(256) void grad_kernel(BatchView v, int ntiles, doub
   while ((ti + 1) * (ti + 2) / 2 <= tile) ++ti;
   const int tj = tile - ti * (ti + 1) / 2;
   const int i0 = ti * 64, j0 = tj * 64;
-  const int n = v.n, D = v.D, ld = v.NP;
+  const int n = v.n, D = v.D, ld = v.LD;
   const double* P = v.P + (size_t)emu * v.PS;
-  const double* Ki = v.Kinv + (size_t)emu * ld * ld;
+  const double* Ki = v.Kinv + (size_t)emu * v.MS;
   const double* alpha = v.alpha + (size_t)emu * ld;
   double* si = sm;
   double* sj = sm + 64 * D;

@@ -189,8 +189,8 @@ __global__ __launch_bounds__(256, (FUSE ? 3 : 2)) void update_kernel(BatchView v
     tj = 0;
   }
   const int emu = slot_to_emu(v.idx, z);
-  double* A = v.A + (size_t)emu * v.NP * v.NP;
-  const int ld = v.NP;
+  double* A = v.A + (size_t)emu * v.MS;
+  const int ld = v.LD;
   const int i0 = c0 + ti * C::BM, j0 = c0 + tj * C::BM;
   v4d acc[WT][WT];
   gemm_mainloop<WT, true, true>(A + (size_t)i0 * ld + k0, ld, A + (size_t)j0 * ld + k0, ld, (k1 - k0) / BK, acc, smem);
@@ -221,7 +221,7 @@ __global__ __launch_bounds__(256, 2) void trtri_merge_kernel(BatchView v, int h,
   using C = Cfg<WT>;
   const int z = blockIdx.z;
   const int emu = slot_to_emu(v.idx, z);
-  const int ld = v.NP;
+  const int ld = v.LD;
   const int base = blockIdx.y * 2 * h;
   if (base + h >= v.NP) return;
   const int m2 = min(h, v.NP - base - h);
@@ -237,9 +237,9 @@ __global__ __launch_bounds__(256, 2) void trtri_merge_kernel(BatchView v, int h,
   }
   const int i0 = ti * C::BM, j0 = tj * C::BM;          // node-local
   if (i0 >= m2) return;
-  const double* L = v.A + (size_t)emu * ld * ld;
-  double* Li = v.Linv + (size_t)emu * ld * ld;
-  double* S = v.Kinv + (size_t)emu * ld * ld;
+  const double* L = v.A + (size_t)emu * v.MS;
+  double* Li = v.Linv + (size_t)emu * v.MS;
+  double* S = v.Kinv + (size_t)emu * v.MS;
   v4d acc[WT][WT];
   if (STEP == 0) {
     // T[i,j] = sum_{k >= j0} L21[i,k] Linv11[k,j]
@@ -271,9 +271,9 @@ __global__ __launch_bounds__(256, 2) void kinv_kernel(BatchView v, int ntiles, i
   while ((ti + 1) * (ti + 2) / 2 <= tile) ++ti;
   const int tj = tile - ti * (ti + 1) / 2;
   const int emu = slot_to_emu(v.idx, z);
-  const int ld = v.NP;
-  const double* Li = v.Linv + (size_t)emu * ld * ld;
-  double* Ki = v.Kinv + (size_t)emu * ld * ld;
+  const int ld = v.LD;
+  const double* Li = v.Linv + (size_t)emu * v.MS;
+  double* Ki = v.Kinv + (size_t)emu * v.MS;
   const int i0 = ti * C::BM, j0 = tj * C::BM;
   v4d acc[4][4];
   gemm_mainloop<4, false, false>(Li + (size_t)i0 * ld + i0, ld, Li + (size_t)i0 * ld + j0, ld, (kend - i0) / BK, acc, smem);
@@ -299,8 +299,8 @@ __global__ __launch_bounds__(256, 2) void predict_var_kernel(BatchView v, const 
   const int ti = (st / nsj) * 8 + (w >> 3), tj = (st % nsj) * 8 + (w & 7);
   if (ti >= nti || tj >= ntj) return;
   const int emu = slot_to_emu(v.idx, z);
-  const int ld = v.NP;
-  const double* Li = v.Linv + (size_t)emu * ld * ld;
+  const int ld = v.LD;
+  const double* Li = v.Linv + (size_t)emu * v.MS;
   const double* K = Ks + (size_t)z * MP * ld;
   const int i0 = ti * C::BM, j0 = tj * C::BM;
   v4d acc[4][4];

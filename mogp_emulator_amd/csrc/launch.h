@@ -4,7 +4,7 @@
 //   X      (n, D) row-major, shared by every emulator of an engine
 //   P      per emulator parameter block of PS doubles: [e_0..e_{D-1} = exp(theta_d), sigma^2, nugget]
 //   T      per emulator residual targets (n)
-//   A      per emulator NP x NP row-major "factor" matrix, NP = roundup(n+1, 128).
+//   A      per emulator NP x NP "factor" matrix, row-major with row stride LD (= NP), NP = roundup(n+1, 128).
 //          rows/cols < n : K + nugget I -> overwritten in place by L (lower triangle)
 //          row n         : the targets t -> overwritten by y^T = (L^-1 t)^T   (free forward solve)
 //          rows > n      : identity padding
@@ -24,6 +24,8 @@ constexpr double PAD_BIG = 1e300;
 
 struct BatchView {
   int n, D, NP, PS;             // PS = parameter block stride (doubles)
+  int LD;                       // row stride of A / Linv / Kinv / Ks / alpha (= NP; padding measured slower)
+  size_t MS;                    // per-emulator matrix stride = NP * LD
   int kernel_type;
   const double* X;              // n*D
   const double* P;              // B*PS
