@@ -180,8 +180,17 @@ def main():
         if dom:
             kd = kern[dom]
             peak = FP64_MFMA_PEAK_TF if kd["bound"] == "mfma" else HBM_PEAK_GBS
+            # HBM-side bytes per launch from rocprofv3 PMC passes (cannot be collected from inside this process):
+            # measured offline on this exact default workload and stored under profiles/; null for any other workload
+            traffic = None
+            try:
+                if (n, d, B, m, args.kernel) == (2000, 10, 64, 10000, "SquaredExponential"):
+                    with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as fh:
+                        traffic = json.load(fh).get(dom, {}).get("traffic_bytes_per_launch")
+            except (OSError, ValueError):
+                traffic = None
             roofline = {"kernel": dom, "bound": kd["bound"], "achieved": kd["achieved"], "peak": peak, "unit": kd["unit"],
-                        "frac": kd["achieved"] / peak, "traffic": None, "avg_launch_ms": kd["avg_ms"], "launches": kd["launches"]}
+                        "frac": kd["achieved"] / peak, "traffic": traffic, "avg_launch_ms": kd["avg_ms"], "launches": kd["launches"]}
         out = {
             "metric": "GP fits/sec (+ fit+grad/s, predict pts/s), %d-output n=%d d=%d per GPU, fp64" % (B, n, d),
             "value": total_emus * K / t_fit, "unit": "fits/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
