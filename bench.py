@@ -155,6 +155,22 @@ def main():
     elapsed = time.perf_counter() - t_start
     lib.mogp_profile_enable(0)
 
+    # outside the timed region: the reference-style host-buffer predict (H2D of X*, D2H of mean/var over PCIe)
+    # and one end-to-end MAP fit (lock-step L-BFGS, theta0 given, 1 start) for orientation
+    extras = {}
+    if rank == 0 and world == 1:
+        means_h = np.zeros((B, m)); vars_h = np.zeros((B, m))
+        mo.predict_variance_batch(Xs, means_h, vars_h)
+        t0 = time.perf_counter()
+        mo.predict_variance_batch(Xs, means_h, vars_h)
+        extras["predict_pts_per_s_host_buffers"] = B * m / (time.perf_counter() - t0)
+        assert np.allclose(means_h, d_mean.cpu().numpy(), rtol=1e-12, atol=1e-12)
+        libgpgpu.set_fit_options(max_iter=30, ftol=1e-9, gtol=1e-6, seed=1)
+        t0 = time.perf_counter()
+        libgpgpu.fit_GP_MAP(mo, 1, theta)
+        extras["fit_GP_MAP_s_64_emulators_1_start_maxiter30"] = time.perf_counter() - t0
+        extras["fit_GP_MAP_all_fit"] = len(mo.get_unfitted_indices()) == 0
+
     # per-kernel device times from HIP events on the launch stream
     kern = {}
     for tag, bound in (("update_wide", "mfma"), ("syrk_trailing", "mfma"), ("trtri_merge", "mfma"), ("kinv", "mfma"), ("predict_var", "mfma"),
@@ -204,6 +220,7 @@ def main():
             "roofline": roofline, "kernels": kern,
             "logpost_checksum": float(np.sum(f_last)),
         }
+        out.update(extras)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(X, T, Xs, theta, nugget)
         print(json.dumps(out))
