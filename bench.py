@@ -89,17 +89,26 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # "nccl" is RCCL over xGMI.  MOGP_BENCH_BACKEND=gloo exists only to exercise the N > 1 control flow on a
+    # single-GPU box (all ranks then share device 0 and the collectives go through host memory).
+    backend = os.environ.get("MOGP_BENCH_BACKEND", "nccl")
+    ndev = max(torch.cuda.device_count(), 1)
+    dev_index = local_rank % ndev if backend != "nccl" else local_rank
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    coll_dev = dev if backend == "nccl" else torch.device("cpu")
 
     import mogp_emulator_amd as M
     from mogp_emulator_amd import _capi, libgpgpu
     from mogp_emulator_amd.Priors import GPPriors
     lib = _capi.load()
-    libgpgpu.set_device(local_rank)
+    libgpgpu.set_device(dev_index)
     assert M.gpu_usable(), "no gfx950 device / library"
 
     n, d, B, m = args.n, args.d, args.outputs, args.m
@@ -114,7 +123,7 @@ def main():
     d_Xs = torch.from_numpy(Xs).to(dev)
     d_mean = torch.empty((B, m), dtype=torch.float64, device=dev)
     d_var = torch.empty((B, m), dtype=torch.float64, device=dev)
-    gathered = torch.empty((world, 2, B, m), dtype=torch.float64, device=dev) if world > 1 else None
+    gathered = torch.empty((world, 2, B, m), dtype=torch.float64, device=coll_dev) if world > 1 else None
     torch.cuda.synchronize()
 
     phase = {"fit": 0.0, "fitgrad": 0.0, "predict": 0.0, "gather": 0.0}
@@ -129,7 +138,7 @@ def main():
         mo.predict_variance_batch_dev(d_Xs.data_ptr(), m, d_mean.data_ptr(), d_var.data_ptr())
         t3 = time.perf_counter()
         if world > 1:
-            dist.all_gather_into_tensor(gathered.view(world, -1), torch.stack([d_mean, d_var]).view(-1))
+            dist.all_gather_into_tensor(gathered.view(-1), torch.stack([d_mean, d_var]).view(-1).to(coll_dev))
             torch.cuda.synchronize()
         t4 = time.perf_counter()
         assert ok.all() and ok2.all() and np.all(np.isfinite(g))
@@ -183,7 +192,7 @@ def main():
                          "unit": "TFLOP/s" if bound == "mfma" else "GB/s"}
 
     # max over ranks of every time
-    times = torch.tensor([elapsed, phase["fit"], phase["fitgrad"], phase["predict"], phase["gather"]], dtype=torch.float64, device=dev)
+    times = torch.tensor([elapsed, phase["fit"], phase["fitgrad"], phase["predict"], phase["gather"]], dtype=torch.float64, device=coll_dev)
     if world > 1:
         dist.all_reduce(times, op=dist.ReduceOp.MAX)
     elapsed, t_fit, t_fg, t_pr, t_ga = [float(x) for x in times.cpu()]

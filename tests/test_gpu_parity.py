@@ -449,3 +449,42 @@ def test_c5_shaped_single_large_identities():
     assert np.all(tv >= 0.) and np.all(tv < 2 * eta)
     L = gp.L
     assert_allclose(2 * np.log(np.diag(L)).sum(), np.linalg.slogdet(K + eta * np.eye(n))[1], rtol=1e-9)
+
+
+def test_c4_shaped_matern_fit_nugget_identities():
+    # C4 family: Matern-5/2 with fitted nugget, d = 20, several outputs, n = 3000 (ragged: NP = 3072)
+    n, d, B = 3000, 20, 4
+    X, T, Xs = synth(20240607 + 4, n, d, B, 300)
+    eta = 1e-4
+    theta = np.array([-2. * np.log(0.3 * np.sqrt(d))] * d + [0., np.log(eta)])
+    mo = M.MultiOutputGP_GPU(X, T, kernel="Matern52", nugget="fit", priors=weak(d, "fit"))
+    f, g, ok = mo._mogp_gpu.eval(np.tile(theta, (B, 1)), grad=True)
+    assert ok.all() and np.all(np.isfinite(g))
+    mo.fit(np.tile(theta, (B, 1)))
+    tm, tv, _ = mo.predict(X[:200], deriv=False, include_nugget=False)
+    for k in range(B):
+        em = mo.emulators[k]
+        assert_allclose(em.nugget, eta, rtol=1e-14)
+        a = em.Kinv_t
+        assert_allclose(tm[k], T[k, :200] - eta * a[:200], rtol=1e-8, atol=1e-9)
+        assert np.all(tv[k] >= 0.) and np.all(tv[k] <= eta * (1 + 1e-9))
+    # finite-difference check of two gradient components at full size
+    h = 1e-5
+    for p in (0, d + 1):
+        e = np.zeros_like(theta); e[p] = h
+        fp, _, _ = mo._mogp_gpu.eval(np.tile(theta + e, (B, 1)), grad=False)
+        fm, _, _ = mo._mogp_gpu.eval(np.tile(theta - e, (B, 1)), grad=False)
+        assert_allclose(g[:, p], (fp - fm) / (2 * h), rtol=2e-5, atol=1e-4)
+
+
+def test_sharded_wrapper_on_one_gpu():
+    # dist.ShardedMultiOutputGP with the real per-rank model (world size 1: no process group needed)
+    from mogp_emulator_amd.dist import ShardedMultiOutputGP
+    g = load_golden("mogp4.npz")
+    D = g["X"].shape[1]
+    sh = ShardedMultiOutputGP(g["X"], g["T"], nugget=1e-6, priors=weak(D, 1e-6))
+    assert (sh.lo, sh.hi) == (0, 4)
+    sh.fit(g["thetas"])
+    mean, unc = sh.predict(g["Xs"])
+    assert_allclose(mean, g["mean"], rtol=1e-7, atol=1e-9)
+    assert_allclose(unc, g["var"], atol=1e-7)
