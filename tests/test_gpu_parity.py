@@ -488,3 +488,27 @@ def test_sharded_wrapper_on_one_gpu():
     mean, unc = sh.predict(g["Xs"])
     assert_allclose(mean, g["mean"], rtol=1e-7, atol=1e-9)
     assert_allclose(unc, g["var"], atol=1e-7)
+
+
+@pytest.mark.parametrize("n", [1, 3, 63, 64, 65, 127, 128, 129, 191, 255, 256, 257, 383, 640])
+def test_tile_boundary_sizes_vs_oracle(n):
+    # n around the 64 / 128 tile edges (the y row sits at index n, padding starts at n+1)
+    rng = np.random.default_rng(100 + n)
+    D = 3
+    X = rng.uniform(0, 1, (n, D))
+    t = np.sin(X.sum(axis=1) * 3) + 0.1 * rng.normal(size=n)
+    Xs = rng.uniform(0, 1, (37, D))
+    theta = np.array([2.0, 1.5, 2.5, 0.3, np.log(1e-3)])
+    for kern in KERNELS:
+        gp = make_gp(X, t, kern, "fit")
+        ref = R.GPRef(X, t, kernel=kern, nugget="fit")
+        assert_allclose(gp.logposterior(theta), ref.fit(theta), rtol=1e-10, atol=1e-9)
+        assert_allclose(gp.logpost_deriv(theta), ref.logpost_deriv(theta), rtol=1e-8, atol=1e-9)
+        assert_allclose(gp.Kinv_t, ref.Kinv_t, rtol=1e-8, atol=1e-10)
+        mean, unc, deriv = gp.predict(Xs)
+        mu, var, rd = ref.predict(Xs, deriv=True)
+        assert_allclose(mean, mu, rtol=1e-9, atol=1e-11)
+        assert_allclose(unc, var, rtol=1e-8, atol=1e-10)
+        assert_allclose(deriv, rd, rtol=1e-8, atol=1e-9)
+        Q = np.zeros((n, n)); gp._densegp_gpu.get_invQ(Q)
+        assert_allclose(Q @ (gp.get_K_matrix() + 1e-3 * np.eye(n)), np.eye(n), atol=1e-9)
