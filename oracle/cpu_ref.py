@@ -392,6 +392,104 @@ class GPRef(object):
 
 
 # ----------------------------------------------------------------------------
+# GaussianProcess.py with a mean function (analytic mean, weak mean priors) -- SURVEY.md section 8f row 1
+# ----------------------------------------------------------------------------
+
+def design_matrix(X, terms, intercept=True):
+    """Design matrix H (n, q) of the polynomial mean formulae the GPU wrapper understands:
+    an intercept column (patsy adds it for formulas like "x[0]", GaussianProcess.py:485-515) followed by
+    x[dim]^power columns for ``terms = [(dim, power), ...]``."""
+    X = np.asarray(X, dtype=np.float64)
+    cols = [np.ones(X.shape[0])] if intercept else []
+    for dim, power in terms:
+        cols.append(X[:, dim] ** power)
+    return np.stack(cols, axis=1) if cols else np.zeros((X.shape[0], 0))
+
+
+class GPRefMean(GPRef):
+    """``GaussianProcess`` with a linear-in-parameters mean whose coefficients are integrated out
+    analytically under weak (improper flat) mean priors: the general branch of
+    GaussianProcess.fit / logpost_deriv / predict (GaussianProcess.py:657-685, 745-778, 885-920) with
+    B^-1 = 0, b = 0 (MeanPriors weak: Priors.py:430-470, inv_cov() = 0, logdet_cov() = 0)."""
+
+    def __init__(self, inputs, targets, terms, intercept=True, **kw):
+        super().__init__(inputs, targets, **kw)
+        self.terms, self.intercept = list(terms), intercept
+        self.H = design_matrix(self.X, self.terms, intercept)
+        self.q = self.H.shape[1]
+
+    def fit(self, theta):
+        theta = np.array(theta, dtype=np.float64)
+        assert theta.shape == (self.n_params,), "bad shape for hyperparameters"
+        self.theta = theta
+        if self.nugget_type == "fit":
+            self.nugget = float(np.exp(theta[-1]))
+        K = self.get_K_matrix()
+        self.L, newnugget = cholesky_factor(K, self.nugget, self.nugget_type)
+        if self.nugget_type == "adaptive":
+            self.nugget = float(newnugget)
+        H = self.H
+        # calc_Ainv, linalg_utils.py:5-40:  A = H^T K^-1 H (+ B^-1 = 0)
+        self.Kinv_H = cho_solve_L(self.L, H)
+        A = np.dot(H.T, self.Kinv_H)
+        self.LA = fixed_cholesky(A)
+        self.Kinv_t = cho_solve_L(self.L, self.t)                       # m = H b = 0
+        H_Kinv_t = np.dot(H.T, self.Kinv_t)
+        # calc_mean_params, linalg_utils.py:88-121
+        self.beta = cho_solve_L(self.LA, H_Kinv_t)
+        self.Kinv_t_mean = cho_solve_L(self.L, self.t - np.dot(H, self.beta))
+        n_coeff = self.n - self.q                                       # weak mean priors, GaussianProcess.py:674-677
+        self.current_logpost = 0.5 * (np.dot(self.t, self.Kinv_t) - np.dot(H_Kinv_t, cho_solve_L(self.LA, H_Kinv_t))
+                                      + logdet_L(self.L) + logdet_L(self.LA) + n_coeff * np.log(2. * np.pi))
+        self.current_logpost -= self.priors.logp(theta)
+        return self.current_logpost
+
+    def logpost_deriv(self, theta):
+        if self._refit(theta):
+            self.fit(theta)
+        D, H = self.D, self.H
+        partials = np.zeros(self.n_params)
+        a = self.Kinv_t
+        u = cho_solve_L(self.L, np.dot(H, cho_solve_L(self.LA, np.dot(H.T, a))))      # Kinv_H_Ainv_H_Kinv_t, :747-749
+
+        def dA(dK):      # calc_A_deriv, linalg_utils.py:42-86
+            return -np.einsum("ic,pij,jd->pcd", self.Kinv_H, dK, self.Kinv_H)
+
+        def quad(dK):
+            return (-np.einsum("i,pij,j->p", a, dK, a) + 2. * np.einsum("i,pij,j->p", a, dK, u)
+                    - np.einsum("i,pij,j->p", u, dK, u))
+
+        dKdtheta = np.exp(self.theta[D]) * kernel_deriv(self.X, self.X, self.theta[:D], self.kernel)
+        partials[:D] = 0.5 * (quad(dKdtheta) + logdet_deriv(self.L, dKdtheta) + logdet_deriv(self.LA, dA(dKdtheta)))
+        dKdcov = self.get_K_matrix().reshape(1, self.n, self.n)
+        partials[D] = 0.5 * (quad(dKdcov) + logdet_deriv(self.L, dKdcov) + logdet_deriv(self.LA, dA(dKdcov)))[0]
+        if self.nugget_type == "fit":
+            eye = np.eye(self.n).reshape(1, self.n, self.n)
+            partials[-1] = 0.5 * self.nugget * (quad(eye) + logdet_deriv(self.L, eye) + logdet_deriv(self.LA, dA(eye)))[0]
+        partials -= self.priors.dlogpdtheta(self.theta)
+        return partials
+
+    def predict(self, testing, unc=True, deriv=False, include_nugget=True):
+        if self.theta is None:
+            raise ValueError("hyperparameters have not been fit for this Gaussian Process")
+        testing = np.asarray(testing, dtype=np.float64)
+        if testing.ndim == 1:
+            testing = testing.reshape(-1, 1) if self.D == 1 else testing.reshape(1, -1)
+        Hs = design_matrix(testing, self.terms, self.intercept)
+        Ktest = self.get_cov_matrix(testing)
+        mu = np.dot(Hs, self.beta) + np.dot(Ktest.T, self.Kinv_t_mean)                  # :888-891
+        var = None
+        if unc:
+            Kinv_Ktest = cho_solve_L(self.L, Ktest)
+            Rm = Hs.T - np.dot(self.H.T, Kinv_Ktest)                                     # calc_R, linalg_utils.py:123-168
+            sigma_2 = np.exp(self.theta[self.D])
+            if include_nugget:
+                sigma_2 = sigma_2 + self.nugget
+            var = np.maximum(sigma_2 - np.sum(Ktest * Kinv_Ktest, axis=0) + np.sum(Rm * cho_solve_L(self.LA, Rm), axis=0), 0.)
+        return mu, var, None
+
+
+# ----------------------------------------------------------------------------
 # fitting.py
 # ----------------------------------------------------------------------------
 

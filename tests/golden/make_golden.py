@@ -213,6 +213,29 @@ def main():
                         mean=mean, var=var,
                         corr_shape=np.array([p.shape for p in gp.priors.corr]),
                         corr_scale=np.array([p.scale for p in gp.priors.corr]))
+    # ---- 10. analytic mean function (CPU semantics, weak mean priors): SURVEY 8f row 1 -----------
+    X, T, Xs = synth(10, 150, 3, 1, 50)
+    tlin = T[0] + 2.0 + 1.5 * X[:, 0] - 0.7 * X[:, 2] ** 2
+    out = dict(X=X, t=tlin, Xs=Xs)
+    for tag, formula in (("lin", "x[0]"), ("two", "x[0]+x[2]"), ("const", "1"), ("quad", "x[0]+I(x[2]**2)")):
+        for kern in KERNELS:
+            for mode, nugget in (("fixed", 1.e-5), ("fit", "fit"), ("adaptive", "adaptive")):
+                theta = [0.4, -0.2, 0.7, 0.3] + ([np.log(2.e-4)] if mode == "fit" else [])
+                nt = nugget if isinstance(nugget, str) else "fixed"
+                gp = GaussianProcess(X, tlin, mean=formula, kernel=KERNELS[kern](), nugget=nugget, priors=weak(3, nt))
+                gp.fit(np.array(theta))
+                pre = "%s_%s_%s_" % (tag, kern, mode)
+                out[pre + "theta"] = np.array(theta)
+                out[pre + "logpost"] = np.array(gp.current_logpost)
+                out[pre + "grad"] = gp.logpost_deriv(np.array(theta))
+                out[pre + "beta"] = np.array(gp.theta.mean)
+                out[pre + "nugget"] = np.array(gp.nugget)
+                out[pre + "Kinv_t_mean"] = gp.Kinv_t_mean
+                mean, var, _ = gp.predict(Xs)
+                out[pre + "mean"] = mean
+                out[pre + "var"] = var
+                out[pre + "dm"] = gp.get_design_matrix(X)[:5]
+    np.savez_compressed(os.path.join(HERE, "meanfunc.npz"), **out)
     print("golden vectors written to", HERE)
 
 

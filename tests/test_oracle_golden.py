@@ -213,3 +213,30 @@ def test_gradient_fd():
             e = np.zeros(4); e[p] = h
             fd = (gp.logposterior(th + e) - gp.logposterior(th - e)) / (2 * h)
             assert_allclose(an[p], fd, rtol=1e-4, atol=1e-4)
+
+
+MEAN_TERMS = {"lin": ([(0, 1)], True), "two": ([(0, 1), (2, 1)], True), "const": ([], True), "quad": ([(0, 1), (2, 2)], True)}
+
+
+@pytest.mark.parametrize("tag", list(MEAN_TERMS))
+@pytest.mark.parametrize("kern", KERNELS)
+@pytest.mark.parametrize("mode", ["fixed", "fit", "adaptive"])
+def test_analytic_mean_branch_vs_reference(tag, kern, mode):
+    # GaussianProcess with a patsy mean formula, weak mean priors
+    g = load_golden("meanfunc.npz")
+    pre = "%s_%s_%s_" % (tag, kern, mode)
+    terms, icpt = MEAN_TERMS[tag]
+    nug = {"fixed": 1.e-5, "fit": "fit", "adaptive": "adaptive"}[mode]
+    gp = R.GPRefMean(g["X"], g["t"], terms, icpt, kernel=kern, nugget=nug)
+    assert_allclose(gp.H[:5], g[pre + "dm"], rtol=1e-14)          # same design matrix as patsy builds
+    theta = g[pre + "theta"]
+    lp = gp.fit(theta)
+    assert_allclose(gp.nugget, g[pre + "nugget"], rtol=1e-13, atol=0)
+    if mode != "adaptive" or kern == "Matern52":
+        assert_allclose(lp, g[pre + "logpost"], rtol=1e-5 if mode == "adaptive" else 1e-9)
+    if mode != "adaptive":       # zero-jitter adaptive factorises a cond ~ 1/eps matrix: not reproducible between LAPACKs
+        assert_allclose(gp.beta, g[pre + "beta"], rtol=1e-6, atol=1e-8)
+        assert_allclose(gp.logpost_deriv(theta), g[pre + "grad"], rtol=1e-6, atol=1e-6)
+        mu, var, _ = gp.predict(g["Xs"])
+        assert_allclose(mu, g[pre + "mean"], rtol=1e-7, atol=1e-8)
+        assert_allclose(var, g[pre + "var"], rtol=1e-6, atol=1e-9)
