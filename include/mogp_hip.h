@@ -63,6 +63,14 @@ int mogp_meanfunc_mean_inputderiv(const mogp_meanfunc*, const double* xs, int m,
  * bindings.cu:14-15 / densegp_gpu.hpp:777-865.  The mean function is cloned. */
 mogp_densegp* mogp_densegp_create(const double* inputs, int n, int D, const double* targets, unsigned testing_size,
                                   const mogp_meanfunc* mean, int kernel_type, int nugget_type, double nugget_size);
+/* Same constructor, but the coefficients of a Const / Poly mean function are integrated out
+ * analytically with weak (flat) mean priors -- the CPU class's semantics (GaussianProcess.py:640-700
+ * fit, :860-940 predict; linalg_utils.py:5-121) instead of living in theta.  n_mean() is then 0 and
+ * the fitted coefficients are read with mogp_densegp_get_beta.  At most 7 mean terms. */
+mogp_densegp* mogp_densegp_create_analytic_mean(const double* inputs, int n, int D, const double* targets, unsigned testing_size,
+                                                const mogp_meanfunc* mean, int kernel_type, int nugget_type, double nugget_size);
+int mogp_densegp_n_beta(const mogp_densegp*);                        /* GPParams.n_mean, GPParams.py */
+int mogp_densegp_get_beta(const mogp_densegp*, double* out /* n_beta */);   /* theta.mean, GaussianProcess.py:669 */
 /* the reference never frees (py::nodelete); the shim may.  Must not be called on a handle
  * obtained from mogp_mogp_emulator(). */
 void mogp_densegp_destroy(mogp_densegp*);
@@ -121,6 +129,8 @@ int mogp_fit_single_GP_MAP(mogp_densegp*, int n_tries, const double* theta0, int
 /* MultiOutputGP_GPU(inputs(n,D), targets (n_out,n), testing_size, meanfunc, kernel, nugget_type, nugget_size) */
 mogp_mogp* mogp_mogp_create(const double* inputs, int n, int D, const double* targets, int n_out, unsigned testing_size,
                             const mogp_meanfunc* mean, int kernel_type, int nugget_type, double nugget_size);
+mogp_mogp* mogp_mogp_create_analytic_mean(const double* inputs, int n, int D, const double* targets, int n_out, unsigned testing_size,
+                                          const mogp_meanfunc* mean, int kernel_type, int nugget_type, double nugget_size);
 void mogp_mogp_destroy(mogp_mogp*);
 int mogp_mogp_n(const mogp_mogp*);
 int mogp_mogp_D(const mogp_mogp*);

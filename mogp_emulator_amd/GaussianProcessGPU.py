@@ -163,7 +163,7 @@ def _resolve_mean(mean):
 
 class GaussianProcessGPU(object):
     def __init__(self, inputs, targets, mean=None, kernel=SquaredExponential(), priors=None, nugget="adaptive",
-                 inputdict={}, use_patsy=True, max_batch_size=2000):
+                 inputdict={}, use_patsy=True, max_batch_size=2000, analytic_mean=False):
         if not LibGPGPU.HAVE_LIBGPGPU:
             raise RuntimeError("Cannot construct GaussianProcessGPU: The GPU library (libgpgpu) could not be loaded")
         if not LibGPGPU.gpu_usable():
@@ -181,6 +181,8 @@ class GaussianProcessGPU(object):
         self.kernel_type, self.kernel = _resolve_kernel(kernel)
         self._nugget_type, self._init_nugget_size = interpret_nugget(nugget)
         self._priors_arg = priors
+        # analytic_mean=True: mean coefficients integrated out with weak priors (GaussianProcess.py:640-700)
+        self._analytic_mean = bool(analytic_mean)
         self._densegp_gpu = None
         self._init_gpu()
         self._set_priors(priors)
@@ -196,12 +198,14 @@ class GaussianProcessGPU(object):
         obj.mean = denseGP_GPU.get_meanfunc()
         obj._max_batch_size = 2000
         obj._priors_arg = None
+        obj._analytic_mean = False
         return obj
 
     def _init_gpu(self):
         if self._densegp_gpu is None:
             self._densegp_gpu = LibGPGPU.DenseGP_GPU(self._inputs, self._targets, self._max_batch_size, self.mean,
-                                                     self.kernel_type, self._nugget_type, self._init_nugget_size)
+                                                     self.kernel_type, self._nugget_type, self._init_nugget_size,
+                                                     analytic_mean=getattr(self, "_analytic_mean", False))
 
     def _set_priors(self, newpriors=None):
         if newpriors:

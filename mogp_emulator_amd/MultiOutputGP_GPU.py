@@ -19,7 +19,7 @@ from .Priors import GPPriors
 
 class MultiOutputGP_GPU(object):
     def __init__(self, inputs, targets, mean=None, kernel="SquaredExponential", priors=None, nugget="adaptive",
-                 inputdict={}, use_patsy=True, batch_size=16000):
+                 inputdict={}, use_patsy=True, batch_size=16000, analytic_mean=False):
         if not LibGPGPU.gpu_usable():
             raise RuntimeError("Cannot construct MultiOutputGP_GPU: the GPU library or a compatible GPU is unavailable")
         inputs = np.array(inputs, dtype=np.float64)
@@ -47,7 +47,10 @@ class MultiOutputGP_GPU(object):
             raise TypeError("nugget parameter must be a string or a non-negative float")
         self._nugget_name = nugget
         ktype, _ = _resolve_kernel(kernel)
-        self._mogp_gpu = LibGPGPU.MultiOutputGP_GPU(inputs, targets, batch_size, _resolve_mean(mean), ktype, nugtype, nugsize)
+        # analytic_mean=True: mean coefficients integrated out with weak priors (the CPU class's
+        # treatment, GaussianProcess.py:640-700) rather than optimised inside theta (the reference GPU class)
+        self._mogp_gpu = LibGPGPU.MultiOutputGP_GPU(inputs, targets, batch_size, _resolve_mean(mean), ktype, nugtype, nugsize,
+                                                    analytic_mean=bool(analytic_mean))
 
         if isinstance(priors, (GPPriors, dict)) or priors is None:
             priorslist = [priors] * self.n_emulators

@@ -52,6 +52,9 @@ SIGNATURES = {
     "mogp_meanfunc_mean_deriv": (c_int, [c_void_p, c_double_p, c_int, c_int, c_double_p, c_int, c_double_p]),
     "mogp_meanfunc_mean_inputderiv": (c_int, [c_void_p, c_double_p, c_int, c_int, c_double_p, c_int, c_double_p]),
     "mogp_densegp_create": (c_void_p, [c_double_p, c_int, c_int, c_double_p, c_uint, c_void_p, c_int, c_int, c_double]),
+    "mogp_densegp_create_analytic_mean": (c_void_p, [c_double_p, c_int, c_int, c_double_p, c_uint, c_void_p, c_int, c_int, c_double]),
+    "mogp_densegp_n_beta": (c_int, [c_void_p]),
+    "mogp_densegp_get_beta": (c_int, [c_void_p, c_double_p]),
     "mogp_densegp_destroy": (None, [c_void_p]),
     "mogp_densegp_n": (c_int, [c_void_p]),
     "mogp_densegp_D": (c_int, [c_void_p]),
@@ -87,6 +90,7 @@ SIGNATURES = {
     "mogp_densegp_get_kernel_type": (c_int, [c_void_p]),
     "mogp_fit_single_GP_MAP": (c_int, [c_void_p, c_int, c_double_p, c_int]),
     "mogp_mogp_create": (c_void_p, [c_double_p, c_int, c_int, c_double_p, c_int, c_uint, c_void_p, c_int, c_int, c_double]),
+    "mogp_mogp_create_analytic_mean": (c_void_p, [c_double_p, c_int, c_int, c_double_p, c_int, c_uint, c_void_p, c_int, c_int, c_double]),
     "mogp_mogp_destroy": (None, [c_void_p]),
     "mogp_mogp_n": (c_int, [c_void_p]),
     "mogp_mogp_D": (c_int, [c_void_p]),

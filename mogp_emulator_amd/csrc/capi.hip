@@ -88,13 +88,13 @@ int mogp_meanfunc_mean_inputderiv(const mogp_meanfunc* m, const double* xs, int 
 }
 
 // ---- DenseGP_GPU --------------------------------------------------------------------------------
-mogp_densegp* mogp_densegp_create(const double* inputs, int n, int D, const double* targets, unsigned testing_size,
-                                  const mogp_meanfunc* mean, int kernel_type, int nugget_type, double nugget_size) {
+static mogp_densegp* densegp_create(const double* inputs, int n, int D, const double* targets, unsigned testing_size,
+                                    const mogp_meanfunc* mean, int kernel_type, int nugget_type, double nugget_size, bool analytic) {
   try {
     MeanFunc mf;
     if (mean) mf = mean->mf;
     auto* h = new mogp_densegp;
-    h->eng = new Engine(inputs, n, D, targets, 1, testing_size, mf, kernel_type, nugget_type, nugget_size);
+    h->eng = new Engine(inputs, n, D, targets, 1, testing_size, mf, kernel_type, nugget_type, nugget_size, analytic);
     h->idx = 0;
     h->owns = true;
     return h;
@@ -102,6 +102,20 @@ mogp_densegp* mogp_densegp_create(const double* inputs, int n, int D, const doub
     g_err = e.what();
     return nullptr;
   }
+}
+mogp_densegp* mogp_densegp_create(const double* inputs, int n, int D, const double* targets, unsigned testing_size,
+                                  const mogp_meanfunc* mean, int kernel_type, int nugget_type, double nugget_size) {
+  return densegp_create(inputs, n, D, targets, testing_size, mean, kernel_type, nugget_type, nugget_size, false);
+}
+mogp_densegp* mogp_densegp_create_analytic_mean(const double* inputs, int n, int D, const double* targets, unsigned testing_size,
+                                                const mogp_meanfunc* mean, int kernel_type, int nugget_type, double nugget_size) {
+  return densegp_create(inputs, n, D, targets, testing_size, mean, kernel_type, nugget_type, nugget_size, true);
+}
+int mogp_densegp_n_beta(const mogp_densegp* h) { return h->eng->q; }
+int mogp_densegp_get_beta(const mogp_densegp* h, double* out) {
+  const auto& b = h->eng->gp[h->idx].beta;
+  for (size_t c = 0; c < b.size(); ++c) out[c] = b[c];
+  return 0;
 }
 void mogp_densegp_destroy(mogp_densegp* h) {
   if (!h || !h->owns) return;
@@ -268,13 +282,23 @@ int mogp_fit_single_GP_MAP(mogp_densegp* h, int n_tries, const double* theta0, i
 }
 
 // ---- MultiOutputGP_GPU ---------------------------------------------------------------------------
+static mogp_mogp* mogp_create(const double* inputs, int n, int D, const double* targets, int n_out, unsigned testing_size,
+                              const mogp_meanfunc* mean, int kernel_type, int nugget_type, double nugget_size, bool analytic);
 mogp_mogp* mogp_mogp_create(const double* inputs, int n, int D, const double* targets, int n_out, unsigned testing_size,
                             const mogp_meanfunc* mean, int kernel_type, int nugget_type, double nugget_size) {
+  return mogp_create(inputs, n, D, targets, n_out, testing_size, mean, kernel_type, nugget_type, nugget_size, false);
+}
+mogp_mogp* mogp_mogp_create_analytic_mean(const double* inputs, int n, int D, const double* targets, int n_out, unsigned testing_size,
+                                          const mogp_meanfunc* mean, int kernel_type, int nugget_type, double nugget_size) {
+  return mogp_create(inputs, n, D, targets, n_out, testing_size, mean, kernel_type, nugget_type, nugget_size, true);
+}
+static mogp_mogp* mogp_create(const double* inputs, int n, int D, const double* targets, int n_out, unsigned testing_size,
+                              const mogp_meanfunc* mean, int kernel_type, int nugget_type, double nugget_size, bool analytic) {
   try {
     MeanFunc mf;
     if (mean) mf = mean->mf;
     auto* h = new mogp_mogp;
-    h->eng.reset(new Engine(inputs, n, D, targets, n_out, testing_size, mf, kernel_type, nugget_type, nugget_size));
+    h->eng.reset(new Engine(inputs, n, D, targets, n_out, testing_size, mf, kernel_type, nugget_type, nugget_size, analytic));
     h->views.resize(n_out);
     for (int i = 0; i < n_out; ++i) h->views[i] = mogp_densegp{h->eng.get(), i, false};
     h->nug_size0 = nugget_size;

@@ -25,12 +25,16 @@ struct GPState {
   bool factored = false;         // A holds L (and y) for `data`
   bool linv = false, kinv = false;
   double nugget_used = 0.;       // value actually added to the diagonal in the last factorisation
+  std::vector<double> beta;      // analytic mean coefficients (q), GaussianProcess.py:669-670
+  std::vector<double> LA;        // q x q lower Cholesky factor of A = H^T K^-1 H
 };
 
 class Engine {
  public:
+  // analytic_mean: the coefficients of a const / polynomial mean are integrated out analytically (CPU
+  // GaussianProcess semantics) instead of living in theta (reference GPU semantics)
   Engine(const double* X, int n, int D, const double* targets, int B, unsigned testing_size, const MeanFunc& mean,
-         int kernel_type, int nug_type, double nug_size);
+         int kernel_type, int nug_type, double nug_size, bool analytic_mean = false);
   ~Engine();
   Engine(const Engine&) = delete;
 
@@ -41,7 +45,9 @@ class Engine {
   std::vector<GPState> gp;
   std::vector<double> hX, hT;    // host copies (inputs()/targets())
 
-  int n_mean() const { return mean.n_params(); }
+  bool analytic = false;
+  int q = 0, R = 1;              // analytic mean columns, right-hand-side rows (1 + q)
+  int n_mean() const { return analytic ? 0 : mean.n_params(); }
   int n_data(int i) const { return D + 1 + (gp[i].nug_type == NUG_FIT ? 1 : 0); }
   int n_theta(int i) const { return n_mean() + n_data(i); }
   double nugget_size(int i) const;
@@ -88,11 +94,13 @@ class Engine {
   double *dX = nullptr, *dP = nullptr, *dT = nullptr, *dA = nullptr, *dLinv = nullptr, *dKinv = nullptr, *dAlpha = nullptr;
   double *dLogdet = nullptr, *dYty = nullptr, *dGradOut = nullptr, *dGradPartial = nullptr;
   int *dInfo = nullptr, *dIdx = nullptr;
-  double* dLpack = nullptr;      // packed transposed diagonal block + reciprocal diagonal (potf2 -> trsm)
+  double* dLpack = nullptr;
+  double *dH = nullptr, *dZ = nullptr, *dM = nullptr, *dGram = nullptr;
+  std::vector<double> hH;        // q x n design-matrix columns      // packed transposed diagonal block + reciprocal diagonal (potf2 -> trsm)
   std::vector<double> hP;
   // predict scratch
   double *dXs = nullptr, *dKs = nullptr, *dMean = nullptr, *dVar = nullptr, *dVarPartial = nullptr, *dDeriv = nullptr;
-  size_t capXs = 0, capKs = 0, capMean = 0, capVarPartial = 0, capDeriv = 0;
+  size_t capXs = 0, capKs = 0, capMean = 0, capVar = 0, capVarPartial = 0, capDeriv = 0;
   std::mt19937_64 rng;
 };
 

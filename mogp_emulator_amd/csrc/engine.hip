@@ -108,14 +108,19 @@ static void grow(T*& p, size_t& cap, size_t need) {
 }
 
 Engine::Engine(const double* X, int n_, int D_, const double* targets, int B_, unsigned testing_size_, const MeanFunc& mean_,
-               int kernel_type_, int nug_type, double nug_size)
+               int kernel_type_, int nug_type, double nug_size, bool analytic_mean)
     : n(n_), D(D_), B(B_), kernel_type(kernel_type_), testing_size(testing_size_), mean(mean_) {
+  analytic = analytic_mean && mean.n_params() > 0;
+  q = analytic ? mean.n_params() : 0;
+  R = 1 + q;
+  if (R > RMAX) throw std::runtime_error("analytic mean: at most " + std::to_string(RMAX - 1) + " mean-function terms are supported");
+  if (analytic && q >= n_) throw std::runtime_error("analytic mean: more mean-function terms than training points");
   if (n < 1 || D < 1 || B < 1) throw std::runtime_error("inputs must have shape (n, D) with n, D >= 1");
   if (kernel_type != 0 && kernel_type != 1) throw std::runtime_error("Unrecognized kernel type\n");
   if (nug_type < 0 || nug_type > 2) throw std::runtime_error("Unrecognized nugget_type");
   for (int d : mean.dims)
     if (d >= D) throw std::runtime_error("Dimension index must be less than " + std::to_string(D));
-  NP = roundup(n + 1, TILE);
+  NP = roundup(n + R, TILE);
   // Row stride.  A non-power-of-two stride (NP + 16) was tried against L2 set aliasing of the
   // 16 KiB-strided tile rows and measured SLOWER on MI355X (fit 7.5 -> 8.2 ms, fit+grad 15.3 -> 16.2 ms),
   // so the default pad is 0; MOGP_LDPAD (even) re-enables it for experiments.
@@ -132,7 +137,8 @@ Engine::Engine(const double* X, int n_, int D_, const double* targets, int B_, u
     g.nug_type = nug_type;
     g.nug_size = nug_size;
     g.data.assign(D + 1 + (nug_type == NUG_FIT ? 1 : 0), 0.);
-    g.meanp.assign(mean.n_params(), 0.);
+    g.meanp.assign(n_mean(), 0.);
+    g.beta.assign(q, 0.);
   }
   HIPCK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
   HIPCK(hipEventCreateWithFlags(&evReady, hipEventDisableTiming));
@@ -146,7 +152,18 @@ Engine::Engine(const double* X, int n_, int D_, const double* targets, int B_, u
   dP = dalloc<double>((size_t)B * PS);
   dT = dalloc<double>((size_t)B * n);
   dA = dalloc<double>((size_t)B * MS);
-  dAlpha = dalloc<double>((size_t)B * LD);
+  dAlpha = dalloc<double>((size_t)B * R * LD);
+  dGram = dalloc<double>((size_t)B * RMAX * RMAX);
+  if (R > 1) {
+    dZ = dalloc<double>((size_t)B * R * LD);
+    dM = dalloc<double>((size_t)B * RMAX * RMAX);
+    // design matrix columns: row c of mean_deriv = d mean / d beta_c = basis function c evaluated at X
+    hH.assign((size_t)q * n, 0.);
+    std::vector<double> dummy(q, 0.);
+    mean.mean_deriv(X, n, D, dummy.data(), q, hH.data());
+    dH = dalloc<double>(hH.size());
+    HIPCK(hipMemcpy(dH, hH.data(), hH.size() * sizeof(double), hipMemcpyHostToDevice));
+  }
   dLogdet = dalloc<double>(B);
   dYty = dalloc<double>(B);
   dInfo = dalloc<int>(B);
@@ -156,7 +173,7 @@ Engine::Engine(const double* X, int n_, int D_, const double* targets, int B_, u
   HIPCK(hipMemcpy(dX, hX.data(), hX.size() * sizeof(double), hipMemcpyHostToDevice));
   // residual targets for parameter-free means are fixed once
   std::vector<double> res(hT);
-  if (mean.n_params() == 0 && mean.kind == 1)
+  if (!analytic && mean.n_params() == 0 && mean.kind == 1)
     for (auto& x : res) x -= mean.value;
   HIPCK(hipMemcpy(dT, res.data(), res.size() * sizeof(double), hipMemcpyHostToDevice));
   rng.seed(fit_options().seed ? fit_options().seed : std::random_device{}());
@@ -165,7 +182,7 @@ Engine::Engine(const double* X, int n_, int D_, const double* targets, int B_, u
 Engine::~Engine() {
   for (void* p : {(void*)dX, (void*)dP, (void*)dT, (void*)dA, (void*)dLinv, (void*)dKinv, (void*)dAlpha, (void*)dLogdet, (void*)dYty,
                   (void*)dGradOut, (void*)dGradPartial, (void*)dInfo, (void*)dIdx, (void*)dXs, (void*)dKs, (void*)dMean, (void*)dVar,
-                  (void*)dVarPartial, (void*)dDeriv, (void*)dLpack})
+                  (void*)dVarPartial, (void*)dDeriv, (void*)dLpack, (void*)dH, (void*)dZ, (void*)dM, (void*)dGram})
     if (p) hipFree(p);
   for (auto st : gstreams) hipStreamDestroy(st);
   if (evReady) hipEventDestroy(evReady);
@@ -187,6 +204,7 @@ BatchView Engine::view(int nb) const {
   v.n = n; v.D = D; v.NP = NP; v.LD = LD; v.MS = MS; v.PS = PS; v.kernel_type = kernel_type;
   v.X = dX; v.P = dP; v.T = dT; v.A = dA; v.Linv = dLinv; v.Kinv = dKinv; v.alpha = dAlpha;
   v.idx = dIdx; v.nb = nb;
+  v.R = R; v.H = dH; v.Z = (R > 1) ? dZ : dAlpha;
   return v;
 }
 
@@ -288,7 +306,7 @@ void Engine::factorize(const std::vector<int>& ids, std::vector<int>& info) {
         HIPCK(hipStreamWaitEvent(gs[g], evReady, 0));
       }
     }
-    for (int o = 0; o < n + 1; o += TILE)
+    for (int o = 0; o < n + R; o += TILE)
       for (int g = 0; g < G; ++g) {
         if (o > 0) {
           // with fewer than ~4 128-tiles per CU (always true at n=2000 x 64, measured 7.6 vs 8.3 ms) use
@@ -332,7 +350,7 @@ void Engine::factorize(const std::vector<int>& ids, std::vector<int>& info) {
     // needs panels < j (K = [0, o), long, runs on the main stream WHILE panel j is factored on the
     // panel stream) and the short K = 128 part that needs panel j itself.
     std::vector<int> cols;
-    for (int o = 0; o < n + 1; o += TILE) cols.push_back(o);
+    for (int o = 0; o < n + R; o += TILE) cols.push_back(o);
     const int K = (int)cols.size();
     while ((int)evPanel.size() < K + 1) {
       hipEvent_t a, b;
@@ -361,7 +379,7 @@ void Engine::factorize(const std::vector<int>& ids, std::vector<int>& info) {
     return;
   }
   std::vector<int> starts;
-  for (int o = 0; o < n + 1; o += OUTER) starts.push_back(o);
+  for (int o = 0; o < n + R; o += OUTER) starts.push_back(o);
   const int K = (int)starts.size();
   while ((int)evPanel.size() < K + 1) {
     hipEvent_t a, b;
@@ -448,14 +466,14 @@ void Engine::eval(const std::vector<int>& ids, const std::vector<const double*>&
   std::vector<int> okids;
   for (int i : ids)
     if (good[i]) okids.push_back(i);
-  std::vector<double> logdet(B, 0.), yty(B, 0.);
+  std::vector<double> logdet(B, 0.), gram((size_t)B * RMAX * RMAX, 0.);
   for (int i : ids) gp[i].factored = good[i] != 0;
   if (!okids.empty()) {
     upload_idx(okids);
     BatchView v = view((int)okids.size());
-    launch_logdet(v, dLogdet, dYty, stream);
+    launch_logdet(v, dLogdet, dGram, stream);
     if (want_grad) {
-      // gradient path: L^-1 is needed anyway, so alpha = L^-T y is one fully parallel gemv with it
+      // gradient path: L^-1 is needed anyway, so K^-1 [t, H] = L^-T Y is one fully parallel gemv with it
       ensure_linv(okids);
       upload_idx(okids);
       v = view((int)okids.size());
@@ -464,18 +482,67 @@ void Engine::eval(const std::vector<int>& ids, const std::vector<const double*>&
       launch_backsolve(v, stream);
     }
     HIPCK(hipMemcpyAsync(logdet.data(), dLogdet, B * sizeof(double), hipMemcpyDeviceToHost, stream));
-    HIPCK(hipMemcpyAsync(yty.data(), dYty, B * sizeof(double), hipMemcpyDeviceToHost, stream));
+    HIPCK(hipMemcpyAsync(gram.data(), dGram, gram.size() * sizeof(double), hipMemcpyDeviceToHost, stream));
     HIPCK(hipStreamSynchronize(stream));
   }
+  std::vector<double> hM;
+  if (R > 1) hM.assign((size_t)B * RMAX * RMAX, 0.);
   for (int k = 0; k < nb; ++k) {
     const int i = ids[k];
     GPState& g = gp[i];
     double val = std::numeric_limits<double>::quiet_NaN();
     bool fine = good[i];
     if (fine) {
-      // GaussianProcess.py:679-685 with mean = None; densegp_gpu.hpp:604-611
-      val = 0.5 * (yty[i] + logdet[i] + n * std::log(2.0 * M_PI)) - g.pri.logp(g.data, D, g.nug_type);
-      if (!std::isfinite(val)) fine = false;
+      const double* G = gram.data() + (size_t)i * RMAX * RMAX;
+      double quad = G[0], logdetA = 0.;
+      if (R > 1) {
+        // A = H^T K^-1 H (weak mean priors: B^-1 = 0), linalg_utils.py:5-40; beta = A^-1 H^T K^-1 t (:88-121)
+        g.LA.assign((size_t)q * q, 0.);
+        for (int r = 0; r < q && fine; ++r)
+          for (int c = 0; c <= r; ++c) {
+            double s = G[(1 + r) * RMAX + (1 + c)];
+            for (int p = 0; p < c; ++p) s -= g.LA[r * q + p] * g.LA[c * q + p];
+            if (r == c) {
+              if (!(s > 0.)) { fine = false; break; }
+              g.LA[r * q + r] = std::sqrt(s);
+            } else {
+              g.LA[r * q + c] = s / g.LA[c * q + c];
+            }
+          }
+        if (fine) {
+          std::vector<double> w(q), Linv((size_t)q * q, 0.);
+          for (int r = 0; r < q; ++r) {               // w = LA^-1 v, v = H^T K^-1 t
+            double s = G[(1 + r) * RMAX];
+            for (int p = 0; p < r; ++p) s -= g.LA[r * q + p] * w[p];
+            w[r] = s / g.LA[r * q + r];
+            quad -= w[r] * w[r];
+            logdetA += 2. * std::log(g.LA[r * q + r]);
+          }
+          for (int r = q - 1; r >= 0; --r) {          // beta = LA^-T w
+            double s = w[r];
+            for (int p = r + 1; p < q; ++p) s -= g.LA[p * q + r] * g.beta[p];
+            g.beta[r] = s / g.LA[r * q + r];
+          }
+          for (int c = 0; c < q; ++c) {               // LA^-1 (lower), column by column
+            for (int r = c; r < q; ++r) {
+              double s = (r == c) ? 1. : 0.;
+              for (int p = c; p < r; ++p) s -= g.LA[r * q + p] * Linv[p * q + c];
+              Linv[r * q + c] = s / g.LA[r * q + r];
+            }
+          }
+          // combination matrix: row 0 -> K^-1 (t - H beta); row c -> g_c = sum_d (LA^-1)[c][d] K^-1 h_d
+          double* M = hM.data() + (size_t)i * RMAX * RMAX;
+          M[0] = 1.;
+          for (int c = 0; c < q; ++c) M[1 + c] = -g.beta[c];
+          for (int c = 0; c < q; ++c)
+            for (int d = 0; d <= c; ++d) M[(1 + c) * RMAX + (1 + d)] = Linv[c * q + d];
+        }
+      }
+      if (fine) {
+        // GaussianProcess.py:679-685 (n_coeff = n - q with weak mean priors); densegp_gpu.hpp:604-611
+        val = 0.5 * (quad + logdet[i] + logdetA + (n - q) * std::log(2.0 * M_PI)) - g.pri.logp(g.data, D, g.nug_type);
+        if (!std::isfinite(val)) fine = false;
+      }
     }
     g.has_data = fine;
     g.factored = fine;
@@ -483,6 +550,12 @@ void Engine::eval(const std::vector<int>& ids, const std::vector<const double*>&
     if (f) f[k] = val;
     if (ok) ok[k] = fine ? 1 : 0;
     if (!fine) good[i] = 0;
+  }
+  if (R > 1 && !okids.empty()) {
+    HIPCK(hipMemcpyAsync(dM, hM.data(), hM.size() * sizeof(double), hipMemcpyHostToDevice, stream));
+    upload_idx(okids);
+    launch_combine_rows(view((int)okids.size()), dM, stream);
+    HIPCK(hipStreamSynchronize(stream));
   }
   if (want_grad && grad) {
     std::vector<int> gids;
@@ -573,7 +646,7 @@ void Engine::grad_current(const std::vector<int>& ids, double* grad, int grad_ld
     if (nm > 0) {
       // densegp_gpu.hpp:734-747: -(d mean / d beta)^T alpha
       std::vector<double> a(n), md((size_t)nm * n);
-      HIPCK(hipMemcpy(a.data(), dAlpha + (size_t)i * LD, n * sizeof(double), hipMemcpyDeviceToHost));
+      HIPCK(hipMemcpy(a.data(), dAlpha + (size_t)i * R * LD, n * sizeof(double), hipMemcpyDeviceToHost));
       mean.mean_deriv(hX.data(), n, D, g.meanp.data(), nm, md.data());
       for (int p = 0; p < nm; ++p) {
         double s = 0.;
@@ -595,6 +668,7 @@ void Engine::predict(const std::vector<int>& ids, const double* Xs, int m, bool 
   if (nb == 0 || m == 0) return;
   for (int i : ids)
     if (!gp[i].factored) throw std::runtime_error("emulator has not been fit");
+  if (R > 1 && out_on_device) throw std::runtime_error("device-resident outputs are not available with an analytic mean function");
   if (vars) ensure_linv(ids);
   upload_idx(ids);
   BatchView v = view(nb);
@@ -604,13 +678,15 @@ void Engine::predict(const std::vector<int>& ids, const double* Xs, int m, bool 
     HIPCK(hipMemcpyAsync(dXs, Xs, (size_t)m * D * sizeof(double), hipMemcpyHostToDevice, stream));
     dXsrc = dXs;
   }
+  // dm: R rows of dot products per emulator (row 0 = k*^T K^-1 (t - H beta), rows 1.. = k*^T K^-1 h_c)
   double* dm = means;
   double* dv = vars;
   long ld = out_ld;
   if (!out_on_device) {
-    grow(dMean, capMean, (size_t)2 * nb * m);
+    grow(dMean, capMean, (size_t)nb * R * m);
+    grow(dVar, capVar, (size_t)nb * m);
     dm = dMean;
-    dv = dMean + (size_t)nb * m;
+    dv = dVar;
     ld = m;
   }
   const int MPtot = roundup(m, 128);
@@ -628,33 +704,69 @@ void Engine::predict(const std::vector<int>& ids, const double* Xs, int m, bool 
     launch_predict_deriv(v, dXsrc, m, dDeriv, (long)m * D, stream);
     HIPCK(hipMemcpyAsync(derivs, dDeriv, (size_t)nb * m * D * sizeof(double), hipMemcpyDeviceToHost, stream));
   }
+  std::vector<double> dots;
   if (!out_on_device) {
+    if (R > 1) {
+      dots.resize((size_t)nb * R * m);
+      HIPCK(hipMemcpyAsync(dots.data(), dm, dots.size() * sizeof(double), hipMemcpyDeviceToHost, stream));
+    }
     for (int k = 0; k < nb; ++k) {
-      HIPCK(hipMemcpyAsync(means + (size_t)k * out_ld, dm + (size_t)k * m, m * sizeof(double), hipMemcpyDeviceToHost, stream));
+      if (R == 1) HIPCK(hipMemcpyAsync(means + (size_t)k * out_ld, dm + (size_t)k * m, m * sizeof(double), hipMemcpyDeviceToHost, stream));
       if (vars) HIPCK(hipMemcpyAsync(vars + (size_t)k * out_ld, dv + (size_t)k * m, m * sizeof(double), hipMemcpyDeviceToHost, stream));
     }
   }
   HIPCK(hipStreamSynchronize(stream));
   HIPCK(hipGetLastError());
-  // mean function contribution (host, O(m)): densegp_gpu.hpp:334-337, 402-405, 443-447
-  if (mean.kind != 0 && !out_on_device) {
-    std::vector<double> hx;
-    const double* xs_h = Xs;
-    if (xs_on_device) {
-      hx.resize((size_t)m * D);
-      HIPCK(hipMemcpy(hx.data(), Xs, hx.size() * sizeof(double), hipMemcpyDeviceToHost));
-      xs_h = hx.data();
-    }
-    std::vector<double> mv(m), mid((size_t)D * m);
+  if (out_on_device || (mean.kind == 0 && R == 1)) return;
+  std::vector<double> hx;
+  const double* xs_h = Xs;
+  if (xs_on_device) {
+    hx.resize((size_t)m * D);
+    HIPCK(hipMemcpy(hx.data(), Xs, hx.size() * sizeof(double), hipMemcpyDeviceToHost));
+    xs_h = hx.data();
+  }
+  std::vector<double> mv(m), mid((size_t)D * m);
+  if (R > 1) {
+    // analytic mean (GaussianProcess.py:906-935): mu = m(x*) + k*^T K^-1 (t - H beta),
+    // var += || LA^-1 (H*^T - H^T K^-1 k*) ||^2  with H* the design matrix of the test points
+    std::vector<double> Hs((size_t)q * m), rm(q);
+    std::vector<double> dummy(q, 0.);
+    mean.mean_deriv(xs_h, m, D, dummy.data(), q, Hs.data());
     for (int k = 0; k < nb; ++k) {
       const GPState& g = gp[ids[k]];
-      mean.mean_f(xs_h, m, D, g.meanp.data(), n_mean(), mv.data());
-      for (int j = 0; j < m; ++j) means[(size_t)k * out_ld + j] += mv[j];
+      const double* dk = dots.data() + (size_t)k * R * m;
+      for (int j = 0; j < m; ++j) {
+        double mu = dk[j];
+        for (int c = 0; c < q; ++c) mu += g.beta[c] * Hs[(size_t)c * m + j];
+        means[(size_t)k * out_ld + j] = mu;
+        if (vars) {
+          double add = 0.;
+          for (int c = 0; c < q; ++c) {
+            double s = Hs[(size_t)c * m + j] - dk[(size_t)(1 + c) * m + j];
+            for (int p = 0; p < c; ++p) s -= g.LA[c * q + p] * rm[p];
+            rm[c] = s / g.LA[c * q + c];
+            add += rm[c] * rm[c];
+          }
+          vars[(size_t)k * out_ld + j] += add;
+        }
+      }
       if (derivs) {
-        mean.mean_inputderiv(xs_h, m, D, g.meanp.data(), n_mean(), mid.data());
+        mean.mean_inputderiv(xs_h, m, D, g.beta.data(), q, mid.data());
         for (int j = 0; j < m; ++j)
           for (int d = 0; d < D; ++d) derivs[((size_t)k * m + j) * D + d] += mid[(size_t)d * m + j];
       }
+    }
+    return;
+  }
+  // mean function contribution (host, O(m)): densegp_gpu.hpp:334-337, 402-405, 443-447
+  for (int k = 0; k < nb; ++k) {
+    const GPState& g = gp[ids[k]];
+    mean.mean_f(xs_h, m, D, g.meanp.data(), n_mean(), mv.data());
+    for (int j = 0; j < m; ++j) means[(size_t)k * out_ld + j] += mv[j];
+    if (derivs) {
+      mean.mean_inputderiv(xs_h, m, D, g.meanp.data(), n_mean(), mid.data());
+      for (int j = 0; j < m; ++j)
+        for (int d = 0; d < D; ++d) derivs[((size_t)k * m + j) * D + d] += mid[(size_t)d * m + j];
     }
   }
 }
@@ -682,7 +794,7 @@ void Engine::get_invQ(int i, double* out) {
 
 void Engine::get_invQt(int i, double* out) {
   if (!gp[i].factored) throw std::runtime_error("emulator has not been fit");
-  HIPCK(hipMemcpy(out, dAlpha + (size_t)i * LD, n * sizeof(double), hipMemcpyDeviceToHost));
+  HIPCK(hipMemcpy(out, dAlpha + (size_t)i * R * LD, n * sizeof(double), hipMemcpyDeviceToHost));
 }
 
 void Engine::get_chol(int i, double* out) {

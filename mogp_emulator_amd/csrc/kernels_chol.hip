@@ -97,31 +97,50 @@ __global__ __launch_bounds__(TRSM_THREADS) void trsm_kernel(BatchView v, int c0,
 // ---------------------------------------------------------------------------------------------
 // logdet = 2 sum_{i<n} log L_ii ;  yty = sum_{c<n} L[n,c]^2   (row n of the factor holds y^T)
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void logdet_kernel(BatchView v, double* __restrict__ logdet, double* __restrict__ yty) {
-  __shared__ double red[2][256];
+__global__ __launch_bounds__(256) void logdet_kernel(BatchView v, double* __restrict__ logdet, double* __restrict__ gram) {
+  __shared__ double red[256];
   const int emu = slot_emu(v.idx, blockIdx.x);
-  const int ld = v.LD;
+  const int ld = v.LD, R = v.R;
   const double* A = v.A + (size_t)emu * v.MS;
-  double s = 0., q = 0.;
+  double s = 0.;
+  double acc[RMAX * (RMAX + 1) / 2];
+#pragma unroll
+  for (int e = 0; e < RMAX * (RMAX + 1) / 2; ++e) acc[e] = 0.;
   for (int i = threadIdx.x; i < v.n; i += 256) {
     s += log(A[(size_t)i * ld + i]);
-    const double y = A[(size_t)v.n * ld + i];
-    q += y * y;
+    double y[RMAX];
+#pragma unroll
+    for (int r = 0; r < RMAX; ++r) y[r] = (r < R) ? A[(size_t)(v.n + r) * ld + i] : 0.0;
+#pragma unroll
+    for (int r = 0; r < RMAX; ++r)
+#pragma unroll
+      for (int c = 0; c <= r; ++c) acc[r * (r + 1) / 2 + c] = __builtin_fma(y[r], y[c], acc[r * (r + 1) / 2 + c]);
   }
-  red[0][threadIdx.x] = s;
-  red[1][threadIdx.x] = q;
-  __syncthreads();
-  for (int w = 128; w > 0; w >>= 1) {
-    if (threadIdx.x < w) {
-      red[0][threadIdx.x] += red[0][threadIdx.x + w];
-      red[1][threadIdx.x] += red[1][threadIdx.x + w];
-    }
+  auto block_sum = [&](double x) {
+    red[threadIdx.x] = x;
     __syncthreads();
-  }
-  if (threadIdx.x == 0) {
-    logdet[emu] = 2.0 * red[0][0];
-    yty[emu] = red[1][0];
-  }
+    for (int w = 128; w > 0; w >>= 1) {
+      if (threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+      __syncthreads();
+    }
+    const double out = red[0];
+    __syncthreads();
+    return out;
+  };
+  const double ls = block_sum(s);
+  if (threadIdx.x == 0) logdet[emu] = 2.0 * ls;
+#pragma unroll
+  for (int r = 0; r < RMAX; ++r)
+#pragma unroll
+    for (int c = 0; c <= r; ++c) {
+      if (r < R) {                    // uniform
+        const double g = block_sum(acc[r * (r + 1) / 2 + c]);
+        if (threadIdx.x == 0) {
+          gram[(size_t)emu * RMAX * RMAX + r * RMAX + c] = g;
+          gram[(size_t)emu * RMAX * RMAX + c * RMAX + r] = g;
+        }
+      }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -138,7 +157,7 @@ __global__ __launch_bounds__(BS_THREADS) void backsolve_kernel(BatchView v) {
   const int emu = slot_emu(v.idx, blockIdx.x);
   const int ld = v.LD, n = v.n;
   const double* A = v.A + (size_t)emu * v.MS;
-  double* w = v.alpha + (size_t)emu * ld;
+  double* w = v.Z + (size_t)emu * v.R * ld;          // R == 1 only (the launcher falls back to the multi-launch path otherwise)
   const int t = threadIdx.x;
   for (int i = t; i < ld; i += BS_THREADS) w[i] = (i < n) ? A[(size_t)n * ld + i] : 0.0;
   __syncthreads();
@@ -189,58 +208,92 @@ __global__ __launch_bounds__(BS_THREADS) void backsolve_kernel(BatchView v) {
 // n=2000, 40 ms at n=16000); here all CUs stream L.
 __global__ __launch_bounds__(256) void backsolve_init_kernel(BatchView v) {
   const int emu = slot_emu(v.idx, blockIdx.y);
-  const int ld = v.LD, n = v.n;
+  const int ld = v.LD, n = v.n, R = v.R;
   const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i < ld) v.alpha[(size_t)emu * ld + i] = (i < n) ? v.A[(size_t)emu * v.MS + (size_t)n * ld + i] : 0.0;
+  if (i >= ld) return;
+  for (int r = 0; r < R; ++r)
+    v.Z[((size_t)emu * R + r) * ld + i] = (i < n) ? v.A[(size_t)emu * v.MS + (size_t)(n + r) * ld + i] : 0.0;
 }
 
 __global__ __launch_bounds__(64) void backsolve_diag_kernel(BatchView v, int k0) {
   const int emu = slot_emu(v.idx, blockIdx.x);
-  const int ld = v.LD, n = v.n;
+  const int ld = v.LD, n = v.n, R = v.R;
   const double* A = v.A + (size_t)emu * v.MS;
-  double* w = v.alpha + (size_t)emu * ld;
   const int t = threadIdx.x;
   double u[64];
 #pragma unroll
   for (int j = 0; j < 64; ++j) u[j] = A[(size_t)(k0 + j) * ld + k0 + t];
   const double rdg = 1.0 / A[(size_t)(k0 + t) * ld + k0 + t];
-  double b = w[k0 + t];
-  double xout = 0.0;
+  for (int r = 0; r < R; ++r) {
+    double* w = v.Z + ((size_t)emu * R + r) * ld;
+    double b = w[k0 + t];
+    double xout = 0.0;
 #pragma unroll
-  for (int j = 63; j >= 0; --j) {
-    double xj = readlane_f64(b * rdg, j);
-    if (k0 + j >= n) xj = 0.0;
-    if (t == j) xout = xj;
-    b = __builtin_fma(-u[j], xj, b);
+    for (int j = 63; j >= 0; --j) {
+      double xj = readlane_f64(b * rdg, j);
+      if (k0 + j >= n) xj = 0.0;
+      if (t == j) xout = xj;
+      b = __builtin_fma(-u[j], xj, b);
+    }
+    w[k0 + t] = xout;
   }
-  w[k0 + t] = xout;
 }
 
-// w[c] -= sum_r L[k0+r][c] alpha[k0+r] for c < k0; one column pair per thread
+// w_r[c] -= sum_i L[k0+i][c] alpha_r[k0+i] for c < k0 and every right-hand side r; one column pair per thread,
+// L is read once for all right-hand sides
 constexpr int BSG_THREADS = 64;     // small workgroups: at n=16000, B=1 a 256-thread version has only 32 workgroups in flight
 __global__ __launch_bounds__(BSG_THREADS) void backsolve_gemv_kernel(BatchView v, int k0) {
-  __shared__ double ab[64];
+  __shared__ double ab[RMAX][64];
   const int emu = slot_emu(v.idx, blockIdx.y);
-  const int ld = v.LD;
+  const int ld = v.LD, R = v.R;
   const double* A = v.A + (size_t)emu * v.MS;
-  double* w = v.alpha + (size_t)emu * ld;
-  if (threadIdx.x < 64) ab[threadIdx.x] = w[k0 + threadIdx.x];
+  double* w = v.Z + (size_t)emu * R * ld;
+  for (int e = threadIdx.x; e < R * 64; e += BSG_THREADS) ab[e >> 6][e & 63] = w[(size_t)(e >> 6) * ld + k0 + (e & 63)];
   __syncthreads();
   const int c = 2 * (blockIdx.x * BSG_THREADS + threadIdx.x);
   if (c >= k0) return;
-  v2d s = {0., 0.};
+  v2d s[RMAX];
+#pragma unroll
+  for (int r = 0; r < RMAX; ++r) s[r] = (v2d){0., 0.};
   const double* p = A + (size_t)k0 * ld + c;
-#pragma unroll 32
-  for (int r = 0; r < 64; ++r) {
-    const v2d x = *reinterpret_cast<const v2d*>(p + (size_t)r * ld);
-    const double ar = ab[r];
-    s[0] = __builtin_fma(x[0], ar, s[0]);
-    s[1] = __builtin_fma(x[1], ar, s[1]);
+#pragma unroll 8
+  for (int i = 0; i < 64; ++i) {
+    const v2d x = *reinterpret_cast<const v2d*>(p + (size_t)i * ld);
+#pragma unroll
+    for (int r = 0; r < RMAX; ++r)
+      if (r < R) {
+        const double ar = ab[r][i];
+        s[r][0] = __builtin_fma(x[0], ar, s[r][0]);
+        s[r][1] = __builtin_fma(x[1], ar, s[r][1]);
+      }
   }
-  v2d cur = *reinterpret_cast<v2d*>(w + c);
-  cur[0] -= s[0];
-  cur[1] -= s[1];
-  *reinterpret_cast<v2d*>(w + c) = cur;
+#pragma unroll
+  for (int r = 0; r < RMAX; ++r)
+    if (r < R) {
+      v2d cur = *reinterpret_cast<v2d*>(w + (size_t)r * ld + c);
+      cur[0] -= s[r][0];
+      cur[1] -= s[r][1];
+      *reinterpret_cast<v2d*>(w + (size_t)r * ld + c) = cur;
+    }
+}
+
+// alpha[c] = sum_r M[emu][c][r] Z[r]  (R > 1: Kinv_t_mean and the rank-correction rows from the raw solves)
+__global__ __launch_bounds__(256) void combine_rows_kernel(BatchView v, const double* __restrict__ M) {
+  const int emu = slot_emu(v.idx, blockIdx.y);
+  const int ld = v.LD, R = v.R;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= ld) return;
+  const double* Zb = v.Z + (size_t)emu * R * ld;
+  const double* Mb = M + (size_t)emu * RMAX * RMAX;
+  double z[RMAX];
+#pragma unroll
+  for (int r = 0; r < RMAX; ++r) z[r] = (r < R) ? Zb[(size_t)r * ld + i] : 0.0;
+  for (int c = 0; c < R; ++c) {
+    double s = 0.;
+#pragma unroll
+    for (int r = 0; r < RMAX; ++r) s = __builtin_fma(Mb[c * RMAX + r], z[r], s);
+    v.alpha[((size_t)emu * R + c) * ld + i] = s;
+  }
 }
 
 // alpha = Linv^T y (fit+gradient path, Linv already available): alpha_i = sum_{i<=k<n} Linv[k][i] y_k.
@@ -248,19 +301,22 @@ __global__ __launch_bounds__(BSG_THREADS) void backsolve_gemv_kernel(BatchView v
 __global__ __launch_bounds__(256) void alpha_linv_kernel(BatchView v) {
   __shared__ double red[4][64];
   const int emu = slot_emu(v.idx, blockIdx.y);
-  const int ld = v.LD, n = v.n;
+  const int ld = v.LD, n = v.n, R = v.R;
   const double* Li = v.Linv + (size_t)emu * v.MS;
-  const double* y = v.A + (size_t)emu * v.MS + (size_t)n * ld;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i0 = blockIdx.x * 64, i = i0 + lane;
-  double s = 0.;
-  if (i0 < n) {
+  for (int r = 0; r < R; ++r) {
+    const double* y = v.A + (size_t)emu * v.MS + (size_t)(n + r) * ld;
+    double s = 0.;
+    if (i0 < n) {
 #pragma unroll 8
-    for (int k = i0 + wave; k < n; k += 4) s = __builtin_fma(Li[(size_t)k * ld + i], y[k], s);   // Linv[k][i] = 0 for k < i
+      for (int k = i0 + wave; k < n; k += 4) s = __builtin_fma(Li[(size_t)k * ld + i], y[k], s);   // Linv[k][i] = 0 for k < i
+    }
+    red[wave][lane] = s;
+    __syncthreads();
+    if (wave == 0) v.Z[((size_t)emu * R + r) * ld + i] = (i < n) ? red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane] : 0.0;
+    __syncthreads();
   }
-  red[wave][lane] = s;
-  __syncthreads();
-  if (wave == 0) v.alpha[(size_t)emu * ld + i] = (i < n) ? red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane] : 0.0;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -326,13 +382,17 @@ void launch_trsm(const BatchView& v, int c0, int r0, const double* Lpack, hipStr
 
 size_t lpack_doubles_per_emulator() { return PACK_STRIDE; }
 
-void launch_logdet(const BatchView& v, double* logdet, double* yty, hipStream_t s) {
-  hipLaunchKernelGGL(logdet_kernel, dim3(v.nb), dim3(256), 0, s, v, logdet, yty);
+void launch_logdet(const BatchView& v, double* logdet, double* gram, hipStream_t s) {
+  hipLaunchKernelGGL(logdet_kernel, dim3(v.nb), dim3(256), 0, s, v, logdet, gram);
+}
+
+void launch_combine_rows(const BatchView& v, const double* M, hipStream_t s) {
+  hipLaunchKernelGGL(combine_rows_kernel, dim3((v.LD + 255) / 256, v.nb), dim3(256), 0, s, v, M);
 }
 
 void launch_backsolve(const BatchView& v, hipStream_t s) {
   static const int mode = [] { const char* e = getenv("MOGP_BACKSOLVE"); return e ? atoi(e) : 1; }();   // 0: one workgroup per emulator
-  if (mode == 0) {
+  if (mode == 0 && v.R == 1) {
     hipLaunchKernelGGL(backsolve_kernel, dim3(v.nb), dim3(BS_THREADS), 0, s, v);
     return;
   }

@@ -109,8 +109,10 @@ __global__ __launch_bounds__(256) void cov_build_kernel(BatchView v, int nt) {
       if (hi < n) {
         x = sig2 * kern_val<KT>(r2[a][b]);
         if (i == j) x += nug;
-      } else if (hi == n) {
-        x = (lo < n) ? T[lo] : PAD_BIG;
+      } else if (hi < n + v.R) {
+        // right-hand-side rows: row n = targets, rows n+1.. = design-matrix columns of the analytic mean
+        if (lo < n) x = (hi == n) ? T[lo] : v.H[(size_t)(hi - n - 1) * n + lo];
+        else x = (lo == hi) ? PAD_BIG : 0.0;
       } else {
         x = (i == j) ? 1.0 : 0.0;
       }
@@ -156,18 +158,23 @@ __global__ __launch_bounds__(256) void cross_cov_mean_kernel(BatchView v, const 
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int z = blockIdx.y;
   const int emu = slot_emu2(v.idx, z);
-  const int n = v.n, D = v.D, ld = v.LD;
+  const int n = v.n, D = v.D, ld = v.LD, R = v.R;
   const int i0 = blockIdx.x * 64;
   const double* P = v.P + (size_t)emu * v.PS;
-  const double* alpha = v.alpha + (size_t)emu * ld;
+  const double* alpha0 = v.alpha + (size_t)emu * R * ld;      // row 0: K^-1 (t - H beta)
+  const double* Zr = v.Z + (size_t)emu * R * ld;              // rows 1..: K^-1 h_c
   double* si = sm;
   double* sj = sm + 64 * D;
-  double* sa = sm + 128 * D;          // alpha tile (64)
-  double* red = sa + 64;              // 64 x 17
+  double* sa = sm + 128 * D;          // R x 64 operand tile
+  double* red = sa + RMAX * 64;       // 64 x 17
   stage_rows(Xs, m, D, i0, si);
   const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
   const double sig2 = P[D];
-  double macc[4] = {0., 0., 0., 0.};
+  double macc[RMAX][4];
+#pragma unroll
+  for (int c = 0; c < RMAX; ++c)
+#pragma unroll
+    for (int a = 0; a < 4; ++a) macc[c][a] = 0.;
   double* Kz = Ks ? Ks + (size_t)z * MP * ld : nullptr;
   const int ntj = v.NP / 64;
   for (int tj = 0; tj < ntj; ++tj) {
@@ -175,7 +182,11 @@ __global__ __launch_bounds__(256) void cross_cov_mean_kernel(BatchView v, const 
     __syncthreads();
     if (j0 < n) {
       stage_rows(v.X, n, D, j0, sj);
-      if (threadIdx.x < 64) sa[threadIdx.x] = (j0 + threadIdx.x < n) ? alpha[j0 + threadIdx.x] : 0.0;
+      for (int e = threadIdx.x; e < R * 64; e += 256) {
+        const int c = e >> 6, jj = e & 63;
+        const double* src = (c == 0) ? alpha0 : Zr + (size_t)c * ld;
+        sa[e] = (j0 + jj < n) ? src[j0 + jj] : 0.0;
+      }
     }
     __syncthreads();
     double r2[4][4];
@@ -190,7 +201,11 @@ __global__ __launch_bounds__(256) void cross_cov_mean_kernel(BatchView v, const 
         double x = 0.0;
         if (j < n && i < m) x = sig2 * kern_val<KT>(r2[a][b]);
         out[b] = x;
-        if (j0 < n) macc[a] = __builtin_fma(x, sa[4 * tx + b], macc[a]);
+        if (j0 < n) {
+#pragma unroll
+          for (int c = 0; c < RMAX; ++c)
+            if (c < R) macc[c][a] = __builtin_fma(x, sa[c * 64 + 4 * tx + b], macc[c][a]);
+        }
       }
       if (Kz) {
         double* p = Kz + (size_t)i * ld + j0 + 4 * tx;
@@ -199,15 +214,20 @@ __global__ __launch_bounds__(256) void cross_cov_mean_kernel(BatchView v, const 
       }
     }
   }
-  __syncthreads();
 #pragma unroll
-  for (int a = 0; a < 4; ++a) red[(4 * ty + a) * 17 + tx] = macc[a];
-  __syncthreads();
-  if (threadIdx.x < 64) {
-    double s = 0.;
-    for (int q = 0; q < 16; ++q) s += red[threadIdx.x * 17 + q];
-    const int i = i0 + threadIdx.x;
-    if (i < m) mean[(size_t)z * mean_ld + i] = s;
+  for (int c = 0; c < RMAX; ++c) {
+    if (c < R) {
+      __syncthreads();
+#pragma unroll
+      for (int a = 0; a < 4; ++a) red[(4 * ty + a) * 17 + tx] = macc[c][a];
+      __syncthreads();
+      if (threadIdx.x < 64) {
+        double s = 0.;
+        for (int q = 0; q < 16; ++q) s += red[threadIdx.x * 17 + q];
+        const int i = i0 + threadIdx.x;
+        if (i < m) mean[((size_t)z * R + c) * mean_ld + i] = s;
+      }
+    }
   }
 }
 
@@ -223,7 +243,7 @@ __global__ __launch_bounds__(256) void predict_deriv_kernel(BatchView v, const d
   const int n = v.n, D = v.D, ld = v.LD;
   const int i0 = blockIdx.x * 64;
   const double* P = v.P + (size_t)emu * v.PS;
-  const double* alpha = v.alpha + (size_t)emu * ld;
+  const double* alpha = v.alpha + (size_t)emu * v.R * ld;
   double* si = sm;                    // [D][64] test points
   double* sj = sm + 64 * D;           // [D][64] training points
   double* G = sm + 128 * D;           // [64][65]  G[m][j] = sig2 * dk/dr2 * 2 * alpha_j
@@ -290,7 +310,8 @@ __global__ __launch_bounds__(256) void grad_kernel(BatchView v, int ntiles, doub
   const int n = v.n, D = v.D, ld = v.LD;
   const double* P = v.P + (size_t)emu * v.PS;
   const double* Ki = v.Kinv + (size_t)emu * v.MS;
-  const double* alpha = v.alpha + (size_t)emu * ld;
+  const double* alpha = v.alpha + (size_t)emu * v.R * ld;     // R rows g_c: W = Kinv - sum_c g_c g_c^T
+  const int R = v.R;
   double* si = sm;
   double* sj = sm + 64 * D;
   double* wsum = sm + 128 * D;        // [4 waves][D+3]
@@ -304,10 +325,31 @@ __global__ __launch_bounds__(256) void grad_kernel(BatchView v, int ntiles, doub
   const double sig2 = P[D];
   double G[4][4];                     // w * W * sigma^2 * dk/dr2
   double scov = 0., strace = 0., saa = 0.;
+  // rank-R correction sum_c g_c[i] g_c[j] for the micro tile (R = 1: alpha_i alpha_j)
+  double corr[4][4], gsq[4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    gsq[a] = 0.;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) corr[a][b] = 0.;
+  }
+  for (int c = 0; c < R; ++c) {
+    const double* g = alpha + (size_t)c * ld;
+    double gi[4], gj[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) gi[a] = (i0 + 4 * ty + a < n) ? g[i0 + 4 * ty + a] : 0.0;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) gj[b] = (j0 + 4 * tx + b < n) ? g[j0 + 4 * tx + b] : 0.0;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      gsq[a] = __builtin_fma(gi[a], gi[a], gsq[a]);
+#pragma unroll
+      for (int b = 0; b < 4; ++b) corr[a][b] = __builtin_fma(gi[a], gj[b], corr[a][b]);
+    }
+  }
 #pragma unroll
   for (int a = 0; a < 4; ++a) {
     const int i = i0 + 4 * ty + a;
-    const double ai = (i < n) ? alpha[i] : 0.0;
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
       const int j = j0 + 4 * tx + b;
@@ -316,12 +358,12 @@ __global__ __launch_bounds__(256) void grad_kernel(BatchView v, int ntiles, doub
       double g = 0.0;
       if (w != 0.0) {
         const double kin = Ki[(size_t)i * ld + j];
-        const double W = kin - ai * alpha[j];
+        const double W = kin - corr[a][b];
         scov += w * W * sig2 * kern_val<KT>(r2[a][b]);
         g = w * W * sig2 * kern_dr2<KT>(r2[a][b]);
         if (i == j) {
           strace += kin;
-          saa += ai * ai;
+          saa += gsq[a];
         }
       }
       G[a][b] = g;
@@ -402,7 +444,7 @@ void launch_cov_full(const BatchView& v, int emu, double* out, hipStream_t s) {
 }
 
 void launch_cross_cov_mean(const BatchView& v, const double* Xs, int m, int MP, double* Ks, double* mean, int mean_ld, hipStream_t s) {
-  const size_t sm = (size_t)(128 * v.D + 64 + 64 * 17) * sizeof(double);
+  const size_t sm = (size_t)(128 * v.D + RMAX * 64 + 64 * 17) * sizeof(double);
   prof_begin("cross_cov", s);
 #define CALL(K) hipLaunchKernelGGL((cross_cov_mean_kernel<K>), dim3(MP / 64, v.nb), dim3(256), sm, s, v, Xs, m, MP, Ks, mean, mean_ld)
   KT_DISPATCH(v.kernel_type, CALL);

@@ -21,6 +21,7 @@ constexpr int TILE = 128;       // MFMA macro tile / padding granule
 constexpr int OUTER = 256;      // outer Cholesky block = K depth of the trailing update
 constexpr int NBI = 64;         // inner panel width (potf2 / trsm / trtri leaf)
 constexpr double PAD_BIG = 1e300;
+constexpr int RMAX = 8;         // max right-hand-side rows (targets + up to 7 mean-function columns)
 
 struct BatchView {
   int n, D, NP, PS;             // PS = parameter block stride (doubles)
@@ -33,7 +34,10 @@ struct BatchView {
   double* A;                    // B*NP*NP
   double* Linv;                 // B*NP*NP (may be null)
   double* Kinv;                 // B*NP*NP (may be null)
-  double* alpha;                // B*NP
+  double* alpha;                // B*R*LD: row 0 = K^-1 (t - H beta) (= K^-1 t when R = 1); rows 1.. = rank correction rows g_c
+  double* Z;                    // B*R*LD raw solves K^-1 [t, h_1 .. h_q]   (same buffer as alpha when R = 1)
+  const double* H;              // q*n design-matrix columns of the analytic mean (shared by all emulators), or null
+  int R;                        // 1 + q right-hand sides carried through the factorisation as rows n .. n+q of A
   const int* idx;               // device: nb entries or null
   int nb;                       // number of batch slots in this launch
 };
@@ -57,8 +61,10 @@ void launch_update_narrow_potf2(const BatchView& v, int c0, int k0, int k1, int*
 void launch_update_wide(const BatchView& v, int c0, int k0, int k1, hipStream_t s);
 // trailing lower-triangular update, rows/cols [c0, NP), k in [k0,k1) (c0 multiple of 128)
 void launch_update_trailing(const BatchView& v, int c0, int k0, int k1, hipStream_t s);
-// logdet[emu] = 2 sum_{i<n} log L_ii ; yty[emu] = sum_{c<n} L[n,c]^2
-void launch_logdet(const BatchView& v, double* logdet, double* yty, hipStream_t s);
+// logdet[emu] = 2 sum_{i<n} log L_ii ; gram[emu][r*R+s] = sum_{c<n} L[n+r,c] L[n+s,c]  (gram[0] = y^T y)
+void launch_logdet(const BatchView& v, double* logdet, double* gram, hipStream_t s);
+// alpha[c] = sum_r M[emu][c][r] Z[r]   (M: nb... indexed by emulator, R x R row-major)
+void launch_combine_rows(const BatchView& v, const double* M, hipStream_t s);
 // alpha = L^-T y (y = row n of A)
 void launch_backsolve(const BatchView& v, hipStream_t s);
 
@@ -74,7 +80,8 @@ void launch_grad(const BatchView& v, double* partial, double* out, hipStream_t s
 
 // --- predict -------------------------------------------------------------------------------
 // Ks: nb * MP * NP (MP = roundup(m,128)) cross-covariance sigma^2 k(x*_m, x_j); mean (nb, m) written;
-// if Ks == null only the mean is computed.
+// if Ks == null only the mean is computed.  With R > 1 the kernel also returns Z_c^T k* (rows 1..R-1 of `mean`,
+// row stride mean_ld per emulator block of R rows).
 void launch_cross_cov_mean(const BatchView& v, const double* Xs, int m, int MP, double* Ks, double* mean, int mean_ld, hipStream_t s);
 // var[z][m] = sigma^2 - sum_i (Linv Ks^T)[i][m]^2 ; partial: nb * (NP/128) * MP scratch
 void launch_predict_var(const BatchView& v, const double* Ks, int m, int MP, double* partial, double* var, int var_ld, hipStream_t s);

@@ -415,7 +415,7 @@ def _pack_priors(n_corr, corr_params, cov_params, nug_params):
 # --------------------------------------------------------------------------------------
 class DenseGP_GPU(object):
     def __init__(self, inputs, targets, testing_size, meanfunc=None, kern=kernel_type.SquaredExponential,
-                 nugtype=nugget_type.adaptive, nugsize=0., _borrowed=None, _parent=None):
+                 nugtype=nugget_type.adaptive, nugsize=0., _borrowed=None, _parent=None, analytic_mean=False):
         if _borrowed is not None:
             self._h, self._owns, self._parent = _borrowed, False, _parent
             self._meanfunc = meanfunc
@@ -427,8 +427,9 @@ class DenseGP_GPU(object):
         if meanfunc is None:
             meanfunc = ZeroMeanFunc()
         self._meanfunc = meanfunc
-        self._h = _lib.mogp_densegp_create(dptr(X), X.shape[0], X.shape[1], dptr(t), int(testing_size), meanfunc._h,
-                                           int(kernel_type(kern)), int(nugget_type(nugtype)), float(nugsize))
+        create = _lib.mogp_densegp_create_analytic_mean if analytic_mean else _lib.mogp_densegp_create
+        self._h = create(dptr(X), X.shape[0], X.shape[1], dptr(t), int(testing_size), meanfunc._h,
+                         int(kernel_type(kern)), int(nugget_type(nugtype)), float(nugsize))
         if not self._h:
             raise RuntimeError(_capi.last_error())
         self._owns, self._parent = True, None
@@ -460,6 +461,13 @@ class DenseGP_GPU(object):
         out = np.zeros(self.n())
         check(_lib.mogp_densegp_targets(self._h, dptr(out)))
         return out
+
+    def get_beta(self):
+        """analytically fitted mean coefficients (analytic_mean=True only; theta.mean of the CPU class)"""
+        nb = int(_lib.mogp_densegp_n_beta(self._h))
+        out = np.zeros(max(nb, 1))
+        check(_lib.mogp_densegp_get_beta(self._h, dptr(out)))
+        return out[:nb].copy()
 
     # -- parameters -----------------------------------------------------------------------
     def theta_fit_status(self):
@@ -601,7 +609,7 @@ class DenseGP_GPU(object):
 # --------------------------------------------------------------------------------------
 class MultiOutputGP_GPU(object):
     def __init__(self, inputs, targets, testing_size, meanfunc=None, kern=kernel_type.SquaredExponential,
-                 nugtype=nugget_type.adaptive, nugsize=0.):
+                 nugtype=nugget_type.adaptive, nugsize=0., analytic_mean=False):
         X = _f64(inputs, 2, "inputs")
         T = np.ascontiguousarray(np.array([np.asarray(t, dtype=np.float64) for t in targets]))
         if T.ndim != 2 or T.shape[1] != X.shape[0]:
@@ -609,8 +617,9 @@ class MultiOutputGP_GPU(object):
         if meanfunc is None:
             meanfunc = ZeroMeanFunc()
         self._meanfunc = meanfunc
-        self._h = _lib.mogp_mogp_create(dptr(X), X.shape[0], X.shape[1], dptr(T), T.shape[0], int(testing_size), meanfunc._h,
-                                        int(kernel_type(kern)), int(nugget_type(nugtype)), float(nugsize))
+        create = _lib.mogp_mogp_create_analytic_mean if analytic_mean else _lib.mogp_mogp_create
+        self._h = create(dptr(X), X.shape[0], X.shape[1], dptr(T), T.shape[0], int(testing_size), meanfunc._h,
+                         int(kernel_type(kern)), int(nugget_type(nugtype)), float(nugsize))
         if not self._h:
             raise RuntimeError(_capi.last_error())
 

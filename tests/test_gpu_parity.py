@@ -512,3 +512,120 @@ def test_tile_boundary_sizes_vs_oracle(n):
         assert_allclose(deriv, rd, rtol=1e-8, atol=1e-9)
         Q = np.zeros((n, n)); gp._densegp_gpu.get_invQ(Q)
         assert_allclose(Q @ (gp.get_K_matrix() + 1e-3 * np.eye(n)), np.eye(n), atol=1e-9)
+
+
+# ----------------------------------------------------------------------------------------------------
+# analytic mean function (CPU-class semantics, weak mean priors) on the device.
+# fp64 tolerances: logpost rtol 1e-8, beta / K^-1(t - H beta) rtol 1e-6 (cond(K) ~ 1e9 at nugget 1e-5),
+# gradient rtol/atol 1e-6, predictions rtol 1e-6.
+# ----------------------------------------------------------------------------------------------------
+MEAN_TERMS = {"lin": [(0, 1)], "two": [(0, 1), (2, 1)], "const": [], "quad": [(0, 1), (2, 2)]}
+
+
+def native_mean(terms):
+    return LibGPGPU.PolyMeanFunc(terms) if terms else LibGPGPU.ConstMeanFunc()
+
+
+@pytest.mark.parametrize("tag", list(MEAN_TERMS))
+@pytest.mark.parametrize("kern", KERNELS)
+@pytest.mark.parametrize("mode", ["fixed", "fit"])
+def test_analytic_mean_vs_reference_golden(tag, kern, mode):
+    g = load_golden("meanfunc.npz")
+    pre = "%s_%s_%s_" % (tag, kern, mode)
+    nug = {"fixed": 1.e-5, "fit": "fit"}[mode]
+    gp = make_gp(g["X"], g["t"], kern, nug, mean=native_mean(MEAN_TERMS[tag]), analytic_mean=True)   # weak priors, as the fixture
+    theta = g[pre + "theta"]
+    assert gp.n_params == theta.shape[0]               # mean coefficients are NOT part of theta in this mode
+    # the value (~40) is a difference of O(1400) terms (quadratic form vs log det) at cond(K) ~ 1e9
+    assert_allclose(gp.logposterior(theta), g[pre + "logpost"], rtol=1e-8)
+    gp.fit(theta)
+    assert_allclose(gp._densegp_gpu.get_beta(), g[pre + "beta"], rtol=1e-6, atol=1e-8)
+    assert_allclose(gp.Kinv_t, g[pre + "Kinv_t_mean"], rtol=1e-6, atol=1e-6 * np.abs(g[pre + "Kinv_t_mean"]).max())
+    assert_allclose(gp.logpost_deriv(theta), g[pre + "grad"], rtol=1e-6, atol=1e-6)
+    mu, var, _ = gp.predict(g["Xs"])
+    assert_allclose(mu, g[pre + "mean"], rtol=1e-7, atol=1e-8)
+    assert_allclose(var, g[pre + "var"], rtol=1e-6, atol=1e-9)
+
+
+def test_analytic_mean_adaptive_nugget_vs_oracle(kern="Matern52"):
+    # (squared exponential with zero jitter has cond(K) ~ 1/eps here: no meaningful reference value)
+    g = load_golden("meanfunc.npz")
+    theta = g["quad_%s_adaptive_theta" % kern]
+    gp = make_gp(g["X"], g["t"], kern, "adaptive", mean=native_mean(MEAN_TERMS["quad"]), analytic_mean=True)
+    gp.fit(theta)
+    ref = R.GPRefMean(g["X"], g["t"], MEAN_TERMS["quad"], True, kernel=kern, nugget=float(gp.nugget))
+    lp = ref.fit(theta)
+    assert_allclose(gp.current_logpost, lp, rtol=1e-8)
+    mu, var, _ = gp.predict(g["Xs"])
+    rmu, rvar, _ = ref.predict(g["Xs"])
+    assert_allclose(mu, rmu, rtol=1e-6, atol=1e-7)
+    assert_allclose(var, rvar, rtol=1e-5, atol=1e-8)
+
+
+@pytest.mark.parametrize("n", [60, 126, 127, 128, 255, 300])
+def test_analytic_mean_multioutput_tile_boundaries(n):
+    # rows n .. n+q of the factorised matrix carry [t, H]: make them straddle 64- and 128-tile edges
+    rng = np.random.default_rng(100 + n)
+    d, n_out, m = 3, 5, 37
+    X = rng.random((n, d))
+    Xs = rng.random((m, d))
+    T = np.stack([np.sin(3 * X[:, 0] + k) + (k + 1) * X[:, 2] ** 2 + 0.5 * k for k in range(n_out)])
+    terms = MEAN_TERMS["quad"]
+    mo = M.MultiOutputGP_GPU(X, T, mean=native_mean(terms), kernel="Matern52", nugget="fit", priors=weak(d, "fit"),
+                             analytic_mean=True)
+    thetas = np.stack([np.r_[rng.uniform(0., 2., d), rng.uniform(-1., 1.), rng.uniform(-9., -6.)] for _ in range(n_out)])
+    f, grad, ok = mo._mogp_gpu.eval(thetas, grad=True)
+    assert ok.all()
+    mo.fit(thetas)
+    mean, unc, deriv = mo.predict(Xs)
+    for k in range(n_out):
+        ref = R.GPRefMean(X, T[k], terms, True, kernel="Matern52", nugget="fit")
+        assert_allclose(f[k], ref.fit(thetas[k]), rtol=1e-9)
+        assert_allclose(grad[k], ref.logpost_deriv(thetas[k]), rtol=1e-6, atol=1e-6)
+        rmu, rvar, _ = ref.predict(Xs)
+        assert_allclose(mean[k], rmu, rtol=1e-7, atol=1e-8)
+        assert_allclose(unc[k], rvar, rtol=1e-6, atol=1e-9)
+        assert_allclose(mo._mogp_gpu.emulator(k).get_beta(), ref.beta, rtol=1e-6, atol=1e-8)
+    # d mean / d x* against central differences of the predictive mean itself
+    h = 1e-6
+    for dd in range(d):
+        e = np.zeros(d)
+        e[dd] = h
+        fd = (mo.predict(Xs + e, unc=False, deriv=False)[0] - mo.predict(Xs - e, unc=False, deriv=False)[0]) / (2 * h)
+        assert_allclose(deriv[:, :, dd], fd, rtol=1e-5, atol=1e-6)
+
+
+def test_analytic_mean_fit_GP_MAP_and_limits():
+    rng = np.random.default_rng(5)
+    n, d, n_out = 80, 2, 3
+    X = rng.random((n, d))
+    T = np.stack([np.cos(4 * X[:, 0]) + 2. * k * X[:, 1] + k + 0.01 * rng.normal(size=n) for k in range(n_out)])
+    # proper priors on the correlation lengths keep the optimum away from the flat directions
+    pri = GPPriors(corr=[InvGammaPrior(3., 1.), InvGammaPrior(3., 1.)], nugget_type="fit")
+    mo = M.MultiOutputGP_GPU(X, T, mean=native_mean([(1, 1)]), kernel="Matern52", nugget="fit", priors=pri, analytic_mean=True)
+    theta0 = np.array([0., 0., 0., np.log(1e-3)])
+    LibGPGPU.set_fit_options(max_iter=500, ftol=1e-12, gtol=1e-8, seed=3)
+    mo = M.fit_GP_MAP(mo, n_tries=1, theta0=theta0)
+    LibGPGPU.set_fit_options(max_iter=200, ftol=1e-9, gtol=1e-6, seed=0)
+    assert len(mo.get_indices_fit()) == n_out
+    for k, em in enumerate(mo.emulators):
+        th = em.theta
+        theta = th.get_data()
+        assert th.get_mean().shape == (0,)
+        rpri = R.GPPriorsRef(d, "fit", corr=[R.Prior("invgamma", 3., 1.), R.Prior("invgamma", 3., 1.)])
+        ref = R.GPRefMean(X, T[k], [(1, 1)], True, kernel="Matern52", nugget="fit", priors=rpri)
+        assert_allclose(em.current_logpost, ref.fit(theta), rtol=1e-7)
+        # trajectory parity is unpinned: the end point must be at least as good as scipy's from the same start
+        sci = R.fit_GP_MAP_ref(R.GPRefMean(X, T[k], [(1, 1)], True, kernel="Matern52", nugget="fit", priors=rpri),
+                               n_tries=1, theta0=theta0)
+        assert em.current_logpost <= sci.current_logpost + 1e-5 * abs(sci.current_logpost)
+        # the slope on x[1] is recovered by the analytic coefficients
+        assert_allclose(em._densegp_gpu.get_beta()[1], 2. * k, atol=0.75)
+    # more than 7 terms is refused loudly rather than silently truncated
+    with pytest.raises(RuntimeError, match="at most"):
+        M.GaussianProcessGPU(X, T[0], mean=native_mean([(0, p) for p in range(1, 9)]), analytic_mean=True)
+    # a parameter-free mean has nothing to integrate out: identical to the plain path
+    a = M.GaussianProcessGPU(X, T[0], nugget=1e-6, analytic_mean=True)
+    b = M.GaussianProcessGPU(X, T[0], nugget=1e-6)
+    th = np.array([0.3, -0.2, 0.1])
+    assert a.logposterior(th) == b.logposterior(th)
