@@ -242,8 +242,9 @@ __global__ __launch_bounds__(64) void backsolve_diag_kernel(BatchView v, int k0)
 // w_r[c] -= sum_i L[k0+i][c] alpha_r[k0+i] for c < k0 and every right-hand side r; one column pair per thread,
 // L is read once for all right-hand sides
 constexpr int BSG_THREADS = 64;     // small workgroups: at n=16000, B=1 a 256-thread version has only 32 workgroups in flight
+template <int RT>     // RT: compile-time bound on the number of right-hand sides (1 = plain fit path)
 __global__ __launch_bounds__(BSG_THREADS) void backsolve_gemv_kernel(BatchView v, int k0) {
-  __shared__ double ab[RMAX][64];
+  __shared__ double ab[RT][64];
   const int emu = slot_emu(v.idx, blockIdx.y);
   const int ld = v.LD, R = v.R;
   const double* A = v.A + (size_t)emu * v.MS;
@@ -252,24 +253,24 @@ __global__ __launch_bounds__(BSG_THREADS) void backsolve_gemv_kernel(BatchView v
   __syncthreads();
   const int c = 2 * (blockIdx.x * BSG_THREADS + threadIdx.x);
   if (c >= k0) return;
-  v2d s[RMAX];
+  v2d s[RT];
 #pragma unroll
-  for (int r = 0; r < RMAX; ++r) s[r] = (v2d){0., 0.};
+  for (int r = 0; r < RT; ++r) s[r] = (v2d){0., 0.};
   const double* p = A + (size_t)k0 * ld + c;
-#pragma unroll 8
+#pragma unroll(RT == 1 ? 32 : 8)
   for (int i = 0; i < 64; ++i) {
     const v2d x = *reinterpret_cast<const v2d*>(p + (size_t)i * ld);
 #pragma unroll
-    for (int r = 0; r < RMAX; ++r)
-      if (r < R) {
+    for (int r = 0; r < RT; ++r)
+      if (RT == 1 || r < R) {
         const double ar = ab[r][i];
         s[r][0] = __builtin_fma(x[0], ar, s[r][0]);
         s[r][1] = __builtin_fma(x[1], ar, s[r][1]);
       }
   }
 #pragma unroll
-  for (int r = 0; r < RMAX; ++r)
-    if (r < R) {
+  for (int r = 0; r < RT; ++r)
+    if (RT == 1 || r < R) {
       v2d cur = *reinterpret_cast<v2d*>(w + (size_t)r * ld + c);
       cur[0] -= s[r][0];
       cur[1] -= s[r][1];
@@ -401,7 +402,11 @@ void launch_backsolve(const BatchView& v, hipStream_t s) {
   for (int kb = nblk - 1; kb >= 0; --kb) {
     const int k0 = kb * 64;
     hipLaunchKernelGGL(backsolve_diag_kernel, dim3(v.nb), dim3(64), 0, s, v, k0);
-    if (k0 > 0) hipLaunchKernelGGL(backsolve_gemv_kernel, dim3((k0 / 2 + BSG_THREADS - 1) / BSG_THREADS, v.nb), dim3(BSG_THREADS), 0, s, v, k0);
+    if (k0 > 0) {
+      const dim3 grid((k0 / 2 + BSG_THREADS - 1) / BSG_THREADS, v.nb);
+      if (v.R == 1) hipLaunchKernelGGL(backsolve_gemv_kernel<1>, grid, dim3(BSG_THREADS), 0, s, v, k0);
+      else hipLaunchKernelGGL(backsolve_gemv_kernel<RMAX>, grid, dim3(BSG_THREADS), 0, s, v, k0);
+    }
   }
 }
 
