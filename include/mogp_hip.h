@@ -109,6 +109,10 @@ int mogp_densegp_predict_batch(mogp_densegp*, const double* testing, int m, int 
 int mogp_densegp_predict_variance_batch(mogp_densegp*, const double* testing, int m, int D, double* mean_out, double* var_out, int out_len);
 /* predict_deriv(testing, out (m,D)) :132-144 / densegp_gpu.hpp:411-448 */
 int mogp_densegp_predict_deriv(mogp_densegp*, const double* testing, int m, int D, double* out, int out_rows, int out_cols);
+/* predict(full_cov=True) of the CPU class, GaussianProcess.py:899-911: mean_out (m) and the
+ * m x m predictive covariance sigma^2 k(X*,X*) - (L^-1 K*)^T (L^-1 K*) [+ analytic-mean term], nugget NOT added.
+ * m is not limited by testing_size; the call fails if the device scratch (2 n m + m^2 doubles per emulator) exceeds 64 GB. */
+int mogp_densegp_predict_full_cov(mogp_densegp*, const double* testing, int m, int D, double* mean_out, double* cov_out /* m*m */);
 /* get_K :168 (sigma^2 k(X,X), no nugget) ; get_invQ :177 ; get_invQt :187 ; get_cholesky_lower :232
  * get_cholesky_lower fills `out` so that tril(out^T) == L  (densegp_gpu.hpp:478-481) */
 int mogp_densegp_get_K(mogp_densegp*, double* out /* n*n */);
@@ -159,6 +163,8 @@ int mogp_mogp_eval(mogp_mogp*, const double* thetas, int n_rows, int n_cols, dou
 int mogp_mogp_predict_batch(mogp_mogp*, const double* testing, int m, int D, double* means);
 int mogp_mogp_predict_variance_batch(mogp_mogp*, const double* testing, int m, int D, double* means, double* vars);
 int mogp_mogp_predict_deriv(mogp_mogp*, const double* testing, int m, int D, double* derivs);
+/* full predictive covariance of every fitted emulator in one batched pass: means (n_out, m), covs (n_out, m, m) */
+int mogp_mogp_predict_full_cov(mogp_mogp*, const double* testing, int m, int D, double* means, double* covs);
 /* same, but testing / outputs are DEVICE pointers (inputs already resident in HBM; results stay in HBM) */
 int mogp_mogp_predict_variance_batch_dev(mogp_mogp*, const double* d_testing, int m, int D, double* d_means, double* d_vars);
 /* fit_GP_MAP(MultiOutputGP_GPU&, n_tries, theta0) bindings.cu:604-605 / fitting.hpp:122-128.

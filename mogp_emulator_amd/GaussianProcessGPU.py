@@ -305,7 +305,7 @@ class GaussianProcessGPU(object):
         raise GPUUnavailableError("The Hessian calculation is not currently implemented in the GPU version of MOGP.")
 
     # -- predict ------------------------------------------------------------------------------------------
-    def predict(self, testing, unc=True, deriv=True, include_nugget=True):
+    def predict(self, testing, unc=True, deriv=True, include_nugget=True, full_cov=False):
         if not self.theta.data_has_been_set():
             raise ValueError("hyperparameters have not been fit for this Gaussian Process")
         testing = ndarray_coerce_type_and_flags(testing)
@@ -314,6 +314,18 @@ class GaussianProcessGPU(object):
         assert testing.ndim == 2
         m, D = testing.shape
         assert D == self.D
+        if unc and full_cov:
+            # CPU-class feature (GaussianProcess.py:899-911): (m, m) covariance, nugget on the diagonal, not clipped
+            means, cov = np.zeros(m), np.zeros((m, m))
+            self._densegp_gpu.predict_full_cov(testing, means, cov)
+            if include_nugget:
+                cov[np.diag_indices(m)] += self.nugget
+            derivs = None
+            if deriv:
+                derivs = np.zeros((m, self.D))
+                for lo in range(0, m, self._max_batch_size):
+                    self._densegp_gpu.predict_deriv(testing[lo:lo + self._max_batch_size], derivs[lo:lo + self._max_batch_size])
+            return PredictResult(mean=means, unc=cov, deriv=derivs)
         step = self._max_batch_size
         means = np.zeros(m)
         variances = np.zeros(m) if unc else None

@@ -102,7 +102,7 @@ class MultiOutputGP_GPU(object):
     def _nuggets(self):
         return np.array([self._mogp_gpu.emulator(i).get_nugget_size() for i in range(self.n_emulators)])
 
-    def predict(self, testing, unc=True, deriv=True, include_nugget=True, allow_not_fit=False, processes=None):
+    def predict(self, testing, unc=True, deriv=True, include_nugget=True, allow_not_fit=False, processes=None, full_cov=False):
         not_fit = self.get_indices_not_fit()
         if not allow_not_fit and len(not_fit) > 0:
             raise ValueError("Hyperparameters have not been fit for this Gaussian Process")
@@ -115,7 +115,13 @@ class MultiOutputGP_GPU(object):
         means = np.zeros((self.n_emulators, m))
         uncs = np.zeros((self.n_emulators, m))
         derivs = np.zeros((self.n_emulators, m, self.D))
-        if unc:
+        if unc and full_cov:
+            # (n_emulators, m, m) covariances, MultiOutputGP.predict(full_cov=True) of the CPU class
+            uncs = np.zeros((self.n_emulators, m, m))
+            self._mogp_gpu.predict_full_cov(testing, means, uncs)
+            if include_nugget:
+                uncs[:, np.arange(m), np.arange(m)] += self._nuggets()[:, None]
+        elif unc:
             self._mogp_gpu.predict_variance_batch(testing, means, uncs)
             if include_nugget:
                 # per-emulator nugget actually in use (adaptive / fit values differ between emulators)

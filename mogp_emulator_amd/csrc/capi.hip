@@ -249,6 +249,13 @@ int mogp_densegp_predict_deriv(mogp_densegp* h, const double* testing, int m, in
     h->eng->predict(ids, testing, m, false, mean.data(), nullptr, m, false, out);
   });
 }
+int mogp_densegp_predict_full_cov(mogp_densegp* h, const double* testing, int m, int D, double* mean_out, double* cov_out) {
+  GUARD({
+    if (D != h->eng->D) throw std::runtime_error("testing points must have D columns");
+    std::vector<int> ids{h->idx};
+    h->eng->predict_full_cov(ids, testing, m, mean_out, cov_out);
+  });
+}
 int mogp_densegp_get_K(mogp_densegp* h, double* out) { GUARD(h->eng->get_K(h->idx, out)); }
 int mogp_densegp_get_invQ(mogp_densegp* h, double* out) { GUARD(h->eng->get_invQ(h->idx, out)); }
 int mogp_densegp_get_invQt(mogp_densegp* h, double* out) { GUARD(h->eng->get_invQt(h->idx, out)); }
@@ -418,6 +425,27 @@ int mogp_mogp_predict_variance_batch(mogp_mogp* h, const double* testing, int m,
 }
 int mogp_mogp_predict_deriv(mogp_mogp* h, const double* testing, int m, int D, double* derivs) {
   GUARD(mogp_predict_common(h, testing, m, D, nullptr, nullptr, derivs));
+}
+int mogp_mogp_predict_full_cov(mogp_mogp* h, const double* testing, int m, int D, double* means, double* covs) {
+  GUARD({
+    Engine* e = h->eng.get();
+    if (D != e->D) throw std::runtime_error("testing points must have D columns");
+    std::vector<int> ids = fitted_ids(h);
+    if (ids.empty()) return 0;
+    if ((int)ids.size() == e->B) {
+      e->predict_full_cov(ids, testing, m, means, covs);
+    } else {
+      const size_t nf = ids.size();
+      const size_t mm = (size_t)m * m;
+      std::vector<double> mu(nf * m);
+      std::vector<double> cc(nf * mm);
+      e->predict_full_cov(ids, testing, m, mu.data(), cc.data());
+      for (size_t k = 0; k < nf; ++k) {
+        std::memcpy(means + (size_t)ids[k] * m, mu.data() + k * m, m * sizeof(double));
+        std::memcpy(covs + (size_t)ids[k] * mm, cc.data() + k * mm, mm * sizeof(double));
+      }
+    }
+  });
 }
 int mogp_mogp_predict_variance_batch_dev(mogp_mogp* h, const double* d_testing, int m, int D, double* d_means, double* d_vars) {
   GUARD({

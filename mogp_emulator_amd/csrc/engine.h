@@ -66,6 +66,8 @@ class Engine {
                long out_ld, bool out_on_device, double* derivs /* host (ids, m, D) or null */);
 
   void get_K(int i, double* out);
+  // predict(full_cov=True), GaussianProcess.py:899-911: means (nb, m), covs (nb, m, m) host buffers, nugget NOT included
+  void predict_full_cov(const std::vector<int>& ids, const double* Xs, int m, double* means, double* covs);
   void get_invQ(int i, double* out);
   void get_invQt(int i, double* out);
   void get_chol(int i, double* out);

@@ -771,6 +771,72 @@ void Engine::predict(const std::vector<int>& ids, const double* Xs, int m, bool 
   }
 }
 
+void Engine::predict_full_cov(const std::vector<int>& ids, const double* Xs, int m, double* means, double* covs) {
+  const int nb = (int)ids.size();
+  if (nb == 0 || m == 0) return;
+  for (int i : ids)
+    if (!gp[i].factored) throw std::runtime_error("emulator has not been fit");
+  const int MP = roundup(m, 128);
+  const double need = (double)nb * 8.0 * ((double)LD * MP * 2.0 + (double)m * m);
+  if (need > 64.0e9)
+    throw std::runtime_error("full_cov: " + std::to_string(nb) + " x " + std::to_string(m) +
+                             " test points need more than 64 GB of device scratch; use fewer points per call");
+  ensure_linv(ids);
+  upload_idx(ids);
+  BatchView v = view(nb);
+  double *dXf = nullptr, *dKf = nullptr, *dV = nullptr, *dC = nullptr, *dDots = nullptr;
+  try {
+    dXf = dalloc<double>((size_t)m * D);
+    dKf = dalloc<double>((size_t)nb * MP * LD);
+    dV = dalloc<double>((size_t)nb * NP * MP);
+    dC = dalloc<double>((size_t)nb * m * m);
+    dDots = dalloc<double>((size_t)nb * R * m);
+    HIPCK(hipMemcpyAsync(dXf, Xs, (size_t)m * D * sizeof(double), hipMemcpyHostToDevice, stream));
+    launch_cross_cov_mean(v, dXf, m, MP, dKf, dDots, m, stream);
+    launch_cov_self_batch(v, dXf, m, dC, stream);
+    launch_predict_fullcov(v, dKf, m, MP, dV, dC, stream);
+    std::vector<double> dots((size_t)nb * R * m);
+    HIPCK(hipMemcpyAsync(dots.data(), dDots, dots.size() * sizeof(double), hipMemcpyDeviceToHost, stream));
+    HIPCK(hipMemcpyAsync(covs, dC, (size_t)nb * m * m * sizeof(double), hipMemcpyDeviceToHost, stream));
+    HIPCK(hipStreamSynchronize(stream));
+    HIPCK(hipGetLastError());
+    std::vector<double> mv(m), Hs((size_t)q * m), rm((size_t)q * m), dummy(std::max(q, 1), 0.);
+    if (R > 1) mean.mean_deriv(Xs, m, D, dummy.data(), q, Hs.data());
+    for (int k = 0; k < nb; ++k) {
+      const GPState& g = gp[ids[k]];
+      const double* dk = dots.data() + (size_t)k * R * m;
+      double* mu = means + (size_t)k * m;
+      for (int j = 0; j < m; ++j) mu[j] = dk[j];
+      if (R > 1) {
+        // + h(x*)^T beta and + (LA^-1 R)^T (LA^-1 R), R = H*^T - H^T K^-1 k*   (calc_R, linalg_utils.py:123-168)
+        for (int j = 0; j < m; ++j) {
+          for (int c = 0; c < q; ++c) {
+            mu[j] += g.beta[c] * Hs[(size_t)c * m + j];
+            double s = Hs[(size_t)c * m + j] - dk[(size_t)(1 + c) * m + j];
+            for (int p = 0; p < c; ++p) s -= g.LA[c * q + p] * rm[(size_t)p * m + j];
+            rm[(size_t)c * m + j] = s / g.LA[c * q + c];
+          }
+        }
+        double* Ck = covs + (size_t)k * m * m;
+        for (int i = 0; i < m; ++i)
+          for (int c = 0; c < q; ++c) {
+            const double ri = rm[(size_t)c * m + i];
+            const double* rc = rm.data() + (size_t)c * m;
+            double* row = Ck + (size_t)i * m;
+            for (int j = 0; j < m; ++j) row[j] += ri * rc[j];
+          }
+      } else if (mean.kind != 0) {
+        mean.mean_f(Xs, m, D, g.meanp.data(), n_mean(), mv.data());
+        for (int j = 0; j < m; ++j) mu[j] += mv[j];
+      }
+    }
+  } catch (...) {
+    for (double* p : {dXf, dKf, dV, dC, dDots}) if (p) hipFree(p);
+    throw;
+  }
+  for (double* p : {dXf, dKf, dV, dC, dDots}) if (p) hipFree(p);
+}
+
 void Engine::get_K(int i, double* out) {
   if (!gp[i].has_data) throw std::runtime_error("emulator has not been fit");
   double* tmp = dalloc<double>((size_t)n * n);

@@ -126,15 +126,19 @@ __global__ __launch_bounds__(256) void cov_build_kernel(BatchView v, int nt) {
 
 // full (n,n) sigma^2 k(X,X) without nugget for get_K (GaussianProcessGPU.py:504-513)
 template <int KT>
-__global__ __launch_bounds__(256) void cov_full_kernel(BatchView v, int emu, double* __restrict__ out) {
+__global__ __launch_bounds__(256) void cov_full_kernel(BatchView v, int emu, const double* __restrict__ Xp, int n, double* __restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int i0 = blockIdx.y * 64, j0 = blockIdx.x * 64;
-  const int n = v.n, D = v.D;
+  const int D = v.D;
+  if (emu < 0) {                     // batched form: one (n, n) matrix per slot
+    emu = slot_emu2(v.idx, blockIdx.z);
+    out += (size_t)blockIdx.z * n * n;
+  }
   const double* P = v.P + (size_t)emu * v.PS;
   double* si = sm;
   double* sj = sm + 64 * D;
-  stage_rows(v.X, n, D, i0, si);
-  stage_rows(v.X, n, D, j0, sj);
+  stage_rows(Xp, n, D, i0, si);
+  stage_rows(Xp, n, D, j0, sj);
   __syncthreads();
   const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
   double r2[4][4];
@@ -435,10 +439,19 @@ void launch_cov_build(const BatchView& v, hipStream_t s) {
   prof_end("cov_build", s, 0., (double)v.nb * (4.0 * v.NP * (double)v.NP + 8.0 * v.n * v.D));
 }
 
+// prior covariance of the test points for every slot: out (nb, m, m) = sigma^2 k(Xs, Xs)
+void launch_cov_self_batch(const BatchView& v, const double* Xs, int m, double* out, hipStream_t s) {
+  const int nt = (m + 63) / 64;
+  const size_t sm = (size_t)128 * v.D * sizeof(double);
+#define CALL(K) hipLaunchKernelGGL((cov_full_kernel<K>), dim3(nt, nt, v.nb), dim3(256), sm, s, v, -1, Xs, m, out)
+  KT_DISPATCH(v.kernel_type, CALL);
+#undef CALL
+}
+
 void launch_cov_full(const BatchView& v, int emu, double* out, hipStream_t s) {
   const int nt = (v.n + 63) / 64;
   const size_t sm = (size_t)128 * v.D * sizeof(double);
-#define CALL(K) hipLaunchKernelGGL((cov_full_kernel<K>), dim3(nt, nt), dim3(256), sm, s, v, emu, out)
+#define CALL(K) hipLaunchKernelGGL((cov_full_kernel<K>), dim3(nt, nt), dim3(256), sm, s, v, emu, v.X, v.n, out)
   KT_DISPATCH(v.kernel_type, CALL);
 #undef CALL
 }

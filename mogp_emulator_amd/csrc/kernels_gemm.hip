@@ -283,6 +283,7 @@ __global__ __launch_bounds__(256, 2) void kinv_kernel(BatchView v, int ntiles, i
 // ---------------------------------------------------------------------------------------------
 // predictive variance partials: V = Linv * Ks^T (never stored);  partial[z][ti][m] = sum_{i in tile ti} V[i,m]^2
 // ---------------------------------------------------------------------------------------------
+template <bool STORE>   // STORE: V itself is written (NP x MP per slot) for the full predictive covariance instead of its column norms
 __global__ __launch_bounds__(256, 2) void predict_var_kernel(BatchView v, const double* __restrict__ Ks, int MP, int nti, int ntj,
                                                            double* __restrict__ partial) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -305,6 +306,11 @@ __global__ __launch_bounds__(256, 2) void predict_var_kernel(BatchView v, const 
   const int i0 = ti * C::BM, j0 = tj * C::BM;
   v4d acc[4][4];
   gemm_mainloop<4, true, true>(Li + (size_t)i0 * ld, ld, K + (size_t)j0 * ld, ld, (i0 + C::BM) / BK, acc, smem);
+  if (STORE) {
+    double* V = partial + (size_t)z * v.NP * MP;
+    for_each_acc<4>(acc, [&](int r, int c, double x) { V[(size_t)(i0 + r) * MP + j0 + c] = x; });
+    return;
+  }
   // column sums of squares over the tile's 128 rows
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wr = wave >> 1, wc = wave & 1;
@@ -323,6 +329,36 @@ __global__ __launch_bounds__(256, 2) void predict_var_kernel(BatchView v, const 
   }
   __syncthreads();
   if (threadIdx.x < 128) partial[((size_t)z * nti + ti) * MP + j0 + threadIdx.x] = red[threadIdx.x] + red[128 + threadIdx.x];
+}
+
+// ---------------------------------------------------------------------------------------------
+// full predictive covariance (GaussianProcess.py:899-911):  C = K** - V^T V, V = Linv Ks^T (kend x MP, stored).
+// C arrives holding K** (m x m, row stride m); lower 128-tiles are computed and mirrored.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void fullcov_kernel(BatchView v, const double* __restrict__ V, int MP, int m, int ntiles, int kend,
+                                                       double* __restrict__ cov) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  using C = Cfg<4>;
+  int z, tile;
+  decode_block(v.nb, ntiles, z, tile);
+  if (z >= v.nb) return;
+  int ti = (int)((sqrt(8.0 * tile + 1.0) - 1.0) * 0.5);
+  while (ti * (ti + 1) / 2 > tile) --ti;
+  while ((ti + 1) * (ti + 2) / 2 <= tile) ++ti;
+  const int tj = tile - ti * (ti + 1) / 2;
+  const double* Vz = V + (size_t)z * v.NP * MP;
+  double* Cz = cov + (size_t)z * m * m;
+  const int i0 = ti * C::BM, j0 = tj * C::BM;
+  v4d acc[4][4];
+  gemm_mainloop<4, false, false>(Vz + i0, MP, Vz + j0, MP, kend / BK, acc, smem);
+  for_each_acc<4>(acc, [&](int r, int c, double x) {
+    const int i = i0 + r, j = j0 + c;
+    if (i < m && j < m) {
+      const double val = Cz[(size_t)i * m + j] - x;
+      Cz[(size_t)i * m + j] = val;
+      if (ti != tj) Cz[(size_t)j * m + i] = val;
+    }
+  });
 }
 
 __global__ void predict_var_finish_kernel(BatchView v, const double* __restrict__ partial, int m, int MP, int nti, double* var, int var_ld) {
@@ -419,9 +455,23 @@ void launch_predict_var(const BatchView& v, const double* Ks, int m, int MP, dou
   const int nti = (v.n + 127) / 128, ntj = MP / 128;
   prof_begin("predict_var", s);
   const int nsup = ((nti + 7) / 8) * ((ntj + 7) / 8) * 64;
-  hipLaunchKernelGGL(predict_var_kernel, dim3(padded_grid(v.nb, nsup)), dim3(256), smem_bytes<4>(), s, v, Ks, MP, nti, ntj, partial);
+  hipLaunchKernelGGL(predict_var_kernel<false>, dim3(padded_grid(v.nb, nsup)), dim3(256), smem_bytes<4>(), s, v, Ks, MP, nti, ntj, partial);
   prof_end("predict_var", s, (double)v.nb * (double)m * v.n * v.n, 0.);
   hipLaunchKernelGGL(predict_var_finish_kernel, dim3((m + 255) / 256, v.nb), dim3(256), 0, s, v, partial, m, MP, nti, var, var_ld);
+}
+
+// cov (nb, m, m) holds K** on entry and the predictive covariance (without nugget) on return; V is nb*NP*MP scratch
+void launch_predict_fullcov(const BatchView& v, const double* Ks, int m, int MP, double* V, double* cov, hipStream_t s) {
+  const int nti = (v.n + 127) / 128, ntj = MP / 128;
+  const int nsup = ((nti + 7) / 8) * ((ntj + 7) / 8) * 64;
+  prof_begin("predict_var", s);
+  hipLaunchKernelGGL(predict_var_kernel<true>, dim3(padded_grid(v.nb, nsup)), dim3(256), smem_bytes<4>(), s, v, Ks, MP, nti, ntj, V);
+  prof_end("predict_var", s, (double)v.nb * (double)m * v.n * v.n, 0.);
+  const int ntiles = ntj * (ntj + 1) / 2;
+  const int kend = ((v.n + 15) / 16) * 16;
+  prof_begin("fullcov_syrk", s);
+  hipLaunchKernelGGL(fullcov_kernel, dim3(padded_grid(v.nb, ntiles)), dim3(256), smem_bytes<4>(), s, v, V, MP, m, ntiles, kend, cov);
+  prof_end("fullcov_syrk", s, (double)v.nb * (double)m * m * v.n, 0.);
 }
 
 }  // namespace mogp

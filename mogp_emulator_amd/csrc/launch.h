@@ -46,6 +46,10 @@ struct BatchView {
 void launch_cov_build(const BatchView& v, hipStream_t s);
 // full symmetric K (no nugget) for get_K: out (n,n) for one emulator
 void launch_cov_full(const BatchView& v, int emu, double* out, hipStream_t s);
+// out (nb, m, m) = sigma^2 k(Xs, Xs) per slot (no nugget)
+void launch_cov_self_batch(const BatchView& v, const double* Xs, int m, double* out, hipStream_t s);
+// full predictive covariance: cov (nb, m, m) holds K** on entry, K** - Ks K^-1 Ks^T on return; V: nb*NP*MP scratch
+void launch_predict_fullcov(const BatchView& v, const double* Ks, int m, int MP, double* V, double* cov, hipStream_t s);
 
 // --- blocked Cholesky ---------------------------------------------------------------------
 // potf2 of the 64x64 diagonal block at c0; info[emu] = first failing (1-based) column or 0

@@ -581,6 +581,15 @@ class DenseGP_GPU(object):
         check(_lib.mogp_densegp_predict_deriv(self._h, dptr(x), x.shape[0], x.shape[1], dptr(result), result.shape[0],
                                               result.shape[1]))
 
+    def predict_full_cov(self, testing, mean, cov):
+        """mean (m,), cov (m, m): full predictive covariance WITHOUT nugget (GaussianProcess.py:899-911)"""
+        x = self._testing(testing)
+        _outbuf(mean, "mean")
+        _outbuf(cov, "cov")
+        if mean.size < x.shape[0] or cov.size < x.shape[0] ** 2:
+            raise RuntimeError("predict_full_cov: The result buffer passed was too small to hold the covariance")
+        check(_lib.mogp_densegp_predict_full_cov(self._h, dptr(x), x.shape[0], x.shape[1], dptr(mean), dptr(cov)))
+
     # -- matrices -------------------------------------------------------------------------------
     def _fill_nn(self, fn, out, name):
         _outbuf(out, name)
@@ -746,6 +755,15 @@ class MultiOutputGP_GPU(object):
         if results.size < self.n_emulators() * x.size:
             raise RuntimeError("predict_deriv: the result buffer passed was the wrong shape to hold the result")
         check(_lib.mogp_mogp_predict_deriv(self._h, dptr(x), x.shape[0], x.shape[1], dptr(results)))
+
+    def predict_full_cov(self, testing, means, covs):
+        """means (n_out, m), covs (n_out, m, m) for every fitted emulator, one batched device pass (no nugget)"""
+        x = self._testing(testing)
+        _outbuf(means, "means")
+        _outbuf(covs, "covs")
+        if means.size < self.n_emulators() * x.shape[0] or covs.size < self.n_emulators() * x.shape[0] ** 2:
+            raise RuntimeError("predict_full_cov: The result buffer passed was too small to hold the covariance")
+        check(_lib.mogp_mogp_predict_full_cov(self._h, dptr(x), x.shape[0], x.shape[1], dptr(means), dptr(covs)))
 
     def predict_variance_batch_dev(self, d_testing, m, d_means, d_vars):
         """Device-pointer variant: inputs already resident in HBM, results stay in HBM."""

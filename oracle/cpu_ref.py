@@ -178,6 +178,11 @@ def cho_solve_L(L, b):
     return cho_solve((L, True), b)
 
 
+def solve_L(L, b):
+    """ChoInv.solve_L, linalg/cholesky.py:44-65: L^-1 b."""
+    return linalg.solve_triangular(L, b, lower=True)
+
+
 def logdet_L(L):
     """ChoInv.logdet, linalg/cholesky.py:67-79."""
     return 2.0 * np.sum(np.log(np.diag(L)))
@@ -364,8 +369,8 @@ class GPRef(object):
         return partials
 
     # -- predict ------------------------------------------------------------
-    def predict(self, testing, unc=True, deriv=False, include_nugget=True):
-        """GaussianProcess.py:818-927 (full_cov=False, R = 0).  ``deriv=True``
+    def predict(self, testing, unc=True, deriv=False, include_nugget=True, full_cov=False):
+        """GaussianProcess.py:818-927 (R = 0; ``full_cov`` :899-911).  ``deriv=True``
         returns the analytic input-derivative of the mean, which is what
         DenseGP_GPU::predict_deriv (densegp_gpu.hpp:411-448) returns."""
         if self.theta is None:
@@ -380,9 +385,16 @@ class GPRef(object):
         if unc:
             Kinv_Ktest = cho_solve_L(self.L, Ktest)
             sigma_2 = np.exp(self.theta[self.D])
-            if include_nugget:
-                sigma_2 = sigma_2 + self.nugget
-            var = np.maximum(sigma_2 - np.sum(Ktest * Kinv_Ktest, axis=0), 0.)
+            if full_cov:
+                Kss = sigma_2 * kernel_f(testing, testing, self.theta[:self.D], self.kernel)
+                if include_nugget:
+                    Kss = Kss + np.eye(testing.shape[0]) * self.nugget
+                Linv_Ktest = solve_L(self.L, Ktest)
+                var = Kss - np.dot(Linv_Ktest.T, Linv_Ktest)
+            else:
+                if include_nugget:
+                    sigma_2 = sigma_2 + self.nugget
+                var = np.maximum(sigma_2 - np.sum(Ktest * Kinv_Ktest, axis=0), 0.)
         d = None
         if deriv:
             dk = np.exp(self.theta[self.D]) * kernel_inputderiv(testing, self.X, self.theta[:self.D],
@@ -469,7 +481,7 @@ class GPRefMean(GPRef):
         partials -= self.priors.dlogpdtheta(self.theta)
         return partials
 
-    def predict(self, testing, unc=True, deriv=False, include_nugget=True):
+    def predict(self, testing, unc=True, deriv=False, include_nugget=True, full_cov=False):
         if self.theta is None:
             raise ValueError("hyperparameters have not been fit for this Gaussian Process")
         testing = np.asarray(testing, dtype=np.float64)
@@ -483,6 +495,14 @@ class GPRefMean(GPRef):
             Kinv_Ktest = cho_solve_L(self.L, Ktest)
             Rm = Hs.T - np.dot(self.H.T, Kinv_Ktest)                                     # calc_R, linalg_utils.py:123-168
             sigma_2 = np.exp(self.theta[self.D])
+            if full_cov:                                                                 # :899-911
+                Kss = sigma_2 * kernel_f(testing, testing, self.theta[:self.D], self.kernel)
+                if include_nugget:
+                    Kss = Kss + np.eye(testing.shape[0]) * self.nugget
+                Linv_Ktest = solve_L(self.L, Ktest)
+                LAinv_R = solve_L(self.LA, Rm)
+                var = Kss - np.dot(Linv_Ktest.T, Linv_Ktest) + np.dot(LAinv_R.T, LAinv_R)
+                return mu, var, None
             if include_nugget:
                 sigma_2 = sigma_2 + self.nugget
             var = np.maximum(sigma_2 - np.sum(Ktest * Kinv_Ktest, axis=0) + np.sum(Rm * cho_solve_L(self.LA, Rm), axis=0), 0.)

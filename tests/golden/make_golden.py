@@ -236,6 +236,26 @@ def main():
                 out[pre + "var"] = var
                 out[pre + "dm"] = gp.get_design_matrix(X)[:5]
     np.savez_compressed(os.path.join(HERE, "meanfunc.npz"), **out)
+
+    # ---- 11. predict(full_cov=True): SURVEY 8f row 3 ------------------------------------------------
+    X, T, Xs = synth(11, 180, 3, 1, 70)
+    tq = T[0] + 1.0 - 0.8 * X[:, 1]
+    out = dict(X=X, t=tq, Xs=Xs)
+    for tag, formula in (("zero", None), ("lin", "x[1]")):
+        for kern in KERNELS:
+            for mode, nugget in (("fixed", 1.e-5), ("fit", "fit")):
+                theta = [0.3, 0.1, -0.4, 0.2] + ([np.log(3.e-4)] if mode == "fit" else [])
+                nt = nugget if isinstance(nugget, str) else "fixed"
+                gp = GaussianProcess(X, tq, mean=formula, kernel=KERNELS[kern](), nugget=nugget, priors=weak(3, nt))
+                gp.fit(np.array(theta))
+                pre = "%s_%s_%s_" % (tag, kern, mode)
+                out[pre + "theta"] = np.array(theta)
+                mean, cov, _ = gp.predict(Xs, full_cov=True)
+                out[pre + "mean"] = mean
+                out[pre + "cov"] = cov
+                out[pre + "cov_nonug"] = gp.predict(Xs, full_cov=True, include_nugget=False)[1]
+                out[pre + "var"] = gp.predict(Xs)[1]
+    np.savez_compressed(os.path.join(HERE, "fullcov.npz"), **out)
     print("golden vectors written to", HERE)
 
 

@@ -629,3 +629,47 @@ def test_analytic_mean_fit_GP_MAP_and_limits():
     b = M.GaussianProcessGPU(X, T[0], nugget=1e-6)
     th = np.array([0.3, -0.2, 0.1])
     assert a.logposterior(th) == b.logposterior(th)
+
+
+# ----------------------------------------------------------------------------------------------------
+# predict(full_cov=True).  Tolerance: rtol 1e-6, atol 1e-7 * max|cov| (fp64, cond(K) ~ 1e9).
+# ----------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("tag", ["zero", "lin"])
+@pytest.mark.parametrize("kern", KERNELS)
+@pytest.mark.parametrize("mode", ["fixed", "fit"])
+def test_full_cov_vs_reference_golden(tag, kern, mode):
+    g = load_golden("fullcov.npz")
+    pre = "%s_%s_%s_" % (tag, kern, mode)
+    nug = {"fixed": 1.e-5, "fit": "fit"}[mode]
+    kw = {} if tag == "zero" else dict(mean=native_mean([(1, 1)]), analytic_mean=True)
+    gp = make_gp(g["X"], g["t"], kern, nug, **kw)
+    gp.fit(g[pre + "theta"])
+    scale = np.abs(g[pre + "cov"]).max()
+    mu, cov, _ = gp.predict(g["Xs"], full_cov=True, deriv=False)
+    assert cov.shape == (70, 70)
+    assert_allclose(mu, g[pre + "mean"], rtol=1e-7, atol=1e-8)
+    assert_allclose(cov, g[pre + "cov"], rtol=1e-6, atol=1e-7 * scale)
+    assert_allclose(gp.predict(g["Xs"], full_cov=True, include_nugget=False)[1], g[pre + "cov_nonug"], rtol=1e-6, atol=1e-7 * scale)
+    assert np.array_equal(cov, cov.T)                                  # mirrored, not recomputed
+    assert_allclose(np.diag(cov), gp.predict(g["Xs"])[1], rtol=1e-6, atol=1e-7 * scale)
+
+
+@pytest.mark.parametrize("m", [1, 127, 128, 129, 300])
+def test_full_cov_multioutput_tile_boundaries(m):
+    X, T, _ = synth(21, 333, 4, 3, 1)
+    Xs = np.random.default_rng(m).random((m, 4))
+    mo = M.MultiOutputGP_GPU(X, T, kernel="Matern52", nugget="fit", priors=weak(4, "fit"))
+    rng = np.random.default_rng(3)
+    thetas = np.stack([np.r_[rng.uniform(0., 2., 4), rng.uniform(-1., 1.), rng.uniform(-9., -6.)] for _ in range(3)])
+    mo.fit_emulator(0, thetas[0])
+    mo.fit_emulator(2, thetas[2])                # emulator 1 stays unfit: NaN rows under allow_not_fit
+    mean, cov, _ = mo.predict(Xs, full_cov=True, deriv=False, allow_not_fit=True)
+    assert cov.shape == (3, m, m) and np.all(np.isnan(cov[1])) and np.all(np.isnan(mean[1]))
+    for k in (0, 2):
+        ref = R.GPRef(X, T[k], kernel="Matern52", nugget="fit")
+        ref.fit(thetas[k])
+        rmu, rcov, _ = ref.predict(Xs, full_cov=True)
+        assert_allclose(mean[k], rmu, rtol=1e-7, atol=1e-8)
+        assert_allclose(cov[k], rcov, rtol=1e-6, atol=1e-7 * np.abs(rcov).max())
+        # positive semi-definite up to rounding
+        assert np.linalg.eigvalsh(cov[k]).min() > -1e-8 * np.abs(rcov).max()

@@ -240,3 +240,25 @@ def test_analytic_mean_branch_vs_reference(tag, kern, mode):
         mu, var, _ = gp.predict(g["Xs"])
         assert_allclose(mu, g[pre + "mean"], rtol=1e-7, atol=1e-8)
         assert_allclose(var, g[pre + "var"], rtol=1e-6, atol=1e-9)
+
+
+@pytest.mark.parametrize("tag", ["zero", "lin"])
+@pytest.mark.parametrize("kern", KERNELS)
+@pytest.mark.parametrize("mode", ["fixed", "fit"])
+def test_full_cov_vs_reference(tag, kern, mode):
+    # predict(full_cov=True), GaussianProcess.py:899-911
+    g = load_golden("fullcov.npz")
+    pre = "%s_%s_%s_" % (tag, kern, mode)
+    nug = {"fixed": 1.e-5, "fit": "fit"}[mode]
+    if tag == "zero":
+        gp = R.GPRef(g["X"], g["t"], kernel=kern, nugget=nug)
+    else:
+        gp = R.GPRefMean(g["X"], g["t"], [(1, 1)], True, kernel=kern, nugget=nug)
+    gp.fit(g[pre + "theta"])
+    mu, cov, _ = gp.predict(g["Xs"], full_cov=True)
+    scale = np.abs(g[pre + "cov"]).max()
+    assert_allclose(mu, g[pre + "mean"], rtol=1e-7, atol=1e-8)
+    assert_allclose(cov, g[pre + "cov"], rtol=1e-6, atol=1e-7 * scale)
+    assert_allclose(gp.predict(g["Xs"], full_cov=True, include_nugget=False)[1], g[pre + "cov_nonug"], rtol=1e-6, atol=1e-7 * scale)
+    # the diagonal is the (unclipped) predictive variance
+    assert_allclose(np.diag(cov), g[pre + "var"], rtol=1e-6, atol=1e-7 * scale)
