@@ -115,6 +115,15 @@ int mogp_densegp_predict_deriv(mogp_densegp*, const double* testing, int m, int 
 int mogp_densegp_predict_full_cov(mogp_densegp*, const double* testing, int m, int D, double* mean_out, double* cov_out /* m*m */);
 /* get_K :168 (sigma^2 k(X,X), no nugget) ; get_invQ :177 ; get_invQt :187 ; get_cholesky_lower :232
  * get_cholesky_lower fills `out` so that tril(out^T) == L  (densegp_gpu.hpp:478-481) */
+/* Consumers of the batched prediction, fused on the device so that a query sweep returns one
+ * score per point instead of means and variances:
+ *  - implausibility |z - E f(x)| / sqrt(Var f(x) [+ nugget] + discrepancy + obs_var)  (HistoryMatching.py:197-276);
+ *    zero / fixed mean functions only;
+ *  - leave-one-out predictive variance at every training input, 1 / [K^-1]_ii: what MICEFastGP.fast_predict(index)
+ *    computes for one index from a Woodbury downdate (SequentialDesign.py:705-747), for all indices at once. */
+int mogp_densegp_implausibility(mogp_densegp*, const double* testing, int m, int D, double obs, double obs_var, double discrepancy,
+                                int include_nugget, double* out /* m */);
+int mogp_densegp_loo_variance(mogp_densegp*, double* out /* n */);
 int mogp_densegp_get_K(mogp_densegp*, double* out /* n*n */);
 int mogp_densegp_get_invQ(mogp_densegp*, double* out /* n*n */);
 int mogp_densegp_get_invQt(mogp_densegp*, double* out /* n */);
@@ -164,6 +173,10 @@ int mogp_mogp_predict_batch(mogp_mogp*, const double* testing, int m, int D, dou
 int mogp_mogp_predict_variance_batch(mogp_mogp*, const double* testing, int m, int D, double* means, double* vars);
 int mogp_mogp_predict_deriv(mogp_mogp*, const double* testing, int m, int D, double* derivs);
 /* full predictive covariance of every fitted emulator in one batched pass: means (n_out, m), covs (n_out, m, m) */
+/* multi-output implausibility: obs / obs_var / discrepancy (n_out); out[j] = the (rank+1)-th largest of the n_out
+ * per-output implausibilities at query point j (rank 0 = maximum; forced to 0 for one output; rank <= 15) */
+int mogp_mogp_implausibility(mogp_mogp*, const double* testing, int m, int D, const double* obs, const double* obs_var,
+                             const double* discrepancy, int include_nugget, int rank, double* out /* m */);
 int mogp_mogp_predict_full_cov(mogp_mogp*, const double* testing, int m, int D, double* means, double* covs);
 /* same, but testing / outputs are DEVICE pointers (inputs already resident in HBM; results stay in HBM) */
 int mogp_mogp_predict_variance_batch_dev(mogp_mogp*, const double* d_testing, int m, int D, double* d_means, double* d_vars);

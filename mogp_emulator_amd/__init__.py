@@ -6,6 +6,8 @@ mogp_emulator_amd -- MI355X (gfx950) native fit + predict backend for mogp_emula
   libgpgpu.py      drop-in for the reference's pybind11 module `libgpgpu`
   LibGPGPU.py, GaussianProcessGPU.py, MultiOutputGP_GPU.py, fitting.py, Priors.py, Kernel.py
                    host-side mirrors of the reference's GPU-facing Python interface
+  HistoryMatching.py, SequentialDesign.py
+                   consumers of the batched prediction (implausibility, MICE scoring), fused on the device
   dist.py          one-process-per-GPU sharding of emulators + single gather (torch.distributed/RCCL)
 """
 from .LibGPGPU import HAVE_LIBGPGPU, gpu_usable            # noqa: F401
@@ -16,5 +18,7 @@ if HAVE_LIBGPGPU:
     from .fitting import fit_GP_MAP                                         # noqa: F401
     from .Kernel import SquaredExponential, Matern52                       # noqa: F401
     from .Priors import GPPriors, InvGammaPrior, GammaPrior, LogNormalPrior, WeakPrior   # noqa: F401
+    from .HistoryMatching import HistoryMatching                           # noqa: F401
+    from .SequentialDesign import MICEFastGP, mice_criterion               # noqa: F401
 
 __version__ = "0.1.0"

@@ -80,6 +80,8 @@ SIGNATURES = {
     "mogp_densegp_predict_variance_batch": (c_int, [c_void_p, c_double_p, c_int, c_int, c_double_p, c_double_p, c_int]),
     "mogp_densegp_predict_deriv": (c_int, [c_void_p, c_double_p, c_int, c_int, c_double_p, c_int, c_int]),
     "mogp_densegp_predict_full_cov": (c_int, [c_void_p, c_double_p, c_int, c_int, c_double_p, c_double_p]),
+    "mogp_densegp_implausibility": (c_int, [c_void_p, c_double_p, c_int, c_int, c_double, c_double, c_double, c_int, c_double_p]),
+    "mogp_densegp_loo_variance": (c_int, [c_void_p, c_double_p]),
     "mogp_densegp_get_K": (c_int, [c_void_p, c_double_p]),
     "mogp_densegp_get_invQ": (c_int, [c_void_p, c_double_p]),
     "mogp_densegp_get_invQt": (c_int, [c_void_p, c_double_p]),
@@ -111,6 +113,7 @@ SIGNATURES = {
     "mogp_mogp_predict_batch": (c_int, [c_void_p, c_double_p, c_int, c_int, c_double_p]),
     "mogp_mogp_predict_variance_batch": (c_int, [c_void_p, c_double_p, c_int, c_int, c_double_p, c_double_p]),
     "mogp_mogp_predict_deriv": (c_int, [c_void_p, c_double_p, c_int, c_int, c_double_p]),
+    "mogp_mogp_implausibility": (c_int, [c_void_p, c_double_p, c_int, c_int, c_double_p, c_double_p, c_double_p, c_int, c_int, c_double_p]),
     "mogp_mogp_predict_full_cov": (c_int, [c_void_p, c_double_p, c_int, c_int, c_double_p, c_double_p]),
     "mogp_mogp_predict_variance_batch_dev": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "mogp_fit_GP_MAP": (c_int, [c_void_p, c_int, c_double_p, c_int]),

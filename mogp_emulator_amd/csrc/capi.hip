@@ -256,6 +256,15 @@ int mogp_densegp_predict_full_cov(mogp_densegp* h, const double* testing, int m,
     h->eng->predict_full_cov(ids, testing, m, mean_out, cov_out);
   });
 }
+int mogp_densegp_implausibility(mogp_densegp* h, const double* testing, int m, int D, double obs, double obs_var, double discrepancy,
+                                int include_nugget, double* out) {
+  GUARD({
+    if (D != h->eng->D) throw std::runtime_error("testing points must have D columns");
+    std::vector<int> ids{h->idx};
+    h->eng->implausibility(ids, testing, m, &obs, &obs_var, &discrepancy, include_nugget != 0, 0, out);
+  });
+}
+int mogp_densegp_loo_variance(mogp_densegp* h, double* out) { GUARD(h->eng->loo_variance(h->idx, out)); }
 int mogp_densegp_get_K(mogp_densegp* h, double* out) { GUARD(h->eng->get_K(h->idx, out)); }
 int mogp_densegp_get_invQ(mogp_densegp* h, double* out) { GUARD(h->eng->get_invQ(h->idx, out)); }
 int mogp_densegp_get_invQt(mogp_densegp* h, double* out) { GUARD(h->eng->get_invQt(h->idx, out)); }
@@ -445,6 +454,16 @@ int mogp_mogp_predict_full_cov(mogp_mogp* h, const double* testing, int m, int D
         std::memcpy(covs + (size_t)ids[k] * mm, cc.data() + k * mm, mm * sizeof(double));
       }
     }
+  });
+}
+int mogp_mogp_implausibility(mogp_mogp* h, const double* testing, int m, int D, const double* obs, const double* obs_var,
+                             const double* discrepancy, int include_nugget, int rank, double* out) {
+  GUARD({
+    Engine* e = h->eng.get();
+    if (D != e->D) throw std::runtime_error("testing points must have D columns");
+    std::vector<int> ids = fitted_ids(h);
+    if ((int)ids.size() != e->B) throw std::runtime_error("Hyperparameters have not been fit for this Gaussian Process");
+    e->implausibility(ids, testing, m, obs, obs_var, discrepancy, include_nugget != 0, rank, out);
   });
 }
 int mogp_mogp_predict_variance_batch_dev(mogp_mogp* h, const double* d_testing, int m, int D, double* d_means, double* d_vars) {

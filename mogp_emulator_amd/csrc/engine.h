@@ -66,6 +66,12 @@ class Engine {
                long out_ld, bool out_on_device, double* derivs /* host (ids, m, D) or null */);
 
   void get_K(int i, double* out);
+  // HistoryMatching.get_implausibility (HistoryMatching.py:197-276) fused behind the batched prediction:
+  // obs / obs_var / discrepancy per entry of ids; out (m) host.  Query points are processed in device chunks.
+  void implausibility(const std::vector<int>& ids, const double* Xs, int m, const double* obs, const double* obs_var,
+                      const double* discrepancy, bool include_nugget, int rank, double* out);
+  // leave-one-out predictive variance of emulator i at its own training inputs (MICEFastGP.fast_predict for every index)
+  void loo_variance(int i, double* out);
   // predict(full_cov=True), GaussianProcess.py:899-911: means (nb, m), covs (nb, m, m) host buffers, nugget NOT included
   void predict_full_cov(const std::vector<int>& ids, const double* Xs, int m, double* means, double* covs);
   void get_invQ(int i, double* out);

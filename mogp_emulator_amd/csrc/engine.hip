@@ -837,6 +837,72 @@ void Engine::predict_full_cov(const std::vector<int>& ids, const double* Xs, int
   for (double* p : {dXf, dKf, dV, dC, dDots}) if (p) hipFree(p);
 }
 
+void Engine::implausibility(const std::vector<int>& ids, const double* Xs, int m, const double* obs, const double* obs_var,
+                            const double* discrepancy, bool include_nugget, int rank, double* out) {
+  const int nb = (int)ids.size();
+  if (nb == 0 || m == 0) return;
+  for (int i : ids)
+    if (!gp[i].factored) throw std::runtime_error("emulator has not been fit");
+  if (R > 1 || n_mean() > 0)
+    throw std::runtime_error("implausibility: the fused device path supports zero / fixed mean functions only");
+  if (nb == 1) rank = 0;                                       // HistoryMatching.py:254-255
+  if (rank < 0) throw std::runtime_error("rank must be a non-negative integer");
+  if (rank >= nb) throw std::runtime_error("rank must be less than the number of observations");
+  if (rank > IMPLAUS_MAX_RANK) throw std::runtime_error("rank above " + std::to_string(IMPLAUS_MAX_RANK) + " is not supported on the device");
+  std::vector<double> prm((size_t)nb * 3);
+  for (int k = 0; k < nb; ++k) {
+    if (discrepancy[k] < 0.) throw std::runtime_error("Model discrepancy variance cannot be negative");
+    if (obs_var[k] < 0.) throw std::runtime_error("observation variance cannot be negative");
+    prm[3 * k] = obs[k];
+    prm[3 * k + 1] = obs_var[k] + discrepancy[k] + (include_nugget ? nugget_size(ids[k]) : 0.);
+    prm[3 * k + 2] = (mean.kind == 1) ? mean.value : 0.;
+  }
+  ensure_linv(ids);
+  upload_idx(ids);
+  BatchView v = view(nb);
+  const int MPtot = roundup(m, 128);
+  long MC = (long)(6.0e9 / ((double)nb * LD * 8.0)) / 128 * 128;
+  MC = std::max<long>(128, std::min<long>(MC, MPtot));
+  ensure_predict_scratch(nb, (int)MC);
+  grow(dXs, capXs, (size_t)MC * D);
+  grow(dMean, capMean, (size_t)nb * MC);
+  grow(dVar, capVar, (size_t)nb * MC);
+  double* dPrm = dalloc<double>(prm.size());
+  double* dOut = dalloc<double>((size_t)MC);
+  try {
+    HIPCK(hipMemcpyAsync(dPrm, prm.data(), prm.size() * sizeof(double), hipMemcpyHostToDevice, stream));
+    for (int c0 = 0; c0 < m; c0 += (int)MC) {
+      const int mc = std::min<int>((int)MC, m - c0);
+      const int MPc = roundup(mc, 128);
+      HIPCK(hipMemcpyAsync(dXs, Xs + (size_t)c0 * D, (size_t)mc * D * sizeof(double), hipMemcpyHostToDevice, stream));
+      launch_cross_cov_mean(v, dXs, mc, MPc, dKs, dMean, (int)MC, stream);
+      launch_predict_var(v, dKs, mc, MPc, dVarPartial, dVar, (int)MC, stream);
+      launch_implausibility(nb, dMean, dVar, (int)MC, mc, dPrm, rank, dOut, stream);
+      HIPCK(hipMemcpyAsync(out + c0, dOut, (size_t)mc * sizeof(double), hipMemcpyDeviceToHost, stream));
+      HIPCK(hipStreamSynchronize(stream));      // dXs is re-used by the next chunk
+    }
+    HIPCK(hipGetLastError());
+  } catch (...) {
+    hipFree(dPrm);
+    hipFree(dOut);
+    throw;
+  }
+  hipFree(dPrm);
+  hipFree(dOut);
+}
+
+void Engine::loo_variance(int i, double* out) {
+  if (!gp[i].factored) throw std::runtime_error("emulator has not been fit");
+  std::vector<int> ids{i};
+  ensure_linv(ids);
+  upload_idx(ids);
+  double* tmp = dalloc<double>((size_t)n);
+  launch_loo_variance(view(1), tmp, n, stream);
+  HIPCK(hipMemcpyAsync(out, tmp, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, stream));
+  HIPCK(hipStreamSynchronize(stream));
+  hipFree(tmp);
+}
+
 void Engine::get_K(int i, double* out) {
   if (!gp[i].has_data) throw std::runtime_error("emulator has not been fit");
   double* tmp = dalloc<double>((size_t)n * n);

@@ -321,6 +321,65 @@ __global__ __launch_bounds__(256) void alpha_linv_kernel(BatchView v) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Leave-one-out predictive variance at every training input: 1 / [K^-1]_ii with
+// [K^-1]_ii = sum_{k >= i} Linv[k][i]^2.  This is what MICEFastGP.fast_predict obtains per point from
+// a Woodbury downdate of the full inverse (SequentialDesign.py:705-747); here all n values come from
+// one pass over L^-1.  Same wave split as alpha_linv_kernel.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void loo_variance_kernel(BatchView v, double* __restrict__ out, int out_ld) {
+  __shared__ double red[4][64];
+  const int emu = slot_emu(v.idx, blockIdx.y);
+  const int ld = v.LD, n = v.n;
+  const double* Li = v.Linv + (size_t)emu * v.MS;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i0 = blockIdx.x * 64, i = i0 + lane;
+  double s = 0.;
+#pragma unroll 8
+  for (int k = i0 + wave; k < n; k += 4) {
+    const double x = Li[(size_t)k * ld + i];
+    s = __builtin_fma(x, x, s);
+  }
+  red[wave][lane] = s;
+  __syncthreads();
+  if (wave == 0 && i < n) out[(size_t)blockIdx.y * out_ld + i] = fmax(1.0 / (red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]), 0.0);
+}
+
+// ---------------------------------------------------------------------------------------------
+// History-matching implausibility fused behind the batched prediction (HistoryMatching.py:262-276):
+//   I_k(x) = |z_k - mu_k(x)| / sqrt(var_k(x) + nugget_k + discrepancy_k + obsvar_k),
+// score(x) = the (rank+1)-th largest I_k(x) over the outputs.  One thread per query point keeps the
+// rank+1 largest values in registers; means / variances never leave HBM.
+//   prm: per slot [z, obsvar + discrepancy (+ nugget), mean offset]
+// ---------------------------------------------------------------------------------------------
+constexpr int IMPL_MAXRANK = 16;
+__global__ __launch_bounds__(256) void implausibility_kernel(int nb, const double* __restrict__ mean, const double* __restrict__ var, int ld,
+                                                             int m, const double* __restrict__ prm, int rank, double* __restrict__ out) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= m) return;
+  double top[IMPL_MAXRANK];
+#pragma unroll
+  for (int r = 0; r < IMPL_MAXRANK; ++r) top[r] = -1.0;
+  for (int k = 0; k < nb; ++k) {
+    const double mu = mean[(size_t)k * ld + j] + prm[3 * k + 2];
+    const double vv = fmax(var[(size_t)k * ld + j], 0.0) + prm[3 * k + 1];
+    double I = fabs(prm[3 * k] - mu) / sqrt(vv);
+    // insert into the descending list of the rank+1 largest
+#pragma unroll
+    for (int r = 0; r < IMPL_MAXRANK; ++r)
+      if (r <= rank && I > top[r]) {
+        const double t = top[r];
+        top[r] = I;
+        I = t;
+      }
+  }
+  double res = top[0];
+#pragma unroll
+  for (int r = 1; r < IMPL_MAXRANK; ++r)
+    if (r == rank) res = top[r];
+  out[j] = res;
+}
+
+// ---------------------------------------------------------------------------------------------
 // trtri leaf: invert every 64x64 diagonal block of L; lane j produces column j of the inverse.
 // Also zeroes the block to the right inside the same 128-tile so that 128-granular consumers can
 // treat diagonal tiles of Linv as dense.
@@ -412,6 +471,15 @@ void launch_backsolve(const BatchView& v, hipStream_t s) {
 
 void launch_alpha_from_linv(const BatchView& v, hipStream_t s) {
   hipLaunchKernelGGL(alpha_linv_kernel, dim3(v.NP / 64, v.nb), dim3(256), 0, s, v);
+}
+
+void launch_loo_variance(const BatchView& v, double* out, int out_ld, hipStream_t s) {
+  hipLaunchKernelGGL(loo_variance_kernel, dim3((v.n + 63) / 64, v.nb), dim3(256), 0, s, v, out, out_ld);
+}
+
+void launch_implausibility(int nb, const double* mean, const double* var, int ld, int m, const double* prm, int rank, double* out,
+                           hipStream_t s) {
+  hipLaunchKernelGGL(implausibility_kernel, dim3((m + 255) / 256), dim3(256), 0, s, nb, mean, var, ld, m, prm, rank, out);
 }
 
 void launch_trtri_merges(const BatchView& v, hipStream_t s);   // kernels_gemm.hip

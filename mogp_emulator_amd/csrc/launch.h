@@ -46,6 +46,13 @@ struct BatchView {
 void launch_cov_build(const BatchView& v, hipStream_t s);
 // full symmetric K (no nugget) for get_K: out (n,n) for one emulator
 void launch_cov_full(const BatchView& v, int emu, double* out, hipStream_t s);
+// leave-one-out predictive variance 1/[K^-1]_ii of every training input (needs Linv): out[slot*out_ld + i]
+void launch_loo_variance(const BatchView& v, double* out, int out_ld, hipStream_t s);
+// history-matching score of m query points from device-resident means / variances (nb, ld); prm (nb, 3) =
+// [observation, obsvar + discrepancy + nugget, mean offset]; out[j] = (rank+1)-th largest implausibility
+constexpr int IMPLAUS_MAX_RANK = 15;
+void launch_implausibility(int nb, const double* mean, const double* var, int ld, int m, const double* prm, int rank, double* out,
+                           hipStream_t s);
 // out (nb, m, m) = sigma^2 k(Xs, Xs) per slot (no nugget)
 void launch_cov_self_batch(const BatchView& v, const double* Xs, int m, double* out, hipStream_t s);
 // full predictive covariance: cov (nb, m, m) holds K** on entry, K** - Ks K^-1 Ks^T on return; V: nb*NP*MP scratch

@@ -590,6 +590,21 @@ class DenseGP_GPU(object):
             raise RuntimeError("predict_full_cov: The result buffer passed was too small to hold the covariance")
         check(_lib.mogp_densegp_predict_full_cov(self._h, dptr(x), x.shape[0], x.shape[1], dptr(mean), dptr(cov)))
 
+    def implausibility(self, testing, obs, obs_var=0., discrepancy=0., include_nugget=True):
+        """|obs - E f(x)| / sqrt(Var f(x) [+ nugget] + discrepancy + obs_var) for every row of testing, computed on
+        the device behind the prediction (HistoryMatching.py:262-276)."""
+        x = self._testing(testing)
+        out = np.zeros(x.shape[0])
+        check(_lib.mogp_densegp_implausibility(self._h, dptr(x), x.shape[0], x.shape[1], float(obs), float(obs_var),
+                                               float(discrepancy), int(bool(include_nugget)), dptr(out)))
+        return out
+
+    def loo_variance(self):
+        """leave-one-out predictive variance 1/[K^-1]_ii at every training input (MICEFastGP.fast_predict for all indices)"""
+        out = np.zeros(self.n())
+        check(_lib.mogp_densegp_loo_variance(self._h, dptr(out)))
+        return out
+
     # -- matrices -------------------------------------------------------------------------------
     def _fill_nn(self, fn, out, name):
         _outbuf(out, name)
@@ -764,6 +779,18 @@ class MultiOutputGP_GPU(object):
         if means.size < self.n_emulators() * x.shape[0] or covs.size < self.n_emulators() * x.shape[0] ** 2:
             raise RuntimeError("predict_full_cov: The result buffer passed was too small to hold the covariance")
         check(_lib.mogp_mogp_predict_full_cov(self._h, dptr(x), x.shape[0], x.shape[1], dptr(means), dptr(covs)))
+
+    def implausibility(self, testing, obs, obs_var, discrepancy, include_nugget=True, rank=1):
+        """history-matching score of every row of testing over all outputs, one number per point (device-fused)"""
+        x = self._testing(testing)
+        ne = self.n_emulators()
+        z = np.ascontiguousarray(np.broadcast_to(np.asarray(obs, dtype=np.float64), (ne,)))
+        ov = np.ascontiguousarray(np.broadcast_to(np.asarray(obs_var, dtype=np.float64), (ne,)))
+        dc = np.ascontiguousarray(np.broadcast_to(np.asarray(discrepancy, dtype=np.float64), (ne,)))
+        out = np.zeros(x.shape[0])
+        check(_lib.mogp_mogp_implausibility(self._h, dptr(x), x.shape[0], x.shape[1], dptr(z), dptr(ov), dptr(dc),
+                                            int(bool(include_nugget)), int(rank), dptr(out)))
+        return out
 
     def predict_variance_batch_dev(self, d_testing, m, d_means, d_vars):
         """Device-pointer variant: inputs already resident in HBM, results stay in HBM."""

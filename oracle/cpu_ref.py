@@ -540,3 +540,50 @@ def fit_GP_MAP_ref(gp, n_tries=15, theta0=None, method="L-BFGS-B", sampler=None,
         return gp
     gp.fit(thetas[int(np.argmin(vals))])
     return gp
+
+
+# ----------------------------------------------------------------------------
+# consumers of predict
+# ----------------------------------------------------------------------------
+
+def implausibility_ref(obs, obs_var, mean, var, discrepancy=0., rank=1):
+    """HistoryMatching.get_implausibility, HistoryMatching.py:236-276, for given predictions.
+    obs / obs_var: (n_obs,), mean / var: (n_obs, m) (or (m,) for one output), discrepancy scalar or (n_obs,)."""
+    obs, obs_var = np.atleast_1d(np.asarray(obs, dtype=np.float64)), np.atleast_1d(np.asarray(obs_var, dtype=np.float64))
+    mean, var = np.atleast_2d(mean), np.atleast_2d(var)
+    discrepancy = np.atleast_1d(discrepancy)
+    n_obs = len(obs)
+    if n_obs == 1:
+        rank = 0
+    assert 0 <= rank < n_obs
+    Vs = np.zeros(mean.shape)
+    Vs += var
+    Vs += discrepancy[:, np.newaxis]
+    Vs += obs_var[:, np.newaxis]
+    I = np.abs(obs[:, np.newaxis] - mean) / np.sqrt(Vs)
+    return np.partition(I, n_obs - rank - 1, axis=0)[n_obs - rank - 1]
+
+
+def mice_fast_predict_ref(gp, index):
+    """MICEFastGP.fast_predict, SequentialDesign.py:705-747: predictive variance at training input ``index``
+    of the fitted GPRef ``gp`` when that point is excluded, via the Woodbury downdate of the full inverse."""
+    n, D = gp.n, gp.D
+    keep = np.arange(n) != index
+    sigma_2 = np.exp(gp.theta[D]) + gp.nugget
+    Ktest = np.exp(gp.theta[D]) * kernel_f(gp.X[keep], gp.X[index:index + 1], gp.theta[:D], gp.kernel)
+    invQ = np.linalg.solve(gp.L.T, np.linalg.solve(gp.L, np.eye(n)))
+    invQ_mod = invQ[keep][:, keep] - np.outer(invQ[keep, index], invQ[keep, index]) / invQ[index, index]
+    return np.maximum(sigma_2 - np.sum(Ktest * np.dot(invQ_mod, Ktest), axis=0), 0.)
+
+
+def mice_criterion_ref(gp, candidates, nugget_s=1.):
+    """MICEDesign._MICE_criterion for every candidate, SequentialDesign.py:884-911 and :941-964 (the candidate GP
+    takes the base GP's correlation lengths and covariance and the nugget base_nugget * nugget_s)."""
+    candidates = np.asarray(candidates, dtype=np.float64)
+    fast = GPRef(candidates, np.ones(len(candidates)), kernel=gp.kernel, nugget=float(gp.nugget * nugget_s))
+    fast.fit(gp.theta[:gp.D + 1])
+    out = np.zeros(len(candidates))
+    for c in range(len(candidates)):
+        unc1 = gp.predict(candidates[c], unc=True)[1]
+        out[c] = unc1[0] / mice_fast_predict_ref(fast, c)[0]
+    return out

@@ -256,6 +256,55 @@ def main():
                 out[pre + "cov_nonug"] = gp.predict(Xs, full_cov=True, include_nugget=False)[1]
                 out[pre + "var"] = gp.predict(Xs)[1]
     np.savez_compressed(os.path.join(HERE, "fullcov.npz"), **out)
+
+    # ---- 12. consumers of predict: HistoryMatching implausibility, MICE criterion ----
+    from mogp_emulator.HistoryMatching import HistoryMatching
+    from mogp_emulator.SequentialDesign import MICEFastGP
+    from mogp_emulator import MultiOutputGP
+    X, T, Xs = synth(12, 90, 2, 3, 150)
+    thetas = np.array([[1.2, 0.4, 0.1], [0.3, 1.5, -0.3], [2.0, 2.2, 0.5]])
+    mo = MultiOutputGP(X, T, nugget=1.e-4, priors=weak(2, "fixed"))
+    for k in range(3):
+        mo.emulators[k].fit(thetas[k])
+    obs = [np.array([0.3, -0.2, 0.6]), np.array([0.01, 0.02, 0.005])]
+    out = dict(X=X, T=T, Xs=Xs, thetas=thetas, obs=obs[0], obs_var=obs[1], disc=np.array([0.1, 0., 0.3]))
+    for rank in range(3):
+        hm = HistoryMatching(gp=mo, obs=obs, coords=Xs)
+        out["I_rank%d" % rank] = hm.get_implausibility(rank=rank)
+        hm = HistoryMatching(gp=mo, obs=obs, coords=Xs)
+        out["I_disc_rank%d" % rank] = hm.get_implausibility(out["disc"], rank=rank)
+    hm = HistoryMatching(gp=mo, obs=obs, coords=Xs, threshold=2.5)
+    out["NROY"] = np.array(hm.get_NROY(0.05, rank=1))
+    out["RO"] = np.array(hm.get_RO(0.05, rank=1))
+    hm1 = HistoryMatching(gp=mo.emulators[1], obs=[-0.2, 0.02], coords=Xs)
+    out["I_single"] = hm1.get_implausibility(0.07)
+    # MICE: base GP on X, candidates = first 60 query points.  MICEFastGP.fast_predict reads ``self.L``, an
+    # attribute the refactored GaussianProcess no longer has (it lives in ``self.Kinv.L``; the reference's own
+    # MICE tests are skipped for that reason, tests/test_SequentialDesign.py:866-945): the attribute is supplied
+    # here so that the reference's arithmetic itself produces the vectors.
+    class MICEFastGP(MICEFastGP):
+        L = property(lambda self: self.Kinv.L)
+    known = MICEFastGP(np.reshape([1., 2., 3., 4], (4, 1)), [1., 1., 1., 1.])
+    known.theta = np.array([0., -1.])
+    out["mice_known_answer"] = np.array(known.fast_predict(3))     # 1.191061906777163 in tests/test_SequentialDesign.py:935
+    cand = Xs[:60]
+    base = mo.emulators[0]
+    for nugget_s in (1., 10.):
+        fast = MICEFastGP(cand, np.ones(len(cand)), nugget=base.theta.nugget * nugget_s)
+        # MICEDesign._eval_metric assigns the base GP's GPParams OBJECT (SequentialDesign.py:946-947), which
+        # replaces the candidate GP's own nugget by the base nugget: nugget_s is then silently ignored.  That
+        # variant is recorded as "*_aliased"; the documented behaviour (nugget = base nugget * nugget_s) is
+        # obtained by assigning the parameter VALUES instead.
+        fast.theta = base.theta
+        out["mice_unc2_s%d_aliased" % int(nugget_s)] = np.array([fast.fast_predict(c)[0] for c in range(len(cand))])
+        fast = MICEFastGP(cand, np.ones(len(cand)), nugget=base.theta.nugget * nugget_s)
+        fast.theta = base.theta.get_data()
+        unc2 = np.array([fast.fast_predict(c)[0] for c in range(len(cand))])
+        unc1 = base.predict(cand, unc=True, deriv=False)[1]
+        out["mice_unc1"] = unc1
+        out["mice_unc2_s%d" % int(nugget_s)] = unc2
+        out["mice_crit_s%d" % int(nugget_s)] = unc1 / unc2
+    np.savez_compressed(os.path.join(HERE, "consumers.npz"), **out)
     print("golden vectors written to", HERE)
 
 

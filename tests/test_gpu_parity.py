@@ -673,3 +673,98 @@ def test_full_cov_multioutput_tile_boundaries(m):
         assert_allclose(cov[k], rcov, rtol=1e-6, atol=1e-7 * np.abs(rcov).max())
         # positive semi-definite up to rounding
         assert np.linalg.eigvalsh(cov[k]).min() > -1e-8 * np.abs(rcov).max()
+
+
+# ----------------------------------------------------------------------------------------------------
+# consumers of the batched prediction, fused on the device.
+# Tolerance: rtol 1e-6 on scores (ratio of an rtol-1e-7 mean difference and the root of an atol-1e-7 variance).
+# ----------------------------------------------------------------------------------------------------
+def _consumer_mogp(g):
+    mo = M.MultiOutputGP_GPU(g["X"], g["T"], nugget=1.e-4, priors=weak(2, 1.e-4))
+    mo.fit(g["thetas"])
+    return mo
+
+
+def test_history_matching_implausibility_vs_reference():
+    g = load_golden("consumers.npz")
+    mo = _consumer_mogp(g)
+    obs = [g["obs"], g["obs_var"]]
+    for rank in range(3):
+        hm = M.HistoryMatching(gp=mo, obs=obs, coords=g["Xs"])
+        assert_allclose(hm.get_implausibility(rank=rank), g["I_rank%d" % rank], rtol=1e-6)
+        hm = M.HistoryMatching(gp=mo, obs=obs, coords=g["Xs"])
+        assert_allclose(hm.get_implausibility(g["disc"], rank=rank), g["I_disc_rank%d" % rank], rtol=1e-6)
+    hm = M.HistoryMatching(gp=mo, obs=obs, coords=g["Xs"], threshold=2.5)
+    assert hm.get_NROY(0.05, rank=1) == list(g["NROY"])
+    assert hm.get_RO(0.05, rank=1) == list(g["RO"])
+    single = M.HistoryMatching(gp=mo.emulators[1], obs=[-0.2, 0.02], coords=g["Xs"])
+    assert_allclose(single.get_implausibility(0.07), g["I_single"], rtol=1e-6)
+    # the fused device score equals the host formula applied to the device predictions
+    mean, unc, _ = mo.predict(g["Xs"], deriv=False)
+    assert_allclose(hm.I, R.implausibility_ref(g["obs"], g["obs_var"], mean, unc, 0.05, 1), rtol=1e-9)
+    # error behaviour of the reference class (tests/test_HistoryMatching.py:393-405, 316-361)
+    with pytest.raises(AssertionError):
+        hm.get_implausibility(-1.)
+    with pytest.raises(AssertionError):
+        hm.get_implausibility(rank=3)
+    with pytest.raises(ValueError):
+        M.HistoryMatching(gp=mo, coords=g["Xs"]).get_implausibility()
+    with pytest.raises(ValueError):
+        M.HistoryMatching(gp=mo, obs=obs, coords=g["Xs"], expectations=M.PredictResult(mean=mean, unc=unc, deriv=None)).get_implausibility()
+    # explicit expectations: the NumPy path, literals of tests/test_HistoryMatching.py:363-426
+    pr = M.PredictResult(mean=np.array([2., 10.]), unc=np.array([0., 0.]), deriv=None)
+    assert_allclose(M.HistoryMatching(obs=[1., 1.], expectations=pr).get_implausibility(), [1., 9.])
+    assert M.HistoryMatching(obs=[1., 1.], expectations=pr).get_NROY() == [0]
+    pr2 = M.PredictResult(mean=np.array([[2., 10.], [4., 6.]]), unc=np.full((2, 2), 0.5), deriv=None)
+    assert_allclose(M.HistoryMatching(obs=[[1., 5.], 0.5], expectations=pr2).get_implausibility(1.), [1. / np.sqrt(2.)] * 2)
+
+
+def test_implausibility_sweep_chunks_and_means():
+    # a sweep larger than one device chunk, a fixed mean function, and 20 outputs with a deep rank
+    X, T, Xs = synth(31, 150, 3, 20, 5000)
+    theta = np.array([1., 0.5, 0.2, 0.1])
+    mo = M.MultiOutputGP_GPU(X, T, mean=LibGPGPU.FixedMeanFunc(0.25), nugget=1e-5, priors=weak(3, 1e-5))
+    mo.fit(np.tile(theta, (20, 1)))
+    z, zv, dc = np.linspace(-1, 1, 20), np.full(20, 0.01), np.linspace(0., 0.2, 20)
+    mean, unc, _ = mo.predict(Xs, deriv=False)
+    for rank in (0, 1, 7, 15):
+        I = mo._mogp_gpu.implausibility(Xs, z, zv, dc, rank=rank)
+        assert_allclose(I, R.implausibility_ref(z, zv, mean, unc, dc, rank), rtol=1e-9)
+    with pytest.raises(RuntimeError, match="rank"):
+        mo._mogp_gpu.implausibility(Xs, z, zv, dc, rank=16)
+    # a mean function with fitted parameters is scored through predict + the host formula
+    mc = M.MultiOutputGP_GPU(X, T[:2], mean=LibGPGPU.ConstMeanFunc(), nugget=1e-5, priors=weak(3, 1e-5))
+    mc.fit(np.tile(np.r_[0.1, theta], (2, 1)))
+    hm = M.HistoryMatching(gp=mc, obs=[z[:2], zv[:2]], coords=Xs[:64])
+    m2, u2, _ = mc.predict(Xs[:64], deriv=False)
+    assert_allclose(hm.get_implausibility(rank=0), R.implausibility_ref(z[:2], zv[:2], m2, u2, 0., 0), rtol=1e-12)
+
+
+def test_mice_criterion_vs_reference():
+    g = load_golden("consumers.npz")
+    base = make_gp(g["X"], g["T"][0], nugget=1.e-4)
+    base.fit(g["thetas"][0])
+    cand = g["Xs"][:60]
+    for s in (1, 10):
+        crit, best = M.mice_criterion(base, cand, nugget_s=float(s))
+        assert_allclose(crit, g["mice_crit_s%d" % s], rtol=1e-6)
+        assert best == int(np.argmax(g["mice_crit_s%d" % s]))
+    fast = M.MICEFastGP(cand, np.ones(60), nugget=1.e-4, priors=weak(2, 1.e-4))
+    fast.fit(g["thetas"][0])
+    assert_allclose(fast.loo_variance(), g["mice_unc2_s1"], rtol=1e-6)
+    assert_allclose(fast.fast_predict(7), g["mice_unc2_s1"][7:8], rtol=1e-6)
+    with pytest.raises(AssertionError):
+        fast.fast_predict(60)
+    # a larger candidate set against the leave-one-out identity evaluated by the oracle
+    X, T, Xs = synth(32, 300, 4, 1, 700)
+    theta = np.array([0.8, 1.1, 0.3, 0.6, 0.2])
+    gp = make_gp(X, T[0], "Matern52", 1e-5)
+    gp.fit(theta)
+    crit, best = M.mice_criterion(gp, Xs, nugget_s=2.)
+    ref = R.GPRef(X, T[0], kernel="Matern52", nugget=1e-5)
+    ref.fit(theta)
+    cg = R.GPRef(Xs, np.ones(700), kernel="Matern52", nugget=2e-5)
+    cg.fit(theta)
+    expected = ref.predict(Xs)[1] * np.diag(R.cho_solve_L(cg.L, np.eye(700)))
+    assert_allclose(crit, expected, rtol=1e-5)
+    assert best == int(np.argmax(expected))
