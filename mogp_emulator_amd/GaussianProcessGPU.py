@@ -17,7 +17,7 @@ import re
 import numpy as np
 
 from . import LibGPGPU
-from .Kernel import KernelBase, Matern52, SquaredExponential
+from .Kernel import KernelBase, Matern52, ProductMat52, SquaredExponential, UniformMat52, UniformSqExp
 from .Priors import GammaPrior, GPPriors, InvGammaPrior, LogNormalPrior, PriorDist, WeakPrior
 
 
@@ -141,11 +141,13 @@ def create_prior_params(**kwargs):
 
 
 def _resolve_kernel(kernel):
-    if kernel == "SquaredExponential" or isinstance(kernel, SquaredExponential):
-        return LibGPGPU.kernel_type.SquaredExponential, SquaredExponential()
-    if kernel == "Matern52" or isinstance(kernel, Matern52):
-        return LibGPGPU.kernel_type.Matern52, Matern52()
-    raise ValueError("GPU implementation requires kernel to be SquaredExponential or Matern52")
+    """name or kernel object -> (native enum, kernel object).  SquaredExponential / Matern52 are the reference GPU
+    kernels (GaussianProcessGPU.py:263-277); ProductMat52 / UniformSqExp / UniformMat52 are CPU-only there."""
+    for cls in (SquaredExponential, Matern52, ProductMat52, UniformSqExp, UniformMat52):
+        if kernel == cls.native_name or type(kernel) is cls:
+            return getattr(LibGPGPU.kernel_type, cls.native_name), cls()
+    raise ValueError("GPU implementation requires kernel to be one of SquaredExponential, Matern52, ProductMat52, "
+                     "UniformSqExp or UniformMat52")
 
 
 def _resolve_mean(mean):

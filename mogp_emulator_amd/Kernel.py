@@ -42,3 +42,29 @@ class Matern52(KernelBase):
 
     def __str__(self):
         return "Matern 5/2 Kernel"
+
+
+class ProductMat52(KernelBase):
+    """product over the inputs of one-dimensional Matern-5/2 kernels (Kernel.py:581-763, 986-997)"""
+    native_name = "ProductMat52"
+
+    def __str__(self):
+        return "Product Matern 5/2 Kernel"
+
+
+class UniformSqExp(KernelBase):
+    """squared exponential with ONE correlation length shared by all inputs (Kernel.py:224-417, 956-964)"""
+    native_name = "UniformSqExp"
+
+    def get_n_params(self, inputs):
+        return 1
+
+    def __str__(self):
+        return "Uniform Squared Exponential Kernel"
+
+
+class UniformMat52(UniformSqExp):
+    native_name = "UniformMat52"
+
+    def __str__(self):
+        return "Uniform Matern 5/2 Kernel"

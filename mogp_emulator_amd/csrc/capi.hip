@@ -30,7 +30,7 @@ struct mogp_mogp { std::unique_ptr<Engine> eng; std::vector<mogp_densegp> views;
 
 static void set_priors(Engine* eng, int i, int n_corr, const int* ct, const double* cp, int covt, const double* covp, int nugt,
                        const double* nugp) {
-  if (n_corr != eng->D) throw std::runtime_error("number of correlation priors must equal the number of inputs");
+  if (n_corr != eng->NC) throw std::runtime_error("number of correlation priors must equal the number of correlation parameters");
   Priors pr;
   pr.corr.resize(n_corr);
   for (int d = 0; d < n_corr; ++d) {
@@ -124,7 +124,7 @@ void mogp_densegp_destroy(mogp_densegp* h) {
 }
 int mogp_densegp_n(const mogp_densegp* h) { return h->eng->n; }
 int mogp_densegp_D(const mogp_densegp* h) { return h->eng->D; }
-int mogp_densegp_n_corr(const mogp_densegp* h) { return h->eng->D; }
+int mogp_densegp_n_corr(const mogp_densegp* h) { return h->eng->NC; }
 int mogp_densegp_n_params(const mogp_densegp* h) { return h->eng->n_data(h->idx); }
 int mogp_densegp_n_mean(const mogp_densegp* h) { return h->eng->n_mean(); }
 int mogp_densegp_n_data(const mogp_densegp* h) { return h->eng->n_data(h->idx); }
@@ -159,14 +159,14 @@ int mogp_densegp_priors_logp(const mogp_densegp* h, const double* th, int len, d
   GUARD({
     if (len != h->eng->n_data(h->idx)) throw std::runtime_error("Shape of new GPParams object does not match existing one");
     std::vector<double> v(th, th + len);
-    *out = h->eng->gp[h->idx].pri.logp(v, h->eng->D, h->eng->gp[h->idx].nug_type);
+    *out = h->eng->gp[h->idx].pri.logp(v, h->eng->NC, h->eng->gp[h->idx].nug_type);
   });
 }
 int mogp_densegp_priors_dlogpdtheta(const mogp_densegp* h, const double* th, int len, double* out) {
   GUARD({
     if (len != h->eng->n_data(h->idx)) throw std::runtime_error("Shape of new GPParams object does not match existing one");
     std::vector<double> v(th, th + len);
-    h->eng->gp[h->idx].pri.dlogpdtheta(v, h->eng->D, h->eng->gp[h->idx].nug_type, out);
+    h->eng->gp[h->idx].pri.dlogpdtheta(v, h->eng->NC, h->eng->gp[h->idx].nug_type, out);
   });
 }
 int mogp_densegp_priors_sample(mogp_densegp* h, double* out) {
@@ -174,7 +174,7 @@ int mogp_densegp_priors_sample(mogp_densegp* h, double* out) {
     static std::mt19937_64 r(std::random_device{}());
     const int nm = h->eng->n_mean();
     for (int k = 0; k < nm; ++k) out[k] = 0.;
-    h->eng->gp[h->idx].pri.sample(r, h->eng->D, h->eng->gp[h->idx].nug_type, out + nm);
+    h->eng->gp[h->idx].pri.sample(r, h->eng->NC, h->eng->gp[h->idx].nug_type, out + nm);
   });
 }
 int mogp_densegp_fit(mogp_densegp* h, const double* theta, int len) { GUARD(h->eng->fit_one(h->idx, theta, len)); }
@@ -283,7 +283,7 @@ int mogp_densegp_set_nugget_type(mogp_densegp* h, int t) {
     GPState& g = h->eng->gp[h->idx];
     if (t != g.nug_type) {
       g.nug_type = t;
-      g.data.assign(h->eng->D + 1 + (t == NUG_FIT ? 1 : 0), 0.);
+      g.data.assign(h->eng->NC + 1 + (t == NUG_FIT ? 1 : 0), 0.);
       g.has_data = false;
       g.factored = g.linv = g.kinv = false;
     }

@@ -15,7 +15,7 @@
 namespace mogp {
 
 struct GPState {
-  std::vector<double> data;      // n_data: corr_raw (D), log sigma^2, [log nugget]
+  std::vector<double> data;      // n_data: corr_raw (NC), log sigma^2, [log nugget]
   std::vector<double> meanp;     // n_mean
   bool has_data = false;
   int nug_type = NUG_ADAPTIVE;
@@ -39,6 +39,12 @@ class Engine {
   Engine(const Engine&) = delete;
 
   int n, D, NP, LD, PS, B, kernel_type;
+  // kernel_type: 0 SquaredExponential, 1 Matern52 (reference enum, types.hpp:29-35) and the CPU-only kernels of
+  // Kernel.py:946-997: 2 ProductMat52, 3 UniformSqExp, 4 UniformMat52.  NC = number of correlation parameters
+  // (1 for the uniform kernels, which run the device kernels 0 / 1 with one shared length scale).
+  int NC = 0;
+  bool uniform() const { return kernel_type == 3 || kernel_type == 4; }
+  int device_kernel() const { return kernel_type == 3 ? 0 : (kernel_type == 4 ? 1 : kernel_type); }
   size_t MS;
   unsigned testing_size;
   MeanFunc mean;
@@ -48,7 +54,7 @@ class Engine {
   bool analytic = false;
   int q = 0, R = 1;              // analytic mean columns, right-hand-side rows (1 + q)
   int n_mean() const { return analytic ? 0 : mean.n_params(); }
-  int n_data(int i) const { return D + 1 + (gp[i].nug_type == NUG_FIT ? 1 : 0); }
+  int n_data(int i) const { return NC + 1 + (gp[i].nug_type == NUG_FIT ? 1 : 0); }
   int n_theta(int i) const { return n_mean() + n_data(i); }
   double nugget_size(int i) const;
 

@@ -116,7 +116,7 @@ Engine::Engine(const double* X, int n_, int D_, const double* targets, int B_, u
   if (R > RMAX) throw std::runtime_error("analytic mean: at most " + std::to_string(RMAX - 1) + " mean-function terms are supported");
   if (analytic && q >= n_) throw std::runtime_error("analytic mean: more mean-function terms than training points");
   if (n < 1 || D < 1 || B < 1) throw std::runtime_error("inputs must have shape (n, D) with n, D >= 1");
-  if (kernel_type != 0 && kernel_type != 1) throw std::runtime_error("Unrecognized kernel type\n");
+  if (kernel_type < 0 || kernel_type > 4) throw std::runtime_error("Unrecognized kernel type\n");
   if (nug_type < 0 || nug_type > 2) throw std::runtime_error("Unrecognized nugget_type");
   for (int d : mean.dims)
     if (d >= D) throw std::runtime_error("Dimension index must be less than " + std::to_string(D));
@@ -129,6 +129,7 @@ Engine::Engine(const double* X, int n_, int D_, const double* targets, int B_, u
     LD = NP + (e ? (atoi(e) & ~1) : 0);
   }
   MS = (size_t)NP * LD;
+  NC = uniform() ? 1 : D;
   PS = D + 2;
   hX.assign(X, X + (size_t)n * D);
   hT.assign(targets, targets + (size_t)B * n);
@@ -136,7 +137,7 @@ Engine::Engine(const double* X, int n_, int D_, const double* targets, int B_, u
   for (auto& g : gp) {
     g.nug_type = nug_type;
     g.nug_size = nug_size;
-    g.data.assign(D + 1 + (nug_type == NUG_FIT ? 1 : 0), 0.);
+    g.data.assign(NC + 1 + (nug_type == NUG_FIT ? 1 : 0), 0.);
     g.meanp.assign(n_mean(), 0.);
     g.beta.assign(q, 0.);
   }
@@ -195,13 +196,13 @@ Engine::~Engine() {
 
 double Engine::nugget_size(int i) const {
   const GPState& g = gp[i];
-  if (g.nug_type == NUG_FIT) return g.has_data ? std::exp(g.data[D + 1]) : g.nug_size;   // gpparams.hpp:176-182
+  if (g.nug_type == NUG_FIT) return g.has_data ? std::exp(g.data[NC + 1]) : g.nug_size;   // gpparams.hpp:176-182
   return g.nug_size;
 }
 
 BatchView Engine::view(int nb) const {
   BatchView v;
-  v.n = n; v.D = D; v.NP = NP; v.LD = LD; v.MS = MS; v.PS = PS; v.kernel_type = kernel_type;
+  v.n = n; v.D = D; v.NP = NP; v.LD = LD; v.MS = MS; v.PS = PS; v.kernel_type = device_kernel();
   v.X = dX; v.P = dP; v.T = dT; v.A = dA; v.Linv = dLinv; v.Kinv = dKinv; v.alpha = dAlpha;
   v.idx = dIdx; v.nb = nb;
   v.R = R; v.H = dH; v.Z = (R > 1) ? dZ : dAlpha;
@@ -234,8 +235,8 @@ void Engine::upload_params(const std::vector<int>& ids) {
   for (int i : ids) {
     const GPState& g = gp[i];
     double* p = hP.data() + (size_t)i * PS;
-    for (int d = 0; d < D; ++d) p[d] = std::exp(g.data[d]);
-    p[D] = std::exp(g.data[D]);
+    for (int d = 0; d < D; ++d) p[d] = std::exp(g.data[uniform() ? 0 : d]);
+    p[D] = std::exp(g.data[NC]);
     p[D + 1] = g.nugget_used;
   }
   HIPCK(hipMemcpyAsync(dP, hP.data(), hP.size() * sizeof(double), hipMemcpyHostToDevice, stream));
@@ -421,7 +422,7 @@ void Engine::eval(const std::vector<int>& ids, const std::vector<const double*>&
   for (int k = 0; k < nb; ++k) {
     set_theta(ids[k], thetas[k]);
     GPState& g = gp[ids[k]];
-    g.nugget_used = (g.nug_type == NUG_FIXED) ? g.nug_size : (g.nug_type == NUG_FIT ? std::exp(g.data[D + 1]) : 0.0);
+    g.nugget_used = (g.nug_type == NUG_FIXED) ? g.nug_size : (g.nug_type == NUG_FIT ? std::exp(g.data[NC + 1]) : 0.0);
   }
   std::vector<int> info;
   factorize(ids, info);
@@ -438,7 +439,7 @@ void Engine::eval(const std::vector<int>& ids, const std::vector<const double*>&
     std::vector<int> retry;
     for (int i : failed)
       if (gp[i].nug_type == NUG_ADAPTIVE) {
-        jitter[i] = std::exp(gp[i].data[D]) * 1e-6;
+        jitter[i] = std::exp(gp[i].data[NC]) * 1e-6;
         retry.push_back(i);
       }
     for (int attempt = 0; attempt < 5 && !retry.empty(); ++attempt) {
@@ -540,7 +541,7 @@ void Engine::eval(const std::vector<int>& ids, const std::vector<const double*>&
       }
       if (fine) {
         // GaussianProcess.py:679-685 (n_coeff = n - q with weak mean priors); densegp_gpu.hpp:604-611
-        val = 0.5 * (quad + logdet[i] + logdetA + (n - q) * std::log(2.0 * M_PI)) - g.pri.logp(g.data, D, g.nug_type);
+        val = 0.5 * (quad + logdet[i] + logdetA + (n - q) * std::log(2.0 * M_PI)) - g.pri.logp(g.data, NC, g.nug_type);
         if (!std::isfinite(val)) fine = false;
       }
     }
@@ -639,10 +640,18 @@ void Engine::grad_current(const std::vector<int>& ids, double* grad, int grad_ld
     const GPState& g = gp[i];
     double* gr = grad + q * grad_ld;
     const double* o = out.data() + (size_t)i * NQ;
-    g.pri.dlogpdtheta(g.data, D, g.nug_type, dpr.data());
+    g.pri.dlogpdtheta(g.data, NC, g.nug_type, dpr.data());
     // GaussianProcess.py:751-780: 0.5 sum W dK/dtheta_p  -  d log prior / d theta_p
-    for (int p = 0; p <= D; ++p) gr[nm + p] = o[p] - dpr[p];
-    if (g.nug_type == NUG_FIT) gr[nm + D + 1] = 0.5 * std::exp(g.data[D + 1]) * (o[D + 1] - o[D + 2]) - dpr[D + 1];
+    if (uniform()) {
+      // one shared length scale: dr2/dtheta_0 = r2 (Kernel.py:338-376) = the sum of the per-dimension terms
+      double s = 0.;
+      for (int p = 0; p < D; ++p) s += o[p];
+      gr[nm] = s - dpr[0];
+    } else {
+      for (int p = 0; p < D; ++p) gr[nm + p] = o[p] - dpr[p];
+    }
+    gr[nm + NC] = o[D] - dpr[NC];
+    if (g.nug_type == NUG_FIT) gr[nm + NC + 1] = 0.5 * std::exp(g.data[NC + 1]) * (o[D + 1] - o[D + 2]) - dpr[NC + 1];
     if (nm > 0) {
       // densegp_gpu.hpp:734-747: -(d mean / d beta)^T alpha
       std::vector<double> a(n), md((size_t)nm * n);
@@ -1016,7 +1025,7 @@ void Engine::fit_map(const std::vector<int>& ids_in, int n_tries, const double* 
       else {
         const int nm = n_mean();
         for (int k = 0; k < nm; ++k) s.x[k] = 0.;
-        gp[ids[e]].pri.sample(rng, D, gp[ids[e]].nug_type, s.x.data() + nm);
+        gp[ids[e]].pri.sample(rng, NC, gp[ids[e]].nug_type, s.x.data() + nm);
       }
       s.xt = s.x;
     }

@@ -69,6 +69,58 @@ __device__ __forceinline__ void micro_r2(const double* si, const double* sj, con
   }
 }
 
+// Product-of-Matern-5/2 kernel (KT = 2, Kernel.py:581-763, 986-997): k = prod_d m52(e_d (x_d - y_d)^2).
+// (dm52/dr2) / m52 needs no exponential: -(5/6)(1+s) / (1+s+s^2/3), s = sqrt(5 r2).
+__device__ __forceinline__ double mat52_dlog(double r2) {
+  const double s = sqrt(5.0 * r2);
+  return -(5.0 / 6.0) * (1.0 + s) / (1.0 + s + (5.0 / 3.0) * r2);
+}
+
+// kernel values (without sigma^2) of the thread's 4x4 micro tile
+template <int KT>
+__device__ __forceinline__ void micro_k(const double* si, const double* sj, const double* __restrict__ P, int D, int ty, int tx,
+                                        double (&k)[4][4]) {
+  if (KT < 2) {
+    micro_r2(si, sj, P, D, ty, tx, k);
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) k[a][b] = kern_val<KT>(k[a][b]);
+    return;
+  }
+  // prod_d (1 + s_d + s_d^2/3) * exp(-sum_d s_d): one exponential per pair
+  double ssum[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      k[a][b] = 1.0;
+      ssum[a][b] = 0.0;
+    }
+  for (int d = 0; d < D; ++d) {
+    const double e = P[d];
+    double xi[4], xj[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) xi[a] = si[d * 64 + 4 * ty + a];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) xj[b] = sj[d * 64 + 4 * tx + b];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const double df = xi[a] - xj[b];
+        const double r2 = e * df * df;
+        const double sd = sqrt(5.0 * r2);
+        k[a][b] *= 1.0 + sd + (5.0 / 3.0) * r2;
+        ssum[a][b] += sd;
+      }
+  }
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) k[a][b] *= exp(-ssum[a][b]);
+}
+
 // ---------------------------------------------------------------------------------------------
 // K build into the factor buffer A (lower tiles only, diagonal tiles in full), with the nugget
 // fused on the diagonal, the targets laid into row n and identity padding beyond.
@@ -94,8 +146,8 @@ __global__ __launch_bounds__(256) void cov_build_kernel(BatchView v, int nt) {
   stage_rows(v.X, n, D, j0, sj);
   __syncthreads();
   const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
-  double r2[4][4];
-  micro_r2(si, sj, P, D, ty, tx, r2);
+  double kv[4][4];
+  micro_k<KT>(si, sj, P, D, ty, tx, kv);
   const double sig2 = P[D], nug = P[D + 1];
 #pragma unroll
   for (int a = 0; a < 4; ++a) {
@@ -107,7 +159,7 @@ __global__ __launch_bounds__(256) void cov_build_kernel(BatchView v, int nt) {
       const int hi = max(i, j), lo = min(i, j);
       double x;
       if (hi < n) {
-        x = sig2 * kern_val<KT>(r2[a][b]);
+        x = sig2 * kv[a][b];
         if (i == j) x += nug;
       } else if (hi < n + v.R) {
         // right-hand-side rows: row n = targets, rows n+1.. = design-matrix columns of the analytic mean
@@ -141,13 +193,13 @@ __global__ __launch_bounds__(256) void cov_full_kernel(BatchView v, int emu, con
   stage_rows(Xp, n, D, j0, sj);
   __syncthreads();
   const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
-  double r2[4][4];
-  micro_r2(si, sj, P, D, ty, tx, r2);
+  double kv[4][4];
+  micro_k<KT>(si, sj, P, D, ty, tx, kv);
   const double sig2 = P[D];
   for (int a = 0; a < 4; ++a)
     for (int b = 0; b < 4; ++b) {
       const int i = i0 + 4 * ty + a, j = j0 + 4 * tx + b;
-      if (i < n && j < n) out[(size_t)i * n + j] = sig2 * kern_val<KT>(r2[a][b]);
+      if (i < n && j < n) out[(size_t)i * n + j] = sig2 * kv[a][b];
     }
 }
 
@@ -193,8 +245,8 @@ __global__ __launch_bounds__(256) void cross_cov_mean_kernel(BatchView v, const 
       }
     }
     __syncthreads();
-    double r2[4][4];
-    if (j0 < n) micro_r2(si, sj, P, D, ty, tx, r2);
+    double kv[4][4];
+    if (j0 < n) micro_k<KT>(si, sj, P, D, ty, tx, kv);
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
       const int i = i0 + 4 * ty + a;
@@ -203,7 +255,7 @@ __global__ __launch_bounds__(256) void cross_cov_mean_kernel(BatchView v, const 
       for (int b = 0; b < 4; ++b) {
         const int j = j0 + 4 * tx + b;
         double x = 0.0;
-        if (j < n && i < m) x = sig2 * kern_val<KT>(r2[a][b]);
+        if (j < n && i < m) x = sig2 * kv[a][b];
         out[b] = x;
         if (j0 < n) {
 #pragma unroll
@@ -261,14 +313,18 @@ __global__ __launch_bounds__(256) void predict_deriv_kernel(BatchView v, const d
     __syncthreads();
     stage_rows(v.X, n, D, j0, sj);
     __syncthreads();
+    // KT < 2: G = 2 sigma^2 dk/dr2 alpha_j;  product kernel: G = 2 sigma^2 k alpha_j and the per-dimension
+    // factor (dm52/dr2)/m52 of dimension d is applied in the contraction below
     double r2[4][4];
-    micro_r2(si, sj, P, D, ty, tx, r2);
+    if (KT < 2) micro_r2(si, sj, P, D, ty, tx, r2);
+    else micro_k<KT>(si, sj, P, D, ty, tx, r2);
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
       for (int b = 0; b < 4; ++b) {
         const int j = j0 + 4 * tx + b;
-        G[(4 * ty + a) * 65 + 4 * tx + b] = (j < n) ? 2.0 * sig2 * kern_dr2<KT>(r2[a][b]) * alpha[j] : 0.0;
+        const double f = (KT < 2) ? kern_dr2<KT>(r2[a][b]) : r2[a][b];
+        G[(4 * ty + a) * 65 + 4 * tx + b] = (j < n) ? 2.0 * sig2 * f * alpha[j] : 0.0;
       }
     __syncthreads();
     for (int d = 0; d < D; ++d) {
@@ -277,7 +333,9 @@ __global__ __launch_bounds__(256) void predict_deriv_kernel(BatchView v, const d
 #pragma unroll 4
       for (int q = 0; q < 16; ++q) {
         const int j = part * 16 + q;
-        s = __builtin_fma(G[row * 65 + j], xm - sj[d * 64 + j], s);
+        const double df = xm - sj[d * 64 + j];
+        if (KT < 2) s = __builtin_fma(G[row * 65 + j], df, s);
+        else s = __builtin_fma(G[row * 65 + j] * mat52_dlog(P[d] * df * df), df, s);
       }
       s += __shfl_xor(s, 1);
       s += __shfl_xor(s, 2);
@@ -324,10 +382,12 @@ __global__ __launch_bounds__(256) void grad_kernel(BatchView v, int ntiles, doub
   __syncthreads();
   const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // KT < 2: r2 holds squared distances; product kernel: r2 holds the kernel values themselves
   double r2[4][4];
-  micro_r2(si, sj, P, D, ty, tx, r2);
+  if (KT < 2) micro_r2(si, sj, P, D, ty, tx, r2);
+  else micro_k<KT>(si, sj, P, D, ty, tx, r2);
   const double sig2 = P[D];
-  double G[4][4];                     // w * W * sigma^2 * dk/dr2
+  double G[4][4];                     // w * W * sigma^2 * dk/dr2   (product kernel: w * W * sigma^2 * k)
   double scov = 0., strace = 0., saa = 0.;
   // rank-R correction sum_c g_c[i] g_c[j] for the micro tile (R = 1: alpha_i alpha_j)
   double corr[4][4], gsq[4];
@@ -363,8 +423,9 @@ __global__ __launch_bounds__(256) void grad_kernel(BatchView v, int ntiles, doub
       if (w != 0.0) {
         const double kin = Ki[(size_t)i * ld + j];
         const double W = kin - corr[a][b];
-        scov += w * W * sig2 * kern_val<KT>(r2[a][b]);
-        g = w * W * sig2 * kern_dr2<KT>(r2[a][b]);
+        const double kval = (KT < 2) ? kern_val<KT>(r2[a][b]) : r2[a][b];
+        scov += w * W * sig2 * kval;
+        g = (KT < 2) ? w * W * sig2 * kern_dr2<KT>(r2[a][b]) : w * W * sig2 * kval;
         if (i == j) {
           strace += kin;
           saa += gsq[a];
@@ -388,7 +449,9 @@ __global__ __launch_bounds__(256) void grad_kernel(BatchView v, int ntiles, doub
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
           const double df = xi[a] - xj[b];
-          s = __builtin_fma(G[a][b], df * df, s);
+          // d k / d theta_p = dk/dr2 * e_p df^2 ; product kernel: k * (dm52/dr2)/m52 (r2_p) * r2_p,  r2_p = e_p df^2
+          if (KT < 2) s = __builtin_fma(G[a][b], df * df, s);
+          else s = __builtin_fma(G[a][b] * mat52_dlog(P[p] * df * df), df * df, s);
         }
       s *= P[p];
     } else if (p == D) s = scov;
@@ -424,7 +487,7 @@ __global__ __launch_bounds__(256) void grad_finish_kernel(BatchView v, int ntile
 // =============================================================================================
 #define KT_DISPATCH(kt, CALL)            \
   do {                                   \
-    if ((kt) == 0) { CALL(0); } else { CALL(1); } \
+    if ((kt) == 0) { CALL(0); } else if ((kt) == 1) { CALL(1); } else { CALL(2); } \
   } while (0)
 
 void launch_cov_build(const BatchView& v, hipStream_t s) {

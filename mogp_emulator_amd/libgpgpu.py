@@ -65,7 +65,10 @@ def _make_enum(name, members):
     return cls
 
 
-kernel_type = _make_enum("kernel_type", [("SquaredExponential", 0), ("Matern52", 1)])
+# 0, 1: the reference enum (types.hpp:29-35).  2-4: the kernels the reference only has on the CPU (Kernel.py:946-997,
+# SURVEY 8f row 4); the uniform kernels share one correlation length over all inputs (n_corr = 1).
+kernel_type = _make_enum("kernel_type", [("SquaredExponential", 0), ("Matern52", 1), ("ProductMat52", 2),
+                                         ("UniformSqExp", 3), ("UniformMat52", 4)])
 nugget_type = _make_enum("nugget_type", [("adaptive", 0), ("fit", 1), ("fixed", 2)])
 prior_type = _make_enum("prior_type", [("InvGamma", 0), ("Gamma", 1), ("LogNormal", 2), ("Weak", 3)])
 
@@ -512,7 +515,7 @@ class DenseGP_GPU(object):
         return kernel_type(_lib.mogp_densegp_get_kernel_type(self._h))
 
     def get_kernel(self):
-        return SquaredExponentialKernel() if self.get_kernel_type() == kernel_type.SquaredExponential else Matern52Kernel()
+        return _KERNEL_OBJECTS[int(self.get_kernel_type())]()
 
     def get_meanfunc(self):
         return self._meanfunc
@@ -684,7 +687,7 @@ class MultiOutputGP_GPU(object):
         return [self.emulator(i).n_params() for i in range(self.n_emulators())]
 
     def n_corr_params(self):
-        return [self.D()] * self.n_emulators()
+        return [self.emulator(0).n_corr()] * self.n_emulators()
 
     def get_nugget_type(self):
         return nugget_type(_lib.mogp_mogp_get_nugget_type(self._h))
@@ -824,8 +827,8 @@ class _KernelBase(object):
     def kernel_f(self, x1, x2, params):
         x1, x2 = np.atleast_2d(_f64(x1)), np.atleast_2d(_f64(x2))
         p = _f64(params, 1)
-        if p.size != x1.shape[1] + 1:
-            raise RuntimeError("kernel_f: expected D+1 hyperparameters")
+        if p.size != self.get_n_params(x1) + 1:
+            raise RuntimeError("kernel_f: expected n_corr+1 hyperparameters")
         gp = DenseGP_GPU(x2, np.zeros(x2.shape[0]), max(x1.shape[0], 1), ZeroMeanFunc(), self._kt, nugget_type.fixed, 1.0)
         gp.fit(p)
         # k(x1_i, x2_j) = d/d alpha_j of the predictive mean: use unit targets trick is wasteful;
@@ -850,3 +853,22 @@ class SquaredExponentialKernel(_KernelBase):
 
 class Matern52Kernel(_KernelBase):
     _kt = kernel_type.Matern52
+
+
+class ProductMat52Kernel(_KernelBase):
+    _kt = kernel_type.ProductMat52
+
+
+class UniformSqExpKernel(_KernelBase):
+    _kt = kernel_type.UniformSqExp
+
+    def get_n_params(self, inputs):
+        return 1
+
+
+class UniformMat52Kernel(UniformSqExpKernel):
+    _kt = kernel_type.UniformMat52
+
+
+_KERNEL_OBJECTS = {0: SquaredExponentialKernel, 1: Matern52Kernel, 2: ProductMat52Kernel, 3: UniformSqExpKernel,
+                   4: UniformMat52Kernel}

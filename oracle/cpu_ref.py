@@ -29,6 +29,16 @@ from scipy.special import gammaln
 
 SQEXP = "SquaredExponential"
 MAT52 = "Matern52"
+# CPU-only kernels of the reference, Kernel.py:946-997
+UNISQEXP = "UniformSqExp"
+UNIMAT52 = "UniformMat52"
+PRODMAT52 = "ProductMat52"
+_BASE = {SQEXP: SQEXP, MAT52: MAT52, UNISQEXP: SQEXP, UNIMAT52: MAT52, PRODMAT52: MAT52}
+
+
+def n_corr_of(kernel, D):
+    """get_n_params: Kernel.py:16-32 (one per input), :229-242 (UniformKernel: 1)."""
+    return 1 if kernel in (UNISQEXP, UNIMAT52) else D
 
 
 # ----------------------------------------------------------------------------
@@ -91,13 +101,55 @@ def calc_dKdr2(r2, kernel=SQEXP):
     raise ValueError("unknown kernel " + str(kernel))
 
 
+def calc_r2_uniform(x1, x2, corr_raw):
+    """UniformKernel.calc_r2, Kernel.py:296-336: one shared length scale exp(theta_0)."""
+    x1 = np.asarray(x1, dtype=np.float64)
+    x2 = np.asarray(x2, dtype=np.float64)
+    exp_theta = np.exp(np.asarray(corr_raw, dtype=np.float64))[0]
+    r2 = np.sum(exp_theta * (x1[:, np.newaxis, :] - x2[np.newaxis, :, :]) ** 2, axis=-1)
+    if np.any(np.isinf(r2)):
+        raise FloatingPointError("Inf enountered in kernel distance computation")
+    return r2
+
+
+def calc_r2_product(x1, x2, corr_raw):
+    """ProductKernel.calc_r2, Kernel.py:584-625: per-dimension scaled squared distances, shape (n1, n2, D)."""
+    x1 = np.asarray(x1, dtype=np.float64)
+    x2 = np.asarray(x2, dtype=np.float64)
+    exp_theta = np.exp(np.asarray(corr_raw, dtype=np.float64))
+    r2 = exp_theta[np.newaxis, np.newaxis, :] * (x1[:, np.newaxis, :] - x2[np.newaxis, :, :]) ** 2
+    if np.any(np.isinf(r2)):
+        raise FloatingPointError("Inf enountered in kernel distance computation")
+    return r2
+
+
 def kernel_f(x1, x2, corr_raw, kernel=SQEXP):
-    """Kernel.py:99-131 (kernel_f = calc_K(calc_r2))."""
+    """Kernel.py:99-131 (kernel_f = calc_K(calc_r2)); ProductKernel.kernel_f :627-659."""
+    if kernel == PRODMAT52:
+        return np.prod(calc_K(calc_r2_product(x1, x2, corr_raw), MAT52), axis=-1)
+    if kernel in (UNISQEXP, UNIMAT52):
+        return calc_K(calc_r2_uniform(x1, x2, corr_raw), _BASE[kernel])
     return calc_K(calc_r2(x1, x2, corr_raw), kernel)
 
 
 def kernel_deriv(x1, x2, corr_raw, kernel=SQEXP):
-    """Kernel.py:133-173: dK/dtheta = dK/dr2 * dr2/dtheta, shape (D, n1, n2)."""
+    """Kernel.py:133-173: dK/dtheta = dK/dr2 * dr2/dtheta, shape (n_corr, n1, n2).
+    Uniform: dr2/dtheta_0 = r2 (:338-376).  Product (:661-705): the factor of dimension p is replaced by
+    dK/dr2(r2_p) r2_p, all other factors are kept."""
+    if kernel == PRODMAT52:
+        r2 = calc_r2_product(x1, x2, corr_raw)
+        D = r2.shape[-1]
+        Kd = calc_K(r2, MAT52)
+        diag = calc_dKdr2(r2, MAT52) * r2
+        out = np.empty((D,) + r2.shape[:2])
+        for p in range(D):
+            f = Kd.copy()
+            f[:, :, p] = diag[:, :, p]
+            out[p] = np.prod(f, axis=-1)
+        return out
+    if kernel in (UNISQEXP, UNIMAT52):
+        r2 = calc_r2_uniform(x1, x2, corr_raw)
+        return (calc_dKdr2(r2, _BASE[kernel]) * r2)[np.newaxis]
     return calc_dKdr2(calc_r2(x1, x2, corr_raw), kernel) * calc_dr2dtheta(x1, x2, corr_raw)
 
 
@@ -113,6 +165,19 @@ def kernel_inputderiv(x1, x2, corr_raw, kernel=SQEXP):
     """
     scale = np.exp(np.asarray(corr_raw, dtype=np.float64))
     diff = x1[:, np.newaxis, :] - x2[np.newaxis, :, :]
+    if kernel == PRODMAT52:
+        r2 = calc_r2_product(x1, x2, corr_raw)
+        Kd = calc_K(r2, MAT52)
+        dfac = calc_dKdr2(r2, MAT52) * 2. * scale * diff
+        out = np.empty((r2.shape[-1],) + r2.shape[:2])
+        for p in range(r2.shape[-1]):
+            f = Kd.copy()
+            f[:, :, p] = dfac[:, :, p]
+            out[p] = np.prod(f, axis=-1)
+        return out
+    if kernel in (UNISQEXP, UNIMAT52):
+        dr2dx = np.transpose(2. * scale[0] * diff, (2, 0, 1))
+        return calc_dKdr2(calc_r2_uniform(x1, x2, corr_raw), _BASE[kernel]) * dr2dx
     dr2dx = np.transpose(2. * scale * diff, (2, 0, 1))
     return calc_dKdr2(calc_r2(x1, x2, corr_raw), kernel) * dr2dx
 
@@ -302,8 +367,9 @@ class GPRef(object):
         else:
             assert float(nugget) >= 0.
             self.nugget_type, self.nugget = "fixed", float(nugget)
-        self.n_params = self.D + 1 + int(self.nugget_type == "fit")
-        self.priors = priors if priors is not None else GPPriorsRef(self.D, self.nugget_type)
+        self.nc = n_corr_of(kernel, self.D)            # number of correlation parameters (1 for the uniform kernels)
+        self.n_params = self.nc + 1 + int(self.nugget_type == "fit")
+        self.priors = priors if priors is not None else GPPriorsRef(self.nc, self.nugget_type)
         self.theta = None
         self.chunk_rows = chunk_rows
         self.L = self.Kinv_t = self.current_logpost = None
@@ -316,7 +382,9 @@ class GPRef(object):
 
     def get_cov_matrix(self, other):
         """GaussianProcess.py:517-543: sigma^2 k(X, other), shape (n, m)."""
-        D = self.D
+        D = self.nc
+        if self.kernel not in (SQEXP, MAT52):
+            return np.exp(self.theta[D]) * kernel_f(self.X, other, self.theta[:D], self.kernel)
         return np.exp(self.theta[D]) * calc_K(self._r2(self.X, other, self.theta[:D]), self.kernel)
 
     def get_K_matrix(self):
@@ -355,7 +423,7 @@ class GPRef(object):
         """GaussianProcess.py:711-782 with w = 0, A = 0x0."""
         if self._refit(theta):
             self.fit(theta)
-        D = self.D
+        D = self.nc
         partials = np.zeros(self.n_params)
         dKdtheta = np.exp(self.theta[D]) * kernel_deriv(self.X, self.X, self.theta[:D], self.kernel)
         a = self.Kinv_t
@@ -384,9 +452,9 @@ class GPRef(object):
         var = None
         if unc:
             Kinv_Ktest = cho_solve_L(self.L, Ktest)
-            sigma_2 = np.exp(self.theta[self.D])
+            sigma_2 = np.exp(self.theta[self.nc])
             if full_cov:
-                Kss = sigma_2 * kernel_f(testing, testing, self.theta[:self.D], self.kernel)
+                Kss = sigma_2 * kernel_f(testing, testing, self.theta[:self.nc], self.kernel)
                 if include_nugget:
                     Kss = Kss + np.eye(testing.shape[0]) * self.nugget
                 Linv_Ktest = solve_L(self.L, Ktest)
@@ -397,7 +465,7 @@ class GPRef(object):
                 var = np.maximum(sigma_2 - np.sum(Ktest * Kinv_Ktest, axis=0), 0.)
         d = None
         if deriv:
-            dk = np.exp(self.theta[self.D]) * kernel_inputderiv(testing, self.X, self.theta[:self.D],
+            dk = np.exp(self.theta[self.nc]) * kernel_inputderiv(testing, self.X, self.theta[:self.nc],
                                                                 self.kernel)
             d = np.einsum("dmj,j->md", dk, self.Kinv_t)
         return mu, var, d
@@ -459,7 +527,7 @@ class GPRefMean(GPRef):
     def logpost_deriv(self, theta):
         if self._refit(theta):
             self.fit(theta)
-        D, H = self.D, self.H
+        D, H = self.nc, self.H
         partials = np.zeros(self.n_params)
         a = self.Kinv_t
         u = cho_solve_L(self.L, np.dot(H, cho_solve_L(self.LA, np.dot(H.T, a))))      # Kinv_H_Ainv_H_Kinv_t, :747-749
@@ -494,9 +562,9 @@ class GPRefMean(GPRef):
         if unc:
             Kinv_Ktest = cho_solve_L(self.L, Ktest)
             Rm = Hs.T - np.dot(self.H.T, Kinv_Ktest)                                     # calc_R, linalg_utils.py:123-168
-            sigma_2 = np.exp(self.theta[self.D])
+            sigma_2 = np.exp(self.theta[self.nc])
             if full_cov:                                                                 # :899-911
-                Kss = sigma_2 * kernel_f(testing, testing, self.theta[:self.D], self.kernel)
+                Kss = sigma_2 * kernel_f(testing, testing, self.theta[:self.nc], self.kernel)
                 if include_nugget:
                     Kss = Kss + np.eye(testing.shape[0]) * self.nugget
                 Linv_Ktest = solve_L(self.L, Ktest)
@@ -567,7 +635,7 @@ def implausibility_ref(obs, obs_var, mean, var, discrepancy=0., rank=1):
 def mice_fast_predict_ref(gp, index):
     """MICEFastGP.fast_predict, SequentialDesign.py:705-747: predictive variance at training input ``index``
     of the fitted GPRef ``gp`` when that point is excluded, via the Woodbury downdate of the full inverse."""
-    n, D = gp.n, gp.D
+    n, D = gp.n, gp.nc
     keep = np.arange(n) != index
     sigma_2 = np.exp(gp.theta[D]) + gp.nugget
     Ktest = np.exp(gp.theta[D]) * kernel_f(gp.X[keep], gp.X[index:index + 1], gp.theta[:D], gp.kernel)
@@ -581,7 +649,7 @@ def mice_criterion_ref(gp, candidates, nugget_s=1.):
     takes the base GP's correlation lengths and covariance and the nugget base_nugget * nugget_s)."""
     candidates = np.asarray(candidates, dtype=np.float64)
     fast = GPRef(candidates, np.ones(len(candidates)), kernel=gp.kernel, nugget=float(gp.nugget * nugget_s))
-    fast.fit(gp.theta[:gp.D + 1])
+    fast.fit(gp.theta[:gp.nc + 1])
     out = np.zeros(len(candidates))
     for c in range(len(candidates)):
         unc1 = gp.predict(candidates[c], unc=True)[1]

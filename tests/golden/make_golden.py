@@ -305,6 +305,36 @@ def main():
         out["mice_unc2_s%d" % int(nugget_s)] = unc2
         out["mice_crit_s%d" % int(nugget_s)] = unc1 / unc2
     np.savez_compressed(os.path.join(HERE, "consumers.npz"), **out)
+
+    # ---- 13. CPU-only kernels: UniformSqExp, UniformMat52, ProductMat52 -------------
+    from mogp_emulator.Kernel import UniformSqExp, UniformMat52, ProductMat52
+    X, T, Xs = synth(13, 160, 3, 1, 60)
+    out = dict(X=X, t=T[0], Xs=Xs)
+    for name, cls, nc in (("UniformSqExp", UniformSqExp, 1), ("UniformMat52", UniformMat52, 1), ("ProductMat52", ProductMat52, 3)):
+        k = cls()
+        corr = np.array([0.7, -0.3, 1.1])[:nc]
+        out[name + "_kf"] = k.kernel_f(X[:7], Xs[:5], corr)
+        out[name + "_kd"] = k.kernel_deriv(X[:7], Xs[:5], corr)
+        for mode, nugget in (("fixed", 1.e-5), ("fit", "fit")):
+            theta = list(corr) + [0.25] + ([np.log(2.e-4)] if mode == "fit" else [])
+            nt = nugget if isinstance(nugget, str) else "fixed"
+            gp = GaussianProcess(X, T[0], kernel=k, nugget=nugget, priors=weak(nc, nt))
+            gp.fit(np.array(theta))
+            pre = "%s_%s_" % (name, mode)
+            out[pre + "theta"] = np.array(theta)
+            out[pre + "logpost"] = np.array(gp.current_logpost)
+            out[pre + "grad"] = gp.logpost_deriv(np.array(theta))
+            out[pre + "Kinv_t"] = gp.Kinv_t
+            mean, var, _ = gp.predict(Xs)
+            out[pre + "mean"] = mean
+            out[pre + "var"] = var
+        # default priors (one InvGamma per correlation parameter; the uniform kernels pool all inputs)
+        gp = GaussianProcess(X, T[0], kernel=k, nugget="fit")
+        theta = np.array(list(corr) + [0.25, np.log(2.e-4)])
+        gp.fit(theta)
+        out[name + "_defprior_logpost"] = np.array(gp.current_logpost)
+        out[name + "_defprior_grad"] = gp.logpost_deriv(theta)
+    np.savez_compressed(os.path.join(HERE, "kernels_cpuonly.npz"), **out)
     print("golden vectors written to", HERE)
 
 

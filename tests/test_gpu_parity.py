@@ -260,7 +260,7 @@ def test_error_behaviour_matches_reference():
     gp.theta = None
     assert not gp.theta.data_has_been_set()
     with pytest.raises(ValueError):
-        M.GaussianProcessGPU(X, T[0], kernel="UniformSqExp")
+        M.GaussianProcessGPU(X, T[0], kernel="RationalQuadratic")
     with pytest.raises(ValueError):
         M.GaussianProcessGPU(X, T[0], nugget="pivot")
 
@@ -768,3 +768,69 @@ def test_mice_criterion_vs_reference():
     expected = ref.predict(Xs)[1] * np.diag(R.cho_solve_L(cg.L, np.eye(700)))
     assert_allclose(crit, expected, rtol=1e-5)
     assert best == int(np.argmax(expected))
+
+
+# ----------------------------------------------------------------------------------------------------
+# the reference's CPU-only kernels on the device.  Same fp64 tolerances as the stationary kernels.
+# ----------------------------------------------------------------------------------------------------
+CPU_ONLY_KERNELS = {"UniformSqExp": 1, "UniformMat52": 1, "ProductMat52": 3}
+
+
+@pytest.mark.parametrize("name", list(CPU_ONLY_KERNELS))
+@pytest.mark.parametrize("mode", ["fixed", "fit"])
+def test_cpu_only_kernels_vs_reference_golden(name, mode):
+    g = load_golden("kernels_cpuonly.npz")
+    pre = "%s_%s_" % (name, mode)
+    nc = CPU_ONLY_KERNELS[name]
+    nug = {"fixed": 1.e-5, "fit": "fit"}[mode]
+    gp = M.GaussianProcessGPU(g["X"], g["t"], kernel=name, nugget=nug, priors=GPPriors(n_corr=nc, nugget_type=mode))
+    theta = g[pre + "theta"]
+    assert gp.n_corr == nc and gp.n_params == theta.shape[0]
+    assert_allclose(gp.logposterior(theta), g[pre + "logpost"], rtol=1e-9)
+    assert_allclose(gp.logpost_deriv(theta), g[pre + "grad"], rtol=1e-6, atol=1e-6)
+    assert_allclose(gp.Kinv_t, g[pre + "Kinv_t"], rtol=1e-6, atol=1e-6 * np.abs(g[pre + "Kinv_t"]).max())
+    mu, var, deriv = gp.predict(g["Xs"])
+    assert_allclose(mu, g[pre + "mean"], rtol=1e-7, atol=1e-8)
+    assert_allclose(var, g[pre + "var"], rtol=1e-6, atol=1e-9)
+    # get_K: sigma^2 k(X, X) without nugget, against the reference's kernel_f restated by the oracle
+    K = gp.get_K_matrix()
+    assert_allclose(K, np.exp(theta[nc]) * R.kernel_f(g["X"], g["X"], theta[:nc], name), rtol=1e-12, atol=1e-15)
+    # d mean / d x* against the oracle's analytic input derivative
+    ref = R.GPRef(g["X"], g["t"], kernel=name, nugget=nug)
+    ref.fit(theta)
+    assert_allclose(deriv, ref.predict(g["Xs"], deriv=True)[2], rtol=1e-6, atol=1e-7)
+    if mode == "fit":
+        # default priors: one InvGamma per correlation parameter (the uniform kernels pool all inputs)
+        gd = M.GaussianProcessGPU(g["X"], g["t"], kernel=name, nugget="fit")
+        assert_allclose(gd.logposterior(theta), g[name + "_defprior_logpost"], rtol=1e-8)
+        assert_allclose(gd.logpost_deriv(theta), g[name + "_defprior_grad"], rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("name", list(CPU_ONLY_KERNELS))
+def test_cpu_only_kernels_multioutput_fit_and_full_cov(name):
+    nc = CPU_ONLY_KERNELS[name]
+    X, T, Xs = synth(41, 260, 3, 4, 90)
+    mo = M.MultiOutputGP_GPU(X, T, kernel=name, nugget="fit", priors=GPPriors(n_corr=nc, nugget_type="fit"))
+    assert mo.n_corr == [nc] * 4 and mo.n_params == [nc + 2] * 4
+    rng = np.random.default_rng(2)
+    thetas = np.stack([np.r_[rng.uniform(0., 2., nc), rng.uniform(-1., 1.), rng.uniform(-9., -6.)] for _ in range(4)])
+    f, grad, ok = mo._mogp_gpu.eval(thetas, grad=True)
+    assert ok.all()
+    mo.fit(thetas)
+    mean, cov, _ = mo.predict(Xs, full_cov=True, deriv=False)
+    for k in range(4):
+        ref = R.GPRef(X, T[k], kernel=name, nugget="fit")
+        assert_allclose(f[k], ref.fit(thetas[k]), rtol=1e-9)
+        assert_allclose(grad[k], ref.logpost_deriv(thetas[k]), rtol=1e-6, atol=1e-6)
+        rmu, rcov, _ = ref.predict(Xs, full_cov=True)
+        assert_allclose(mean[k], rmu, rtol=1e-7, atol=1e-8)
+        assert_allclose(cov[k], rcov, rtol=1e-6, atol=1e-7 * np.abs(rcov).max())
+    # the optimiser runs on the reduced parameter vector
+    LibGPGPU.set_fit_options(seed=5)
+    mo = M.fit_GP_MAP(mo, n_tries=1, theta0=np.r_[np.zeros(nc), 0., np.log(1e-4)])
+    LibGPGPU.set_fit_options(seed=0)
+    assert mo.get_indices_not_fit() == []
+    f1 = np.array([em.current_logpost for em in mo.emulators])
+    f0, _, _ = M.MultiOutputGP_GPU(X, T, kernel=name, nugget="fit", priors=GPPriors(n_corr=nc, nugget_type="fit"))._mogp_gpu.eval(
+        np.tile(np.r_[np.zeros(nc), 0., np.log(1e-4)], (4, 1)), grad=False)
+    assert np.all(f1 < f0)

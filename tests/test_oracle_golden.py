@@ -312,3 +312,35 @@ def test_mice_criterion_vs_reference():
     known = R.GPRef(np.reshape([1., 2., 3., 4.], (4, 1)), np.ones(4), nugget="adaptive")
     known.fit(np.array([0., -1.]))
     assert_allclose(R.mice_fast_predict_ref(known, 3), g["mice_known_answer"], rtol=1e-8)
+
+
+CPU_ONLY_KERNELS = {"UniformSqExp": 1, "UniformMat52": 1, "ProductMat52": 3}
+
+
+@pytest.mark.parametrize("name", list(CPU_ONLY_KERNELS))
+def test_cpu_only_kernels_vs_reference(name):
+    # Kernel.py:224-417 (uniform), :581-763 (product)
+    g = load_golden("kernels_cpuonly.npz")
+    nc = CPU_ONLY_KERNELS[name]
+    corr = np.array([0.7, -0.3, 1.1])[:nc]
+    assert_allclose(R.kernel_f(g["X"][:7], g["Xs"][:5], corr, name), g[name + "_kf"], rtol=1e-13)
+    assert_allclose(R.kernel_deriv(g["X"][:7], g["Xs"][:5], corr, name), g[name + "_kd"], rtol=1e-12, atol=1e-15)
+    # input derivative against central differences of kernel_f
+    h = 1e-6
+    d_an = R.kernel_inputderiv(g["Xs"][:5], g["X"][:7], corr, name)
+    for d in range(3):
+        e = np.zeros(3)
+        e[d] = h
+        fd = (R.kernel_f(g["Xs"][:5] + e, g["X"][:7], corr, name) - R.kernel_f(g["Xs"][:5] - e, g["X"][:7], corr, name)) / (2 * h)
+        assert_allclose(d_an[d], fd, rtol=1e-6, atol=1e-8)
+    for mode in ("fixed", "fit"):
+        pre = "%s_%s_" % (name, mode)
+        gp = R.GPRef(g["X"], g["t"], kernel=name, nugget={"fixed": 1.e-5, "fit": "fit"}[mode])
+        theta = g[pre + "theta"]
+        assert gp.n_params == theta.shape[0]
+        assert_allclose(gp.fit(theta), g[pre + "logpost"], rtol=1e-9)
+        assert_allclose(gp.logpost_deriv(theta), g[pre + "grad"], rtol=1e-6, atol=1e-6)
+        assert_allclose(gp.Kinv_t, g[pre + "Kinv_t"], rtol=1e-6, atol=1e-6 * np.abs(g[pre + "Kinv_t"]).max())
+        mu, var, _ = gp.predict(g["Xs"])
+        assert_allclose(mu, g[pre + "mean"], rtol=1e-7, atol=1e-8)
+        assert_allclose(var, g[pre + "var"], rtol=1e-6, atol=1e-9)
