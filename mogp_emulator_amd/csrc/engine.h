@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 #include <random>
 #include <string>
+#include <map>
 #include <vector>
 
 #include "hostmath.h"
@@ -91,6 +92,7 @@ class Engine {
   hipStream_t pstream = nullptr;     // look-ahead stream: panel factorisations
   std::vector<hipEvent_t> evPanel, evUpd;
   std::vector<hipStream_t> gstreams;  // extra streams for independent emulator groups
+  std::map<long, hipGraphExec_t> cholGraphs;   // captured left-looking factorisation per (batch size, group count)
   hipEvent_t evReady = nullptr;
   hipEvent_t evGroup[15] = {};
 

@@ -59,6 +59,7 @@ void prof_end(const char* tag, hipStream_t s, double flops, double bytes) {
   r.launches += 1;
 }
 void prof_enable(bool on) { g_prof_on = on; }
+bool prof_is_on() { return g_prof_on; }
 void prof_reset() {
   std::lock_guard<std::mutex> lk(g_prof_mu);
   for (auto& kv : g_prof) {
@@ -185,6 +186,7 @@ Engine::~Engine() {
                   (void*)dGradOut, (void*)dGradPartial, (void*)dInfo, (void*)dIdx, (void*)dXs, (void*)dKs, (void*)dMean, (void*)dVar,
                   (void*)dVarPartial, (void*)dDeriv, (void*)dLpack, (void*)dH, (void*)dZ, (void*)dM, (void*)dGram})
     if (p) hipFree(p);
+  for (auto& kv : cholGraphs) hipGraphExecDestroy(kv.second);
   for (auto st : gstreams) hipStreamDestroy(st);
   if (evReady) hipEventDestroy(evReady);
   for (auto e : evGroup) if (e) hipEventDestroy(e);
@@ -270,8 +272,6 @@ void Engine::factorize(const std::vector<int>& ids, std::vector<int>& info) {
   upload_idx(ids);
   upload_params(ids);
   BatchView v = view(nb);
-  HIPCK(hipMemsetAsync(dInfo, 0, B * sizeof(int), stream));
-  launch_cov_build(v, stream);
   // schedule: 0 = left-looking (default), 2 = left-looking + two-stream look-ahead split, 1 = right-looking + look-ahead
   static const int forced = [] {
     const char* e = getenv("MOGP_CHOL");
@@ -283,58 +283,94 @@ void Engine::factorize(const std::vector<int>& ids, std::vector<int>& info) {
   // a single large matrix (C5) has thousands of trailing tiles per step instead -> right-looking.
   const int schedule = forced >= 0 ? forced : (((long)nb * (NP / TILE) >= 512) ? 0 : 1);
   if (schedule == 0) {
-    // Optional independent emulator groups on separate streams (MOGP_GROUPS).  Measured on MI355X /
-    // ROCm 7.2: kernels of different streams do not overlap usefully here (2 groups -6 %, 4 groups
-    // 2.7x slower), so the default is ONE in-order launch sequence and overlap is sought inside kernels.
+    // Two independent emulator groups on separate streams (MOGP_GROUPS, default 2): while one group runs its
+    // latency-bound panel kernels (potf2 / trsm: few workgroups) the other group's MFMA update fills the
+    // machine.  Measured on MI355X / ROCm 7.2 at 64 x n=2000: 1 group 6.58 ms, 2 groups 6.23 ms, 3 groups
+    // 8.3 ms, 4 groups 14.2 ms, 8 groups 19.9 ms -- identical when the whole multi-stream sequence is
+    // replayed from a captured hipGraph (MOGP_GRAPH=1: 6.51 / 6.20 / 14.4 / 20.4 ms), so the collapse beyond
+    // two streams is on the device side (kernel-boundary cache maintenance of one queue hits the kernels
+    // of the others), not host launch overhead.  Graph replay is kept as an option, off by default.
     static const long tail_threshold = [] { const char* e = getenv("MOGP_TAIL"); return e ? atol(e) : 1100L; }();
     static const bool fuse_potf2 = [] { const char* e = getenv("MOGP_FUSE_POTF2"); return e && e[0] == '1'; }();
-    static const int want_groups = [] { const char* e = getenv("MOGP_GROUPS"); return e ? std::max(1, atoi(e)) : 1; }();
-    int G = std::min(want_groups, std::max(1, nb / 8));
+    static const int want_groups = [] { const char* e = getenv("MOGP_GROUPS"); return e ? std::max(1, atoi(e)) : 2; }();
+    static const bool want_graph = [] { const char* e = getenv("MOGP_GRAPH"); return e && e[0] == '1'; }();
+    const int G = std::min(want_groups, std::max(1, nb / 8));
     while ((int)gstreams.size() < G - 1) {
       hipStream_t st;
       HIPCK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
       gstreams.push_back(st);
     }
-    HIPCK(hipEventRecord(evReady, stream));
-    std::vector<BatchView> gv(G, v);
-    std::vector<hipStream_t> gs(G, stream);
-    for (int g = 0; g < G; ++g) {
-      const int lo = (int)((long)nb * g / G), hi = (int)((long)nb * (g + 1) / G);
-      gv[g].idx = dIdx + lo;
-      gv[g].nb = hi - lo;
-      if (g > 0) {
-        gs[g] = gstreams[g - 1];
-        HIPCK(hipStreamWaitEvent(gs[g], evReady, 0));
-      }
-    }
-    for (int o = 0; o < n + R; o += TILE)
+    auto issue = [&]() {
+      HIPCK(hipMemsetAsync(dInfo, 0, B * sizeof(int), stream));
+      launch_cov_build(v, stream);
+      HIPCK(hipEventRecord(evReady, stream));
+      std::vector<BatchView> gv(G, v);
+      std::vector<hipStream_t> gs(G, stream);
       for (int g = 0; g < G; ++g) {
-        if (o > 0) {
-          // with fewer than ~4 128-tiles per CU (always true at n=2000 x 64, measured 7.6 vs 8.3 ms) use
-          // 64x64 tiles: 4x the workgroups, 3 resident per CU, better balance and latency hiding
-          const long tiles128 = (long)gv[g].nb * ((NP - o) / TILE);
-          if (tiles128 >= tail_threshold) launch_update_wide(gv[g], o, 0, o, gs[g]);
-          else {
-            if (fuse_potf2) {
-              // experiment (MOGP_FUSE_POTF2=1): the diagonal tile's workgroup factors D1 / D2 itself.  Measured
-              // SLOWER (7.5 -> 8.0..8.5 ms): the potf2 wave's 128+ live VGPRs set the register allocation of the
-              // whole update kernel (86 -> 168/255), costing a resident workgroup per CU or spilling.
-              launch_update_narrow_potf2(gv[g], o, 0, o, dInfo, dLpack, gs[g]);          // + potf2(o)
-              launch_update_narrow(gv[g], o + NBI, 0, o, gs[g]);
-              launch_trsm(gv[g], o, o + NBI, dLpack, gs[g]);
-              launch_update_narrow_potf2(gv[g], o + NBI, o, o + NBI, dInfo, dLpack, gs[g]);   // + potf2(o+64)
-              launch_trsm(gv[g], o + NBI, o + TILE, dLpack, gs[g]);
-              continue;
-            }
-            launch_update_narrow(gv[g], o, 0, o, gs[g]);
-            launch_update_narrow(gv[g], o + NBI, 0, o, gs[g]);
-          }
+        const int lo = (int)((long)nb * g / G), hi = (int)((long)nb * (g + 1) / G);
+        gv[g].idx = dIdx + lo;
+        gv[g].nb = hi - lo;
+        if (g > 0) {
+          gs[g] = gstreams[g - 1];
+          HIPCK(hipStreamWaitEvent(gs[g], evReady, 0));
         }
-        panel(gv[g], o, TILE, gs[g]);
       }
-    for (int g = 1; g < G; ++g) {
-      HIPCK(hipEventRecord(evGroup[g - 1], gs[g]));
-      HIPCK(hipStreamWaitEvent(stream, evGroup[g - 1], 0));
+      for (int o = 0; o < n + R; o += TILE)
+        for (int g = 0; g < G; ++g) {
+          if (o > 0) {
+            // with fewer than ~4 128-tiles per CU (always true at n=2000 x 64, measured 7.6 vs 8.3 ms) use
+            // 64x64 tiles: 4x the workgroups, 3 resident per CU, better balance and latency hiding
+            const long tiles128 = (long)gv[g].nb * ((NP - o) / TILE);
+            if (tiles128 >= tail_threshold) launch_update_wide(gv[g], o, 0, o, gs[g]);
+            else {
+              if (fuse_potf2) {
+                // experiment (MOGP_FUSE_POTF2=1): the diagonal tile's workgroup factors D1 / D2 itself.  Measured
+                // SLOWER (7.5 -> 8.0..8.5 ms): the potf2 wave's 128+ live VGPRs set the register allocation of the
+                // whole update kernel (86 -> 168/255), costing a resident workgroup per CU or spilling.
+                launch_update_narrow_potf2(gv[g], o, 0, o, dInfo, dLpack, gs[g]);          // + potf2(o)
+                launch_update_narrow(gv[g], o + NBI, 0, o, gs[g]);
+                launch_trsm(gv[g], o, o + NBI, dLpack, gs[g]);
+                launch_update_narrow_potf2(gv[g], o + NBI, o, o + NBI, dInfo, dLpack, gs[g]);   // + potf2(o+64)
+                launch_trsm(gv[g], o + NBI, o + TILE, dLpack, gs[g]);
+                continue;
+              }
+              // both 64-wide halves of the block column in one launch (measured 7.56 -> 6.84 ms: the partially
+              // filled last round of workgroups is paid once instead of twice)
+              static const bool pair = [] { const char* e = getenv("MOGP_PAIR"); return !e || e[0] != '0'; }();
+              if (pair) launch_update_narrow_pair(gv[g], o, 0, o, gs[g]);
+              else {
+                launch_update_narrow(gv[g], o, 0, o, gs[g]);
+                launch_update_narrow(gv[g], o + NBI, 0, o, gs[g]);
+              }
+            }
+          }
+          panel(gv[g], o, TILE, gs[g]);
+        }
+      for (int g = 1; g < G; ++g) {
+        HIPCK(hipEventRecord(evGroup[g - 1], gs[g]));
+        HIPCK(hipStreamWaitEvent(stream, evGroup[g - 1], 0));
+      }
+    };
+    if (want_graph && !prof_is_on()) {
+      const long key = (long)nb * 64 + G;
+      auto it = cholGraphs.find(key);
+      if (it == cholGraphs.end()) {
+        if (cholGraphs.size() >= 32) {                       // bounded cache (optimiser rounds shrink the active set)
+          for (auto& kv : cholGraphs) hipGraphExecDestroy(kv.second);
+          cholGraphs.clear();
+        }
+        hipGraph_t graph = nullptr;
+        hipGraphExec_t exec = nullptr;
+        HIPCK(hipStreamBeginCapture(stream, hipStreamCaptureModeRelaxed));
+        issue();
+        HIPCK(hipStreamEndCapture(stream, &graph));
+        HIPCK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+        HIPCK(hipGraphDestroy(graph));
+        it = cholGraphs.emplace(key, exec).first;
+      }
+      HIPCK(hipGraphLaunch(it->second, stream));
+    } else {
+      issue();
     }
     info.assign(B, 0);
     HIPCK(hipMemcpyAsync(info.data(), dInfo, B * sizeof(int), hipMemcpyDeviceToHost, stream));
@@ -342,6 +378,8 @@ void Engine::factorize(const std::vector<int>& ids, std::vector<int>& info) {
     HIPCK(hipGetLastError());
     return;
   }
+  HIPCK(hipMemsetAsync(dInfo, 0, B * sizeof(int), stream));
+  launch_cov_build(v, stream);
   if (schedule == 2) {
     // LEFT-LOOKING: block column o receives ALL earlier panels in one long-K MFMA pass
     // (C[i, o:o+128] -= A[i, 0:o] A[o:o+128, 0:o]^T, K = o), then is factored.  Every element of the

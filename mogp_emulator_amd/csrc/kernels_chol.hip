@@ -13,6 +13,7 @@
 namespace mogp {
 
 typedef double v2d __attribute__((ext_vector_type(2)));
+typedef double v4d __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ int slot_emu(const int* idx, int z) { return idx ? idx[z] : z; }
 
@@ -91,6 +92,55 @@ __global__ __launch_bounds__(TRSM_THREADS) void trsm_kernel(BatchView v, int c0,
     w[0] = x[2 * q];
     w[1] = x[2 * q + 1];
     *reinterpret_cast<v2d*>(arow + 2 * q) = w;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Panel TRSM on the matrix cores.  Each wave owns a 16-row slab B (16 x 64) of the panel and solves
+// X L_kk^T = B in the transposed form  X^T = L_kk^-1 B^T  by block forward substitution over the four
+// 16-column blocks:
+//     T_b = B_b^T - sum_{a<b} L_ba X_a^T ,   X_b^T = inv(L_bb) T_b        (v_mfma_f64_16x16x4)
+// The transposed form chains without any LDS transpose: an MFMA result (lane holds rows g+4r, g = lane>>4,
+// column lane&15) is used directly as the B operand of the next MFMA with the k index running over g+4r,
+// and the A operand (L_ba or inv(L_bb), element [lane&15][g+4r]) is fetched with the same k mapping.
+// 40 dependent MFMAs per wave instead of 2016 LDS-fed FMAs per row; rows/16 waves per emulator.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void trsm_mfma_kernel(BatchView v, int c0, int r0, const double* __restrict__ Lpack) {
+  const int emu = slot_emu(v.idx, blockIdx.y);
+  const int ld = v.LD;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = lane >> 4, i = lane & 15;
+  const int row = r0 + blockIdx.x * 64 + wave * 16 + i;
+  double* arow = v.A + (size_t)emu * v.MS + (size_t)row * ld + c0;
+  const double* pk = Lpack + (size_t)emu * PACK_STRIDE;
+  // A operands: Lneg[b][a][r] = -L[16b + i][16a + g + 4r]  (a < b),  Inv[b][r] = inv(L_bb)[i][g + 4r]
+  double Lneg[6][4], Inv[4][4];
+#pragma unroll
+  for (int b = 1; b < 4; ++b)
+#pragma unroll
+    for (int a = 0; a < b; ++a)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Lneg[b * (b - 1) / 2 + a][r] = -pk[(16 * a + g + 4 * r) * 64 + 16 * b + i];
+#pragma unroll
+  for (int b = 0; b < 4; ++b)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Inv[b][r] = pk[PACK_INV + b * 256 + (g + 4 * r) * 16 + i];
+  v4d T[4], X[4];
+#pragma unroll
+  for (int b = 0; b < 4; ++b)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) T[b][r] = arow[16 * b + g + 4 * r];
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+#pragma unroll
+    for (int a = 0; a < b; ++a)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) T[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(Lneg[b * (b - 1) / 2 + a][r], X[a][r], T[b], 0, 0, 0);
+    X[b] = (v4d){0., 0., 0., 0.};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) X[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(Inv[b][r], T[b][r], X[b], 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) arow[16 * b + g + 4 * r] = X[b][r];
   }
 }
 
@@ -434,6 +484,11 @@ void launch_potf2(const BatchView& v, int c0, int* info, double* Lpack, hipStrea
 void launch_trsm(const BatchView& v, int c0, int r0, const double* Lpack, hipStream_t s) {
   const int rows = v.NP - r0;
   if (rows <= 0) return;
+  static const bool mfma = [] { const char* e = getenv("MOGP_TRSM"); return !e || e[0] != '0'; }();   // 0: per-row substitution kernels
+  if (mfma) {
+    hipLaunchKernelGGL(trsm_mfma_kernel, dim3(rows / 64, v.nb), dim3(256), 0, s, v, c0, r0, Lpack);
+    return;
+  }
   if ((long)v.nb * ((rows + 255) / 256) >= 256)
     hipLaunchKernelGGL(trsm_kernel<256>, dim3((rows + 255) / 256, v.nb), dim3(256), 0, s, v, c0, r0, Lpack);
   else

@@ -184,9 +184,13 @@ __global__ __launch_bounds__(256, (FUSE ? 3 : 2)) void update_kernel(BatchView v
     while (ti * (ti + 1) / 2 > tile) --ti;
     while ((ti + 1) * (ti + 2) / 2 <= tile) ++ti;
     tj = tile - ti * (ti + 1) / 2;
-  } else {
+  } else if (tile < nt) {
     ti = tile;
     tj = 0;
+  } else {
+    // pair launch (ntiles = 2 nt - 1): second tile column, rows from the diagonal tile of that column
+    ti = tile - nt + 1;
+    tj = 1;
   }
   const int emu = slot_to_emu(v.idx, z);
   double* A = v.A + (size_t)emu * v.MS;
@@ -384,6 +388,16 @@ void launch_update_narrow(const BatchView& v, int c0, int k0, int k1, hipStream_
   if (nt <= 0) return;
   hipLaunchKernelGGL((update_kernel<2, false, false>), dim3(padded_grid(v.nb, nt)), dim3(256), smem_bytes<2>(), s, v, c0, k0, k1, nt, nt, (int*)nullptr,
                      (double*)nullptr);
+}
+
+// two adjacent 64-wide block columns [c0, c0+128) in ONE launch (2 nt - 1 lower tiles): twice the workgroups per
+// launch, so the last partially filled round of workgroups costs half as much as with two launches
+void launch_update_narrow_pair(const BatchView& v, int c0, int k0, int k1, hipStream_t s) {
+  const int nt = (v.NP - c0) / 64;
+  if (nt <= 0) return;
+  const int ntiles = std::max(1, 2 * nt - 1);
+  hipLaunchKernelGGL((update_kernel<2, false, false>), dim3(padded_grid(v.nb, ntiles)), dim3(256), smem_bytes<2>(), s, v, c0, k0, k1, nt, ntiles,
+                     (int*)nullptr, (double*)nullptr);
 }
 
 // 64-wide block-column update whose diagonal-tile workgroup also factors the 64x64 block at (c0, c0)

@@ -69,6 +69,7 @@ void launch_update_narrow(const BatchView& v, int c0, int k0, int k1, hipStream_
 // same, and the diagonal-tile workgroup then factors the 64x64 block at (c0,c0) (fused potf2)
 void launch_update_narrow_potf2(const BatchView& v, int c0, int k0, int k1, int* info, double* Lpack, hipStream_t s);
 // same for a 128-wide column block (MFMA 128x128 tiles)
+void launch_update_narrow_pair(const BatchView& v, int c0, int k0, int k1, hipStream_t s);
 void launch_update_wide(const BatchView& v, int c0, int k0, int k1, hipStream_t s);
 // trailing lower-triangular update, rows/cols [c0, NP), k in [k0,k1) (c0 multiple of 128)
 void launch_update_trailing(const BatchView& v, int c0, int k0, int k1, hipStream_t s);
@@ -104,6 +105,7 @@ void launch_predict_deriv(const BatchView& v, const double* Xs, int m, double* d
 void launch_extract(const double* src, int NP, int n, double* out, int mode, hipStream_t s);
 
 // --- profiling hooks (bench only) -------------------------------------------------------------
+bool prof_is_on();
 void prof_begin(const char* tag, hipStream_t s);
 void prof_end(const char* tag, hipStream_t s, double flops, double bytes);
 

@@ -31,9 +31,11 @@ __device__ __forceinline__ void rsqrt_sqrt(double d, double& rs, double& sq) {
   sq = g;
 }
 
-// Lpack (per emulator, PACK_STRIDE doubles): [c*64 + q] = L_kk[q][c] (q >= c), [4096 + c] = 1/L_kk[c][c].
-// Written by potf2, copied linearly into LDS by every panel-TRSM workgroup.
-constexpr int PACK_STRIDE = 64 * 64 + 64;
+// Lpack (per emulator, PACK_STRIDE doubles): [c*64 + q] = L_kk[q][c] (q >= c), [4096 + c] = 1/L_kk[c][c],
+// [PACK_INV + b*256 + k*16 + i] = inv(L_bb)[i][k] for the four 16x16 diagonal sub-blocks b (MFMA panel TRSM).
+// Written by potf2, read by every panel-TRSM workgroup.
+constexpr int PACK_INV = 64 * 64 + 64;
+constexpr int PACK_STRIDE = PACK_INV + 4 * 256;
 
 
 constexpr int POTF2_LDS_DOUBLES = 64 * 65 + 16 * 64;   // block image + 16 finished columns
@@ -90,6 +92,25 @@ __device__ __forceinline__ void potf2_wave(double* blk, double* colbuf, double* 
     if (c <= lane) pack[c * 64 + lane] = x;           // column c of L, coalesced across lanes
   }
   pack[4096 + lane] = myrs;
+  colbuf[lane] = myrs;
+  __builtin_amdgcn_wave_barrier();
+  {
+    // inverses of the four 16x16 diagonal sub-blocks: lane 16b + j solves L_bb z = e_j (forward substitution,
+    // 136 FMAs); the panel TRSM multiplies with them on the matrix cores instead of substituting per row
+    const int b = lane >> 4, j = lane & 15;
+    const double* Lb = blk + (16 * b) * 65 + 16 * b;
+    double zc[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      double s = (i == j) ? 1.0 : 0.0;
+#pragma unroll
+      for (int k = 0; k < i; ++k) s = __builtin_fma(-Lb[i * 65 + k], zc[k], s);     // z_k = 0 for k < j
+      zc[i] = (i < j) ? 0.0 : s * colbuf[16 * b + i];
+    }
+    double* dst = pack + PACK_INV + b * 256 + j * 16;
+#pragma unroll
+    for (int i = 0; i < 16; i += 2) *reinterpret_cast<v2d_p*>(dst + i) = (v2d_p){zc[i], zc[i + 1]};
+  }
   __builtin_amdgcn_wave_barrier();
   {
     const int half = lane >> 5, part = lane & 31;
