@@ -95,6 +95,7 @@ class Engine {
   std::map<long, hipGraphExec_t> cholGraphs;   // captured left-looking factorisation per (batch size, group count)
   hipEvent_t evReady = nullptr;
   hipEvent_t evGroup[15] = {};
+  std::vector<hipEvent_t> evAlt;      // update-slot hand-over events of the alternating two-group schedule
 
  private:
   void upload_params(const std::vector<int>& ids);

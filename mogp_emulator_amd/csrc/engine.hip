@@ -190,6 +190,7 @@ Engine::~Engine() {
   for (auto st : gstreams) hipStreamDestroy(st);
   if (evReady) hipEventDestroy(evReady);
   for (auto e : evGroup) if (e) hipEventDestroy(e);
+  for (auto e : evAlt) hipEventDestroy(e);
   for (auto e : evPanel) hipEventDestroy(e);
   for (auto e : evUpd) hipEventDestroy(e);
   if (pstream) hipStreamDestroy(pstream);
@@ -315,8 +316,23 @@ void Engine::factorize(const std::vector<int>& ids, std::vector<int>& info) {
           HIPCK(hipStreamWaitEvent(gs[g], evReady, 0));
         }
       }
+      // MOGP_ALT=1 (two groups): the long updates of the two groups strictly alternate (each waits for the other
+      // group's previous update), so a group's panel chain always runs under the other group's update
+      static const bool alternate = [] { const char* e = getenv("MOGP_ALT"); return e && e[0] == '1'; }();
+      const bool alt = alternate && G == 2;
+      size_t nev = 0;
+      hipEvent_t prev_update = nullptr;
+      auto next_event = [&]() {
+        if (nev == evAlt.size()) {
+          hipEvent_t e;
+          HIPCK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+          evAlt.push_back(e);
+        }
+        return evAlt[nev++];
+      };
       for (int o = 0; o < n + R; o += TILE)
         for (int g = 0; g < G; ++g) {
+          if (alt && prev_update) HIPCK(hipStreamWaitEvent(gs[g], prev_update, 0));
           if (o > 0) {
             // with fewer than ~4 128-tiles per CU (always true at n=2000 x 64, measured 7.6 vs 8.3 ms) use
             // 64x64 tiles: 4x the workgroups, 3 resident per CU, better balance and latency hiding
@@ -344,6 +360,13 @@ void Engine::factorize(const std::vector<int>& ids, std::vector<int>& info) {
               }
             }
           }
+          if (alt) {
+            // the "update slot" of this group ends here (at o = 0: after its first panel, which offsets the groups)
+            if (o == 0) panel(gv[g], o, TILE, gs[g]);
+            prev_update = next_event();
+            HIPCK(hipEventRecord(prev_update, gs[g]));
+            if (o == 0) continue;
+          }
           panel(gv[g], o, TILE, gs[g]);
         }
       for (int g = 1; g < G; ++g) {
@@ -351,6 +374,92 @@ void Engine::factorize(const std::vector<int>& ids, std::vector<int>& info) {
         HIPCK(hipStreamWaitEvent(stream, evGroup[g - 1], 0));
       }
     };
+    // Role-fused software pipeline (experiment, MOGP_FUSED=1): two emulator groups in anti-phase; every launch
+    // carries one panel-chain kernel of one group (potf2 / trsm / 64-wide update: few workgroups, latency
+    // bound) and a slice of the other group's long-K update (MFMA bound) as two jobs of ONE kernel, so they
+    // overlap by construction.  Bit-identical results, but measured SLOWER than two free-running streams
+    // (64 x n=2000: 6.07 ms two streams; fused 11.4 ms with the update cut in 5 slices, 7.9 ms in 2, 7.5 ms
+    // uncut): a slice can never finish faster than one long-K tile (27-55 us), and the half-batch panel
+    // kernels then run alone on the machine, one after the other, in a single stream.
+    static const bool want_fused = [] { const char* e = getenv("MOGP_FUSED"); return e && e[0] == '1'; }();
+    if (want_fused && nb >= 16 && !fuse_potf2 && (long)(nb / 2) * (NP / TILE) < tail_threshold) {
+      static const std::vector<double> weights = [] {
+        std::vector<double> w{32., 13., 10., 32., 13.};
+        if (const char* e = getenv("MOGP_FUSEW")) {
+          std::vector<double> u;
+          for (const char* p = e; *p;) {
+            u.push_back(atof(p));
+            while (*p && *p != ',') ++p;
+            if (*p == ',') ++p;
+          }
+          if (u.size() == 5) w = u;
+        }
+        return w;
+      }();
+      HIPCK(hipMemsetAsync(dInfo, 0, B * sizeof(int), stream));
+      launch_cov_build(v, stream);
+      const int off[2] = {0, nb / 2}, cnt[2] = {nb / 2, nb - nb / 2};
+      auto job = [&](int role, int g, int per_emu, int c0, int k0, int k1, int nt, int tile0, int r0) {
+        FusedJob j{};
+        j.role = role; j.idx_off = off[g]; j.nb = cnt[g]; j.per_emu = per_emu;
+        j.c0 = c0; j.k0 = k0; j.k1 = k1; j.nt = nt; j.tile0 = tile0; j.r0 = r0;
+        j.wg_count = (per_emu > 0) ? cnt[g] * per_emu : 0;
+        return j;
+      };
+      auto chain_op = [&](int g, int o, int i) {
+        switch (i) {
+          case 0: return job(ROLE_POTF2, g, 1, o, 0, 0, 0, 0, 0);
+          case 1: return job(ROLE_TRSM, g, (NP - o - NBI) / 64, o, 0, 0, 0, 0, o + NBI);
+          case 2: return job(ROLE_UPDATE, g, (NP - o - NBI) / 64, o + NBI, o, o + NBI, (NP - o - NBI) / 64, 0, 0);
+          case 3: return job(ROLE_POTF2, g, (o + NBI < NP) ? 1 : 0, o + NBI, 0, 0, 0, 0, 0);
+          default: return job(ROLE_TRSM, g, (NP - o - TILE) / 64, o + NBI, 0, 0, 0, 0, o + TILE);
+        }
+      };
+      // slice i (of 5) of the block-column update of group g at column o; i < 0: the whole update
+      auto update_piece = [&](int g, int o, int i) {
+        const int nt = (NP - o) / 64, ntiles = std::max(0, 2 * nt - 1);
+        int t0 = 0, t1 = ntiles;
+        if (i >= 0) {
+          double tot = 0., acc0 = 0.;
+          for (double x : weights) tot += x;
+          for (int q = 0; q < i; ++q) acc0 += weights[q];
+          t0 = (int)std::lround(ntiles * acc0 / tot);
+          t1 = (i == 4) ? ntiles : (int)std::lround(ntiles * (acc0 + weights[i]) / tot);
+        }
+        return job(ROLE_UPDATE, g, t1 - t0, o, 0, o, nt, t0, 0);
+      };
+      auto launch2 = [&](FusedJob a, FusedJob b) {
+        FusedArgs fa{};
+        if (a.wg_count == 0) std::swap(a, b);
+        if (a.wg_count == 0) return;
+        a.wg_begin = 0;
+        fa.job[0] = a;
+        fa.njobs = 1;
+        int total = a.wg_count;
+        if (b.wg_count > 0) {
+          b.wg_begin = roundup(a.wg_count, 8);
+          fa.job[1] = b;
+          fa.njobs = 2;
+          total = b.wg_begin + b.wg_count;
+        }
+        launch_fused_step(v, fa, total, dInfo, dLpack, stream);
+      };
+      std::vector<int> cols;
+      for (int o = 0; o < n + R; o += TILE) cols.push_back(o);
+      const int K = (int)cols.size();
+      const FusedJob none{};
+      for (int i = 0; i < 5; ++i) launch2(chain_op(0, cols[0], i), chain_op(1, cols[0], i));   // first panel: both groups
+      if (K > 1) launch2(update_piece(0, cols[1], -1), none);                                    // offsets the groups by half a period
+      for (int k = 1; k < K; ++k) {
+        for (int i = 0; i < 5; ++i) launch2(chain_op(0, cols[k], i), update_piece(1, cols[k], i));
+        for (int i = 0; i < 5; ++i) launch2(chain_op(1, cols[k], i), (k + 1 < K) ? update_piece(0, cols[k + 1], i) : none);
+      }
+      info.assign(B, 0);
+      HIPCK(hipMemcpyAsync(info.data(), dInfo, B * sizeof(int), hipMemcpyDeviceToHost, stream));
+      HIPCK(hipStreamSynchronize(stream));
+      HIPCK(hipGetLastError());
+      return;
+    }
     if (want_graph && !prof_is_on()) {
       const long key = (long)nb * 64 + G;
       auto it = cholGraphs.find(key);

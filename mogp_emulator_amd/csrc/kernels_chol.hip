@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include "launch.h"
 #include "potf2_dev.h"
+#include "trsm_dev.h"
 
 namespace mogp {
 
@@ -42,6 +43,14 @@ __global__ __launch_bounds__(64) void potf2_kernel(BatchView v, int c0, int* __r
   }
   __builtin_amdgcn_wave_barrier();
   potf2_wave(lds, lds + 64 * 65, A, ld, Lpack + (size_t)emu * PACK_STRIDE, info + emu, c0);
+}
+
+// four-wave version (potf2_block_dev): lane = row, wave = 16-column block
+__global__ __launch_bounds__(256) void potf2_block_kernel(BatchView v, int c0, int* __restrict__ info, double* __restrict__ Lpack) {
+  __shared__ __attribute__((aligned(16))) double lds[POTF2B_LDS_DOUBLES];
+  const int emu = slot_emu(v.idx, blockIdx.x);
+  double* A = v.A + (size_t)emu * v.MS + (size_t)c0 * v.LD + c0;
+  potf2_block_dev(A, v.LD, Lpack + (size_t)emu * PACK_STRIDE, info + emu, c0, lds);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -106,42 +115,7 @@ __global__ __launch_bounds__(TRSM_THREADS) void trsm_kernel(BatchView v, int c0,
 // 40 dependent MFMAs per wave instead of 2016 LDS-fed FMAs per row; rows/16 waves per emulator.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void trsm_mfma_kernel(BatchView v, int c0, int r0, const double* __restrict__ Lpack) {
-  const int emu = slot_emu(v.idx, blockIdx.y);
-  const int ld = v.LD;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int g = lane >> 4, i = lane & 15;
-  const int row = r0 + blockIdx.x * 64 + wave * 16 + i;
-  double* arow = v.A + (size_t)emu * v.MS + (size_t)row * ld + c0;
-  const double* pk = Lpack + (size_t)emu * PACK_STRIDE;
-  // A operands: Lneg[b][a][r] = -L[16b + i][16a + g + 4r]  (a < b),  Inv[b][r] = inv(L_bb)[i][g + 4r]
-  double Lneg[6][4], Inv[4][4];
-#pragma unroll
-  for (int b = 1; b < 4; ++b)
-#pragma unroll
-    for (int a = 0; a < b; ++a)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) Lneg[b * (b - 1) / 2 + a][r] = -pk[(16 * a + g + 4 * r) * 64 + 16 * b + i];
-#pragma unroll
-  for (int b = 0; b < 4; ++b)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) Inv[b][r] = pk[PACK_INV + b * 256 + (g + 4 * r) * 16 + i];
-  v4d T[4], X[4];
-#pragma unroll
-  for (int b = 0; b < 4; ++b)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) T[b][r] = arow[16 * b + g + 4 * r];
-#pragma unroll
-  for (int b = 0; b < 4; ++b) {
-#pragma unroll
-    for (int a = 0; a < b; ++a)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) T[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(Lneg[b * (b - 1) / 2 + a][r], X[a][r], T[b], 0, 0, 0);
-    X[b] = (v4d){0., 0., 0., 0.};
-#pragma unroll
-    for (int r = 0; r < 4; ++r) X[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(Inv[b][r], T[b][r], X[b], 0, 0, 0);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) arow[16 * b + g + 4 * r] = X[b][r];
-  }
+  trsm_mfma_dev(v, c0, r0, Lpack, slot_emu(v.idx, blockIdx.y), blockIdx.x);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -478,6 +452,11 @@ __global__ void extract_kernel(const double* __restrict__ src, int NP, int n, do
 
 // =============================================================================================
 void launch_potf2(const BatchView& v, int c0, int* info, double* Lpack, hipStream_t s) {
+  static const bool one_wave = [] { const char* e = getenv("MOGP_POTF2"); return e && e[0] == '1'; }();   // 1: single-wave kernel
+  if (!one_wave) {
+    hipLaunchKernelGGL(potf2_block_kernel, dim3(v.nb), dim3(256), 0, s, v, c0, info, Lpack);
+    return;
+  }
   hipLaunchKernelGGL(potf2_kernel, dim3(v.nb), dim3(64), 0, s, v, c0, info, Lpack);
 }
 

@@ -23,6 +23,7 @@
 #include <cstdlib>
 #include "launch.h"
 #include "potf2_dev.h"
+#include "trsm_dev.h"
 
 namespace mogp {
 
@@ -211,6 +212,61 @@ __global__ __launch_bounds__(256, (FUSE ? 3 : 2)) void update_kernel(BatchView v
     __syncthreads();
     if (threadIdx.x < 64)
       potf2_wave(smem, smem + 64 * 65, A + (size_t)i0 * ld + j0, ld, Lpack + (size_t)emu * PACK_STRIDE, info + emu, c0);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Role-fused factorisation step.  Kernels of different HIP streams overlap poorly on this stack, but
+// workgroups of ONE launch run concurrently by construction: a launch carries up to two jobs for two
+// disjoint emulator groups -- a slice of the long-K MFMA update of one group and one latency-bound
+// panel kernel (potf2 / MFMA trsm / 64-wide update) of the other -- so the panel chain of a group is
+// hidden under the other group's update (engine.hip, schedule "fused").
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void update_tile64_dev(const BatchView& v, int emu, int c0, int k0, int k1, int nt, int tile, double* smem) {
+  int ti, tj;
+  if (tile < nt) {
+    ti = tile;
+    tj = 0;
+  } else {
+    ti = tile - nt + 1;
+    tj = 1;
+  }
+  double* A = v.A + (size_t)emu * v.MS;
+  const int ld = v.LD;
+  const int i0 = c0 + ti * 64, j0 = c0 + tj * 64;
+  v4d acc[2][2];
+  gemm_mainloop<2, true, true>(A + (size_t)i0 * ld + k0, ld, A + (size_t)j0 * ld + k0, ld, (k1 - k0) / BK, acc, smem);
+  for_each_acc<2>(acc, [&](int r, int c, double x) {
+    double* p = A + (size_t)(i0 + r) * ld + (j0 + c);
+    *p -= x;
+  });
+}
+
+__global__ __launch_bounds__(256, 2) void fused_step_kernel(BatchView v, FusedArgs fa, int* __restrict__ info, double* __restrict__ Lpack) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int j = (fa.njobs > 1 && (int)blockIdx.x >= fa.job[1].wg_begin) ? 1 : 0;
+  const FusedJob& job = fa.job[j];
+  const int local = blockIdx.x - job.wg_begin;
+  if (local >= job.wg_count) return;                    // padding between jobs
+  const int* idx = v.idx + job.idx_off;
+  int z, part;
+  if ((job.nb & 7) == 0) {                              // same XCD-aware decode as decode_block (wg_begin is a multiple of 8)
+    const int xcd = local & 7, w = local >> 3;
+    z = (w / job.per_emu) * 8 + xcd;
+    part = w % job.per_emu;
+  } else {
+    z = local / job.per_emu;
+    part = local % job.per_emu;
+  }
+  if (z >= job.nb) return;
+  const int emu = idx[z];
+  if (job.role == ROLE_UPDATE) {
+    update_tile64_dev(v, emu, job.c0, job.k0, job.k1, job.nt, job.tile0 + part, smem);
+  } else if (job.role == ROLE_TRSM) {
+    trsm_mfma_dev(v, job.c0, job.r0, Lpack, emu, part);
+  } else {                                               // ROLE_POTF2: four-wave block potf2
+    double* A = v.A + (size_t)emu * v.MS + (size_t)job.c0 * v.LD + job.c0;
+    potf2_block_dev(A, v.LD, Lpack + (size_t)emu * PACK_STRIDE, info + emu, job.c0, smem);
   }
 }
 
@@ -472,6 +528,12 @@ void launch_predict_var(const BatchView& v, const double* Ks, int m, int MP, dou
   hipLaunchKernelGGL(predict_var_kernel<false>, dim3(padded_grid(v.nb, nsup)), dim3(256), smem_bytes<4>(), s, v, Ks, MP, nti, ntj, partial);
   prof_end("predict_var", s, (double)v.nb * (double)m * v.n * v.n, 0.);
   hipLaunchKernelGGL(predict_var_finish_kernel, dim3((m + 255) / 256, v.nb), dim3(256), 0, s, v, partial, m, MP, nti, var, var_ld);
+}
+
+void launch_fused_step(const BatchView& v, const FusedArgs& fa, int total_wgs, int* info, double* Lpack, hipStream_t s) {
+  if (total_wgs <= 0) return;
+  const size_t sm = std::max(smem_bytes<2>(), (size_t)POTF2B_LDS_DOUBLES * sizeof(double));
+  hipLaunchKernelGGL(fused_step_kernel, dim3(total_wgs), dim3(256), sm, s, v, fa, info, Lpack);
 }
 
 // cov (nb, m, m) holds K** on entry and the predictive covariance (without nugget) on return; V is nb*NP*MP scratch

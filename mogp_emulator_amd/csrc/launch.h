@@ -69,6 +69,20 @@ void launch_update_narrow(const BatchView& v, int c0, int k0, int k1, hipStream_
 // same, and the diagonal-tile workgroup then factors the 64x64 block at (c0,c0) (fused potf2)
 void launch_update_narrow_potf2(const BatchView& v, int c0, int k0, int k1, int* info, double* Lpack, hipStream_t s);
 // same for a 128-wide column block (MFMA 128x128 tiles)
+// Role-fused step launch: up to two jobs over disjoint emulator groups (see kernels_gemm.hip)
+enum { ROLE_UPDATE = 0, ROLE_POTF2 = 1, ROLE_TRSM = 2 };
+struct FusedJob {
+  int role;
+  int wg_begin, wg_count;   // workgroup range of the job inside the launch (wg_begin is a multiple of 8)
+  int idx_off, nb;          // emulator group: idx[idx_off .. idx_off + nb)
+  int per_emu;              // workgroups per emulator (tiles of this slice / row blocks / 1)
+  int c0, k0, k1, nt, tile0, r0;
+};
+struct FusedArgs {
+  FusedJob job[2];
+  int njobs;
+};
+void launch_fused_step(const BatchView& v, const FusedArgs& fa, int total_wgs, int* info, double* Lpack, hipStream_t s);
 void launch_update_narrow_pair(const BatchView& v, int c0, int k0, int k1, hipStream_t s);
 void launch_update_wide(const BatchView& v, int c0, int k0, int k1, hipStream_t s);
 // trailing lower-triangular update, rows/cols [c0, NP), k in [k0,k1) (c0 multiple of 128)

@@ -126,4 +126,108 @@ __device__ __forceinline__ void potf2_wave(double* blk, double* colbuf, double* 
   if (lane == 0 && fail != 0 && *info_slot == 0) *info_slot = c0 + fail;
 }
 
+// ---------------------------------------------------------------------------------------------
+// 64x64 potf2 by a 256-thread workgroup: wave w owns the 16 columns [16w, 16w+16) of all 64 rows
+// (lane = row, 16 values per lane instead of 64: ~60 VGPRs, so the routine can live inside the MFMA
+// update kernel without costing it occupancy).  Block step b: wave b factors its 16 columns exactly
+// like potf2_wave does inside a block (pivot / multipliers by v_readlane), publishes them through
+// an 8 KB LDS image, and the waves to its right apply the rank-16 update to their own columns in
+// parallel.  Arithmetic (operation order per element) is identical to potf2_wave.
+//   lds: POTF2B_LDS_DOUBLES doubles.  All 256 threads must call.
+// ---------------------------------------------------------------------------------------------
+constexpr int POTF2B_LDS_DOUBLES = 16 * 64 + 4 * 16 * 17 + 64;   // finished columns + diagonal blocks + reciprocal diagonal
+
+__device__ __forceinline__ void potf2_block_dev(double* A, int ld, double* pack, int* info_slot, int c0, double* lds) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  double* colbuf = lds;                    // [16][64]
+  double* dblk = lds + 16 * 64;            // [4][16][17]
+  double* rdg = dblk + 4 * 16 * 17;        // [64]
+  double a[16];
+  {
+    const v2d_p* src = reinterpret_cast<const v2d_p*>(A + (size_t)lane * ld + 16 * w);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const v2d_p x = src[q];
+      a[2 * q] = x[0];
+      a[2 * q + 1] = x[1];
+    }
+  }
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    if (w == b) {
+      int fail = 0;
+#pragma unroll
+      for (int jl = 0; jl < 16; ++jl) {
+        const int j = 16 * b + jl;
+        double d = readlane_f64(a[jl], j);
+        if (!(d > 0.0) || !(d < 1e308)) {   // wave-uniform; catches <= 0, NaN and Inf
+          if (fail == 0) fail = j + 1;
+          d = 1.0;
+        }
+        double rs, dj;
+        rsqrt_sqrt(d, rs, dj);
+        const double l = (lane == j) ? dj : a[jl] * rs;
+        a[jl] = l;
+        if (lane == j) rdg[j] = rs;
+        colbuf[jl * 64 + lane] = l;
+#pragma unroll
+        for (int c = jl + 1; c < 16; ++c) a[c] = __builtin_fma(-l, readlane_f64(l, 16 * b + c), a[c]);
+      }
+      if (lane >= 16 * b && lane < 16 * b + 16) {
+#pragma unroll
+        for (int c = 0; c < 16; ++c) dblk[(b * 16 + (lane - 16 * b)) * 17 + c] = a[c];
+      }
+      if (lane == 0 && fail != 0 && *info_slot == 0) *info_slot = c0 + fail;
+    }
+    __syncthreads();
+    if (w > b) {
+      double mine[16];
+#pragma unroll
+      for (int jl = 0; jl < 16; ++jl) mine[jl] = colbuf[jl * 64 + lane];
+#pragma unroll
+      for (int c = 0; c < 16; c += 2) {
+#pragma unroll
+        for (int jl = 0; jl < 16; ++jl) {
+          const v2d_p lc = *reinterpret_cast<const v2d_p*>(&colbuf[jl * 64 + 16 * w + c]);
+          a[c] = __builtin_fma(-mine[jl], lc[0], a[c]);
+          a[c + 1] = __builtin_fma(-mine[jl], lc[1], a[c + 1]);
+        }
+      }
+    }
+    __syncthreads();
+  }
+  // L (lower, upper zeroed) back to A; packed transposed copy for the panel TRSM
+  {
+    v2d_p* dst = reinterpret_cast<v2d_p*>(A + (size_t)lane * ld + 16 * w);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int c = 16 * w + 2 * q;
+      v2d_p x;
+      x[0] = (c <= lane) ? a[2 * q] : 0.0;
+      x[1] = (c + 1 <= lane) ? a[2 * q + 1] : 0.0;
+      dst[q] = x;
+    }
+#pragma unroll
+    for (int c = 0; c < 16; ++c)
+      if (16 * w + c <= lane) pack[(16 * w + c) * 64 + lane] = a[c];
+  }
+  if (w == 0) {
+    pack[4096 + lane] = rdg[lane];
+    // inverses of the four 16x16 diagonal sub-blocks (see potf2_wave)
+    const int b = lane >> 4, j = lane & 15;
+    const double* Lb = dblk + b * 16 * 17;
+    double zc[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      double s = (i == j) ? 1.0 : 0.0;
+#pragma unroll
+      for (int k = 0; k < i; ++k) s = __builtin_fma(-Lb[i * 17 + k], zc[k], s);
+      zc[i] = (i < j) ? 0.0 : s * rdg[16 * b + i];
+    }
+    double* dst = pack + PACK_INV + b * 256 + j * 16;
+#pragma unroll
+    for (int i = 0; i < 16; i += 2) *reinterpret_cast<v2d_p*>(dst + i) = (v2d_p){zc[i], zc[i + 1]};
+  }
+}
+
 }  // namespace mogp

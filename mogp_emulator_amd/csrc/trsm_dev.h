@@ -1,0 +1,49 @@
+// Panel TRSM on the matrix cores (device function shared by the stand-alone kernel and the role-fused step kernel).
+#pragma once
+#include "launch.h"
+#include "potf2_dev.h"
+
+namespace mogp {
+
+typedef double v4d_t __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void trsm_mfma_dev(const BatchView& v, int c0, int r0, const double* __restrict__ Lpack, int emu, int rowblock) {
+  const int ld = v.LD;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = lane >> 4, i = lane & 15;
+  const int row = r0 + rowblock * 64 + wave * 16 + i;
+  double* arow = v.A + (size_t)emu * v.MS + (size_t)row * ld + c0;
+  const double* pk = Lpack + (size_t)emu * PACK_STRIDE;
+  // A operands: Lneg[b][a][r] = -L[16b + i][16a + g + 4r]  (a < b),  Inv[b][r] = inv(L_bb)[i][g + 4r]
+  double Lneg[6][4], Inv[4][4];
+#pragma unroll
+  for (int b = 1; b < 4; ++b)
+#pragma unroll
+    for (int a = 0; a < b; ++a)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Lneg[b * (b - 1) / 2 + a][r] = -pk[(16 * a + g + 4 * r) * 64 + 16 * b + i];
+#pragma unroll
+  for (int b = 0; b < 4; ++b)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Inv[b][r] = pk[PACK_INV + b * 256 + (g + 4 * r) * 16 + i];
+  v4d_t T[4], X[4];
+#pragma unroll
+  for (int b = 0; b < 4; ++b)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) T[b][r] = arow[16 * b + g + 4 * r];
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+#pragma unroll
+    for (int a = 0; a < b; ++a)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) T[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(Lneg[b * (b - 1) / 2 + a][r], X[a][r], T[b], 0, 0, 0);
+    X[b] = (v4d_t){0., 0., 0., 0.};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) X[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(Inv[b][r], T[b][r], X[b], 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) arow[16 * b + g + 4 * r] = X[b][r];
+  }
+}
+
+
+}  // namespace mogp
