@@ -151,16 +151,19 @@ def _resolve_kernel(kernel):
 
 
 def _resolve_mean(mean):
+    """None, a native mean function, a formula string, or an object whose ``str()`` is a canonical formula (the
+    reference's MeanBase); anything else -- numbers included -- is a ValueError (GaussianProcessGPU.py:279-300)."""
     if mean is None:
         return LibGPGPU.ZeroMeanFunc()
     if isinstance(mean, LibGPGPU.BaseMeanFunc):
         return mean
-    if isinstance(mean, (str, int, float)) or hasattr(mean, "__str__"):
-        native = parse_meanfunc_formula(str(mean))
-        if native is None:
-            raise ValueError("GPU implementation was unable to parse mean function formula {}.".format(mean))
-        return native
-    raise ValueError("provided mean function must be a formula string, a native mean function, or None")
+    formula_like = isinstance(mean, str) or (hasattr(mean, "get_n_params") and not isinstance(mean, (int, float, complex)))
+    if not formula_like:
+        raise ValueError("provided mean function must be a formula string, a native mean function, or None")
+    native = parse_meanfunc_formula(str(mean))
+    if native is None:
+        raise ValueError("GPU implementation was unable to parse mean function formula {}.".format(mean))
+    return native
 
 
 class GaussianProcessGPU(object):

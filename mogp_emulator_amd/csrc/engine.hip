@@ -199,7 +199,7 @@ Engine::~Engine() {
 
 double Engine::nugget_size(int i) const {
   const GPState& g = gp[i];
-  if (g.nug_type == NUG_FIT) return g.has_data ? std::exp(g.data[NC + 1]) : g.nug_size;   // gpparams.hpp:176-182
+  if (g.nug_type == NUG_FIT) return std::exp(g.data[NC + 1]);   // zero-initialised data -> 1 before the first fit   // gpparams.hpp:176-182
   return g.nug_size;
 }
 
@@ -256,11 +256,13 @@ void Engine::panel(const BatchView& v, int o, int w, hipStream_t st) {
     launch_trsm(v, o, o + NBI, dLpack, st);
     return;
   }
-  const int h = w / 2;
+  int h = NBI;                       // largest power of two below w (w is 128 or a multiple of 128)
+  while (2 * h < w) h *= 2;
   panel(v, o, h, st);
   if (h == NBI) launch_update_narrow(v, o + h, o, o + h, st);
-  else launch_update_wide(v, o + h, o, o + h, st);
-  panel(v, o + h, h, st);
+  else
+    for (int c = o + h; c < o + w; c += TILE) launch_update_wide(v, c, o, o + h, st);
+  panel(v, o + h, w - h, st);
 }
 
 // Look-ahead schedule on two HIP streams: as soon as the columns of the NEXT outer block have
@@ -527,7 +529,9 @@ void Engine::factorize(const std::vector<int>& ids, std::vector<int>& info) {
     return;
   }
   std::vector<int> starts;
-  for (int o = 0; o < n + R; o += OUTER) starts.push_back(o);
+  // outer block = K depth of the trailing update (MOGP_OUTER: 256 / 512 / 1024)
+  static const int OUTERW = [] { const char* e = getenv("MOGP_OUTER"); const int w = e ? atoi(e) : OUTER; return (w == 512 || w == 1024) ? w : OUTER; }();
+  for (int o = 0; o < n + R; o += OUTERW) starts.push_back(o);
   const int K = (int)starts.size();
   while ((int)evPanel.size() < K + 1) {
     hipEvent_t a, b;
@@ -536,7 +540,7 @@ void Engine::factorize(const std::vector<int>& ids, std::vector<int>& info) {
     evPanel.push_back(a);
     evUpd.push_back(b);
   }
-  auto width = [&](int k) { return std::min(OUTER, NP - starts[k]); };
+  auto width = [&](int k) { return std::min(OUTERW, NP - starts[k]); };
   HIPCK(hipEventRecord(evUpd[K], stream));                 // K build done
   HIPCK(hipStreamWaitEvent(pstream, evUpd[K], 0));
   panel(v, starts[0], width(0), pstream);

@@ -1,0 +1,334 @@
+"""
+The reference's own GPU test cases, restated against this package (``-m gpu``).
+
+Each test names the reference test it follows (mogp_emulator/tests/*.py).  Inputs and expected values
+are the reference's (the 2 x 3 fixture, the 50-point parabola, the 6-point history-matching
+simulator); where the reference compares the GPU class with the CPU class, the comparison here is with
+the CPU oracle (oracle/cpu_ref.py), which is pinned to the CPU class by tests/test_oracle_golden.py.
+"""
+import numpy as np
+import pytest
+from numpy.testing import assert_allclose
+
+import mogp_emulator_amd as M
+from mogp_emulator_amd import LibGPGPU
+from mogp_emulator_amd.LibGPGPU import kernel_type
+from mogp_emulator_amd.Priors import GPPriors
+from oracle import cpu_ref as R
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture
+def x():
+    return np.array([[1., 2., 3.], [4., 5., 6.]])
+
+
+@pytest.fixture
+def y():
+    return np.array([2., 4.])
+
+
+@pytest.fixture
+def dx():
+    return 1.e-6
+
+
+def test_GaussianProcessGPU_init(x, y):
+    # tests/test_GaussianProcess.py:63-89
+    gp = M.GaussianProcessGPU(x, y)
+    assert_allclose(x, gp.inputs)
+    assert_allclose(y, gp.targets)
+    assert (gp.D, gp.n) == (3, 2)
+    assert gp.nugget == 0. and gp.nugget_type == "adaptive"
+    assert M.GaussianProcessGPU(y, y).inputs.shape == (2, 1)
+    assert_allclose(M.GaussianProcessGPU(x, y, nugget=1.e-12).nugget, 1.e-12)
+    gp = M.GaussianProcessGPU(x, y, kernel="SquaredExponential")
+    assert isinstance(gp.kernel_type, kernel_type) and gp.kernel_type is kernel_type.SquaredExponential
+    assert isinstance(gp.kernel, M.SquaredExponential)
+    assert M.GaussianProcessGPU(x, y, mean="x[0]").mean.get_n_params() == 2
+    assert M.GaussianProcessGPU(x, y, mean="y ~ x[0]").mean.get_n_params() == 2      # formula with a left-hand side
+
+
+def test_GPGPU_init_failures(x, y):
+    # tests/test_GaussianProcess.py:120-142
+    with pytest.raises(AssertionError):
+        M.GaussianProcessGPU(np.ones((2, 2, 2)), y)
+    with pytest.raises(AssertionError):
+        M.GaussianProcessGPU(x, x)
+    with pytest.raises(AssertionError):
+        M.GaussianProcessGPU(np.ones((2, 3)), np.ones(3))
+    with pytest.raises(ValueError):
+        M.GaussianProcessGPU(x, y, mean=1)
+    with pytest.raises(ValueError):
+        M.GaussianProcessGPU(x, y, kernel="blah")
+    with pytest.raises(ValueError):
+        M.GaussianProcessGPU(x, y, kernel=1)
+    with pytest.raises(ValueError):
+        M.GaussianProcessGPU(x, y, nugget="a")
+
+
+def test_GaussianProcessGPU_n_params_and_str(x, y):
+    # tests/test_GaussianProcess.py:160-164, 1259-1263
+    gp = M.GaussianProcessGPU(x, y)
+    assert gp.n_params == x.shape[1] + 1
+    assert str(gp) == "Gaussian Process with {} training examples and {} input variables".format(x.shape[0], x.shape[1])
+
+
+def test_GaussianProcessGPU_nugget(x, y):
+    # tests/test_GaussianProcess.py:199-227: the GPU class HAS a nugget setter
+    gp = M.GaussianProcessGPU(x, y)
+    assert gp.nugget == 0. and gp.nugget_type == "adaptive"
+    gp.nugget = "fit"
+    assert gp.nugget == 1. and gp.nugget_type == "fit"
+    gp.nugget = 1.
+    assert_allclose(gp.nugget, 1.)
+    assert gp.nugget_type == "fixed"
+    gp.nugget = 0
+    assert_allclose(gp.nugget, 0.)
+    assert gp.nugget_type == "fixed"
+    with pytest.raises(TypeError):
+        gp.nugget = [1]
+    with pytest.raises(ValueError):
+        gp.nugget = "blah"
+    with pytest.raises(ValueError):
+        gp.nugget = -1.
+
+
+@pytest.mark.parametrize("mean,nugget,sn", [(None, 0., 1.), (None, "adaptive", 0.), ("x[0]", "fit", np.log(1.e-6))])
+def test_GaussianProcessGPU_theta(x, y, mean, nugget, sn):
+    # tests/test_GaussianProcess.py:336-375 (+ the checks the reference left "TBD for GPU", against the oracle)
+    nugget_type = "fixed" if isinstance(nugget, float) else nugget
+    gp = M.GaussianProcessGPU(x, y, mean=mean, nugget=nugget, priors=GPPriors(n_corr=3, nugget_type=nugget_type))
+    with pytest.raises(RuntimeError):
+        gp.theta = np.ones(gp.n_params + 1)
+    theta = np.ones(gp.n_params)
+    if nugget == "fit":
+        theta[-1] = sn
+    gp.theta = theta
+    if nugget == "adaptive" or nugget == 0.:
+        assert gp.nugget == 0.
+    else:
+        assert_allclose(gp.nugget, np.exp(sn))
+    if mean is None:
+        ref = R.GPRef(x, y, nugget=nugget)
+        lp = ref.fit(theta)
+        assert_allclose(gp.L, ref.L, rtol=1e-12, atol=1e-14)
+        assert_allclose(gp.Kinv_t, ref.Kinv_t, rtol=1e-10)
+        assert_allclose(gp.current_logpost, lp, rtol=1e-12)
+
+
+def test_GaussianProcessGPU_logposterior(x, y):
+    # tests/test_GaussianProcess.py:587-618
+    gp = M.GaussianProcessGPU(x, y, nugget=0., priors=GPPriors(n_corr=3, nugget_type="fixed"))
+    gp.fit(np.ones(gp.n_params))
+    theta = np.zeros(gp.n_params)
+    K = np.exp(theta[-1]) * R.kernel_f(x, x, theta[:-1])
+    L_expect = np.linalg.cholesky(K)
+    Kinv_t_expect = np.linalg.solve(K, y)
+    logpost_expect = 0.5 * (np.log(np.linalg.det(K)) + np.dot(y, Kinv_t_expect) + gp.n * np.log(2. * np.pi))
+    assert_allclose(logpost_expect, gp.logposterior(theta))          # re-fits because theta changed
+    assert_allclose(gp.L, L_expect)
+    assert_allclose(Kinv_t_expect, gp.Kinv_t)
+    assert_allclose(logpost_expect, gp.current_logpost)
+    gp.theta = None
+    assert_allclose(gp.theta.get_data(), np.zeros(gp.n_params))       # the GPU implementation resets to zero
+    assert gp.Kinv_t is None
+    assert gp.current_logpost is None
+
+
+@pytest.mark.parametrize("nugget,sn", [(0., 1.), ("adaptive", 1.), ("fit", np.log(1.e-6))])
+def test_GaussianProcessGPU_logpost_deriv(x, y, dx, nugget, sn):
+    # tests/test_GaussianProcess.py:663-683: the 2 x 3 fixture, default priors, one-sided differences
+    gp = M.GaussianProcessGPU(x, y, nugget=nugget)
+    n = gp.n_params
+    theta = np.zeros(n)
+    theta[:2] = -1.
+    theta[2] = -2.
+    if gp.nugget_type == "fit":
+        theta[-1] = sn
+    deriv = np.zeros(n)
+    for i in range(n):
+        e = np.zeros(n)
+        e[i] = dx
+        deriv[i] = (gp.logposterior(theta) - gp.logposterior(theta - e)) / dx
+    assert_allclose(deriv, gp.logpost_deriv(theta), atol=1.e-4, rtol=1.e-4)
+    with pytest.raises(Exception):
+        gp.logpost_hessian(theta)                                     # not available on the GPU (GaussianProcessGPU.py:560-575)
+
+
+def test_GaussianProcessGPU_predict(x, y, dx):
+    # tests/test_GaussianProcess.py:993-1033
+    gp = M.GaussianProcessGPU(x, y, nugget=0.)
+    theta = np.ones(gp.n_params)
+    gp.fit(theta)
+    x_test = np.array([[2., 3., 4.]])
+    mu, var, deriv = gp.predict(x_test)
+    ref = R.GPRef(x, y, nugget=0.)
+    ref.fit(theta)
+    mu_expect, var_expect, _ = ref.predict(x_test)
+    deriv_expect = np.zeros((1, gp.D))
+    for i in range(gp.D):
+        e = np.zeros(gp.D)
+        e[i] = dx
+        deriv_expect[0, i] = (gp.predict(x_test)[0][0] - gp.predict(x_test - e)[0][0]) / dx
+    assert_allclose(mu, mu_expect)
+    assert_allclose(var, var_expect)
+    assert_allclose(deriv, deriv_expect, atol=1.e-7, rtol=1.e-5)
+    mu1, var1, deriv1 = gp.predict(np.array([2., 3., 4.]))             # a single point given as (D,)
+    assert_allclose(mu1, mu_expect)
+    assert_allclose(var1, var_expect)
+    # nonzero mean function (GPU semantics: coefficients are part of theta)
+    gpm = M.GaussianProcessGPU(x, y, mean="x[0]", nugget=0.)
+    gpm.fit(np.ones(gpm.n_params))
+    mu_m, var_m, _ = gpm.predict(x_test)
+    assert np.all(np.isfinite(mu_m)) and np.all(var_m >= 0.)
+
+
+def test_GaussianProcessGPU_predict_nugget(x, y):
+    # tests/test_GaussianProcess.py:1099-1118
+    gp = M.GaussianProcessGPU(x, y, nugget=1.)
+    theta = np.ones(gp.n_params)
+    gp.fit(theta)
+    ref = R.GPRef(x, y, nugget=1.)
+    ref.fit(theta)
+    assert_allclose(gp.predict(x).unc, ref.predict(x)[1], atol=1.e-7)
+    assert_allclose(gp.predict(x, include_nugget=False).unc, ref.predict(x, include_nugget=False)[1], atol=1.e-7)
+
+
+def test_GaussianProcessGPU_predict_failures(x, y):
+    # tests/test_GaussianProcess.py:1234-1249
+    gp = M.GaussianProcessGPU(x, y)
+    with pytest.raises(ValueError):
+        gp.predict(np.array([2., 3., 4.]))
+    gp.fit(np.ones(gp.n_params))
+    with pytest.raises(AssertionError):
+        gp.predict(np.ones((2, 2, 2)))
+    with pytest.raises(AssertionError):
+        gp.predict(np.array([[2., 4.]]))
+
+
+# -- tests/test_MultiOutputGP.py -----------------------------------------------------------------------
+@pytest.fixture
+def y2():
+    return np.array([[2., 4.], [3., 5.]])
+
+
+def test_MultiOutputGP_GPU_init_and_check(x, y2):
+    # tests/test_MultiOutputGP.py:49-55, 225-243
+    gp = M.MultiOutputGP_GPU(x, y2)
+    assert (gp.D, gp.n, gp.n_emulators) == (3, 2, 2)
+    gp = M.MultiOutputGP_GPU(x, y2, nugget=0.)
+    theta = np.ones(gp.n_params[0])
+    assert gp.get_indices_fit() == [] and gp.get_indices_not_fit() == [0, 1]
+    gp.fit_emulator(0, theta)
+    assert gp.get_indices_fit() == [0] and gp.get_indices_not_fit() == [1]
+    gp.fit_emulator(1, theta)
+    assert gp.get_indices_fit() == [0, 1] and gp.get_indices_not_fit() == []
+
+
+def test_MultiOutputGP_GPU_predict(x, y2):
+    # tests/test_MultiOutputGP.py:137-176 (the reference's 1e-3 bar; the oracle comparison below is tighter)
+    x_test = np.array([[2., 3., 4.]])
+    for nugget, include in ((0., True), (1., False)):
+        gp = M.MultiOutputGP_GPU(x, y2, nugget=nugget)
+        theta = np.ones(gp.n_params[0])
+        gp.fit_emulator(0, theta)
+        gp.fit_emulator(1, theta)
+        mu, var, deriv = gp.predict(x_test, include_nugget=include)
+        K = np.exp(theta[-1]) * R.kernel_f(x, x, theta[:-1]) + np.eye(gp.n) * nugget
+        Ktest = np.exp(theta[-1]) * R.kernel_f(x_test, x, theta[:-1])
+        var_expect = np.exp(theta[-1]) - np.diag(np.dot(Ktest, np.linalg.solve(K, Ktest.T)))
+        for i in range(2):
+            assert_allclose(var[i], var_expect, atol=1e-3)
+            ref = R.GPRef(x, y2[i], nugget=nugget)
+            ref.fit(theta)
+            rmu, rvar, _ = ref.predict(x_test, include_nugget=include)
+            assert_allclose(mu[i], rmu, rtol=1e-10)
+            assert_allclose(var[i], rvar, atol=1e-10)
+        assert deriv.shape == (2, 1, 3)
+
+
+# -- tests/test_fitting.py ----------------------------------------------------------------------------------
+def test_fit_GP_MAP_GPU():
+    # tests/test_fitting.py:46-65 (no value checks in the reference either)
+    xs = np.linspace(0., 1.)
+    ys = xs ** 2
+    gp = M.GaussianProcessGPU(xs, ys, nugget="fit")
+    theta_exp = np.array([1.6, -2.1, -0.8])
+    logpost_exp = gp.logposterior(theta_exp)
+    gp = M.fit_GP_MAP(gp, theta0=theta_exp)
+    assert isinstance(gp, M.GaussianProcessGPU)
+    assert gp.theta.data_has_been_set()
+    assert gp.theta.get_data().shape == theta_exp.shape
+    assert gp.current_logpost <= logpost_exp + 1e-8 * abs(logpost_exp)          # never worse than the start
+
+
+def test_fit_GP_MAP_GPU_failures():
+    # tests/test_fitting.py:103-136
+    xs = np.linspace(0., 1.)
+    ys = xs ** 2
+    gp = M.GaussianProcessGPU(xs, ys)
+    with pytest.raises(RuntimeError):
+        M.fit_GP_MAP(gp, n_tries=1, theta0=-1000000. * np.ones(3))
+    gp = M.GaussianProcessGPU(xs, ys, nugget=0.)
+    with pytest.raises(RuntimeError):
+        M.fit_GP_MAP(gp, theta0=np.array([800., 0., 0.]), n_tries=1)
+    with pytest.raises(TypeError):
+        M.fit_GP_MAP(xs)
+    with pytest.raises(TypeError):
+        M.fit_GP_MAP()
+    with pytest.raises(AssertionError):
+        M.fit_GP_MAP(gp, n_tries=-1)
+    with pytest.raises(RuntimeError):
+        M.fit_GP_MAP(gp, theta0=np.ones(1))
+
+
+# -- tests/test_HistoryMatching.py ------------------------------------------------------------------------
+def _simulator_1d(xv):
+    n_points = len(xv)
+    f = np.zeros(n_points)
+    for i in range(n_points):
+        f[i] = np.sin(2. * np.pi * xv[i] / 50.)
+    return f
+
+
+def test_history_matching_sanity_checks_GPU(capsys):
+    # tests/test_HistoryMatching.py:141-259
+    x_training = np.array([[0.], [10.], [20.], [30.], [43.], [50.]])
+    y_training = _simulator_1d(x_training[:, 0])
+    LibGPGPU.set_fit_options(seed=47)
+    gp = M.fit_GP_MAP(M.GaussianProcessGPU(x_training, y_training))
+    LibGPGPU.set_fit_options(seed=0)
+    obs = [-0.8, 0.0004]
+    rng = np.random.default_rng(47)
+    coords = np.sort(rng.random(2000)) * 56. - 3.
+    coords = coords[:, None]
+    expectations = gp.predict(coords)
+    for kw in (dict(), dict(obs=obs), dict(obs=[3.]), dict(obs=3.), dict(gp=gp), dict(coords=coords),
+               dict(coords=rng.random(2000)), dict(coords=[a for a in range(2000)]), dict(expectations=expectations),
+               dict(threshold=3.)):
+        M.HistoryMatching(**kw).status()
+    hm = M.HistoryMatching(obs)            # positional argument = gp slot: a list is ignored there
+    hm.set_gp(gp)
+    hm = M.HistoryMatching(gp)
+    hm.set_obs(obs)
+    hm = M.HistoryMatching()
+    hm.set_coords(coords)
+    hm.set_expectations(None)
+    hm = M.HistoryMatching()
+    hm.set_expectations(expectations)
+    hm.set_threshold(3.)
+    hm.status()
+    assert "History Matching" in capsys.readouterr().out
+    I = M.HistoryMatching(obs=obs, gp=gp, coords=coords).get_implausibility()
+    mean, unc, _ = expectations
+    assert_allclose(I, np.abs(obs[0] - mean) / np.sqrt(unc + obs[1]), rtol=1e-9)
+    I7 = M.HistoryMatching(obs=obs, gp=gp, coords=coords).get_implausibility(7.)
+    assert_allclose(I7, np.abs(obs[0] - mean) / np.sqrt(unc + obs[1] + 7.), rtol=1e-9)
+    # tests/test_HistoryMatching.py:502-545: set_gp accepts GPU emulators only
+    with pytest.raises(TypeError):
+        M.HistoryMatching().set_gp(3.)
+    hm = M.HistoryMatching()
+    hm.set_gp(gp)
+    assert hm.gp is gp
