@@ -27,7 +27,9 @@ extern "C" {
 #endif
 
 /* enums: values are those of mogp_gpu/src/types.hpp:29-35 (bindings.cu:585-598) */
-enum mogp_kernel_type { MOGP_SQUARED_EXPONENTIAL = 0, MOGP_MATERN52 = 1 };
+/* 2-4: kernels the reference only has on the CPU (Kernel.py:946-997); the uniform kernels have one correlation parameter */
+enum mogp_kernel_type { MOGP_SQUARED_EXPONENTIAL = 0, MOGP_MATERN52 = 1, MOGP_PRODUCT_MATERN52 = 2, MOGP_UNIFORM_SQUARED_EXPONENTIAL = 3,
+                        MOGP_UNIFORM_MATERN52 = 4 };
 enum mogp_nugget_type { MOGP_NUG_ADAPTIVE = 0, MOGP_NUG_FIT = 1, MOGP_NUG_FIXED = 2 };
 enum mogp_prior_type { MOGP_PRIOR_INVGAMMA = 0, MOGP_PRIOR_GAMMA = 1, MOGP_PRIOR_LOGNORMAL = 2, MOGP_PRIOR_WEAK = 3 };
 

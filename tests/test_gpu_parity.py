@@ -7,6 +7,7 @@ Stated fp64 tolerances: K rtol 1e-13; L, alpha rtol 1e-8 
 fixtures; logpost rtol 1e-10 (1e-9 where cond(K) > 1e8); gradient rtol 1e-7 / atol 1e-8;
 predictive mean rtol 1e-7; variance atol 1e-7 * sigma^2 (the reference's own GPU-vs-CPU bar,
 tests/test_GaussianProcess.py:1017-1018, 1113-1118)."""
+import os
 import pickle
 
 import numpy as np
@@ -834,3 +835,23 @@ def test_cpu_only_kernels_multioutput_fit_and_full_cov(name):
     f0, _, _ = M.MultiOutputGP_GPU(X, T, kernel=name, nugget="fit", priors=GPPriors(n_corr=nc, nugget_type="fit"))._mogp_gpu.eval(
         np.tile(np.r_[np.zeros(nc), 0., np.log(1e-4)], (4, 1)), grad=False)
     assert np.all(f1 < f0)
+
+
+def test_c_abi_from_plain_c(tmp_path):
+    # the drop-in boundary is usable from C with nothing but include/mogp_hip.h and the shared library
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "abi_roundtrip")
+    libdir = os.path.join(root, "mogp_emulator_amd")
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I" + os.path.join(root, "include"),
+                    os.path.join(root, "tests", "c", "abi_roundtrip.c"), "-o", exe, "-L" + libdir, "-lmogp_hip",
+                    "-Wl,-rpath," + libdir], check=True)
+    out = subprocess.run([exe], check=True, capture_output=True, text=True, timeout=120).stdout
+    vals = {line.split()[0]: line.split()[1:] for line in out.strip().splitlines()}
+    # known answers of the reference's 2 x 3 fixture (tests/test_GaussianProcess.py:556-585)
+    assert_allclose(float(vals["logpost"][0]), 6.516671478123768, rtol=1e-12)
+    assert_allclose([float(v) for v in vals["alpha"]], [0.7357588823428844, 1.471517764685769], rtol=1e-12)
+    assert_allclose(float(vals["grad3"][0]), -2.6787944117144216, rtol=1e-10)
+    assert_allclose(float(vals["mean"][0]), 0.03390252374096476, rtol=1e-10)
+    assert_allclose(float(vals["var"][0]), 2.717500758226203, rtol=1e-10)
+    assert "Shape of new GPParams object does not match existing one" in out
