@@ -348,47 +348,59 @@ __global__ __launch_bounds__(256, 2) void predict_var_kernel(BatchView v, const 
                                                            double* __restrict__ partial) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   using C = Cfg<4>;
-  // L2 blocking: the tiles of an emulator are walked in 8x8 super-tiles (64 workgroups = one XCD's
-  // resident set), so the 8 Linv row panels and the 8 K* panels of a super-tile are each fetched from
-  // HBM once and re-used 8 times out of the 4 MiB L2 while the 64 workgroups sweep k together.
-  // (Row-major tile order streamed every K* panel from HBM once per row tile: ~47 GB per launch.)
-  const int nsj = (ntj + 7) / 8, nsi = (nti + 7) / 8;
+  // Work decomposition for L2 reuse.  L^-1 is lower triangular, so row tile ti needs K = 128 (ti + 1): a workgroup
+  // takes the PAIR of row tiles (nti-1-p, p) for its column tile, which makes every workgroup of the launch equally
+  // long (K = 128 (nti + 1)).  Tiles are walked in super-tiles of 4 pairs x 16 column tiles (64 workgroups = one
+  // XCD's resident set): the 16 workgroups that share an L^-1 row panel have identical K and the 4 that share a
+  // K* panel differ by at most 3 x 128, and because all workgroups finish together the next super-tile also starts
+  // together -- panels are fetched from HBM once per super-tile and re-used out of the 4 MiB L2 while the 64
+  // workgroups sweep k in step.  (Unpaired 8 x 8 super-tiles drifted apart: short row tiles finished early, their
+  // successors started staggered, and the L2 hit rate fell to ~50 %: 49.5 GB of HBM traffic per launch by PMC.)
+  const int npairs = (nti + 1) / 2;
+  const int nsr = (npairs + 3) / 4, nsc = (ntj + 15) / 16;
   int z, tile;
-  decode_block(v.nb, nsi * nsj * 64, z, tile);
+  decode_block(v.nb, nsr * nsc * 64, z, tile);
   if (z >= v.nb) return;
   const int st = tile >> 6, w = tile & 63;
-  const int ti = (st / nsj) * 8 + (w >> 3), tj = (st % nsj) * 8 + (w & 7);
-  if (ti >= nti || tj >= ntj) return;
+  const int pr = (st / nsc) * 4 + (w >> 4), tj = (st % nsc) * 16 + (w & 15);
+  if (pr >= npairs || tj >= ntj) return;
   const int emu = slot_to_emu(v.idx, z);
   const int ld = v.LD;
   const double* Li = v.Linv + (size_t)emu * v.MS;
   const double* K = Ks + (size_t)z * MP * ld;
-  const int i0 = ti * C::BM, j0 = tj * C::BM;
-  v4d acc[4][4];
-  gemm_mainloop<4, true, true>(Li + (size_t)i0 * ld, ld, K + (size_t)j0 * ld, ld, (i0 + C::BM) / BK, acc, smem);
-  if (STORE) {
-    double* V = partial + (size_t)z * v.NP * MP;
-    for_each_acc<4>(acc, [&](int r, int c, double x) { V[(size_t)(i0 + r) * MP + j0 + c] = x; });
-    return;
-  }
-  // column sums of squares over the tile's 128 rows
+  const int j0 = tj * C::BM;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wr = wave >> 1, wc = wave & 1;
-  __syncthreads();
-  double* red = smem;  // [2 (wr)][128]
+  const int ti_long = nti - 1 - pr, ti_short = pr;
+  for (int pass = 0; pass < 2; ++pass) {
+    if (pass == 1 && ti_short == ti_long) break;
+    const int ti = pass == 0 ? ti_long : ti_short;
+    const int i0 = ti * C::BM;
+    v4d acc[4][4];
+    gemm_mainloop<4, true, true>(Li + (size_t)i0 * ld, ld, K + (size_t)j0 * ld, ld, (i0 + C::BM) / BK, acc, smem);
+    if (STORE) {
+      double* V = partial + (size_t)z * v.NP * MP;
+      for_each_acc<4>(acc, [&](int r, int c, double x) { V[(size_t)(i0 + r) * MP + j0 + c] = x; });
+      continue;
+    }
+    // column sums of squares over the tile's 128 rows
+    __syncthreads();
+    double* red = smem;  // [2 (wr)][128]
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    double s = 0.;
+    for (int j = 0; j < 4; ++j) {
+      double s = 0.;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) s += acc[i][j][r] * acc[i][j][r];
-    s += __shfl_xor(s, 16);
-    s += __shfl_xor(s, 32);
-    if (lane < 16) red[wr * 128 + wc * 64 + j * 16 + lane] = s;
+        for (int r = 0; r < 4; ++r) s += acc[i][j][r] * acc[i][j][r];
+      s += __shfl_xor(s, 16);
+      s += __shfl_xor(s, 32);
+      if (lane < 16) red[wr * 128 + wc * 64 + j * 16 + lane] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < 128) partial[((size_t)z * nti + ti) * MP + j0 + threadIdx.x] = red[threadIdx.x] + red[128 + threadIdx.x];
+    __syncthreads();                 // red aliases the operand buffers of the next pass
   }
-  __syncthreads();
-  if (threadIdx.x < 128) partial[((size_t)z * nti + ti) * MP + j0 + threadIdx.x] = red[threadIdx.x] + red[128 + threadIdx.x];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -524,7 +536,7 @@ void launch_kinv(const BatchView& v, hipStream_t s) {
 void launch_predict_var(const BatchView& v, const double* Ks, int m, int MP, double* partial, double* var, int var_ld, hipStream_t s) {
   const int nti = (v.n + 127) / 128, ntj = MP / 128;
   prof_begin("predict_var", s);
-  const int nsup = ((nti + 7) / 8) * ((ntj + 7) / 8) * 64;
+  const int nsup = (((nti + 1) / 2 + 3) / 4) * ((ntj + 15) / 16) * 64;
   hipLaunchKernelGGL(predict_var_kernel<false>, dim3(padded_grid(v.nb, nsup)), dim3(256), smem_bytes<4>(), s, v, Ks, MP, nti, ntj, partial);
   prof_end("predict_var", s, (double)v.nb * (double)m * v.n * v.n, 0.);
   hipLaunchKernelGGL(predict_var_finish_kernel, dim3((m + 255) / 256, v.nb), dim3(256), 0, s, v, partial, m, MP, nti, var, var_ld);
@@ -539,7 +551,7 @@ void launch_fused_step(const BatchView& v, const FusedArgs& fa, int total_wgs, i
 // cov (nb, m, m) holds K** on entry and the predictive covariance (without nugget) on return; V is nb*NP*MP scratch
 void launch_predict_fullcov(const BatchView& v, const double* Ks, int m, int MP, double* V, double* cov, hipStream_t s) {
   const int nti = (v.n + 127) / 128, ntj = MP / 128;
-  const int nsup = ((nti + 7) / 8) * ((ntj + 7) / 8) * 64;
+  const int nsup = (((nti + 1) / 2 + 3) / 4) * ((ntj + 15) / 16) * 64;
   prof_begin("predict_var", s);
   hipLaunchKernelGGL(predict_var_kernel<true>, dim3(padded_grid(v.nb, nsup)), dim3(256), smem_bytes<4>(), s, v, Ks, MP, nti, ntj, V);
   prof_end("predict_var", s, (double)v.nb * (double)m * v.n * v.n, 0.);
