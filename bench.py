@@ -48,26 +48,53 @@ def synth(config_id, n, d, n_out, m):
     return X, T, Xs
 
 
-def cpu_baseline(X, T, Xs, theta, nugget, budget_s=25.0):
-    """Oracle timed on the host cores: 1 emulator fit, 1 gradient, predict on a 1000-point sample."""
+def cpu_baseline(X, T, Xs, theta, nugget):
+    """Oracle timed on the host cores, ~10-30 s of CPU work in total:
+    (a) BLAS-threaded, one emulator at a time: 3 fits, 1 gradient, predict on 4000 points;
+    (b) the reference's own parallel model for many outputs: a process pool over emulators with one BLAS thread
+        each (MultiOutputGP / fitting.py:333-335), all emulators of the workload fitted once.
+    ``value`` is the better of the two fit rates; ``cores`` the threads / processes that produced it."""
+    import multiprocessing as mp
     from oracle import cpu_ref as R
     try:
         from threadpoolctl import threadpool_info
         threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
     except Exception:
         threads = os.cpu_count() or 1
-    gp = R.GPRef(X, T[0], nugget=nugget)
-    t0 = time.perf_counter(); gp.fit(theta); t_fit = time.perf_counter() - t0
+    fits = []
+    for k in range(min(3, T.shape[0])):
+        gp = R.GPRef(X, T[k], nugget=nugget)
+        t0 = time.perf_counter(); gp.fit(theta); fits.append(time.perf_counter() - t0)
+    t_fit = float(np.median(fits))
     t0 = time.perf_counter(); gp.logpost_deriv(theta); t_grad = time.perf_counter() - t0
-    ms = min(1000, Xs.shape[0])
+    ms = min(4000, Xs.shape[0])
     t0 = time.perf_counter(); gp.predict(Xs[:ms]); t_pred = time.perf_counter() - t0
-    return {
+    out = {
         "value": 1.0 / t_fit, "unit": "fits/s", "cores": int(threads), "kind": "port",
-        "sample": "1 emulator n=%d d=%d: fit %.2fs, gradient %.2fs, predict %d pts %.2fs (NumPy/LAPACK oracle)" % (
-            X.shape[0], X.shape[1], t_fit, t_grad, ms, t_pred),
+        "sample": "BLAS-threaded, n=%d d=%d: fit %.2fs (median of %d emulators), gradient %.2fs, predict %d pts %.2fs (NumPy/LAPACK oracle)" % (
+            X.shape[0], X.shape[1], t_fit, len(fits), t_grad, ms, t_pred),
         "fit_grad_per_s": 1.0 / (t_fit + t_grad), "predict_pts_per_s": ms / t_pred,
-        "host_cpus": os.cpu_count(), "affinity": len(os.sched_getaffinity(0)),
+        "host_cpus": os.cpu_count(), "affinity": len(os.sched_getaffinity(0)), "threaded_fits_per_s": 1.0 / t_fit,
     }
+    # (b) process pool, one BLAS thread per worker (~0.35 GB per worker for the (n, n, d) distance temporary);
+    # a separate script under a hard timeout so that a pool that fails to start can never wedge the bench
+    try:
+        import subprocess
+        workers = max(1, min(T.shape[0], len(os.sched_getaffinity(0)) // 2, 32))
+        cmd = [sys.executable, os.path.join(ROOT, "oracle", "pool_fit.py"), "2", str(X.shape[0]), str(X.shape[1]),
+               str(T.shape[0]), str(workers)]
+        env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
+        res = json.loads(subprocess.run(cmd, check=True, capture_output=True, text=True, timeout=180, env=env).stdout.strip().splitlines()[-1])
+        pool_rate = res["fits"] / res["wall_s"]
+        out["pool_fits_per_s"] = pool_rate
+        out["pool_workers"] = workers
+        out["sample"] += "; process pool x%d, 1 BLAS thread each: %d fits in %.2fs (%.2fs per fit per worker)" % (
+            workers, res["fits"], res["wall_s"], res["mean_fit_s"])
+        if pool_rate > out["value"]:
+            out["value"], out["cores"] = pool_rate, workers
+    except Exception as exc:                                              # the pool is a bonus measurement
+        out["pool_error"] = repr(exc)[:200]
+    return out
 
 
 def main():
