@@ -201,6 +201,21 @@ def main():
         mo.predict_variance_batch(Xs, means_h, vars_h)
         extras["predict_pts_per_s_host_buffers"] = B * m / (time.perf_counter() - t0)
         assert np.allclose(means_h, d_mean.cpu().numpy(), rtol=1e-12, atol=1e-12)
+        # default predict of the GPU wrapper also returns d mean / d x* (deriv=True), SURVEY 8d: reported separately
+        derivs_h = np.zeros((B, m, d))
+        t0 = time.perf_counter()
+        mo.predict_deriv(Xs, derivs_h)
+        extras["predict_deriv_pts_per_s_host_buffers"] = B * m / (time.perf_counter() - t0)
+        # consumers fused behind the prediction: one score per query point leaves the device
+        t0 = time.perf_counter()
+        imp = mo.implausibility(Xs, np.zeros(B), np.full(B, 0.01), np.zeros(B), rank=1)
+        extras["implausibility_pts_per_s"] = B * m / (time.perf_counter() - t0)
+        mfc = min(m, 1024)
+        mu_fc, cov_fc = np.zeros((B, mfc)), np.zeros((B, mfc, mfc))
+        t0 = time.perf_counter()
+        mo.predict_full_cov(Xs[:mfc], mu_fc, cov_fc)
+        extras["full_cov_s_%dx%d_pts" % (B, mfc)] = time.perf_counter() - t0
+        assert np.all(np.isfinite(imp)) and np.allclose(mu_fc, means_h[:, :mfc], rtol=1e-9, atol=1e-9)
         libgpgpu.set_fit_options(max_iter=30, ftol=1e-9, gtol=1e-6, seed=1)
         t0 = time.perf_counter()
         libgpgpu.fit_GP_MAP(mo, 1, theta)
