@@ -404,6 +404,123 @@ __global__ __launch_bounds__(256, 2) void predict_var_kernel(BatchView v, const 
 }
 
 // ---------------------------------------------------------------------------------------------
+// Predictive-variance kernel with WR x WC waves per 128 x 128 block tile (same LDS layout and k-step as
+// gemm_mainloop, both operands K-major).  2 x 4 waves (512 threads, 64 x 32 wave tiles, 64 accumulator VGPRs)
+// keeps four waves per SIMD resident instead of the two of the 2 x 2 / 128-accumulator configuration, which covers
+// more of the LDS and barrier latency: 59.5 -> 61.8 TFLOP/s on 64 x n=2000 x m=10^4.
+// ---------------------------------------------------------------------------------------------
+template <int WR, int WC>
+__global__ __launch_bounds__(64 * WR * WC, (WR * WC >= 16 ? 8 : (WR * WC >= 8 ? 4 : 2))) void predict_var_w_kernel(
+    BatchView v, const double* __restrict__ Ks, int MP, int nti, int ntj, double* __restrict__ partial) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  constexpr int NT = 64 * WR * WC;          // threads
+  constexpr int CH = 1024 / NT;             // 16-byte chunks per thread per operand tile (128 rows x 16 doubles)
+  constexpr int TI = 8 / WR, TJ = 8 / WC;   // 16 x 16 MFMA tiles per wave
+  constexpr int OPSZ = 128 * LDK;
+  const int npairs = (nti + 1) / 2;
+  const int nsr = (npairs + 3) / 4, nsc = (ntj + 15) / 16;
+  int z, tile;
+  decode_block(v.nb, nsr * nsc * 64, z, tile);
+  if (z >= v.nb) return;
+  const int st = tile >> 6, w = tile & 63;
+  const int pr = (st / nsc) * 4 + (w >> 4), tj = (st % nsc) * 16 + (w & 15);
+  if (pr >= npairs || tj >= ntj) return;
+  const int emu = slot_to_emu(v.idx, z);
+  const int ld = v.LD;
+  const double* Li = v.Linv + (size_t)emu * v.MS;
+  const double* K = Ks + (size_t)z * MP * ld;
+  const int j0 = tj * 128;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wr = wave / WC, wc = wave % WC;
+  const int fr = lane & 15, fk = lane >> 4;
+  auto g2r = [&](const double* g, v2d (&r)[CH]) {
+#pragma unroll
+    for (int q = 0; q < CH; ++q) {
+      const int c = t + NT * q;
+      r[q] = *reinterpret_cast<const v2d*>(g + (size_t)(c >> 3) * ld + (c & 7) * 2);
+    }
+  };
+  auto r2s = [&](double* sdst, const v2d (&r)[CH]) {
+#pragma unroll
+    for (int q = 0; q < CH; ++q) {
+      const int c = t + NT * q;
+      *reinterpret_cast<v2d*>(sdst + (c >> 3) * LDK + (c & 7) * 2) = r[q];
+    }
+  };
+  const int ti_long = nti - 1 - pr, ti_short = pr;
+  for (int pass = 0; pass < 2; ++pass) {
+    if (pass == 1 && ti_short == ti_long) break;
+    const int ti = pass == 0 ? ti_long : ti_short;
+    const int i0 = ti * 128;
+    const int nk = (i0 + 128) / BK;
+    v4d acc[TI][TJ];
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+      for (int j = 0; j < TJ; ++j) acc[i][j] = (v4d){0., 0., 0., 0.};
+    const double* Ag = Li + (size_t)i0 * ld;
+    const double* Bg = K + (size_t)j0 * ld;
+    v2d ra[CH], rb[CH];
+    g2r(Ag, ra);
+    g2r(Bg, rb);
+    r2s(smem, ra);
+    r2s(smem + OPSZ, rb);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+      const double* sA = smem + (kt & 1) * 2 * OPSZ;
+      const double* sB = sA + OPSZ;
+      const bool more = (kt + 1 < nk);
+      if (more) {
+        Ag += BK;
+        Bg += BK;
+        g2r(Ag, ra);
+        g2r(Bg, rb);
+      }
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        double a[TI], b[TJ];
+        const int k = kk * 4 + fk;
+#pragma unroll
+        for (int i = 0; i < TI; ++i) a[i] = sA[(wr * 16 * TI + i * 16 + fr) * LDK + k];
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) b[j] = sB[(wc * 16 * TJ + j * 16 + fr) * LDK + k];
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+          for (int j = 0; j < TJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+      }
+      if (more) {
+        double* dA = smem + ((kt + 1) & 1) * 2 * OPSZ;
+        r2s(dA, ra);
+        r2s(dA + OPSZ, rb);
+      }
+      __syncthreads();
+    }
+    // column sums of squares over the tile's 128 rows: red[wr][128]
+    double* red = smem;
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) {
+      double s = 0.;
+#pragma unroll
+      for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s += acc[i][j][r] * acc[i][j][r];
+      s += __shfl_xor(s, 16);
+      s += __shfl_xor(s, 32);
+      if (lane < 16) red[wr * 128 + wc * 16 * TJ + j * 16 + lane] = s;
+    }
+    __syncthreads();
+    if (t < 128) {
+      double s = 0.;
+#pragma unroll
+      for (int q = 0; q < WR; ++q) s += red[q * 128 + t];
+      partial[((size_t)z * nti + ti) * MP + j0 + t] = s;
+    }
+    __syncthreads();                 // red aliases the operand buffers of the next pass
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // full predictive covariance (GaussianProcess.py:899-911):  C = K** - V^T V, V = Linv Ks^T (kend x MP, stored).
 // C arrives holding K** (m x m, row stride m); lower 128-tiles are computed and mirrored.
 // ---------------------------------------------------------------------------------------------
@@ -537,7 +654,11 @@ void launch_predict_var(const BatchView& v, const double* Ks, int m, int MP, dou
   const int nti = (v.n + 127) / 128, ntj = MP / 128;
   prof_begin("predict_var", s);
   const int nsup = (((nti + 1) / 2 + 3) / 4) * ((ntj + 15) / 16) * 64;
-  hipLaunchKernelGGL(predict_var_kernel<false>, dim3(padded_grid(v.nb, nsup)), dim3(256), smem_bytes<4>(), s, v, Ks, MP, nti, ntj, partial);
+  // measured (TFLOP/s): 2 x 2 waves 59.2, 2 x 4 waves 61.1, 4 x 2 waves 60.7, 4 x 4 waves 57.3; MOGP_PV_WAVES=4 selects the 2 x 2 kernel
+  static const int waves = [] { const char* e = getenv("MOGP_PV_WAVES"); return e ? atoi(e) : 8; }();
+  const dim3 grid(padded_grid(v.nb, nsup));
+  if (waves == 8) hipLaunchKernelGGL((predict_var_w_kernel<2, 4>), grid, dim3(512), smem_bytes<4>(), s, v, Ks, MP, nti, ntj, partial);
+  else hipLaunchKernelGGL(predict_var_kernel<false>, grid, dim3(256), smem_bytes<4>(), s, v, Ks, MP, nti, ntj, partial);
   prof_end("predict_var", s, (double)v.nb * (double)m * v.n * v.n, 0.);
   hipLaunchKernelGGL(predict_var_finish_kernel, dim3((m + 255) / 256, v.nb), dim3(256), 0, s, v, partial, m, MP, nti, var, var_ld);
 }
