@@ -404,19 +404,105 @@ __global__ __launch_bounds__(256, 2) void predict_var_kernel(BatchView v, const 
 }
 
 // ---------------------------------------------------------------------------------------------
-// Predictive-variance kernel with WR x WC waves per 128 x 128 block tile (same LDS layout and k-step as
-// gemm_mainloop, both operands K-major).  2 x 4 waves (512 threads, 64 x 32 wave tiles, 64 accumulator VGPRs)
-// keeps four waves per SIMD resident instead of the two of the 2 x 2 / 128-accumulator configuration, which covers
-// more of the LDS and barrier latency: 59.5 -> 61.8 TFLOP/s on 64 x n=2000 x m=10^4.
+// Main loop with WR x WC waves per BM x BN block tile, both operands K-major (same LDS layout and k-step as
+// gemm_mainloop).  More, smaller wave tiles than the 2 x 2 configuration: fewer accumulator VGPRs per wave, so
+// more waves per SIMD are resident and more of the LDS / barrier latency is covered.
+//   acc[i][j]: MFMA tile rows wr*16*TI + 16 i, columns wc*16*TJ + 16 j  (TI = BM/16/WR, TJ = BN/16/WC)
+// ---------------------------------------------------------------------------------------------
+template <int BM, int BN, int WR, int WC>
+struct WCfg {
+  static constexpr int NT = 64 * WR * WC;               // threads
+  static constexpr int TI = BM / 16 / WR, TJ = BN / 16 / WC;
+  static constexpr int CHA = BM * 8 / NT, CHB = BN * 8 / NT;   // 16-byte chunks per thread per operand tile
+  static constexpr int OPA = BM * LDK, OPB = BN * LDK;
+  static constexpr int SMEM_DOUBLES = 2 * (OPA + OPB);
+  static_assert(CHA >= 1 && CHB >= 1, "operand tile smaller than one chunk per thread");
+};
+
+template <int BM, int BN, int WR, int WC>
+__device__ __forceinline__ void mainloop_w(const double* __restrict__ Ag, int lda, const double* __restrict__ Bg, int ldb, int nk,
+                                           v4d (&acc)[WCfg<BM, BN, WR, WC>::TI][WCfg<BM, BN, WR, WC>::TJ], double* smem) {
+  using C = WCfg<BM, BN, WR, WC>;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wr = wave / WC, wc = wave % WC;
+  const int fr = lane & 15, fk = lane >> 4;
+#pragma unroll
+  for (int i = 0; i < C::TI; ++i)
+#pragma unroll
+    for (int j = 0; j < C::TJ; ++j) acc[i][j] = (v4d){0., 0., 0., 0.};
+  if (nk <= 0) return;
+  v2d ra[C::CHA], rb[C::CHB];
+  auto loadA = [&]() {
+#pragma unroll
+    for (int q = 0; q < C::CHA; ++q) {
+      const int c = t + C::NT * q;
+      ra[q] = *reinterpret_cast<const v2d*>(Ag + (size_t)(c >> 3) * lda + (c & 7) * 2);
+    }
+  };
+  auto loadB = [&]() {
+#pragma unroll
+    for (int q = 0; q < C::CHB; ++q) {
+      const int c = t + C::NT * q;
+      rb[q] = *reinterpret_cast<const v2d*>(Bg + (size_t)(c >> 3) * ldb + (c & 7) * 2);
+    }
+  };
+  auto store = [&](double* sA, double* sB) {
+#pragma unroll
+    for (int q = 0; q < C::CHA; ++q) {
+      const int c = t + C::NT * q;
+      *reinterpret_cast<v2d*>(sA + (c >> 3) * LDK + (c & 7) * 2) = ra[q];
+    }
+#pragma unroll
+    for (int q = 0; q < C::CHB; ++q) {
+      const int c = t + C::NT * q;
+      *reinterpret_cast<v2d*>(sB + (c >> 3) * LDK + (c & 7) * 2) = rb[q];
+    }
+  };
+  loadA();
+  loadB();
+  store(smem, smem + C::OPA);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const double* sA = smem + (kt & 1) * (C::OPA + C::OPB);
+    const double* sB = sA + C::OPA;
+    const bool more = (kt + 1 < nk);
+    if (more) {
+      Ag += BK;
+      Bg += BK;
+      loadA();
+      loadB();
+    }
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      double a[C::TI], b[C::TJ];
+      const int k = kk * 4 + fk;
+#pragma unroll
+      for (int i = 0; i < C::TI; ++i) a[i] = sA[(wr * 16 * C::TI + i * 16 + fr) * LDK + k];
+#pragma unroll
+      for (int j = 0; j < C::TJ; ++j) b[j] = sB[(wc * 16 * C::TJ + j * 16 + fr) * LDK + k];
+#pragma unroll
+      for (int i = 0; i < C::TI; ++i)
+#pragma unroll
+        for (int j = 0; j < C::TJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    if (more) {
+      double* dA = smem + ((kt + 1) & 1) * (C::OPA + C::OPB);
+      store(dA, dA + C::OPA);
+    }
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Predictive-variance kernel, 2 x 4 waves per 128 x 128 block tile (512 threads, 64 x 32 wave tiles, 64 accumulator
+// VGPRs -> four waves per SIMD instead of the two of the 2 x 2 / 128-accumulator configuration):
+// 59.2 -> 61.1 TFLOP/s on 64 x n=2000 x m=10^4 (4 x 2 waves 60.7, 4 x 4 waves 57.3).
 // ---------------------------------------------------------------------------------------------
 template <int WR, int WC>
-__global__ __launch_bounds__(64 * WR * WC, (WR * WC >= 16 ? 8 : (WR * WC >= 8 ? 4 : 2))) void predict_var_w_kernel(
+__global__ __launch_bounds__(64 * WR * WC, (WR * WC >= 8 ? 4 : 2)) void predict_var_w_kernel(
     BatchView v, const double* __restrict__ Ks, int MP, int nti, int ntj, double* __restrict__ partial) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
-  constexpr int NT = 64 * WR * WC;          // threads
-  constexpr int CH = 1024 / NT;             // 16-byte chunks per thread per operand tile (128 rows x 16 doubles)
-  constexpr int TI = 8 / WR, TJ = 8 / WC;   // 16 x 16 MFMA tiles per wave
-  constexpr int OPSZ = 128 * LDK;
+  using C = WCfg<128, 128, WR, WC>;
   const int npairs = (nti + 1) / 2;
   const int nsr = (npairs + 3) / 4, nsc = (ntj + 15) / 16;
   int z, tile;
@@ -432,82 +518,25 @@ __global__ __launch_bounds__(64 * WR * WC, (WR * WC >= 16 ? 8 : (WR * WC >= 8 ? 
   const int j0 = tj * 128;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int wr = wave / WC, wc = wave % WC;
-  const int fr = lane & 15, fk = lane >> 4;
-  auto g2r = [&](const double* g, v2d (&r)[CH]) {
-#pragma unroll
-    for (int q = 0; q < CH; ++q) {
-      const int c = t + NT * q;
-      r[q] = *reinterpret_cast<const v2d*>(g + (size_t)(c >> 3) * ld + (c & 7) * 2);
-    }
-  };
-  auto r2s = [&](double* sdst, const v2d (&r)[CH]) {
-#pragma unroll
-    for (int q = 0; q < CH; ++q) {
-      const int c = t + NT * q;
-      *reinterpret_cast<v2d*>(sdst + (c >> 3) * LDK + (c & 7) * 2) = r[q];
-    }
-  };
   const int ti_long = nti - 1 - pr, ti_short = pr;
   for (int pass = 0; pass < 2; ++pass) {
     if (pass == 1 && ti_short == ti_long) break;
     const int ti = pass == 0 ? ti_long : ti_short;
     const int i0 = ti * 128;
-    const int nk = (i0 + 128) / BK;
-    v4d acc[TI][TJ];
-#pragma unroll
-    for (int i = 0; i < TI; ++i)
-#pragma unroll
-      for (int j = 0; j < TJ; ++j) acc[i][j] = (v4d){0., 0., 0., 0.};
-    const double* Ag = Li + (size_t)i0 * ld;
-    const double* Bg = K + (size_t)j0 * ld;
-    v2d ra[CH], rb[CH];
-    g2r(Ag, ra);
-    g2r(Bg, rb);
-    r2s(smem, ra);
-    r2s(smem + OPSZ, rb);
-    __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-      const double* sA = smem + (kt & 1) * 2 * OPSZ;
-      const double* sB = sA + OPSZ;
-      const bool more = (kt + 1 < nk);
-      if (more) {
-        Ag += BK;
-        Bg += BK;
-        g2r(Ag, ra);
-        g2r(Bg, rb);
-      }
-#pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {
-        double a[TI], b[TJ];
-        const int k = kk * 4 + fk;
-#pragma unroll
-        for (int i = 0; i < TI; ++i) a[i] = sA[(wr * 16 * TI + i * 16 + fr) * LDK + k];
-#pragma unroll
-        for (int j = 0; j < TJ; ++j) b[j] = sB[(wc * 16 * TJ + j * 16 + fr) * LDK + k];
-#pragma unroll
-        for (int i = 0; i < TI; ++i)
-#pragma unroll
-          for (int j = 0; j < TJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
-      }
-      if (more) {
-        double* dA = smem + ((kt + 1) & 1) * 2 * OPSZ;
-        r2s(dA, ra);
-        r2s(dA + OPSZ, rb);
-      }
-      __syncthreads();
-    }
+    v4d acc[C::TI][C::TJ];
+    mainloop_w<128, 128, WR, WC>(Li + (size_t)i0 * ld, ld, K + (size_t)j0 * ld, ld, (i0 + 128) / BK, acc, smem);
     // column sums of squares over the tile's 128 rows: red[wr][128]
     double* red = smem;
 #pragma unroll
-    for (int j = 0; j < TJ; ++j) {
+    for (int j = 0; j < C::TJ; ++j) {
       double s = 0.;
 #pragma unroll
-      for (int i = 0; i < TI; ++i)
+      for (int i = 0; i < C::TI; ++i)
 #pragma unroll
         for (int r = 0; r < 4; ++r) s += acc[i][j][r] * acc[i][j][r];
       s += __shfl_xor(s, 16);
       s += __shfl_xor(s, 32);
-      if (lane < 16) red[wr * 128 + wc * 16 * TJ + j * 16 + lane] = s;
+      if (lane < 16) red[wr * 128 + wc * 16 * C::TJ + j * 16 + lane] = s;
     }
     __syncthreads();
     if (t < 128) {
