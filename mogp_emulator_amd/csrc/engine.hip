@@ -118,6 +118,10 @@ Engine::Engine(const double* X, int n_, int D_, const double* targets, int B_, u
   if (analytic && q >= n_) throw std::runtime_error("analytic mean: more mean-function terms than training points");
   if (n < 1 || D < 1 || B < 1) throw std::runtime_error("inputs must have shape (n, D) with n, D >= 1");
   if (kernel_type < 0 || kernel_type > 4) throw std::runtime_error("Unrecognized kernel type\n");
+  if (D < 1) throw std::runtime_error("inputs must have at least one column");
+  if (D > MAX_D)
+    throw std::runtime_error("at most " + std::to_string(MAX_D) + " input dimensions are supported by the device kernels (" +
+                             std::to_string(D) + " given): the per-tile copy of the inputs must fit the 160 KB LDS");
   if (nug_type < 0 || nug_type > 2) throw std::runtime_error("Unrecognized nugget_type");
   for (int d : mean.dims)
     if (d >= D) throw std::runtime_error("Dimension index must be less than " + std::to_string(D));

@@ -837,6 +837,26 @@ def test_cpu_only_kernels_multioutput_fit_and_full_cov(name):
     assert np.all(f1 < f0)
 
 
+def test_input_dimension_limits():
+    # D up to 80 runs (LDS-staged coordinate tiles); beyond that the constructor refuses with a clear message
+    rng = np.random.default_rng(80)
+    n, m, D = 200, 30, 80
+    X, Xs = rng.random((n, D)), rng.random((m, D))
+    t = np.sin(X.sum(1))
+    theta = np.r_[np.full(D, -2 * np.log(0.3 * np.sqrt(D))), 0.1]
+    gp = make_gp(X, t, "Matern52", 1e-6)
+    ref = R.GPRef(X, t, kernel="Matern52", nugget=1e-6)
+    assert_allclose(gp.logposterior(theta), ref.fit(theta), rtol=1e-10)
+    assert_allclose(gp.logpost_deriv(theta), ref.logpost_deriv(theta), rtol=1e-7, atol=1e-8)
+    mu, var, dv = gp.predict(Xs)
+    rmu, rvar, rd = ref.predict(Xs, deriv=True)
+    assert_allclose(mu, rmu, rtol=1e-7, atol=1e-9)
+    assert_allclose(var, rvar, atol=1e-7 * np.exp(0.1))
+    assert_allclose(dv, rd, rtol=1e-6, atol=1e-8)
+    with pytest.raises(RuntimeError, match="input dimensions"):
+        M.GaussianProcessGPU(rng.random((50, 81)), rng.random(50))
+
+
 def test_c_abi_from_plain_c(tmp_path):
     # the drop-in boundary is usable from C with nothing but include/mogp_hip.h and the shared library
     import subprocess
