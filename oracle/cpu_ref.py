@@ -24,7 +24,7 @@ the branch restated here.
 
 import numpy as np
 from scipy import linalg
-from scipy.linalg import lapack, cho_solve
+from scipy.linalg import cho_factor, lapack, cho_solve
 from scipy.special import gammaln
 
 SQEXP = "SquaredExponential"
@@ -492,11 +492,41 @@ class GPRefMean(GPRef):
     GaussianProcess.fit / logpost_deriv / predict (GaussianProcess.py:657-685, 745-778, 885-920) with
     B^-1 = 0, b = 0 (MeanPriors weak: Priors.py:430-470, inv_cov() = 0, logdet_cov() = 0)."""
 
-    def __init__(self, inputs, targets, terms, intercept=True, **kw):
+    def __init__(self, inputs, targets, terms, intercept=True, mean_prior=None, **kw):
+        """``mean_prior``: None (weak) or ``(b, cov)`` -- MeanPriors(mean=b, cov=cov), Priors.py:423-581, cov a
+        scalar / vector of variances / covariance matrix."""
         super().__init__(inputs, targets, **kw)
         self.terms, self.intercept = list(terms), intercept
         self.H = design_matrix(self.X, self.terms, intercept)
         self.q = self.H.shape[1]
+        if mean_prior is None:
+            self.b = self.Bcov = None
+        else:
+            self.b = np.reshape(np.array(mean_prior[0], dtype=np.float64), (-1,))
+            self.Bcov = np.array(mean_prior[1], dtype=np.float64)
+            assert len(self.b) == self.q
+
+    # MeanPriors.inv_cov / inv_cov_b / logdet_cov / dm_dot_b, Priors.py:493-579
+    def _inv_cov(self):
+        if self.b is None:
+            return 0.
+        if self.Bcov.ndim < 2:
+            return np.diag(np.broadcast_to(1. / self.Bcov, (self.q,)))
+        return cho_solve(cho_factor(self.Bcov), np.eye(self.q))
+
+    def _inv_cov_b(self):
+        if self.b is None:
+            return 0.
+        if self.Bcov.ndim < 2:
+            return self.b / self.Bcov
+        return cho_solve(cho_factor(self.Bcov), self.b)
+
+    def _logdet_cov(self):
+        if self.b is None:
+            return 0.
+        if self.Bcov.ndim < 2:
+            return float(np.sum(np.log(np.broadcast_to(self.Bcov, (self.q,)))))
+        return 2. * float(np.sum(np.log(np.diag(cho_factor(self.Bcov)[0]))))
 
     def fit(self, theta):
         theta = np.array(theta, dtype=np.float64)
@@ -504,23 +534,24 @@ class GPRefMean(GPRef):
         self.theta = theta
         if self.nugget_type == "fit":
             self.nugget = float(np.exp(theta[-1]))
+        H = self.H
+        m = np.zeros(self.n) if self.b is None else np.dot(H, self.b)          # priors.mean.dm_dot_b, GaussianProcess.py:657
         K = self.get_K_matrix()
         self.L, newnugget = cholesky_factor(K, self.nugget, self.nugget_type)
         if self.nugget_type == "adaptive":
             self.nugget = float(newnugget)
-        H = self.H
-        # calc_Ainv, linalg_utils.py:5-40:  A = H^T K^-1 H (+ B^-1 = 0)
+        # calc_Ainv, linalg_utils.py:5-40:  A = H^T K^-1 H + B^-1
         self.Kinv_H = cho_solve_L(self.L, H)
-        A = np.dot(H.T, self.Kinv_H)
+        A = np.dot(H.T, self.Kinv_H) + self._inv_cov()
         self.LA = fixed_cholesky(A)
-        self.Kinv_t = cho_solve_L(self.L, self.t)                       # m = H b = 0
+        self.Kinv_t = cho_solve_L(self.L, self.t - m)
         H_Kinv_t = np.dot(H.T, self.Kinv_t)
         # calc_mean_params, linalg_utils.py:88-121
-        self.beta = cho_solve_L(self.LA, H_Kinv_t)
+        self.beta = cho_solve_L(self.LA, H_Kinv_t + self._inv_cov_b())
         self.Kinv_t_mean = cho_solve_L(self.L, self.t - np.dot(H, self.beta))
-        n_coeff = self.n - self.q                                       # weak mean priors, GaussianProcess.py:674-677
-        self.current_logpost = 0.5 * (np.dot(self.t, self.Kinv_t) - np.dot(H_Kinv_t, cho_solve_L(self.LA, H_Kinv_t))
-                                      + logdet_L(self.L) + logdet_L(self.LA) + n_coeff * np.log(2. * np.pi))
+        n_coeff = self.n - self.q if self.b is None else self.n             # GaussianProcess.py:674-677
+        self.current_logpost = 0.5 * (np.dot(self.t - m, self.Kinv_t) - np.dot(H_Kinv_t, cho_solve_L(self.LA, H_Kinv_t))
+                                      + logdet_L(self.L) + logdet_L(self.LA) + self._logdet_cov() + n_coeff * np.log(2. * np.pi))
         self.current_logpost -= self.priors.logp(theta)
         return self.current_logpost
 

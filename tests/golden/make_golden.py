@@ -335,6 +335,36 @@ def main():
         out[name + "_defprior_logpost"] = np.array(gp.current_logpost)
         out[name + "_defprior_grad"] = gp.logpost_deriv(theta)
     np.savez_compressed(os.path.join(HERE, "kernels_cpuonly.npz"), **out)
+
+    # ---- 14. analytic mean with informative mean priors (MeanPriors mean / cov), Priors.py:423-581 ------
+    from mogp_emulator.Priors import MeanPriors
+    X, T, Xs = synth(10, 150, 3, 1, 50)
+    tlin = T[0] + 2.0 + 1.5 * X[:, 0] - 0.7 * X[:, 2] ** 2
+    out = dict(X=X, t=tlin, Xs=Xs)
+    Bfull = np.array([[2.0, 0.3, -0.1], [0.3, 1.0, 0.2], [-0.1, 0.2, 0.5]])
+    cases = {"scalar": ("x[0]", [1.5, 1.0], 4.0), "vector": ("x[0]+I(x[2]**2)", [2.0, 1.0, -1.0], [3.0, 1.0, 0.25]),
+             "matrix": ("x[0]+I(x[2]**2)", [2.0, 1.0, -1.0], Bfull), "tight": ("1", [0.5], 1.e-3)}
+    for tag, (formula, b, cov) in cases.items():
+        for kern in KERNELS:
+            for mode, nugget in (("fixed", 1.e-5), ("fit", "fit")):
+                theta = [0.4, -0.2, 0.7, 0.3] + ([np.log(2.e-4)] if mode == "fit" else [])
+                nt = nugget if isinstance(nugget, str) else "fixed"
+                pri = GPPriors(mean=MeanPriors(mean=b, cov=cov), n_corr=3, nugget_type=nt)
+                gp = GaussianProcess(X, tlin, mean=formula, kernel=KERNELS[kern](), nugget=nugget, priors=pri)
+                gp.fit(np.array(theta))
+                pre = "%s_%s_%s_" % (tag, kern, mode)
+                out[pre + "theta"] = np.array(theta)
+                out[pre + "b"] = np.array(b, dtype=float)
+                out[pre + "cov"] = np.array(cov, dtype=float)
+                out[pre + "logpost"] = np.array(gp.current_logpost)
+                out[pre + "grad"] = gp.logpost_deriv(np.array(theta))
+                out[pre + "beta"] = np.array(gp.theta.mean)
+                out[pre + "Kinv_t_mean"] = gp.Kinv_t_mean
+                mean, var, _ = gp.predict(Xs)
+                out[pre + "mean"] = mean
+                out[pre + "var"] = var
+                out[pre + "cov_full"] = gp.predict(Xs, full_cov=True)[1]
+    np.savez_compressed(os.path.join(HERE, "meanpriors.npz"), **out)
     print("golden vectors written to", HERE)
 
 

@@ -344,3 +344,26 @@ def test_cpu_only_kernels_vs_reference(name):
         mu, var, _ = gp.predict(g["Xs"])
         assert_allclose(mu, g[pre + "mean"], rtol=1e-7, atol=1e-8)
         assert_allclose(var, g[pre + "var"], rtol=1e-6, atol=1e-9)
+
+
+MEANPRIOR_TERMS = {"scalar": [(0, 1)], "vector": [(0, 1), (2, 2)], "matrix": [(0, 1), (2, 2)], "tight": []}
+
+
+@pytest.mark.parametrize("tag", list(MEANPRIOR_TERMS))
+@pytest.mark.parametrize("kern", KERNELS)
+@pytest.mark.parametrize("mode", ["fixed", "fit"])
+def test_informative_mean_priors_vs_reference(tag, kern, mode):
+    # MeanPriors(mean, cov) with scalar / vector / matrix covariance, Priors.py:423-581; GaussianProcess.py:657-685
+    g = load_golden("meanpriors.npz")
+    pre = "%s_%s_%s_" % (tag, kern, mode)
+    nug = {"fixed": 1.e-5, "fit": "fit"}[mode]
+    gp = R.GPRefMean(g["X"], g["t"], MEANPRIOR_TERMS[tag], True, mean_prior=(g[pre + "b"], g[pre + "cov"]), kernel=kern, nugget=nug)
+    theta = g[pre + "theta"]
+    assert_allclose(gp.fit(theta), g[pre + "logpost"], rtol=1e-9)
+    assert_allclose(gp.beta, g[pre + "beta"], rtol=1e-6, atol=1e-8)
+    assert_allclose(gp.Kinv_t_mean, g[pre + "Kinv_t_mean"], rtol=1e-6, atol=1e-6 * np.abs(g[pre + "Kinv_t_mean"]).max())
+    assert_allclose(gp.logpost_deriv(theta), g[pre + "grad"], rtol=1e-6, atol=1e-6)
+    mu, var, _ = gp.predict(g["Xs"])
+    assert_allclose(mu, g[pre + "mean"], rtol=1e-7, atol=1e-8)
+    assert_allclose(var, g[pre + "var"], rtol=1e-6, atol=1e-9)
+    assert_allclose(gp.predict(g["Xs"], full_cov=True)[1], g[pre + "cov_full"], rtol=1e-6, atol=1e-7 * np.abs(g[pre + "cov_full"]).max())
