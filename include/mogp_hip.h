@@ -71,6 +71,10 @@ mogp_densegp* mogp_densegp_create(const double* inputs, int n, int D, const doub
  * the fitted coefficients are read with mogp_densegp_get_beta.  At most 7 mean terms. */
 mogp_densegp* mogp_densegp_create_analytic_mean(const double* inputs, int n, int D, const double* targets, unsigned testing_size,
                                                 const mogp_meanfunc* mean, int kernel_type, int nugget_type, double nugget_size);
+/* MeanPriors(mean = b, cov = B) for the analytic mean (Priors.py:423-581, GPPriors.mean): the caller passes b (q),
+ * B^-1 (q x q row-major), B^-1 b (q) and log|B|; q = 0 restores weak priors.  Works on borrowed handles
+ * (mogp_mogp_emulator) too, so every emulator can carry its own prior. */
+int mogp_densegp_set_mean_priors(mogp_densegp*, int q, const double* b, const double* Binv, const double* Binv_b, double logdetB);
 int mogp_densegp_n_beta(const mogp_densegp*);                        /* GPParams.n_mean, GPParams.py */
 int mogp_densegp_get_beta(const mogp_densegp*, double* out /* n_beta */);   /* theta.mean, GaussianProcess.py:669 */
 /* the reference never frees (py::nodelete); the shim may.  Must not be called on a handle

@@ -18,7 +18,7 @@ import numpy as np
 
 from . import LibGPGPU
 from .Kernel import KernelBase, Matern52, ProductMat52, SquaredExponential, UniformMat52, UniformSqExp
-from .Priors import GammaPrior, GPPriors, InvGammaPrior, LogNormalPrior, PriorDist, WeakPrior
+from .Priors import GammaPrior, GPPriors, InvGammaPrior, LogNormalPrior, MeanPriors, PriorDist, WeakPrior
 
 
 class GPUUnavailableError(RuntimeError):
@@ -140,6 +140,23 @@ def create_prior_params(**kwargs):
             _native_prior(priors.nugget)]
 
 
+def apply_mean_priors(native, priors, analytic_mean):
+    """hand the MeanPriors part of a GPPriors (or of its dict form) to a native emulator; weak priors reset it"""
+    mp = None
+    if isinstance(priors, GPPriors):
+        mp = priors.mean
+    elif isinstance(priors, dict) and priors.get("mean") is not None:
+        mp = priors["mean"] if isinstance(priors["mean"], MeanPriors) else MeanPriors(*priors["mean"])
+    if mp is None or mp.has_weak_priors:
+        if analytic_mean:
+            native.set_mean_priors(0, np.zeros(1), np.zeros(1), np.zeros(1), 0.)
+        return
+    if not analytic_mean:
+        raise NotImplementedError("mean-function priors need the analytic mean function: construct the emulator with "
+                                  "analytic_mean=True (the reference GPU path optimises the coefficients inside theta)")
+    native.set_mean_priors(*mp.native_params())
+
+
 def _resolve_kernel(kernel):
     """name or kernel object -> (native enum, kernel object).  SquaredExponential / Matern52 are the reference GPU
     kernels (GaussianProcessGPU.py:263-277); ProductMat52 / UniformSqExp / UniformMat52 are CPU-only there."""
@@ -219,6 +236,7 @@ class GaussianProcessGPU(object):
             params = create_prior_params(inputs=self.inputs, n_corr=self.n_corr, nugget_type=self.nugget_type)
         assert params[0] == self.n_corr, "bad number of correlation lengths in new GPPriors object"
         self._densegp_gpu.create_gppriors(*params)
+        apply_mean_priors(self._densegp_gpu, newpriors, getattr(self, "_analytic_mean", False))
 
     # -- read-only views of the native state --------------------------------------------------------
     priors = property(lambda self: self._densegp_gpu.get_gppriors())

@@ -13,7 +13,7 @@ import numpy as np
 
 from . import LibGPGPU
 from .GaussianProcessGPU import (GaussianProcessGPU, PredictResult, _resolve_kernel, _resolve_mean,
-                                 create_prior_params)
+                                 apply_mean_priors, create_prior_params)
 from .Priors import GPPriors
 
 
@@ -49,6 +49,7 @@ class MultiOutputGP_GPU(object):
         ktype, _ = _resolve_kernel(kernel)
         # analytic_mean=True: mean coefficients integrated out with weak priors (the CPU class's
         # treatment, GaussianProcess.py:640-700) rather than optimised inside theta (the reference GPU class)
+        self._analytic_mean = bool(analytic_mean)
         self._mogp_gpu = LibGPGPU.MultiOutputGP_GPU(inputs, targets, batch_size, _resolve_mean(mean), ktype, nugtype, nugsize,
                                                     analytic_mean=bool(analytic_mean))
 
@@ -69,6 +70,7 @@ class MultiOutputGP_GPU(object):
                     default = create_prior_params(inputs=self.inputs, n_corr=self.n_corr[i], nugget_type=nugget_type)
                 params = default
             self._mogp_gpu.create_priors_for_emulator(i, *params)
+            apply_mean_priors(self._mogp_gpu.emulator(i), pr, self._analytic_mean)
 
     inputs = property(lambda self: self._mogp_gpu.inputs())
     targets = property(lambda self: np.array(self._mogp_gpu.targets()))

@@ -102,6 +102,66 @@ class LogNormalPrior(_NativeLogNormal, PriorDist):
 _FAMILIES = {"invgamma": InvGammaPrior, "gamma": GammaPrior, "lognormal": LogNormalPrior}
 
 
+class MeanPriors(object):
+    """Multivariate-normal prior N(mean, cov) on the coefficients of an analytic mean function: the value object
+    of mogp_emulator/Priors.py:423-581 (``cov`` a positive scalar, a vector of variances or a covariance matrix;
+    both ``None`` = weak prior).  The device only ever sees b, B^-1, B^-1 b and log|B| (``native_params``)."""
+
+    def __init__(self, mean=None, cov=None):
+        if mean is None:
+            if cov is not None:
+                import warnings
+                warnings.warn("Both mean and cov need to be set to form a valid nontrivial MeanPriors object. mean is not "
+                              "provided, so ignoring the provided cov.")
+            self.mean = self.cov = None
+            return
+        if cov is None:
+            raise ValueError("Both mean and cov need to be set to form a valid MeanPriors object")
+        self.mean = np.reshape(np.array(mean, dtype=np.float64), (-1,))
+        self.cov = np.array(cov, dtype=np.float64)
+        q = len(self.mean)
+        if self.cov.ndim == 0:
+            assert self.cov > 0., "covariance term must be greater than zero in MeanPriors"
+        elif self.cov.ndim == 1:
+            assert len(self.cov) == q, "mean and variances must have the same length in MeanPriors"
+            assert np.all(self.cov > 0.), "all variances must be greater than zero in MeanPriors"
+        elif self.cov.ndim == 2:
+            assert self.cov.shape == (q, q), "mean and covariances must have the same shape in MeanPriors"
+            assert np.all(np.diag(self.cov) > 0.), "all covariances must be greater than zero in MeanPriors"
+        else:
+            raise ValueError("Bad shape for the covariance in MeanPriors")
+
+    n_params = property(lambda self: 0 if self.mean is None else len(self.mean))
+    has_weak_priors = property(lambda self: self.mean is None)
+
+    def _full_cov(self):
+        q = len(self.mean)
+        return self.cov if self.cov.ndim == 2 else np.diag(np.broadcast_to(self.cov, (q,)))
+
+    def dm_dot_b(self, dm):
+        dm = np.asarray(dm)
+        return np.zeros(dm.shape[0]) if self.mean is None else np.dot(dm, self.mean)
+
+    def inv_cov(self):
+        return 0. if self.mean is None else np.linalg.inv(self._full_cov())
+
+    def inv_cov_b(self):
+        return 0. if self.mean is None else np.linalg.solve(self._full_cov(), self.mean)
+
+    def logdet_cov(self):
+        return 0. if self.mean is None else float(np.linalg.slogdet(self._full_cov())[1])
+
+    def native_params(self):
+        """(q, b, B^-1 row-major, B^-1 b, log|B|) for ``mogp_densegp_set_mean_priors``; q = 0 for weak priors"""
+        if self.mean is None:
+            return 0, np.zeros(1), np.zeros(1), np.zeros(1), 0.
+        return (len(self.mean), np.ascontiguousarray(self.mean), np.ascontiguousarray(self.inv_cov()),
+                np.ascontiguousarray(self.inv_cov_b()), self.logdet_cov())
+
+    def __str__(self):
+        return "MeanPriors with mean = {} and cov = {}".format(self.mean, self.cov)
+
+
 class GPPriors(object):
     """Container: one prior per correlation length, one for the covariance scale, one for the
     nugget (only meaningful when the nugget is fit).  ``None`` entries mean weak priors."""
@@ -111,9 +171,17 @@ class GPPriors(object):
             raise ValueError("Must provide an argument for either corr or n_corr in GPPriors")
         if nugget_type not in NUGGET_TYPES:
             raise AssertionError("Bad value for nugget type in GPPriors")
-        if mean is not None:
-            raise NotImplementedError("mean-function priors are not supported by the GPU backend")
-        self.mean = None
+        # mean-coefficient priors apply to the analytic mean function (analytic_mean=True); None = weak
+        if mean is None:
+            self.mean = MeanPriors()
+        elif isinstance(mean, MeanPriors):
+            self.mean = mean
+        else:
+            try:
+                self.mean = MeanPriors(*mean)
+            except TypeError:
+                raise ValueError("Bad value for defining a MeanPriors object in GPPriors, argument must be an iterable "
+                                 "containing the mean vector and the covariance as a float/vector/matrix")
         self._nugget_type = nugget_type
         self.corr = corr if corr is not None else [WeakPrior() for _ in range(int(n_corr))]
         self.cov = cov
@@ -141,7 +209,7 @@ class GPPriors(object):
 
     @property
     def n_mean(self):
-        return 0
+        return self.mean.n_params
 
     @property
     def cov(self):

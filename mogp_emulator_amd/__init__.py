@@ -17,7 +17,7 @@ if HAVE_LIBGPGPU:
     from .MultiOutputGP_GPU import MultiOutputGP_GPU                      # noqa: F401
     from .fitting import fit_GP_MAP                                         # noqa: F401
     from .Kernel import SquaredExponential, Matern52, ProductMat52, UniformSqExp, UniformMat52   # noqa: F401
-    from .Priors import GPPriors, InvGammaPrior, GammaPrior, LogNormalPrior, WeakPrior   # noqa: F401
+    from .Priors import GPPriors, MeanPriors, InvGammaPrior, GammaPrior, LogNormalPrior, WeakPrior   # noqa: F401
     from .HistoryMatching import HistoryMatching                           # noqa: F401
     from .SequentialDesign import MICEFastGP, mice_criterion               # noqa: F401
 

@@ -53,6 +53,7 @@ SIGNATURES = {
     "mogp_meanfunc_mean_inputderiv": (c_int, [c_void_p, c_double_p, c_int, c_int, c_double_p, c_int, c_double_p]),
     "mogp_densegp_create": (c_void_p, [c_double_p, c_int, c_int, c_double_p, c_uint, c_void_p, c_int, c_int, c_double]),
     "mogp_densegp_create_analytic_mean": (c_void_p, [c_double_p, c_int, c_int, c_double_p, c_uint, c_void_p, c_int, c_int, c_double]),
+    "mogp_densegp_set_mean_priors": (c_int, [c_void_p, c_int, c_double_p, c_double_p, c_double_p, c_double]),
     "mogp_densegp_n_beta": (c_int, [c_void_p]),
     "mogp_densegp_get_beta": (c_int, [c_void_p, c_double_p]),
     "mogp_densegp_destroy": (None, [c_void_p]),

@@ -111,6 +111,9 @@ mogp_densegp* mogp_densegp_create_analytic_mean(const double* inputs, int n, int
                                                 const mogp_meanfunc* mean, int kernel_type, int nugget_type, double nugget_size) {
   return densegp_create(inputs, n, D, targets, testing_size, mean, kernel_type, nugget_type, nugget_size, true);
 }
+int mogp_densegp_set_mean_priors(mogp_densegp* h, int q, const double* b, const double* Binv, const double* Binv_b, double logdetB) {
+  GUARD(h->eng->set_mean_priors(h->idx, q, b, Binv, Binv_b, logdetB));
+}
 int mogp_densegp_n_beta(const mogp_densegp* h) { return h->eng->q; }
 int mogp_densegp_get_beta(const mogp_densegp* h, double* out) {
   const auto& b = h->eng->gp[h->idx].beta;

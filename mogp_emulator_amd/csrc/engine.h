@@ -27,7 +27,10 @@ struct GPState {
   bool linv = false, kinv = false;
   double nugget_used = 0.;       // value actually added to the diagonal in the last factorisation
   std::vector<double> beta;      // analytic mean coefficients (q), GaussianProcess.py:669-670
-  std::vector<double> LA;        // q x q lower Cholesky factor of A = H^T K^-1 H
+  std::vector<double> LA;        // q x q lower Cholesky factor of A = H^T K^-1 H + B^-1
+  // informative mean priors beta ~ N(b, B) of the analytic mean (Priors.py:423-581); empty = weak
+  std::vector<double> mp_b, mp_Binv, mp_Binvb;
+  double mp_logdetB = 0.;
 };
 
 class Engine {
@@ -53,7 +56,9 @@ class Engine {
   std::vector<double> hX, hT;    // host copies (inputs()/targets())
 
   bool analytic = false;
-  int q = 0, R = 1;              // analytic mean columns, right-hand-side rows (1 + q)
+  int q = 0, R = 1, RA = 1;      // analytic mean columns, right-hand-side rows (1 + q), rows of alpha per emulator
+  // MeanPriors(mean = b, cov = B) of emulator i: b (q), B^-1 (q x q), B^-1 b (q), log|B|; q_in = 0 resets to weak
+  void set_mean_priors(int i, int q_in, const double* b, const double* Binv, const double* Binvb, double logdetB);
   int n_mean() const { return analytic ? 0 : mean.n_params(); }
   int n_data(int i) const { return NC + 1 + (gp[i].nug_type == NUG_FIT ? 1 : 0); }
   int n_theta(int i) const { return n_mean() + n_data(i); }

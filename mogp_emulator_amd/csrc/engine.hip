@@ -158,11 +158,12 @@ Engine::Engine(const double* X, int n_, int D_, const double* targets, int B_, u
   dP = dalloc<double>((size_t)B * PS);
   dT = dalloc<double>((size_t)B * n);
   dA = dalloc<double>((size_t)B * MS);
-  dAlpha = dalloc<double>((size_t)B * R * LD);
+  RA = (R > 1) ? R + 1 : 1;
+  dAlpha = dalloc<double>((size_t)B * RA * LD);
   dGram = dalloc<double>((size_t)B * RMAX * RMAX);
   if (R > 1) {
     dZ = dalloc<double>((size_t)B * R * LD);
-    dM = dalloc<double>((size_t)B * RMAX * RMAX);
+    dM = dalloc<double>((size_t)B * (RMAX + 1) * RMAX);
     // design matrix columns: row c of mean_deriv = d mean / d beta_c = basis function c evaluated at X
     hH.assign((size_t)q * n, 0.);
     std::vector<double> dummy(q, 0.);
@@ -212,13 +213,29 @@ BatchView Engine::view(int nb) const {
   v.n = n; v.D = D; v.NP = NP; v.LD = LD; v.MS = MS; v.PS = PS; v.kernel_type = device_kernel();
   v.X = dX; v.P = dP; v.T = dT; v.A = dA; v.Linv = dLinv; v.Kinv = dKinv; v.alpha = dAlpha;
   v.idx = dIdx; v.nb = nb;
-  v.R = R; v.H = dH; v.Z = (R > 1) ? dZ : dAlpha;
+  v.R = R; v.RA = RA; v.H = dH; v.Z = (R > 1) ? dZ : dAlpha;
   return v;
 }
 
 void Engine::upload_idx(const std::vector<int>& ids) {
   HIPCK(hipMemcpyAsync(dIdx, ids.data(), ids.size() * sizeof(int), hipMemcpyHostToDevice, stream));
   HIPCK(hipStreamSynchronize(stream));   // ids may be a temporary
+}
+
+void Engine::set_mean_priors(int i, int q_in, const double* b, const double* Binv, const double* Binvb, double logdetB) {
+  GPState& g = gp[i];
+  if (q_in == 0) {
+    g.mp_b.clear(); g.mp_Binv.clear(); g.mp_Binvb.clear(); g.mp_logdetB = 0.;
+  } else {
+    if (!analytic) throw std::runtime_error("mean priors need the analytic mean function (analytic_mean=True)");
+    if (q_in != q) throw std::runtime_error("mean priors must have one entry per mean-function term (" + std::to_string(q) + ")");
+    g.mp_b.assign(b, b + q);
+    g.mp_Binv.assign(Binv, Binv + (size_t)q * q);
+    g.mp_Binvb.assign(Binvb, Binvb + q);
+    g.mp_logdetB = logdetB;
+  }
+  g.has_data = false;
+  g.factored = g.linv = g.kinv = false;
 }
 
 void Engine::set_theta(int i, const double* theta) {
@@ -642,21 +659,43 @@ void Engine::eval(const std::vector<int>& ids, const std::vector<const double*>&
     HIPCK(hipStreamSynchronize(stream));
   }
   std::vector<double> hM;
-  if (R > 1) hM.assign((size_t)B * RMAX * RMAX, 0.);
+  if (R > 1) hM.assign((size_t)B * (RMAX + 1) * RMAX, 0.);
   for (int k = 0; k < nb; ++k) {
     const int i = ids[k];
     GPState& g = gp[i];
     double val = std::numeric_limits<double>::quiet_NaN();
     bool fine = good[i];
+    int n_coeff = n;
     if (fine) {
       const double* G = gram.data() + (size_t)i * RMAX * RMAX;
       double quad = G[0], logdetA = 0.;
       if (R > 1) {
-        // A = H^T K^-1 H (weak mean priors: B^-1 = 0), linalg_utils.py:5-40; beta = A^-1 H^T K^-1 t (:88-121)
+        // Analytic mean with priors beta ~ N(b, B) (weak: B^-1 = 0, b = 0), from the Gram matrix G = [t,H]^T K^-1 [t,H]:
+        //   A = H^T K^-1 H + B^-1 (calc_Ainv, linalg_utils.py:5-40),  r = H^T K^-1 (t - H b),
+        //   beta_hat = A^-1 (r + B^-1 b) (calc_mean_params, :88-121),  quadratic form (t-Hb)^T K^-1 (t-Hb) - r^T A^-1 r
+        const bool weak = g.mp_b.empty();
+        std::vector<double> Am((size_t)q * q), rv(q), bb(q, 0.);
+        if (!weak) bb = g.mp_b;
+        for (int r = 0; r < q; ++r) {
+          double s = G[(1 + r) * RMAX];
+          for (int c = 0; c < q; ++c) {
+            s -= G[(1 + r) * RMAX + (1 + c)] * bb[c];
+            Am[r * q + c] = G[(1 + r) * RMAX + (1 + c)] + (weak ? 0. : g.mp_Binv[r * q + c]);
+          }
+          rv[r] = s;
+        }
+        if (!weak) {
+          double bSb = 0., bv = 0.;
+          for (int r = 0; r < q; ++r) {
+            bv += bb[r] * G[(1 + r) * RMAX];
+            for (int c = 0; c < q; ++c) bSb += bb[r] * G[(1 + r) * RMAX + (1 + c)] * bb[c];
+          }
+          quad = G[0] - 2. * bv + bSb;
+        }
         g.LA.assign((size_t)q * q, 0.);
         for (int r = 0; r < q && fine; ++r)
           for (int c = 0; c <= r; ++c) {
-            double s = G[(1 + r) * RMAX + (1 + c)];
+            double s = Am[r * q + c];
             for (int p = 0; p < c; ++p) s -= g.LA[r * q + p] * g.LA[c * q + p];
             if (r == c) {
               if (!(s > 0.)) { fine = false; break; }
@@ -666,19 +705,32 @@ void Engine::eval(const std::vector<int>& ids, const std::vector<const double*>&
             }
           }
         if (fine) {
+          auto solveA = [&](std::vector<double> x) {          // A^-1 x by the two triangular solves with LA
+            for (int r = 0; r < q; ++r) {
+              double s = x[r];
+              for (int p = 0; p < r; ++p) s -= g.LA[r * q + p] * x[p];
+              x[r] = s / g.LA[r * q + r];
+            }
+            for (int r = q - 1; r >= 0; --r) {
+              double s = x[r];
+              for (int p = r + 1; p < q; ++p) s -= g.LA[p * q + r] * x[p];
+              x[r] = s / g.LA[r * q + r];
+            }
+            return x;
+          };
           std::vector<double> w(q), Linv((size_t)q * q, 0.);
-          for (int r = 0; r < q; ++r) {               // w = LA^-1 v, v = H^T K^-1 t
-            double s = G[(1 + r) * RMAX];
+          for (int r = 0; r < q; ++r) {               // w = LA^-1 r
+            double s = rv[r];
             for (int p = 0; p < r; ++p) s -= g.LA[r * q + p] * w[p];
             w[r] = s / g.LA[r * q + r];
             quad -= w[r] * w[r];
             logdetA += 2. * std::log(g.LA[r * q + r]);
           }
-          for (int r = q - 1; r >= 0; --r) {          // beta = LA^-T w
-            double s = w[r];
-            for (int p = r + 1; p < q; ++p) s -= g.LA[p * q + r] * g.beta[p];
-            g.beta[r] = s / g.LA[r * q + r];
-          }
+          const std::vector<double> bgrad = solveA(rv);           // beta' = A^-1 r: residual of the gradient's quadratic form
+          std::vector<double> rhs(rv);
+          if (!weak)
+            for (int r = 0; r < q; ++r) rhs[r] += g.mp_Binvb[r];
+          g.beta = solveA(rhs);
           for (int c = 0; c < q; ++c) {               // LA^-1 (lower), column by column
             for (int r = c; r < q; ++r) {
               double s = (r == c) ? 1. : 0.;
@@ -686,17 +738,25 @@ void Engine::eval(const std::vector<int>& ids, const std::vector<const double*>&
               Linv[r * q + c] = s / g.LA[r * q + r];
             }
           }
-          // combination matrix: row 0 -> K^-1 (t - H beta); row c -> g_c = sum_d (LA^-1)[c][d] K^-1 h_d
-          double* M = hM.data() + (size_t)i * RMAX * RMAX;
+          // combination matrix over Z = K^-1 [t, h_1..h_q]:
+          //   row 0 -> K^-1 (t - H beta_hat) (predictions);  row c -> g_c = sum_d (LA^-1)[c][d] K^-1 h_d  (d log|A|);
+          //   row R -> K^-1 (t - H (b + beta')) (gradient of the quadratic form; = row 0 with weak priors)
+          double* M = hM.data() + (size_t)i * (RMAX + 1) * RMAX;
           M[0] = 1.;
-          for (int c = 0; c < q; ++c) M[1 + c] = -g.beta[c];
+          M[R * RMAX] = 1.;
+          for (int c = 0; c < q; ++c) {
+            M[1 + c] = -g.beta[c];
+            M[R * RMAX + 1 + c] = -(bb[c] + bgrad[c]);
+          }
           for (int c = 0; c < q; ++c)
             for (int d = 0; d <= c; ++d) M[(1 + c) * RMAX + (1 + d)] = Linv[c * q + d];
+          if (weak) n_coeff = n - q;                  // GaussianProcess.py:674-677
+          else logdetA += g.mp_logdetB;               // + log|B| (priors.mean.logdet_cov)
         }
       }
       if (fine) {
-        // GaussianProcess.py:679-685 (n_coeff = n - q with weak mean priors); densegp_gpu.hpp:604-611
-        val = 0.5 * (quad + logdet[i] + logdetA + (n - q) * std::log(2.0 * M_PI)) - g.pri.logp(g.data, NC, g.nug_type);
+        // GaussianProcess.py:679-685; densegp_gpu.hpp:604-611
+        val = 0.5 * (quad + logdet[i] + logdetA + n_coeff * std::log(2.0 * M_PI)) - g.pri.logp(g.data, NC, g.nug_type);
         if (!std::isfinite(val)) fine = false;
       }
     }
@@ -810,7 +870,7 @@ void Engine::grad_current(const std::vector<int>& ids, double* grad, int grad_ld
     if (nm > 0) {
       // densegp_gpu.hpp:734-747: -(d mean / d beta)^T alpha
       std::vector<double> a(n), md((size_t)nm * n);
-      HIPCK(hipMemcpy(a.data(), dAlpha + (size_t)i * R * LD, n * sizeof(double), hipMemcpyDeviceToHost));
+      HIPCK(hipMemcpy(a.data(), dAlpha + (size_t)i * RA * LD, n * sizeof(double), hipMemcpyDeviceToHost));
       mean.mean_deriv(hX.data(), n, D, g.meanp.data(), nm, md.data());
       for (int p = 0; p < nm; ++p) {
         double s = 0.;
@@ -1090,7 +1150,7 @@ void Engine::get_invQ(int i, double* out) {
 
 void Engine::get_invQt(int i, double* out) {
   if (!gp[i].factored) throw std::runtime_error("emulator has not been fit");
-  HIPCK(hipMemcpy(out, dAlpha + (size_t)i * R * LD, n * sizeof(double), hipMemcpyDeviceToHost));
+  HIPCK(hipMemcpy(out, dAlpha + (size_t)i * RA * LD, n * sizeof(double), hipMemcpyDeviceToHost));
 }
 
 void Engine::get_chol(int i, double* out) {

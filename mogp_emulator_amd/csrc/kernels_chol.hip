@@ -309,15 +309,15 @@ __global__ __launch_bounds__(256) void combine_rows_kernel(BatchView v, const do
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= ld) return;
   const double* Zb = v.Z + (size_t)emu * R * ld;
-  const double* Mb = M + (size_t)emu * RMAX * RMAX;
+  const double* Mb = M + (size_t)emu * (RMAX + 1) * RMAX;
   double z[RMAX];
 #pragma unroll
   for (int r = 0; r < RMAX; ++r) z[r] = (r < R) ? Zb[(size_t)r * ld + i] : 0.0;
-  for (int c = 0; c < R; ++c) {
+  for (int c = 0; c < v.RA; ++c) {
     double s = 0.;
 #pragma unroll
     for (int r = 0; r < RMAX; ++r) s = __builtin_fma(Mb[c * RMAX + r], z[r], s);
-    v.alpha[((size_t)emu * R + c) * ld + i] = s;
+    v.alpha[((size_t)emu * v.RA + c) * ld + i] = s;
   }
 }
 

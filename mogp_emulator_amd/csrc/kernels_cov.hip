@@ -217,7 +217,7 @@ __global__ __launch_bounds__(256) void cross_cov_mean_kernel(BatchView v, const 
   const int n = v.n, D = v.D, ld = v.LD, R = v.R;
   const int i0 = blockIdx.x * 64;
   const double* P = v.P + (size_t)emu * v.PS;
-  const double* alpha0 = v.alpha + (size_t)emu * R * ld;      // row 0: K^-1 (t - H beta)
+  const double* alpha0 = v.alpha + (size_t)emu * v.RA * ld;   // row 0: K^-1 (t - H beta)
   const double* Zr = v.Z + (size_t)emu * R * ld;              // rows 1..: K^-1 h_c
   double* si = sm;
   double* sj = sm + 64 * D;
@@ -299,7 +299,7 @@ __global__ __launch_bounds__(256) void predict_deriv_kernel(BatchView v, const d
   const int n = v.n, D = v.D, ld = v.LD;
   const int i0 = blockIdx.x * 64;
   const double* P = v.P + (size_t)emu * v.PS;
-  const double* alpha = v.alpha + (size_t)emu * v.R * ld;
+  const double* alpha = v.alpha + (size_t)emu * v.RA * ld;
   double* si = sm;                    // [D][64] test points
   double* sj = sm + 64 * D;           // [D][64] training points
   double* G = sm + 128 * D;           // [64][65]  G[m][j] = sig2 * dk/dr2 * 2 * alpha_j
@@ -372,8 +372,9 @@ __global__ __launch_bounds__(256) void grad_kernel(BatchView v, int ntiles, doub
   const int n = v.n, D = v.D, ld = v.LD;
   const double* P = v.P + (size_t)emu * v.PS;
   const double* Ki = v.Kinv + (size_t)emu * v.MS;
-  const double* alpha = v.alpha + (size_t)emu * v.R * ld;     // R rows g_c: W = Kinv - sum_c g_c g_c^T
-  const int R = v.R;
+  // W = Kinv - sum_c g_c g_c^T over the gradient rows of alpha: the single row when R = 1, rows 1..R otherwise
+  const int R = v.RA - (v.R > 1 ? 1 : 0);
+  const double* alpha = v.alpha + ((size_t)emu * v.RA + (v.R > 1 ? 1 : 0)) * ld;
   double* si = sm;
   double* sj = sm + 64 * D;
   double* wsum = sm + 128 * D;        // [4 waves][D+3]

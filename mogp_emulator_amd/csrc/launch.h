@@ -37,10 +37,12 @@ struct BatchView {
   double* A;                    // B*NP*NP
   double* Linv;                 // B*NP*NP (may be null)
   double* Kinv;                 // B*NP*NP (may be null)
-  double* alpha;                // B*R*LD: row 0 = K^-1 (t - H beta) (= K^-1 t when R = 1); rows 1.. = rank correction rows g_c
+  double* alpha;                // B*RA*LD.  R = 1: the single row K^-1 t.  R > 1 (analytic mean): row 0 = K^-1 (t - H beta_hat) (predictions),
+                                // rows 1..q = rank-correction rows g_c, row R = K^-1 (t - H (b + beta')) (gradient; equals row 0 with weak mean priors)
   double* Z;                    // B*R*LD raw solves K^-1 [t, h_1 .. h_q]   (same buffer as alpha when R = 1)
   const double* H;              // q*n design-matrix columns of the analytic mean (shared by all emulators), or null
   int R;                        // 1 + q right-hand sides carried through the factorisation as rows n .. n+q of A
+  int RA;                       // rows per emulator in alpha: 1 (R = 1) or R + 1
   const int* idx;               // device: nb entries or null
   int nb;                       // number of batch slots in this launch
 };
@@ -92,7 +94,7 @@ void launch_update_wide(const BatchView& v, int c0, int k0, int k1, hipStream_t 
 void launch_update_trailing(const BatchView& v, int c0, int k0, int k1, hipStream_t s);
 // logdet[emu] = 2 sum_{i<n} log L_ii ; gram[emu][r*R+s] = sum_{c<n} L[n+r,c] L[n+s,c]  (gram[0] = y^T y)
 void launch_logdet(const BatchView& v, double* logdet, double* gram, hipStream_t s);
-// alpha[c] = sum_r M[emu][c][r] Z[r]   (M: nb... indexed by emulator, R x R row-major)
+// alpha[c] = sum_r M[emu][c][r] Z[r], c < RA   (M: indexed by emulator, (RMAX+1) x RMAX row-major)
 void launch_combine_rows(const BatchView& v, const double* M, hipStream_t s);
 // alpha = L^-T y (y = row n of A)
 void launch_backsolve(const BatchView& v, hipStream_t s);

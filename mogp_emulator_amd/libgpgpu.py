@@ -465,6 +465,11 @@ class DenseGP_GPU(object):
         check(_lib.mogp_densegp_targets(self._h, dptr(out)))
         return out
 
+    def set_mean_priors(self, q, b, Binv, Binv_b, logdetB):
+        """MeanPriors of the analytic mean: b (q), B^-1 (q, q), B^-1 b (q), log|B|; q = 0 -> weak"""
+        b, Binv, Binv_b = _f64(b, 1, "b"), np.ascontiguousarray(Binv, dtype=np.float64), _f64(Binv_b, 1, "Binv_b")
+        check(_lib.mogp_densegp_set_mean_priors(self._h, int(q), dptr(b), dptr(Binv), dptr(Binv_b), float(logdetB)))
+
     def get_beta(self):
         """analytically fitted mean coefficients (analytic_mean=True only; theta.mean of the CPU class)"""
         nb = int(_lib.mogp_densegp_n_beta(self._h))

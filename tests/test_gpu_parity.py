@@ -875,3 +875,67 @@ def test_c_abi_from_plain_c(tmp_path):
     assert_allclose(float(vals["mean"][0]), 0.03390252374096476, rtol=1e-10)
     assert_allclose(float(vals["var"][0]), 2.717500758226203, rtol=1e-10)
     assert "Shape of new GPParams object does not match existing one" in out
+
+
+# ----------------------------------------------------------------------------------------------------
+# Analytic mean with informative mean priors: MeanPriors(mean = b, cov = scalar / vector / matrix), Priors.py:423-581.
+# ----------------------------------------------------------------------------------------------------
+MEANPRIOR_TERMS = {"scalar": [(0, 1)], "vector": [(0, 1), (2, 2)], "matrix": [(0, 1), (2, 2)], "tight": []}
+
+
+@pytest.mark.parametrize("tag", list(MEANPRIOR_TERMS))
+@pytest.mark.parametrize("kern", KERNELS)
+@pytest.mark.parametrize("mode", ["fixed", "fit"])
+def test_informative_mean_priors_vs_reference_golden(tag, kern, mode):
+    from mogp_emulator_amd.Priors import MeanPriors
+    g = load_golden("meanpriors.npz")
+    pre = "%s_%s_%s_" % (tag, kern, mode)
+    nug = {"fixed": 1.e-5, "fit": "fit"}[mode]
+    pri = GPPriors(mean=MeanPriors(mean=g[pre + "b"], cov=g[pre + "cov"]), n_corr=3, nugget_type=mode)
+    gp = M.GaussianProcessGPU(g["X"], g["t"], mean=native_mean(MEANPRIOR_TERMS[tag]), kernel=kern, nugget=nug, priors=pri,
+                              analytic_mean=True)
+    theta = g[pre + "theta"]
+    assert_allclose(gp.logposterior(theta), g[pre + "logpost"], rtol=1e-8)
+    gp.fit(theta)
+    assert_allclose(gp._densegp_gpu.get_beta(), g[pre + "beta"], rtol=1e-6, atol=1e-8)
+    assert_allclose(gp.Kinv_t, g[pre + "Kinv_t_mean"], rtol=1e-6, atol=1e-6 * np.abs(g[pre + "Kinv_t_mean"]).max())
+    assert_allclose(gp.logpost_deriv(theta), g[pre + "grad"], rtol=1e-6, atol=1e-6)
+    mu, var, _ = gp.predict(g["Xs"])
+    assert_allclose(mu, g[pre + "mean"], rtol=1e-7, atol=1e-8)
+    assert_allclose(var, g[pre + "var"], rtol=1e-6, atol=1e-9)
+    cov = gp.predict(g["Xs"], full_cov=True, deriv=False)[1]
+    assert_allclose(cov, g[pre + "cov_full"], rtol=1e-6, atol=1e-7 * np.abs(g[pre + "cov_full"]).max())
+
+
+def test_mean_priors_per_emulator_and_errors():
+    from mogp_emulator_amd.Priors import MeanPriors
+    rng = np.random.default_rng(9)
+    n, d = 140, 3
+    X = rng.random((n, d))
+    T = np.stack([np.sin(3 * X[:, 0]) + (k + 1) * X[:, 1] + 0.5 * k for k in range(3)])
+    Xs = rng.random((25, d))
+    terms = [(1, 1)]
+    mps = [None, ([0.2, 1.0], 2.0), ([1.0, 3.0], [[1.0, 0.2], [0.2, 0.5]])]
+    priors = [GPPriors(mean=mp, n_corr=d, nugget_type="fit") for mp in mps]
+    mo = M.MultiOutputGP_GPU(X, T, mean=native_mean(terms), kernel="Matern52", nugget="fit", priors=priors, analytic_mean=True)
+    thetas = np.stack([np.r_[rng.uniform(0., 2., d), rng.uniform(-1., 1.), rng.uniform(-9., -6.)] for _ in range(3)])
+    f, grad, ok = mo._mogp_gpu.eval(thetas, grad=True)
+    mo.fit(thetas)
+    mean, unc, _ = mo.predict(Xs, deriv=False)
+    for k in range(3):
+        ref = R.GPRefMean(X, T[k], terms, True, mean_prior=mps[k], kernel="Matern52", nugget="fit")
+        assert_allclose(f[k], ref.fit(thetas[k]), rtol=1e-9)
+        assert_allclose(grad[k], ref.logpost_deriv(thetas[k]), rtol=1e-6, atol=1e-6)
+        rmu, rvar, _ = ref.predict(Xs)
+        assert_allclose(mean[k], rmu, rtol=1e-7, atol=1e-8)
+        assert_allclose(unc[k], rvar, rtol=1e-6, atol=1e-9)
+    # mean priors without the analytic mean, or with the wrong length, are refused
+    with pytest.raises(NotImplementedError):
+        M.GaussianProcessGPU(X, T[0], mean=native_mean(terms), priors=GPPriors(mean=mps[1], n_corr=d, nugget_type="adaptive"))
+    with pytest.raises(RuntimeError, match="one entry per mean-function term"):
+        M.GaussianProcessGPU(X, T[0], mean=native_mean(terms), priors=GPPriors(mean=([1., 2., 3.], 1.0), n_corr=d, nugget_type="adaptive"),
+                             analytic_mean=True)
+    with pytest.raises(ValueError):
+        MeanPriors(mean=[1., 2.])
+    with pytest.raises(AssertionError):
+        MeanPriors(mean=[1., 2.], cov=-1.)
