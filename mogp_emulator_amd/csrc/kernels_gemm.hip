@@ -351,8 +351,8 @@ __global__ __launch_bounds__(256, 2) void predict_var_kernel(BatchView v, const 
   // Work decomposition for L2 reuse.  L^-1 is lower triangular, so row tile ti needs K = 128 (ti + 1): a workgroup
   // takes the PAIR of row tiles (nti-1-p, p) for its column tile, which makes every workgroup of the launch equally
   // long (K = 128 (nti + 1)).  Tiles are walked in super-tiles of 4 pairs x 16 column tiles (64 workgroups = one
-  // XCD's resident set): the 16 workgroups that share an L^-1 row panel have identical K and the 4 that share a
-  // K* panel differ by at most 3 x 128, and because all workgroups finish together the next super-tile also starts
+  // XCD's resident set; the 8-wave kernel below uses 8 x 8): the workgroups that share an L^-1 row panel have identical K and those that
+  // share a K* panel differ by a few x 128, and because all workgroups finish together the next super-tile also starts
   // together -- panels are fetched from HBM once per super-tile and re-used out of the 4 MiB L2 while the 64
   // workgroups sweep k in step.  (Unpaired 8 x 8 super-tiles drifted apart: short row tiles finished early, their
   // successors started staggered, and the L2 hit rate fell to ~50 %: 49.5 GB of HBM traffic per launch by PMC.)
@@ -500,16 +500,17 @@ __device__ __forceinline__ void mainloop_w(const double* __restrict__ Ag, int ld
 // ---------------------------------------------------------------------------------------------
 template <int WR, int WC>
 __global__ __launch_bounds__(64 * WR * WC, (WR * WC >= 8 ? 4 : 2)) void predict_var_w_kernel(
-    BatchView v, const double* __restrict__ Ks, int MP, int nti, int ntj, double* __restrict__ partial) {
+    BatchView v, const double* __restrict__ Ks, int MP, int nti, int ntj, double* __restrict__ partial, int lgc) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   using C = WCfg<128, 128, WR, WC>;
   const int npairs = (nti + 1) / 2;
-  const int nsr = (npairs + 3) / 4, nsc = (ntj + 15) / 16;
+  const int SC = 1 << lgc, SR = 64 >> lgc;           // super-tile = SR pairs x SC column tiles
+  const int nsr = (npairs + SR - 1) / SR, nsc = (ntj + SC - 1) / SC;
   int z, tile;
   decode_block(v.nb, nsr * nsc * 64, z, tile);
   if (z >= v.nb) return;
   const int st = tile >> 6, w = tile & 63;
-  const int pr = (st / nsc) * 4 + (w >> 4), tj = (st % nsc) * 16 + (w & 15);
+  const int pr = (st / nsc) * SR + (w >> lgc), tj = (st % nsc) * SC + (w & (SC - 1));
   if (pr >= npairs || tj >= ntj) return;
   const int emu = slot_to_emu(v.idx, z);
   const int ld = v.LD;
@@ -682,12 +683,20 @@ void launch_kinv(const BatchView& v, hipStream_t s) {
 void launch_predict_var(const BatchView& v, const double* Ks, int m, int MP, double* partial, double* var, int var_ld, hipStream_t s) {
   const int nti = (v.n + 127) / 128, ntj = MP / 128;
   prof_begin("predict_var", s);
-  const int nsup = (((nti + 1) / 2 + 3) / 4) * ((ntj + 15) / 16) * 64;
   // measured (TFLOP/s): 2 x 2 waves 59.2, 2 x 4 waves 61.1, 4 x 2 waves 60.7, 4 x 4 waves 57.3; MOGP_PV_WAVES=4 selects the 2 x 2 kernel
   static const int waves = [] { const char* e = getenv("MOGP_PV_WAVES"); return e ? atoi(e) : 8; }();
-  const dim3 grid(padded_grid(v.nb, nsup));
-  if (waves == 8) hipLaunchKernelGGL((predict_var_w_kernel<2, 4>), grid, dim3(512), smem_bytes<4>(), s, v, Ks, MP, nti, ntj, partial);
-  else hipLaunchKernelGGL(predict_var_kernel<false>, grid, dim3(256), smem_bytes<4>(), s, v, Ks, MP, nti, ntj, partial);
+  // super-tile = 2^lgc column tiles x 64/2^lgc row-tile pairs.  Measured at nti = 16 (8 pairs), m = 5632, L2-miss bytes per launch /
+  // TFLOP/s: 8x8 37 GB / 62.3, 4 pairs x 16 44 GB / 61.9, 2 x 32 53 GB / 60.4, 1 x 64 54 GB / 60.4; without the XCD-aware
+  // block decode (workgroups of a super-tile spread over all eight L2s) 47 GB but only 52.1 TFLOP/s
+  static const int lgc = [] { const char* e = getenv("MOGP_PV_LGC"); return e ? atoi(e) : 3; }();
+  if (waves == 8) {
+    const int SC = 1 << lgc, SR = 64 >> lgc;
+    const int nsup = (((nti + 1) / 2 + SR - 1) / SR) * ((ntj + SC - 1) / SC) * 64;
+    hipLaunchKernelGGL((predict_var_w_kernel<2, 4>), dim3(padded_grid(v.nb, nsup)), dim3(512), smem_bytes<4>(), s, v, Ks, MP, nti, ntj, partial, lgc);
+  } else {
+    const int nsup = (((nti + 1) / 2 + 3) / 4) * ((ntj + 15) / 16) * 64;
+    hipLaunchKernelGGL(predict_var_kernel<false>, dim3(padded_grid(v.nb, nsup)), dim3(256), smem_bytes<4>(), s, v, Ks, MP, nti, ntj, partial);
+  }
   prof_end("predict_var", s, (double)v.nb * (double)m * v.n * v.n, 0.);
   hipLaunchKernelGGL(predict_var_finish_kernel, dim3((m + 255) / 256, v.nb), dim3(256), 0, s, v, partial, m, MP, nti, var, var_ld);
 }
