@@ -276,24 +276,30 @@ __global__ __launch_bounds__(256, 2) void fused_step_kernel(BatchView v, FusedAr
 //   STEP 1:  Linv21 = -Linv22 * T
 // ---------------------------------------------------------------------------------------------
 template <int WT, int STEP>
-__global__ __launch_bounds__(256, 2) void trtri_merge_kernel(BatchView v, int h, int tiles_per_dim) {
+__global__ __launch_bounds__(256, 2) void trtri_merge_kernel(BatchView v, int h, int tiles_per_dim, int nodes) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   using C = Cfg<WT>;
-  const int z = blockIdx.z;
+  // 1-D grid decoded so that each XCD walks through whole emulators (decode_block): the tiles of a node share
+  // their operand panels through one L2 instead of being dealt round-robin over all eight
+  const int tpn = tiles_per_dim * tiles_per_dim;
+  int z, t;
+  decode_block(v.nb, nodes * tpn, z, t);
+  if (z >= v.nb) return;
+  const int node = t / tpn, bx = t % tpn;
   const int emu = slot_to_emu(v.idx, z);
   const int ld = v.LD;
-  const int base = blockIdx.y * 2 * h;
+  const int base = node * 2 * h;
   if (base + h >= v.NP) return;
   const int m2 = min(h, v.NP - base - h);
   // longest-K tiles are dispatched first (STEP 0: K = h - j0 -> small tj first; STEP 1: K = i0 + BM ->
   // large ti first) so the tail of the launch is made of short tiles
   int ti, tj;
   if (STEP == 0) {
-    tj = blockIdx.x / tiles_per_dim;
-    ti = blockIdx.x % tiles_per_dim;
+    tj = bx / tiles_per_dim;
+    ti = bx % tiles_per_dim;
   } else {
-    ti = tiles_per_dim - 1 - (int)(blockIdx.x / tiles_per_dim);
-    tj = blockIdx.x % tiles_per_dim;
+    ti = tiles_per_dim - 1 - (bx / tiles_per_dim);
+    tj = bx % tiles_per_dim;
   }
   const int i0 = ti * C::BM, j0 = tj * C::BM;          // node-local
   if (i0 >= m2) return;
@@ -657,14 +663,14 @@ void launch_trtri_merges(const BatchView& v, hipStream_t s) {
     if (h == 64 || wt == 2) {
       const int tpd = h / 64;
       if (h > 64) prof_begin("trtri_merge", s);
-      hipLaunchKernelGGL((trtri_merge_kernel<2, 0>), dim3(tpd * tpd, nodes, v.nb), dim3(256), smem_bytes<2>(), s, v, h, tpd);
-      hipLaunchKernelGGL((trtri_merge_kernel<2, 1>), dim3(tpd * tpd, nodes, v.nb), dim3(256), smem_bytes<2>(), s, v, h, tpd);
+      hipLaunchKernelGGL((trtri_merge_kernel<2, 0>), dim3(padded_grid(v.nb, tpd * tpd * nodes)), dim3(256), smem_bytes<2>(), s, v, h, tpd, nodes);
+      hipLaunchKernelGGL((trtri_merge_kernel<2, 1>), dim3(padded_grid(v.nb, tpd * tpd * nodes)), dim3(256), smem_bytes<2>(), s, v, h, tpd, nodes);
       if (h > 64) prof_end("trtri_merge", s, (double)v.nb * nodes * 2.0 * h * h * h / 2.0, 0.);
     } else {
       const int tpd = h / 128;
       prof_begin("trtri_merge", s);
-      hipLaunchKernelGGL((trtri_merge_kernel<4, 0>), dim3(tpd * tpd, nodes, v.nb), dim3(256), smem_bytes<4>(), s, v, h, tpd);
-      hipLaunchKernelGGL((trtri_merge_kernel<4, 1>), dim3(tpd * tpd, nodes, v.nb), dim3(256), smem_bytes<4>(), s, v, h, tpd);
+      hipLaunchKernelGGL((trtri_merge_kernel<4, 0>), dim3(padded_grid(v.nb, tpd * tpd * nodes)), dim3(256), smem_bytes<4>(), s, v, h, tpd, nodes);
+      hipLaunchKernelGGL((trtri_merge_kernel<4, 1>), dim3(padded_grid(v.nb, tpd * tpd * nodes)), dim3(256), smem_bytes<4>(), s, v, h, tpd, nodes);
       // algorithmic flops: two triangular-times-square products of size h per node = 2 * h^3 / 2 * 2 flops... = 2 h^3
       prof_end("trtri_merge", s, (double)v.nb * nodes * 2.0 * h * h * h / 2.0, 0.);
     }
