@@ -421,6 +421,10 @@ static void mogp_predict_common(mogp_mogp* h, const double* testing, int m, int 
   std::vector<int> ids = fitted_ids(h);
   if (ids.empty()) return;
   const size_t nf = ids.size();
+  if ((int)nf == e->B && means) {    // every emulator fitted: results go straight into the caller's arrays
+    e->predict(ids, testing, m, false, means, vars, m, false, derivs);
+    return;
+  }
   std::vector<double> mm(nf * m), vv(vars ? nf * m : 0), dd(derivs ? nf * m * D : 0);
   e->predict(ids, testing, m, false, mm.data(), vars ? vv.data() : nullptr, m, false, derivs ? dd.data() : nullptr);
   for (size_t k = 0; k < nf; ++k) {

@@ -934,9 +934,14 @@ void Engine::predict(const std::vector<int>& ids, const double* Xs, int m, bool 
       dots.resize((size_t)nb * R * m);
       HIPCK(hipMemcpyAsync(dots.data(), dm, dots.size() * sizeof(double), hipMemcpyDeviceToHost, stream));
     }
-    for (int k = 0; k < nb; ++k) {
-      if (R == 1) HIPCK(hipMemcpyAsync(means + (size_t)k * out_ld, dm + (size_t)k * m, m * sizeof(double), hipMemcpyDeviceToHost, stream));
-      if (vars) HIPCK(hipMemcpyAsync(vars + (size_t)k * out_ld, dv + (size_t)k * m, m * sizeof(double), hipMemcpyDeviceToHost, stream));
+    if (out_ld == m) {               // contiguous result arrays: one transfer each instead of one per emulator
+      if (R == 1) HIPCK(hipMemcpyAsync(means, dm, (size_t)nb * m * sizeof(double), hipMemcpyDeviceToHost, stream));
+      if (vars) HIPCK(hipMemcpyAsync(vars, dv, (size_t)nb * m * sizeof(double), hipMemcpyDeviceToHost, stream));
+    } else {
+      for (int k = 0; k < nb; ++k) {
+        if (R == 1) HIPCK(hipMemcpyAsync(means + (size_t)k * out_ld, dm + (size_t)k * m, m * sizeof(double), hipMemcpyDeviceToHost, stream));
+        if (vars) HIPCK(hipMemcpyAsync(vars + (size_t)k * out_ld, dv + (size_t)k * m, m * sizeof(double), hipMemcpyDeviceToHost, stream));
+      }
     }
   }
   HIPCK(hipStreamSynchronize(stream));
