@@ -265,6 +265,11 @@ def main():
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": "MultiOutputGP %d outputs/GPU x n=%d x d=%d, %s kernel, fixed nugget 1e-6, predict m=%d (unc=True)" % (
                 B, n, d, args.kernel, m), "outputs_per_gpu": B, "n": n, "d": d, "m_predict": m, "parallelism": "emulator-shard x%d" % world},
+            # one step = fit phase + fit+gradient phase + predict phase (+ gather); the headline metric has two parts
+            # (fits/s and predict pts/s), each taken from its own phase of the SAME timed K steps, max over ranks:
+            "value_definition": "value = outputs * steps / (time of the fit phases inside the timed steps); "
+                                "predict_pts_per_s = outputs * m * steps / (time of the predict + gather phases); "
+                                "ms_per_step covers all three phases",
             "fit_grad_per_s": total_emus * K / t_fg,
             "predict_pts_per_s": total_emus * m * K / (t_pr + t_ga),
             "phase_ms_per_step": {"fit": t_fit / K * 1e3, "fit_grad": t_fg / K * 1e3, "predict": t_pr / K * 1e3, "gather": t_ga / K * 1e3},
