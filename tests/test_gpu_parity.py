@@ -235,6 +235,33 @@ def test_adaptive_jitter_ladder_on_duplicated_inputs():
     assert not bad.theta.data_has_been_set()
 
 
+def test_adaptive_jitter_mixed_batch_two_stream_groups():
+    # 24 emulators (two stream groups of 12) on duplicated inputs: exactly singular K, every emulator walks the ladder
+    rng = np.random.default_rng(17)
+    X = rng.uniform(0, 1, (150, 3)); X = np.vstack([X, X[:7]])
+    B = 24
+    T = np.stack([np.sin(X.sum(axis=1) + k) for k in range(B)])
+    mo = M.MultiOutputGP_GPU(X, T, nugget="adaptive", priors=weak(3, "adaptive"))
+    thetas = np.stack([np.r_[rng.uniform(-1., 1., 3), rng.uniform(-2., 2.)] for _ in range(B)])
+    f, g, ok = mo._mogp_gpu.eval(thetas, grad=True)
+    assert ok.all()
+    mo.fit(thetas)
+    nug = mo._nuggets()
+    assert np.all(nug > 0.)                     # exactly singular K: every emulator needs jitter
+    for k in range(0, B, 5):
+        ref = R.GPRef(X, T[k], nugget="adaptive")
+        lp = ref.fit(thetas[k])
+        assert_allclose(nug[k], ref.nugget, rtol=1e-12)
+        assert_allclose(f[k], lp, rtol=1e-5)    # cond(K + jitter) ~ 1e6 / eps-level cancellations in the reference value
+    # the same batch shape on a regular design with short length scales: zero jitter suffices for every emulator
+    Xg = rng.uniform(0, 1, (157, 3))
+    mg = M.MultiOutputGP_GPU(Xg, T, nugget="adaptive", priors=weak(3, "adaptive"))
+    th = np.tile(np.r_[np.full(3, 6.), 0.], (B, 1))      # short length scales: well conditioned, zero jitter suffices
+    fg, _, okg = mg._mogp_gpu.eval(th, grad=False)
+    mg.fit(th)
+    assert okg.all() and np.all(mg._nuggets() == 0.)
+
+
 def test_error_behaviour_matches_reference():
     X, T, Xs = synth(5, 30, 2, 1, 4)
     gp = make_gp(X, T[0], nugget="fit")
