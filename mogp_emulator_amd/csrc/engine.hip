@@ -271,6 +271,15 @@ void Engine::upload_params(const std::vector<int>& ids) {
 // (K = w/2, MFMA) -> [right half], down to 64-wide leaves (potf2 + trsm).  The outer block is 256
 // wide so the big trailing update runs with K = 256: per 128x128 tile the MFMA work (64k cycles)
 // then outweighs the read-modify-write of C (256 KB at ~10 B/clk/CU), which it does not at K = 128.
+// One 128-wide block column [c, c+128), rows [c, NP), K = [k0, k1).  With few 128 x 128 tiles in the launch (a single
+// large matrix: (NP - c)/128 <= 125 workgroups on 256 CUs) the 64 x 64 tiling gives 4x the workgroups and the launch
+// takes one short tile instead of one long one; MOGP_COLTILE=128 restores the wide tiles everywhere.
+static void update_column_block(const BatchView& v, int c, int k0, int k1, hipStream_t st) {
+  static const long few = [] { const char* e = getenv("MOGP_COLTILE"); return (e && atoi(e) == 128) ? 0L : 512L; }();
+  if ((long)v.nb * ((v.NP - c) / TILE) < few) launch_update_narrow_pair(v, c, k0, k1, st);
+  else launch_update_wide(v, c, k0, k1, st);
+}
+
 void Engine::panel(const BatchView& v, int o, int w, hipStream_t st) {
   if (w == NBI) {
     launch_potf2(v, o, dInfo, dLpack, st);
@@ -282,7 +291,7 @@ void Engine::panel(const BatchView& v, int o, int w, hipStream_t st) {
   panel(v, o, h, st);
   if (h == NBI) launch_update_narrow(v, o + h, o, o + h, st);
   else
-    for (int c = o + h; c < o + w; c += TILE) launch_update_wide(v, c, o, o + h, st);
+    for (int c = o + h; c < o + w; c += TILE) update_column_block(v, c, o, o + h, st);
   panel(v, o + h, w - h, st);
 }
 
@@ -571,7 +580,7 @@ void Engine::factorize(const std::vector<int>& ids, std::vector<int>& info) {
     HIPCK(hipStreamWaitEvent(stream, evPanel[k], 0));
     if (k + 1 < K) {
       const int on = starts[k + 1], wn = width(k + 1);
-      for (int c = on; c < on + wn; c += TILE) launch_update_wide(v, c, o, o + w, stream);     // U_a
+      for (int c = on; c < on + wn; c += TILE) update_column_block(v, c, o, o + w, stream);     // U_a
       HIPCK(hipEventRecord(evUpd[k], stream));
       HIPCK(hipStreamWaitEvent(pstream, evUpd[k], 0));
       panel(v, on, wn, pstream);
