@@ -499,6 +499,43 @@ __device__ __forceinline__ void mainloop_w(const double* __restrict__ Ag, int ld
   }
 }
 
+// f(row_in_tile, col_in_tile, value) over the accumulator fragment of mainloop_w
+template <int WC, int TI, int TJ, typename F>
+__device__ __forceinline__ void for_each_acc_w(v4d (&acc)[TI][TJ], F f) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wr = wave / WC, wc = wave % WC;
+#pragma unroll
+  for (int i = 0; i < TI; ++i)
+#pragma unroll
+    for (int j = 0; j < TJ; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) f(wr * 16 * TI + i * 16 + (lane >> 4) + 4 * r, wc * 16 * TJ + j * 16 + (lane & 15), acc[i][j][r]);
+}
+
+// Trailing symmetric update (lower 128 x 128 tiles over rows / columns [c0, NP)) with the 2 x 4-wave main loop:
+// the right-looking schedule of a single large matrix spends most of its time here.
+__global__ __launch_bounds__(512, 4) void update_tri8_kernel(BatchView v, int c0, int k0, int k1, int ntiles) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  using C = WCfg<128, 128, 2, 4>;
+  int z, tile;
+  decode_block(v.nb, ntiles, z, tile);
+  if (z >= v.nb) return;
+  int ti = (int)((sqrt(8.0 * tile + 1.0) - 1.0) * 0.5);
+  while (ti * (ti + 1) / 2 > tile) --ti;
+  while ((ti + 1) * (ti + 2) / 2 <= tile) ++ti;
+  const int tj = tile - ti * (ti + 1) / 2;
+  const int emu = slot_to_emu(v.idx, z);
+  double* A = v.A + (size_t)emu * v.MS;
+  const int ld = v.LD;
+  const int i0 = c0 + ti * 128, j0 = c0 + tj * 128;
+  v4d acc[C::TI][C::TJ];
+  mainloop_w<128, 128, 2, 4>(A + (size_t)i0 * ld + k0, ld, A + (size_t)j0 * ld + k0, ld, (k1 - k0) / BK, acc, smem);
+  for_each_acc_w<4>(acc, [&](int r, int c, double x) {
+    double* p = A + (size_t)(i0 + r) * ld + (j0 + c);
+    *p -= x;
+  });
+}
+
 // ---------------------------------------------------------------------------------------------
 // Predictive-variance kernel, 2 x 4 waves per 128 x 128 block tile (512 threads, 64 x 32 wave tiles, 64 accumulator
 // VGPRs -> four waves per SIMD instead of the two of the 2 x 2 / 128-accumulator configuration):
@@ -650,8 +687,11 @@ void launch_update_trailing(const BatchView& v, int c0, int k0, int k1, hipStrea
   const int ntiles = nt * (nt + 1) / 2;
   const double m = (double)(v.NP - c0);
   prof_begin("syrk_trailing", s);
-  hipLaunchKernelGGL((update_kernel<4, true, false>), dim3(padded_grid(v.nb, ntiles)), dim3(256), smem_bytes<4>(), s, v, c0, k0, k1, nt, ntiles,
-                     (int*)nullptr, (double*)nullptr);
+  static const bool w8 = [] { const char* e = getenv("MOGP_TRI_WAVES"); return !e || atoi(e) != 4; }();   // 4: 2 x 2-wave kernel
+  if (w8) hipLaunchKernelGGL(update_tri8_kernel, dim3(padded_grid(v.nb, ntiles)), dim3(512), smem_bytes<4>(), s, v, c0, k0, k1, ntiles);
+  else
+    hipLaunchKernelGGL((update_kernel<4, true, false>), dim3(padded_grid(v.nb, ntiles)), dim3(256), smem_bytes<4>(), s, v, c0, k0, k1, nt, ntiles,
+                       (int*)nullptr, (double*)nullptr);
   // algorithmic: lower half of an m x m rank-(k1-k0) update = m^2 (k1-k0) flops; bytes: read+write C lower half + panel
   prof_end("syrk_trailing", s, (double)v.nb * m * m * (k1 - k0), (double)v.nb * (8.0 * m * m + 8.0 * m * (k1 - k0)));
 }
