@@ -175,7 +175,7 @@ Engine::Engine(const double* X, int n_, int D_, const double* targets, int B_, u
   dYty = dalloc<double>(B);
   dInfo = dalloc<int>(B);
   dIdx = dalloc<int>(B);
-  dLpack = dalloc<double>((size_t)B * lpack_doubles_per_emulator());
+  dLpack = dalloc<double>((size_t)B * std::max(lpack_doubles_per_emulator(), lpack128_doubles_per_emulator()));
   hP.assign((size_t)B * PS, 0.);
   HIPCK(hipMemcpy(dX, hX.data(), hX.size() * sizeof(double), hipMemcpyHostToDevice));
   // residual targets for parameter-free means are fixed once
@@ -281,6 +281,11 @@ static void update_column_block(const BatchView& v, int c, int k0, int k1, hipSt
 }
 
 void Engine::panel(const BatchView& v, int o, int w, hipStream_t st) {
+  static const bool p128 = [] { const char* e = getenv("MOGP_P128"); return e && e[0] == '1'; }();
+  if (w == TILE && p128) {
+    launch_panel128(v, o, dInfo, dLpack, st);
+    return;
+  }
   if (w == NBI) {
     launch_potf2(v, o, dInfo, dLpack, st);
     launch_trsm(v, o, o + NBI, dLpack, st);

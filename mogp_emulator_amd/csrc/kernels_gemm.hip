@@ -271,6 +271,39 @@ __global__ __launch_bounds__(256, 2) void fused_step_kernel(BatchView v, FusedAr
 }
 
 // ---------------------------------------------------------------------------------------------
+// 128 x 128 diagonal block in ONE launch (one workgroup per emulator): potf2(D1) -> L21 = A21 L11^-T (MFMA block
+// substitution, 4 waves x 16 rows) -> D2 -= L21 L21^T (64 x 64 x 64 on the MFMA main loop) -> potf2(D2).  Replaces the
+// diagonal-block share of four dependent launches (potf2, trsm, 64-wide update, potf2); the rows below are solved by
+// trsm128_kernel in one pass over the 128-wide panel.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void potf2_128_kernel(BatchView v, int c0, int* __restrict__ info, double* __restrict__ Lpack128) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int emu = slot_to_emu(v.idx, blockIdx.x);
+  const int ld = v.LD;
+  double* A = v.A + (size_t)emu * v.MS;
+  double* pk = Lpack128 + (size_t)emu * PACK128_STRIDE;
+  potf2_block_dev(A + (size_t)c0 * ld + c0, ld, pk, info + emu, c0, smem);
+  __syncthreads();
+  trsm_mfma_pk(v, c0, c0 + 64, pk, emu, 0);
+  __syncthreads();
+  {
+    // L21^T for trsm128: thread (row q, 16-column group w)
+    const int q = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const double* src = A + (size_t)(c0 + 64 + q) * ld + c0 + 16 * w;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) pk[2 * PACK_STRIDE + (16 * w + c) * 64 + q] = src[c];
+  }
+  update_tile64_dev(v, emu, c0 + 64, c0, c0 + 64, 1, 0, smem);
+  __syncthreads();
+  potf2_block_dev(A + (size_t)(c0 + 64) * ld + c0 + 64, ld, pk + PACK_STRIDE, info + emu, c0 + 64, smem);
+}
+
+__global__ __launch_bounds__(256) void trsm128_kernel(BatchView v, int c0, int r0, const double* __restrict__ Lpack128) {
+  const int emu = slot_to_emu(v.idx, blockIdx.y);
+  trsm128_dev(v, c0, r0, Lpack128 + (size_t)emu * PACK128_STRIDE, emu, blockIdx.x);
+}
+
+// ---------------------------------------------------------------------------------------------
 // trtri merge, level h:  node q covers [base, base+2h), base = q*2h
 //   STEP 0:  T     = L21 * Linv11          (T kept in scratch at the position of block 21)
 //   STEP 1:  Linv21 = -Linv22 * T
@@ -745,6 +778,16 @@ void launch_predict_var(const BatchView& v, const double* Ks, int m, int MP, dou
   }
   prof_end("predict_var", s, (double)v.nb * (double)m * v.n * v.n, 0.);
   hipLaunchKernelGGL(predict_var_finish_kernel, dim3((m + 255) / 256, v.nb), dim3(256), 0, s, v, partial, m, MP, nti, var, var_ld);
+}
+
+size_t lpack128_doubles_per_emulator() { return PACK128_STRIDE; }
+
+// factor the 128 x 128 diagonal block at c0 and solve the panel rows [c0 + 128, NP) below it
+void launch_panel128(const BatchView& v, int c0, int* info, double* Lpack128, hipStream_t s) {
+  const size_t sm = std::max(smem_bytes<2>(), (size_t)POTF2B_LDS_DOUBLES * sizeof(double));
+  hipLaunchKernelGGL(potf2_128_kernel, dim3(v.nb), dim3(256), sm, s, v, c0, info, Lpack128);
+  const int rows = v.NP - c0 - 128;
+  if (rows > 0) hipLaunchKernelGGL(trsm128_kernel, dim3(rows / 64, v.nb), dim3(256), 0, s, v, c0, c0 + 128, (const double*)Lpack128);
 }
 
 void launch_fused_step(const BatchView& v, const FusedArgs& fa, int total_wgs, int* info, double* Lpack, hipStream_t s) {

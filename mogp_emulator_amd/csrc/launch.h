@@ -67,6 +67,9 @@ void launch_predict_fullcov(const BatchView& v, const double* Ks, int m, int MP,
 // potf2 of the 64x64 diagonal block at c0; info[emu] = first failing (1-based) column or 0
 void launch_potf2(const BatchView& v, int c0, int* info, double* Lpack, hipStream_t s);
 size_t lpack_doubles_per_emulator();   // scratch written by potf2, read by trsm
+size_t lpack128_doubles_per_emulator();
+// 128 x 128 diagonal block (potf2 + trsm + update + potf2 in one workgroup per emulator) and the panel below it
+void launch_panel128(const BatchView& v, int c0, int* info, double* Lpack128, hipStream_t s);
 // rows [r0, NP) of column block [c0, c0+64): X L_kk^T = A
 void launch_trsm(const BatchView& v, int c0, int r0, const double* Lpack, hipStream_t s);
 // C[i,j] -= sum_{k in [k0,k1)} A[i,k] A[j,k] for the 64-wide column block [c0,c0+64), rows [c0, NP)

@@ -7,13 +7,12 @@ namespace mogp {
 
 typedef double v4d_t __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ void trsm_mfma_dev(const BatchView& v, int c0, int r0, const double* __restrict__ Lpack, int emu, int rowblock) {
+__device__ __forceinline__ void trsm_mfma_pk(const BatchView& v, int c0, int r0, const double* __restrict__ pk, int emu, int rowblock) {
   const int ld = v.LD;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int g = lane >> 4, i = lane & 15;
   const int row = r0 + rowblock * 64 + wave * 16 + i;
   double* arow = v.A + (size_t)emu * v.MS + (size_t)row * ld + c0;
-  const double* pk = Lpack + (size_t)emu * PACK_STRIDE;
   // A operands: Lneg[b][a][r] = -L[16b + i][16a + g + 4r]  (a < b),  Inv[b][r] = inv(L_bb)[i][g + 4r]
   double Lneg[6][4], Inv[4][4];
 #pragma unroll
@@ -45,5 +44,50 @@ __device__ __forceinline__ void trsm_mfma_dev(const BatchView& v, int c0, int r0
   }
 }
 
+
+__device__ __forceinline__ void trsm_mfma_dev(const BatchView& v, int c0, int r0, const double* __restrict__ Lpack, int emu, int rowblock) {
+  trsm_mfma_pk(v, c0, r0, Lpack + (size_t)emu * PACK_STRIDE, emu, rowblock);
+}
+
+// ---------------------------------------------------------------------------------------------
+// 128-wide panel solve X L^T = B for a factored 128 x 128 diagonal block L = [L11 0; L21 L22]: the same block forward
+// substitution over EIGHT 16-column blocks, so the rank-64 update of the second half with the first is part of the
+// substitution (no separate 64-wide update launch, the panel is read and written once instead of 7/4 times).
+//   pack128: [0, PACK_STRIDE) pack of L11, [PACK_STRIDE, 2 PACK_STRIDE) pack of L22, then [c*64 + q] = L21[q][c]
+// ---------------------------------------------------------------------------------------------
+constexpr int PACK128_STRIDE = 2 * PACK_STRIDE + 64 * 64;
+
+__device__ __forceinline__ double pack128_L(const double* __restrict__ pk, int br, int bc, int i, int k) {
+  // L[16 br + i][16 bc + k] of the 128 x 128 block, br > bc
+  if (br < 4) return pk[(16 * bc + k) * 64 + 16 * br + i];
+  if (bc >= 4) return pk[PACK_STRIDE + (16 * (bc - 4) + k) * 64 + 16 * (br - 4) + i];
+  return pk[2 * PACK_STRIDE + (16 * bc + k) * 64 + 16 * (br - 4) + i];
+}
+
+__device__ __forceinline__ void trsm128_dev(const BatchView& v, int c0, int r0, const double* __restrict__ pk, int emu, int rowblock) {
+  const int ld = v.LD;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = lane >> 4, i = lane & 15;
+  const int row = r0 + rowblock * 64 + wave * 16 + i;
+  double* arow = v.A + (size_t)emu * v.MS + (size_t)row * ld + c0;
+  v4d_t T[8], X[8];
+#pragma unroll
+  for (int b = 0; b < 8; ++b)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) T[b][r] = arow[16 * b + g + 4 * r];
+#pragma unroll
+  for (int b = 0; b < 8; ++b) {
+#pragma unroll
+    for (int a = 0; a < b; ++a)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) T[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(-pack128_L(pk, b, a, i, g + 4 * r), X[a][r], T[b], 0, 0, 0);
+    const double* inv = pk + (b < 4 ? 0 : PACK_STRIDE) + PACK_INV + (b & 3) * 256;
+    X[b] = (v4d_t){0., 0., 0., 0.};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) X[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(inv[(g + 4 * r) * 16 + i], T[b][r], X[b], 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) arow[16 * b + g + 4 * r] = X[b][r];
+  }
+}
 
 }  // namespace mogp
