@@ -268,9 +268,9 @@ void Engine::upload_params(const std::vector<int>& ids) {
 
 // Blocked right-looking Cholesky of K + nugget I for the emulators in `ids` (one batched sequence).
 // Recursive panel: a block column of width w is factored as [left half] -> update of the right half
-// (K = w/2, MFMA) -> [right half], down to 64-wide leaves (potf2 + trsm).  The outer block is 256
-// wide so the big trailing update runs with K = 256: per 128x128 tile the MFMA work (64k cycles)
-// then outweighs the read-modify-write of C (256 KB at ~10 B/clk/CU), which it does not at K = 128.
+// (K = w/2, MFMA) -> [right half], down to 64-wide leaves (potf2 + trsm).  The outer block is 512
+// wide so the big trailing update runs with K = 512: per 128x128 tile the MFMA work then clearly outweighs the
+// read-modify-write of C (256 KB per tile), which it does not at K = 128 (measured on C5: 256 -> 45.7 ms, 512 -> 41.7 ms).
 // One 128-wide block column [c, c+128), rows [c, NP), K = [k0, k1).  With few 128 x 128 tiles in the launch (a single
 // large matrix: (NP - c)/128 <= 125 workgroups on 256 CUs) the 64 x 64 tiling gives 4x the workgroups and the launch
 // takes one short tile instead of one long one; MOGP_COLTILE=128 restores the wide tiles everywhere.

@@ -21,7 +21,6 @@ constexpr int TILE = 128;       // MFMA macro tile / padding granule
 // The covariance kernels stage two 64-row blocks of X (and, for predict_deriv, a 64 x 65 work tile and a 64 x D
 // accumulator) in LDS: (192 D + 4160) doubles <= 160 KB  ->  D <= 85.
 constexpr int MAX_D = 80;
-constexpr int OUTER = 256;      // outer Cholesky block = K depth of the trailing update
 constexpr int NBI = 64;         // inner panel width (potf2 / trsm / trtri leaf)
 constexpr double PAD_BIG = 1e300;
 constexpr int RMAX = 8;         // max right-hand-side rows (targets + up to 7 mean-function columns)
