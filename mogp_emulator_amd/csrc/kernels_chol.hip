@@ -114,8 +114,10 @@ __global__ __launch_bounds__(TRSM_THREADS) void trsm_kernel(BatchView v, int c0,
 // and the A operand (L_ba or inv(L_bb), element [lane&15][g+4r]) is fetched with the same k mapping.
 // 40 dependent MFMAs per wave instead of 2016 LDS-fed FMAs per row; rows/16 waves per emulator.
 // ---------------------------------------------------------------------------------------------
+template <bool STAGED>
 __global__ __launch_bounds__(256) void trsm_mfma_kernel(BatchView v, int c0, int r0, const double* __restrict__ Lpack) {
-  trsm_mfma_dev(v, c0, r0, Lpack, slot_emu(v.idx, blockIdx.y), blockIdx.x);
+  __shared__ __attribute__((aligned(16))) double stage[STAGED ? 4 * TRSM_STAGE : 2];
+  trsm_mfma_dev(v, c0, r0, Lpack, slot_emu(v.idx, blockIdx.y), blockIdx.x, STAGED ? stage : nullptr);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -465,7 +467,9 @@ void launch_trsm(const BatchView& v, int c0, int r0, const double* Lpack, hipStr
   if (rows <= 0) return;
   static const bool mfma = [] { const char* e = getenv("MOGP_TRSM"); return !e || e[0] != '0'; }();   // 0: per-row substitution kernels
   if (mfma) {
-    hipLaunchKernelGGL(trsm_mfma_kernel, dim3(rows / 64, v.nb), dim3(256), 0, s, v, c0, r0, Lpack);
+    static const bool staged = [] { const char* e = getenv("MOGP_TRSM_STAGE"); return !e || e[0] != '0'; }();
+    if (staged) hipLaunchKernelGGL(trsm_mfma_kernel<true>, dim3(rows / 64, v.nb), dim3(256), 0, s, v, c0, r0, Lpack);
+    else hipLaunchKernelGGL(trsm_mfma_kernel<false>, dim3(rows / 64, v.nb), dim3(256), 0, s, v, c0, r0, Lpack);
     return;
   }
   if ((long)v.nb * ((rows + 255) / 256) >= 256)

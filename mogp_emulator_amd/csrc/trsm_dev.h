@@ -7,12 +7,29 @@ namespace mogp {
 
 typedef double v4d_t __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ void trsm_mfma_pk(const BatchView& v, int c0, int r0, const double* __restrict__ pk, int emu, int rowblock) {
+// stage: optional wave-private LDS slab of TRSM_STAGE doubles per wave.  The MFMA C/D layout makes a lane touch eight
+// 8-byte pieces of its row, 32 bytes apart -- with four waves per workgroup that working set overflows the L1 and every
+// 128-byte line is fetched several times.  Staged, the slab is read and written as full 512-byte rows (16-byte pieces,
+// two rows per instruction) and transposed into the MFMA layout through LDS (row stride 66 doubles: conflict free).
+constexpr int TRSM_STAGE = 16 * 66;
+
+__device__ __forceinline__ void trsm_mfma_pk(const BatchView& v, int c0, int r0, const double* __restrict__ pk, int emu, int rowblock,
+                                             double* stage = nullptr) {
   const int ld = v.LD;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int g = lane >> 4, i = lane & 15;
   const int row = r0 + rowblock * 64 + wave * 16 + i;
   double* arow = v.A + (size_t)emu * v.MS + (size_t)row * ld + c0;
+  double* slab = v.A + (size_t)emu * v.MS + (size_t)(r0 + rowblock * 64 + wave * 16) * ld + c0;   // 16 rows x 64 columns
+  if (stage) {
+    stage += wave * TRSM_STAGE;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int c = lane + 64 * q, rl = c >> 5, ch = c & 31;
+      *reinterpret_cast<v2d_p*>(stage + rl * 66 + 2 * ch) = *reinterpret_cast<const v2d_p*>(slab + (size_t)rl * ld + 2 * ch);
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
   // A operands: Lneg[b][a][r] = -L[16b + i][16a + g + 4r]  (a < b),  Inv[b][r] = inv(L_bb)[i][g + 4r]
   double Lneg[6][4], Inv[4][4];
 #pragma unroll
@@ -29,7 +46,7 @@ __device__ __forceinline__ void trsm_mfma_pk(const BatchView& v, int c0, int r0,
 #pragma unroll
   for (int b = 0; b < 4; ++b)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) T[b][r] = arow[16 * b + g + 4 * r];
+    for (int r = 0; r < 4; ++r) T[b][r] = stage ? stage[i * 66 + 16 * b + g + 4 * r] : arow[16 * b + g + 4 * r];
 #pragma unroll
   for (int b = 0; b < 4; ++b) {
 #pragma unroll
@@ -40,13 +57,25 @@ __device__ __forceinline__ void trsm_mfma_pk(const BatchView& v, int c0, int r0,
 #pragma unroll
     for (int r = 0; r < 4; ++r) X[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(Inv[b][r], T[b][r], X[b], 0, 0, 0);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) arow[16 * b + g + 4 * r] = X[b][r];
+    for (int r = 0; r < 4; ++r) {
+      if (stage) stage[i * 66 + 16 * b + g + 4 * r] = X[b][r];
+      else arow[16 * b + g + 4 * r] = X[b][r];
+    }
+  }
+  if (stage) {
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int c = lane + 64 * q, rl = c >> 5, ch = c & 31;
+      *reinterpret_cast<v2d_p*>(slab + (size_t)rl * ld + 2 * ch) = *reinterpret_cast<const v2d_p*>(stage + rl * 66 + 2 * ch);
+    }
   }
 }
 
 
-__device__ __forceinline__ void trsm_mfma_dev(const BatchView& v, int c0, int r0, const double* __restrict__ Lpack, int emu, int rowblock) {
-  trsm_mfma_pk(v, c0, r0, Lpack + (size_t)emu * PACK_STRIDE, emu, rowblock);
+__device__ __forceinline__ void trsm_mfma_dev(const BatchView& v, int c0, int r0, const double* __restrict__ Lpack, int emu, int rowblock,
+                                              double* stage = nullptr) {
+  trsm_mfma_pk(v, c0, r0, Lpack + (size_t)emu * PACK_STRIDE, emu, rowblock, stage);
 }
 
 // ---------------------------------------------------------------------------------------------
