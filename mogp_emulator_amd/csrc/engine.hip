@@ -338,9 +338,18 @@ void Engine::factorize(const std::vector<int>& ids, std::vector<int>& info) {
       HIPCK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
       gstreams.push_back(st);
     }
+    // Experiment (MOGP_FUSEK=1): the long-K update of block column j is the first kernel to touch its tiles, so it can
+    // generate their covariance entries itself and the K build shrinks to the first block column.  Bit-identical, but
+    // measured slower (6.00 -> 6.05 ms; single stream 6.07 -> 6.18 ms): the per-entry distance + exp in the epilogue of
+    // the MFMA kernel costs more than the 0.3 ms K build and the read of C it saves.
+    static const bool fuse_k = [] { const char* e = getenv("MOGP_FUSEK"); return e && e[0] == '1'; }();
+    static const bool pair = [] { const char* e = getenv("MOGP_PAIR"); return !e || e[0] != '0'; }();
+    bool gen_cov = fuse_k && pair && !fuse_potf2;
+    for (int o = TILE; o < n + R && gen_cov; o += TILE)
+      if ((long)((nb + G - 1) / G) * ((NP - o) / TILE) >= tail_threshold) gen_cov = false;      // a wide-tile update would be used
     auto issue = [&]() {
       HIPCK(hipMemsetAsync(dInfo, 0, B * sizeof(int), stream));
-      launch_cov_build(v, stream);
+      launch_cov_build(v, stream, gen_cov ? TILE : 0);
       HIPCK(hipEventRecord(evReady, stream));
       std::vector<BatchView> gv(G, v);
       std::vector<hipStream_t> gs(G, stream);
@@ -389,8 +398,7 @@ void Engine::factorize(const std::vector<int>& ids, std::vector<int>& info) {
               }
               // both 64-wide halves of the block column in one launch (measured 7.56 -> 6.84 ms: the partially
               // filled last round of workgroups is paid once instead of twice)
-              static const bool pair = [] { const char* e = getenv("MOGP_PAIR"); return !e || e[0] != '0'; }();
-              if (pair) launch_update_narrow_pair(gv[g], o, 0, o, gs[g]);
+              if (pair) launch_update_narrow_pair(gv[g], o, 0, o, gs[g], gen_cov);
               else {
                 launch_update_narrow(gv[g], o, 0, o, gs[g]);
                 launch_update_narrow(gv[g], o + NBI, 0, o, gs[g]);

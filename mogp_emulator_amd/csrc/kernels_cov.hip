@@ -14,36 +14,13 @@
 // every staged coordinate is reused 4 times from registers and K rows are written as 32-byte
 // pieces of full 512-byte row segments.  exp(theta_d) is precomputed once per emulator on the
 // host (parameter block P), not per pair as in the reference.
+#include <algorithm>
 #include "launch.h"
+#include "cov_dev.h"
 
 namespace mogp {
 
 __device__ __forceinline__ int slot_emu2(const int* idx, int z) { return idx ? idx[z] : z; }
-
-template <int KT>
-__device__ __forceinline__ double kern_val(double r2) {
-  if (KT == 0) return exp(-0.5 * r2);
-  const double s = sqrt(5.0 * r2);
-  return (1.0 + s + (5.0 / 3.0) * r2) * exp(-s);
-}
-// dk/d(r2)
-template <int KT>
-__device__ __forceinline__ double kern_dr2(double r2) {
-  if (KT == 0) return -0.5 * exp(-0.5 * r2);
-  const double s = sqrt(5.0 * r2);
-  return -(5.0 / 6.0) * (1.0 + s) * exp(-s);
-}
-
-// stage rows [r0, r0+64) of Xg (nrows, D) into sx[d*64 + r]; rows >= nrows are zero filled
-__device__ __forceinline__ void stage_rows(const double* __restrict__ Xg, int nrows, int D, int r0, double* sx) {
-  const int cnt = 64 * D;
-  const int avail = max(0, min(64, nrows - r0)) * D;
-  const double* src = Xg + (size_t)r0 * D;
-  for (int e = threadIdx.x; e < cnt; e += 256) {
-    const int r = e / D, d = e - r * D;
-    sx[d * 64 + r] = (e < avail) ? src[e] : 0.0;
-  }
-}
 
 // r2 for the thread's 4x4 micro tile (rows 4*ty.., cols 4*tx..)
 __device__ __forceinline__ void micro_r2(const double* si, const double* sj, const double* __restrict__ P, int D, int ty, int tx,
@@ -126,15 +103,23 @@ __device__ __forceinline__ void micro_k(const double* si, const double* sj, cons
 // fused on the diagonal, the targets laid into row n and identity padding beyond.
 // ---------------------------------------------------------------------------------------------
 template <int KT>
-__global__ __launch_bounds__(256) void cov_build_kernel(BatchView v, int nt) {
+__global__ __launch_bounds__(256) void cov_build_kernel(BatchView v, int nt, int ncol) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int z = blockIdx.y;
   const int emu = slot_emu2(v.idx, z);
   int tile = blockIdx.x;
-  int ti = (int)((sqrt(8.0 * tile + 1.0) - 1.0) * 0.5);
-  while (ti * (ti + 1) / 2 > tile) --ti;
-  while ((ti + 1) * (ti + 2) / 2 <= tile) ++ti;
-  const int tj = tile - ti * (ti + 1) / 2;
+  int ti, tj;
+  if (ncol > 0) {
+    // only the first ncol tile columns: tile = tj * nt + ti, lower part (ti >= tj)
+    tj = tile / nt;
+    ti = tile % nt;
+    if (ti < tj) return;
+  } else {
+    ti = (int)((sqrt(8.0 * tile + 1.0) - 1.0) * 0.5);
+    while (ti * (ti + 1) / 2 > tile) --ti;
+    while ((ti + 1) * (ti + 2) / 2 <= tile) ++ti;
+    tj = tile - ti * (ti + 1) / 2;
+  }
   const int i0 = ti * 64, j0 = tj * 64;
   const int n = v.n, D = v.D, ld = v.LD;
   const double* P = v.P + (size_t)emu * v.PS;
@@ -156,19 +141,7 @@ __global__ __launch_bounds__(256) void cov_build_kernel(BatchView v, int nt) {
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
       const int j = j0 + 4 * tx + b;
-      const int hi = max(i, j), lo = min(i, j);
-      double x;
-      if (hi < n) {
-        x = sig2 * kv[a][b];
-        if (i == j) x += nug;
-      } else if (hi < n + v.R) {
-        // right-hand-side rows: row n = targets, rows n+1.. = design-matrix columns of the analytic mean
-        if (lo < n) x = (hi == n) ? T[lo] : v.H[(size_t)(hi - n - 1) * n + lo];
-        else x = (lo == hi) ? PAD_BIG : 0.0;
-      } else {
-        x = (i == j) ? 1.0 : 0.0;
-      }
-      out[b] = x;
+      out[b] = cov_entry(v, T, i, j, sig2 * kv[a][b], nug);
     }
     double* p = A + (size_t)i * ld + j0 + 4 * tx;
     *reinterpret_cast<double2*>(p) = make_double2(out[0], out[1]);
@@ -491,16 +464,18 @@ __global__ __launch_bounds__(256) void grad_finish_kernel(BatchView v, int ntile
     if ((kt) == 0) { CALL(0); } else if ((kt) == 1) { CALL(1); } else { CALL(2); } \
   } while (0)
 
-void launch_cov_build(const BatchView& v, hipStream_t s) {
+void launch_cov_build(const BatchView& v, hipStream_t s, int first_cols) {
   const int nt = v.NP / 64;
-  const int ntiles = nt * (nt + 1) / 2;
+  const int ncol = std::min(nt, first_cols / 64);
+  const int ntiles = ncol > 0 ? ncol * nt : nt * (nt + 1) / 2;
   const size_t sm = (size_t)128 * v.D * sizeof(double);
   prof_begin("cov_build", s);
-#define CALL(K) hipLaunchKernelGGL((cov_build_kernel<K>), dim3(ntiles, v.nb), dim3(256), sm, s, v, nt)
+#define CALL(K) hipLaunchKernelGGL((cov_build_kernel<K>), dim3(ntiles, v.nb), dim3(256), sm, s, v, nt, ncol)
   KT_DISPATCH(v.kernel_type, CALL);
 #undef CALL
   // algorithmic bytes: lower triangle written once (4 n^2) + X read once per emulator
-  prof_end("cov_build", s, 0., (double)v.nb * (4.0 * v.NP * (double)v.NP + 8.0 * v.n * v.D));
+  const double cols = ncol > 0 ? 64.0 * ncol : 0.5 * v.NP;
+  prof_end("cov_build", s, 0., (double)v.nb * (8.0 * cols * (double)v.NP + 8.0 * v.n * v.D));
 }
 
 // prior covariance of the test points for every slot: out (nb, m, m) = sigma^2 k(Xs, Xs)

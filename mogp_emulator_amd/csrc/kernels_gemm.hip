@@ -24,6 +24,7 @@
 #include "launch.h"
 #include "potf2_dev.h"
 #include "trsm_dev.h"
+#include "cov_dev.h"
 
 namespace mogp {
 
@@ -170,7 +171,10 @@ __device__ __forceinline__ void decode_block(int nb, int ntiles, int& z, int& ti
 //   TRI = true : lower-triangular tile set over rows/cols [c0, NP)  (WT = 4)
 //   TRI = false: single tile column [c0, c0+BM), rows [c0, NP)     (WT = 2, "narrow" update)
 // ---------------------------------------------------------------------------------------------
-template <int WT, bool TRI, bool FUSE>
+// KF >= 0: the tile is touched for the first time by this launch (left-looking long-K pass, k0 = 0), so its covariance
+// entries are generated here (kernel type KF, same arithmetic as cov_build_kernel) instead of being written by the K
+// build and read back: C = K(x_i, x_j) - acc.  Saves the K write and the C read of everything but the first block column.
+template <int WT, bool TRI, bool FUSE, int KF = -1>
 __global__ __launch_bounds__(256, (FUSE ? 3 : 2)) void update_kernel(BatchView v, int c0, int k0, int k1, int nt, int ntiles, int* __restrict__ info,
                                                         double* __restrict__ Lpack) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -201,6 +205,23 @@ __global__ __launch_bounds__(256, (FUSE ? 3 : 2)) void update_kernel(BatchView v
   gemm_mainloop<WT, true, true>(A + (size_t)i0 * ld + k0, ld, A + (size_t)j0 * ld + k0, ld, (k1 - k0) / BK, acc, smem);
   // FUSE (64x64 tiles only): the workgroup that owns the diagonal tile keeps its updated block in LDS
   // and one of its waves factors it right away (potf2), hidden under the rest of this launch.
+  if (KF >= 0) {
+    const int n = v.n, D = v.D;
+    double* si = smem;
+    double* sj = smem + 64 * D;
+    stage_rows(v.X, n, D, i0, si);                 // the main loop ended on a barrier: smem is free
+    stage_rows(v.X, n, D, j0, sj);
+    __syncthreads();
+    const double* P = v.P + (size_t)emu * v.PS;
+    const double* T = v.T + (size_t)emu * n;
+    const double sig2 = P[D], nug = P[D + 1];
+    for_each_acc<WT>(acc, [&](int r, int c, double x) {
+      const int i = i0 + r, j = j0 + c;
+      const double sk = (i < n && j < n) ? sig2 * pair_kval<(KF < 0 ? 0 : KF)>(si, sj, P, D, r, c) : 0.0;
+      A[(size_t)i * ld + j] = cov_entry(v, T, i, j, sk, nug) - x;
+    });
+    return;
+  }
   const bool fuse_tile = FUSE && WT == 2 && tile == 0;
   for_each_acc<WT>(acc, [&](int r, int c, double x) {
     double* p = A + (size_t)(i0 + r) * ld + (j0 + c);
@@ -683,12 +704,19 @@ void launch_update_narrow(const BatchView& v, int c0, int k0, int k1, hipStream_
 
 // two adjacent 64-wide block columns [c0, c0+128) in ONE launch (2 nt - 1 lower tiles): twice the workgroups per
 // launch, so the last partially filled round of workgroups costs half as much as with two launches
-void launch_update_narrow_pair(const BatchView& v, int c0, int k0, int k1, hipStream_t s) {
+void launch_update_narrow_pair(const BatchView& v, int c0, int k0, int k1, hipStream_t s, bool generate_cov) {
   const int nt = (v.NP - c0) / 64;
   if (nt <= 0) return;
   const int ntiles = std::max(1, 2 * nt - 1);
-  hipLaunchKernelGGL((update_kernel<2, false, false>), dim3(padded_grid(v.nb, ntiles)), dim3(256), smem_bytes<2>(), s, v, c0, k0, k1, nt, ntiles,
-                     (int*)nullptr, (double*)nullptr);
+  const dim3 grid(padded_grid(v.nb, ntiles));
+  if (generate_cov) {
+    const size_t sm = std::max(smem_bytes<2>(), (size_t)128 * v.D * sizeof(double));
+    if (v.kernel_type == 0) hipLaunchKernelGGL((update_kernel<2, false, false, 0>), grid, dim3(256), sm, s, v, c0, k0, k1, nt, ntiles, (int*)nullptr, (double*)nullptr);
+    else if (v.kernel_type == 1) hipLaunchKernelGGL((update_kernel<2, false, false, 1>), grid, dim3(256), sm, s, v, c0, k0, k1, nt, ntiles, (int*)nullptr, (double*)nullptr);
+    else hipLaunchKernelGGL((update_kernel<2, false, false, 2>), grid, dim3(256), sm, s, v, c0, k0, k1, nt, ntiles, (int*)nullptr, (double*)nullptr);
+    return;
+  }
+  hipLaunchKernelGGL((update_kernel<2, false, false>), grid, dim3(256), smem_bytes<2>(), s, v, c0, k0, k1, nt, ntiles, (int*)nullptr, (double*)nullptr);
 }
 
 // 64-wide block-column update whose diagonal-tile workgroup also factors the 64x64 block at (c0, c0)
