@@ -281,7 +281,9 @@ static void update_column_block(const BatchView& v, int c, int k0, int k1, hipSt
 }
 
 void Engine::panel(const BatchView& v, int o, int w, hipStream_t st) {
-  static const bool p128 = [] { const char* e = getenv("MOGP_P128"); return e && e[0] == '1'; }();
+  // 128 x 128 diagonal block + 128-wide panel solve in two launches (default); MOGP_P128=0: the recursive 64-wide chain
+  // potf2 -> trsm -> 64-wide update -> potf2 -> trsm (five launches, the 64-wide update is a memory-bound pass at ~20 TF)
+  static const bool p128 = [] { const char* e = getenv("MOGP_P128"); return !e || e[0] != '0'; }();
   if (w == TILE && p128) {
     launch_panel128(v, o, dInfo, dLpack, st);
     return;

@@ -320,8 +320,9 @@ __global__ __launch_bounds__(256, 2) void potf2_128_kernel(BatchView v, int c0, 
 }
 
 __global__ __launch_bounds__(256) void trsm128_kernel(BatchView v, int c0, int r0, const double* __restrict__ Lpack128) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
   const int emu = slot_to_emu(v.idx, blockIdx.y);
-  trsm128_dev(v, c0, r0, Lpack128 + (size_t)emu * PACK128_STRIDE, emu, blockIdx.x);
+  trsm128_dev(v, c0, r0, Lpack128 + (size_t)emu * PACK128_STRIDE, emu, blockIdx.x, smem);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -815,7 +816,8 @@ void launch_panel128(const BatchView& v, int c0, int* info, double* Lpack128, hi
   const size_t sm = std::max(smem_bytes<2>(), (size_t)POTF2B_LDS_DOUBLES * sizeof(double));
   hipLaunchKernelGGL(potf2_128_kernel, dim3(v.nb), dim3(256), sm, s, v, c0, info, Lpack128);
   const int rows = v.NP - c0 - 128;
-  if (rows > 0) hipLaunchKernelGGL(trsm128_kernel, dim3(rows / 64, v.nb), dim3(256), 0, s, v, c0, c0 + 128, (const double*)Lpack128);
+  if (rows > 0)
+    hipLaunchKernelGGL(trsm128_kernel, dim3(rows / 64, v.nb), dim3(256), 4 * TRSM128_STAGE * sizeof(double), s, v, c0, c0 + 128, (const double*)Lpack128);
 }
 
 void launch_fused_step(const BatchView& v, const FusedArgs& fa, int total_wgs, int* info, double* Lpack, hipStream_t s) {

@@ -93,17 +93,27 @@ __device__ __forceinline__ double pack128_L(const double* __restrict__ pk, int b
   return pk[2 * PACK_STRIDE + (16 * bc + k) * 64 + 16 * (br - 4) + i];
 }
 
-__device__ __forceinline__ void trsm128_dev(const BatchView& v, int c0, int r0, const double* __restrict__ pk, int emu, int rowblock) {
+constexpr int TRSM128_STAGE = 16 * 130;      // wave-private slab of 16 rows x 128 columns, row stride 130 (conflict free)
+
+__device__ __forceinline__ void trsm128_dev(const BatchView& v, int c0, int r0, const double* __restrict__ pk, int emu, int rowblock,
+                                            double* stage) {
   const int ld = v.LD;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int g = lane >> 4, i = lane & 15;
-  const int row = r0 + rowblock * 64 + wave * 16 + i;
-  double* arow = v.A + (size_t)emu * v.MS + (size_t)row * ld + c0;
+  double* slab = v.A + (size_t)emu * v.MS + (size_t)(r0 + rowblock * 64 + wave * 16) * ld + c0;   // 16 rows x 128 columns
+  stage += wave * TRSM128_STAGE;
+  // full 1 KB rows in, 16 bytes per lane (see trsm_mfma_pk)
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const int c = lane + 64 * q, rl = c >> 6, ch = c & 63;
+    *reinterpret_cast<v2d_p*>(stage + rl * 130 + 2 * ch) = *reinterpret_cast<const v2d_p*>(slab + (size_t)rl * ld + 2 * ch);
+  }
+  __builtin_amdgcn_wave_barrier();
   v4d_t T[8], X[8];
 #pragma unroll
   for (int b = 0; b < 8; ++b)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) T[b][r] = arow[16 * b + g + 4 * r];
+    for (int r = 0; r < 4; ++r) T[b][r] = stage[i * 130 + 16 * b + g + 4 * r];
 #pragma unroll
   for (int b = 0; b < 8; ++b) {
 #pragma unroll
@@ -115,7 +125,13 @@ __device__ __forceinline__ void trsm128_dev(const BatchView& v, int c0, int r0, 
 #pragma unroll
     for (int r = 0; r < 4; ++r) X[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(inv[(g + 4 * r) * 16 + i], T[b][r], X[b], 0, 0, 0);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) arow[16 * b + g + 4 * r] = X[b][r];
+    for (int r = 0; r < 4; ++r) stage[i * 130 + 16 * b + g + 4 * r] = X[b][r];
+  }
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const int c = lane + 64 * q, rl = c >> 6, ch = c & 63;
+    *reinterpret_cast<v2d_p*>(slab + (size_t)rl * ld + 2 * ch) = *reinterpret_cast<const v2d_p*>(stage + rl * 130 + 2 * ch);
   }
 }
 
