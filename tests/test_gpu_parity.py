@@ -505,6 +505,44 @@ def test_c4_shaped_matern_fit_nugget_identities():
         assert_allclose(g[:, p], (fp - fm) / (2 * h), rtol=2e-5, atol=1e-4)
 
 
+def test_c4_full_size_vs_oracle():
+    # C4 at BASELINE size (n = 5000, d = 20, Matern-5/2, fitted nugget), two of the 16 outputs against the oracle with a
+    # row-chunked distance build (the faithful (n, n, d) temporary would be 4 GB; per-entry arithmetic is unchanged)
+    n, d, B = 5000, 20, 2
+    X, T, Xs = synth(4, n, d, B, 200)
+    theta = np.array([-2. * np.log(0.3 * np.sqrt(d))] * d + [0., np.log(1e-4)])
+    mo = M.MultiOutputGP_GPU(X, T, kernel="Matern52", nugget="fit", priors=weak(d, "fit"))
+    f, _, ok = mo._mogp_gpu.eval(np.tile(theta, (B, 1)), grad=False)
+    assert ok.all()
+    mo.fit(np.tile(theta, (B, 1)))
+    mean, unc, _ = mo.predict(Xs, deriv=False)
+    for k in range(B):
+        ref = R.GPRef(X, T[k], kernel="Matern52", nugget="fit", chunk_rows=256)
+        assert_allclose(f[k], ref.fit(theta), rtol=1e-10)
+        rmu, rvar, _ = ref.predict(Xs)
+        assert_allclose(mean[k], rmu, rtol=1e-7, atol=1e-9)
+        assert_allclose(unc[k], rvar, atol=1e-7)
+        assert_allclose(mo.emulators[k].Kinv_t, ref.Kinv_t, rtol=1e-7, atol=1e-7 * np.abs(ref.Kinv_t).max())
+
+
+def test_c5_full_size_vs_oracle():
+    # C5 at BASELINE size (one emulator, n = 16000, d = 8): log-posterior, K^-1 t and predictions against the oracle
+    # (LAPACK dpotrf on the host, distance build in row chunks).  cond(K + 1e-6 I) ~ 1e8: logpost rtol 1e-9.
+    n, d = 16000, 8
+    X, T, Xs = synth(5, n, d, 1, 64)
+    theta = np.array([-2. * np.log(0.3 * np.sqrt(d))] * d + [0.])
+    gp = make_gp(X, T[0], "SquaredExponential", 1e-6)
+    lp = gp.logposterior(theta)
+    gp.fit(theta)
+    mean, unc, _ = gp.predict(Xs, deriv=False)
+    ref = R.GPRef(X, T[0], nugget=1e-6, chunk_rows=128)
+    assert_allclose(lp, ref.fit(theta), rtol=1e-9)
+    rmu, rvar, _ = ref.predict(Xs)
+    assert_allclose(mean, rmu, rtol=1e-6, atol=1e-7)
+    assert_allclose(unc, rvar, atol=1e-7)
+    assert_allclose(gp.Kinv_t, ref.Kinv_t, rtol=1e-5, atol=1e-5 * np.abs(ref.Kinv_t).max())
+
+
 def test_sharded_wrapper_on_one_gpu():
     # dist.ShardedMultiOutputGP with the real per-rank model (world size 1: no process group needed)
     from mogp_emulator_amd.dist import ShardedMultiOutputGP
