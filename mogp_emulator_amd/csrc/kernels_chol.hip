@@ -304,6 +304,42 @@ __global__ __launch_bounds__(BSG_THREADS) void backsolve_gemv_kernel(BatchView v
     }
 }
 
+// single right-hand side, 256 threads: the 64 rows of the block are split over the four waves (16 loads in flight per
+// thread instead of two batches of 32), partial sums are combined in a fixed order through LDS
+__global__ __launch_bounds__(256) void backsolve_gemv4_kernel(BatchView v, int k0) {
+  __shared__ double ab[64];
+  __shared__ v2d part[3][64];
+  const int emu = slot_emu(v.idx, blockIdx.y);
+  const int ld = v.LD;
+  const double* A = v.A + (size_t)emu * v.MS;
+  double* w = v.Z + (size_t)emu * ld;
+  const int lane = threadIdx.x & 63, rg = threadIdx.x >> 6;
+  if (threadIdx.x < 64) ab[threadIdx.x] = w[k0 + threadIdx.x];
+  __syncthreads();
+  const int c = 2 * (blockIdx.x * 64 + lane);
+  v2d s = {0., 0.};
+  if (c < k0) {
+    const double* p = A + (size_t)(k0 + 16 * rg) * ld + c;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const v2d x = *reinterpret_cast<const v2d*>(p + (size_t)i * ld);
+      const double ar = ab[16 * rg + i];
+      s[0] = __builtin_fma(x[0], ar, s[0]);
+      s[1] = __builtin_fma(x[1], ar, s[1]);
+    }
+  }
+  if (rg > 0) part[rg - 1][lane] = s;
+  __syncthreads();
+  if (rg == 0 && c < k0) {
+    s += part[0][lane];
+    s += part[1][lane];
+    s += part[2][lane];
+    v2d cur = *reinterpret_cast<v2d*>(w + c);
+    cur -= s;
+    *reinterpret_cast<v2d*>(w + c) = cur;
+  }
+}
+
 // alpha[c] = sum_r M[emu][c][r] Z[r]  (R > 1: Kinv_t_mean and the rank-correction rows from the raw solves)
 __global__ __launch_bounds__(256) void combine_rows_kernel(BatchView v, const double* __restrict__ M) {
   const int emu = slot_emu(v.idx, blockIdx.y);
@@ -501,7 +537,9 @@ void launch_backsolve(const BatchView& v, hipStream_t s) {
     hipLaunchKernelGGL(backsolve_diag_kernel, dim3(v.nb), dim3(64), 0, s, v, k0);
     if (k0 > 0) {
       const dim3 grid((k0 / 2 + BSG_THREADS - 1) / BSG_THREADS, v.nb);
-      if (v.R == 1) hipLaunchKernelGGL(backsolve_gemv_kernel<1>, grid, dim3(BSG_THREADS), 0, s, v, k0);
+      static const bool four = [] { const char* e = getenv("MOGP_BSGEMV"); return !e || atoi(e) != 1; }();   // 1: one-wave gemv
+      if (v.R == 1 && four) hipLaunchKernelGGL(backsolve_gemv4_kernel, grid, dim3(256), 0, s, v, k0);
+      else if (v.R == 1) hipLaunchKernelGGL(backsolve_gemv_kernel<1>, grid, dim3(BSG_THREADS), 0, s, v, k0);
       else hipLaunchKernelGGL(backsolve_gemv_kernel<RMAX>, grid, dim3(BSG_THREADS), 0, s, v, k0);
     }
   }
