@@ -241,6 +241,28 @@ __global__ __launch_bounds__(256) void backsolve_init_kernel(BatchView v) {
     v.Z[((size_t)emu * R + r) * ld + i] = (i < n) ? v.A[(size_t)emu * v.MS + (size_t)(n + r) * ld + i] : 0.0;
 }
 
+// one wave: x = L_kk^-T w[k0 .. k0+64) for a single right-hand side (lane t holds column t of L_kk)
+__device__ __forceinline__ void backsolve_diag1_wave(const BatchView& v, int emu, int k0) {
+  const int ld = v.LD, n = v.n;
+  const double* A = v.A + (size_t)emu * v.MS;
+  const int t = threadIdx.x & 63;
+  double u[64];
+#pragma unroll
+  for (int j = 0; j < 64; ++j) u[j] = A[(size_t)(k0 + j) * ld + k0 + t];
+  const double rdg = 1.0 / A[(size_t)(k0 + t) * ld + k0 + t];
+  double* w = v.Z + (size_t)emu * ld;
+  double b = w[k0 + t];
+  double xout = 0.0;
+#pragma unroll
+  for (int j = 63; j >= 0; --j) {
+    double xj = readlane_f64(b * rdg, j);
+    if (k0 + j >= n) xj = 0.0;
+    if (t == j) xout = xj;
+    b = __builtin_fma(-u[j], xj, b);
+  }
+  w[k0 + t] = xout;
+}
+
 __global__ __launch_bounds__(64) void backsolve_diag_kernel(BatchView v, int k0) {
   const int emu = slot_emu(v.idx, blockIdx.x);
   const int ld = v.LD, n = v.n, R = v.R;
@@ -306,6 +328,9 @@ __global__ __launch_bounds__(BSG_THREADS) void backsolve_gemv_kernel(BatchView v
 
 // single right-hand side, 256 threads: the 64 rows of the block are split over the four waves (16 loads in flight per
 // thread instead of two batches of 32), partial sums are combined in a fixed order through LDS
+// FUSE_DIAG: the workgroup that owns the columns of the NEXT diagonal block [k0-64, k0) finishes them here and solves that
+// block right away (one wave), so the separate diagonal-solve launch of the next step disappears
+template <bool FUSE_DIAG>
 __global__ __launch_bounds__(256) void backsolve_gemv4_kernel(BatchView v, int k0) {
   __shared__ double ab[64];
   __shared__ v2d part[3][64];
@@ -337,6 +362,10 @@ __global__ __launch_bounds__(256) void backsolve_gemv4_kernel(BatchView v, int k
     v2d cur = *reinterpret_cast<v2d*>(w + c);
     cur -= s;
     *reinterpret_cast<v2d*>(w + c) = cur;
+  }
+  if (FUSE_DIAG && (int)blockIdx.x == (k0 - 64) / 128) {      // workgroup-uniform
+    __syncthreads();
+    if (threadIdx.x < 64) backsolve_diag1_wave(v, emu, k0 - 64);
   }
 }
 
@@ -532,13 +561,16 @@ void launch_backsolve(const BatchView& v, hipStream_t s) {
   }
   hipLaunchKernelGGL(backsolve_init_kernel, dim3((v.NP + 255) / 256, v.nb), dim3(256), 0, s, v);
   const int nblk = (v.n + 63) / 64;
+  // MOGP_BSGEMV: 1 one-wave gemv, 4 four-wave gemv, default (5) four-wave gemv that also solves the next diagonal block
+  static const int bsg = [] { const char* e = getenv("MOGP_BSGEMV"); return e ? atoi(e) : 5; }();
   for (int kb = nblk - 1; kb >= 0; --kb) {
     const int k0 = kb * 64;
-    hipLaunchKernelGGL(backsolve_diag_kernel, dim3(v.nb), dim3(64), 0, s, v, k0);
+    const bool fused = v.R == 1 && bsg == 5;
+    if (!fused || kb == nblk - 1) hipLaunchKernelGGL(backsolve_diag_kernel, dim3(v.nb), dim3(64), 0, s, v, k0);
     if (k0 > 0) {
       const dim3 grid((k0 / 2 + BSG_THREADS - 1) / BSG_THREADS, v.nb);
-      static const bool four = [] { const char* e = getenv("MOGP_BSGEMV"); return !e || atoi(e) != 1; }();   // 1: one-wave gemv
-      if (v.R == 1 && four) hipLaunchKernelGGL(backsolve_gemv4_kernel, grid, dim3(256), 0, s, v, k0);
+      if (fused) hipLaunchKernelGGL(backsolve_gemv4_kernel<true>, grid, dim3(256), 0, s, v, k0);
+      else if (v.R == 1 && bsg == 4) hipLaunchKernelGGL(backsolve_gemv4_kernel<false>, grid, dim3(256), 0, s, v, k0);
       else if (v.R == 1) hipLaunchKernelGGL(backsolve_gemv_kernel<1>, grid, dim3(BSG_THREADS), 0, s, v, k0);
       else hipLaunchKernelGGL(backsolve_gemv_kernel<RMAX>, grid, dim3(BSG_THREADS), 0, s, v, k0);
     }
