@@ -92,6 +92,8 @@ class Engine {
 
   // multi-start MAP fit of emulators `ids` in lock-step (fitting.hpp:61-128)
   void fit_map(const std::vector<int>& ids, int n_tries, const double* theta0, int theta0_len);
+  void run_starts(const std::vector<int>& ids, const std::vector<std::vector<double>>& x0, std::vector<double>& f_out,
+                  std::vector<std::vector<double>>& x_out);
 
   hipStream_t stream = nullptr;      // main stream: covariance build, trailing updates, everything else
   hipStream_t pstream = nullptr;     // look-ahead stream: panel factorisations

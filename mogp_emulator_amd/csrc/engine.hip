@@ -1248,29 +1248,21 @@ struct Lbfgs {
 };
 }  // namespace
 
-void Engine::fit_map(const std::vector<int>& ids_in, int n_tries, const double* theta0, int theta0_len) {
+// One L-BFGS run per listed emulator from the given starting points, all in lock-step (every round is one batched
+// objective + gradient evaluation of the emulators still active).  f_out[e] = +inf and x_out[e] empty for a failed run.
+void Engine::run_starts(const std::vector<int>& ids, const std::vector<std::vector<double>>& x0, std::vector<double>& f_out,
+                        std::vector<std::vector<double>>& x_out) {
   const FitOptions& opt = fit_options();
-  std::vector<int> ids(ids_in);
-  if (ids.empty()) return;
-  if (n_tries < 1) throw std::runtime_error("number of attempts must be positive");
-  for (int i : ids)
-    if (theta0_len > 0 && theta0_len != n_theta(i)) throw std::runtime_error("length of theta0 must equal n_params of GP.");
   const int ne = (int)ids.size();
-  std::vector<double> best_f(ne, std::numeric_limits<double>::infinity());
-  std::vector<std::vector<double>> best_x(ne);
-
-  for (int start = 0; start < n_tries; ++start) {
+  f_out.assign(ne, std::numeric_limits<double>::infinity());
+  x_out.assign(ne, {});
+  {
     std::vector<Lbfgs> st(ne);
     for (int e = 0; e < ne; ++e) {
       Lbfgs& s = st[e];
       s.np = n_theta(ids[e]);
-      s.x.resize(s.np); s.g.resize(s.np); s.d.resize(s.np); s.xt.resize(s.np); s.gt.resize(s.np);
-      if (start == 0 && theta0_len > 0) s.x.assign(theta0, theta0 + theta0_len);
-      else {
-        const int nm = n_mean();
-        for (int k = 0; k < nm; ++k) s.x[k] = 0.;
-        gp[ids[e]].pri.sample(rng, NC, gp[ids[e]].nug_type, s.x.data() + nm);
-      }
+      s.g.resize(s.np); s.d.resize(s.np); s.gt.resize(s.np);
+      s.x = x0[e];
       s.xt = s.x;
     }
     for (int round = 0; round < opt.max_iter * 25; ++round) {
@@ -1367,10 +1359,96 @@ void Engine::fit_map(const std::vector<int>& ids_in, int n_tries, const double* 
     for (int e = 0; e < ne; ++e) {
       const Lbfgs& s = st[e];
       if (s.state == Lbfgs::FAILED || s.state == Lbfgs::NEED_F0) continue;
-      if (std::isfinite(s.f) && s.f < best_f[e]) {
-        best_f[e] = s.f;
-        best_x[e] = s.x;
+      if (std::isfinite(s.f)) {
+        f_out[e] = s.f;
+        x_out[e] = s.x;
       }
+    }
+  }
+}
+
+// Multi-start MAP fit (fitting.hpp:61-128, fitting.py:219-266): n_tries L-BFGS runs per emulator, the best end point wins.
+// The starts of an emulator are independent, so as many of them as fit into device memory run CONCURRENTLY on a replica
+// engine (emulator e, start s -> replica e * chunk + s: same inputs, targets, priors): small problems, whose batches do
+// not fill the GPU, then cost about one start instead of n_tries (MOGP_PARALLEL_STARTS=0: one start after the other).
+void Engine::fit_map(const std::vector<int>& ids_in, int n_tries, const double* theta0, int theta0_len) {
+  std::vector<int> ids(ids_in);
+  if (ids.empty()) return;
+  if (n_tries < 1) throw std::runtime_error("number of attempts must be positive");
+  for (int i : ids)
+    if (theta0_len > 0 && theta0_len != n_theta(i)) throw std::runtime_error("length of theta0 must equal n_params of GP.");
+  const int ne = (int)ids.size();
+  // starting points: start 0 = theta0 if given, everything else drawn from the priors (Priors.py:394-418)
+  std::vector<std::vector<std::vector<double>>> x0(n_tries, std::vector<std::vector<double>>(ne));
+  for (int s = 0; s < n_tries; ++s)
+    for (int e = 0; e < ne; ++e) {
+      std::vector<double>& x = x0[s][e];
+      x.assign(n_theta(ids[e]), 0.);
+      if (s == 0 && theta0_len > 0) x.assign(theta0, theta0 + theta0_len);
+      else gp[ids[e]].pri.sample(rng, NC, gp[ids[e]].nug_type, x.data() + n_mean());
+    }
+  std::vector<double> best_f(ne, std::numeric_limits<double>::infinity());
+  std::vector<std::vector<double>> best_x(ne);
+  auto keep_best = [&](int e, double f, const std::vector<double>& x) {
+    if (!x.empty() && std::isfinite(f) && f < best_f[e]) {
+      best_f[e] = f;
+      best_x[e] = x;
+    }
+  };
+  // how many starts fit beside this engine: A, L^-1, K^-1 per replica emulator plus the small per-emulator buffers
+  static const bool parallel_starts = [] { const char* e = getenv("MOGP_PARALLEL_STARTS"); return !e || e[0] != '0'; }();
+  int chunk = 1;
+  if (parallel_starts && n_tries > 1) {
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+      const double per_emu = 3.0 * (double)MS * sizeof(double) + 16.0 * LD * sizeof(double);
+      const double fit = 0.5 * (double)free_b / (per_emu * ne);
+      chunk = (int)std::max(1.0, std::min((double)n_tries, std::floor(fit)));
+    }
+  }
+  if (chunk <= 1) {
+    std::vector<double> f;
+    std::vector<std::vector<double>> x;
+    for (int s = 0; s < n_tries; ++s) {
+      run_starts(ids, x0[s], f, x);
+      for (int e = 0; e < ne; ++e) keep_best(e, f[e], x[e]);
+    }
+  } else {
+    for (int s0 = 0; s0 < n_tries; s0 += chunk) {
+      const int c = std::min(chunk, n_tries - s0);
+      if (c == 1) {
+        std::vector<double> f;
+        std::vector<std::vector<double>> x;
+        run_starts(ids, x0[s0], f, x);
+        for (int e = 0; e < ne; ++e) keep_best(e, f[e], x[e]);
+        continue;
+      }
+      // replica engine: c copies of every listed emulator
+      std::vector<double> targets((size_t)ne * c * n);
+      for (int e = 0; e < ne; ++e)
+        for (int s = 0; s < c; ++s)
+          std::copy(hT.begin() + (size_t)ids[e] * n, hT.begin() + (size_t)(ids[e] + 1) * n, targets.begin() + ((size_t)e * c + s) * n);
+      Engine rep(hX.data(), n, D, targets.data(), ne * c, testing_size, mean, kernel_type, gp[ids[0]].nug_type, gp[ids[0]].nug_size, analytic);
+      std::vector<int> rids(ne * c);
+      std::vector<std::vector<double>> rx0(ne * c);
+      for (int e = 0; e < ne; ++e)
+        for (int s = 0; s < c; ++s) {
+          const int r = e * c + s;
+          const GPState& src = gp[ids[e]];
+          GPState& dst = rep.gp[r];
+          dst.nug_type = src.nug_type;
+          dst.nug_size = src.nug_size;
+          dst.pri = src.pri;
+          dst.mp_b = src.mp_b; dst.mp_Binv = src.mp_Binv; dst.mp_Binvb = src.mp_Binvb; dst.mp_logdetB = src.mp_logdetB;
+          dst.data.assign(src.data.size(), 0.);
+          rids[r] = r;
+          rx0[r] = x0[s0 + s][e];
+        }
+      std::vector<double> f;
+      std::vector<std::vector<double>> x;
+      rep.run_starts(rids, rx0, f, x);
+      for (int e = 0; e < ne; ++e)
+        for (int s = 0; s < c; ++s) keep_best(e, f[e * c + s], x[e * c + s]);
     }
   }
   // refit at the best point of every emulator (fitting.hpp:115-117); failures -> "not fit" (:111-113)
