@@ -30,7 +30,8 @@ extern "C" {
 /* 2-4: kernels the reference only has on the CPU (Kernel.py:946-997); the uniform kernels have one correlation parameter */
 enum mogp_kernel_type { MOGP_SQUARED_EXPONENTIAL = 0, MOGP_MATERN52 = 1, MOGP_PRODUCT_MATERN52 = 2, MOGP_UNIFORM_SQUARED_EXPONENTIAL = 3,
                         MOGP_UNIFORM_MATERN52 = 4 };
-enum mogp_nugget_type { MOGP_NUG_ADAPTIVE = 0, MOGP_NUG_FIT = 1, MOGP_NUG_FIXED = 2 };
+/* 3: the CPU class's nugget="pivot" (GPParams.py:185-186; cholesky_factor(..., "pivot"), linalg/cholesky.py:182-184) */
+enum mogp_nugget_type { MOGP_NUG_ADAPTIVE = 0, MOGP_NUG_FIT = 1, MOGP_NUG_FIXED = 2, MOGP_NUG_PIVOT = 3 };
 enum mogp_prior_type { MOGP_PRIOR_INVGAMMA = 0, MOGP_PRIOR_GAMMA = 1, MOGP_PRIOR_LOGNORMAL = 2, MOGP_PRIOR_WEAK = 3 };
 
 typedef struct mogp_meanfunc mogp_meanfunc;   /* BaseMeanFunc   meanfunc.hpp:24-66            */
@@ -134,6 +135,12 @@ int mogp_densegp_get_K(mogp_densegp*, double* out /* n*n */);
 int mogp_densegp_get_invQ(mogp_densegp*, double* out /* n*n */);
 int mogp_densegp_get_invQt(mogp_densegp*, double* out /* n */);
 int mogp_densegp_get_cholesky_lower(mogp_densegp*, double* out /* n*n */);
+/* ChoInvPivot.P of the current fit (linalg/cholesky.py:82-104): K[P][:, P] = L L^T with L = get_cholesky_lower; the identity
+ * and rank n for the other nugget types.  rank_out may be NULL. */
+int mogp_densegp_get_pivot(mogp_densegp*, int* P_out /* n */, int* rank_out);
+/* pivot_cholesky(A), linalg/cholesky.py:284-327 (LAPACK dpstrf + the replacement diagonal of the skipped rows), for any
+ * symmetric matrix with positive diagonal: host buffers, row-major; L_out lower triangular, P_out zero-based. */
+int mogp_pivot_cholesky(const double* A, int n, double* L_out /* n*n */, int* P_out /* n */, int* rank_out);
 double mogp_densegp_get_nugget_size(const mogp_densegp*);     /* :209 */
 int mogp_densegp_set_nugget_size(mogp_densegp*, double);      /* :213 */
 int mogp_densegp_get_nugget_type(const mogp_densegp*);        /* :217 */

@@ -93,15 +93,16 @@ def parse_meanfunc_formula(formula):
 
 
 def interpret_nugget(nugget):
-    """(LibGPGPU.nugget_type, size) from ``"adaptive"`` / ``"fit"`` / non-negative number."""
+    """(LibGPGPU.nugget_type, size) from ``"adaptive"`` / ``"fit"`` / ``"pivot"`` / non-negative number (``"pivot"`` is the
+    CPU class's pivoted-Cholesky mode, GPParams.py:185-186, which the reference's GPU class does not have)."""
     if not isinstance(nugget, (str, float)):
         try:
             nugget = float(nugget)
         except TypeError:
             raise TypeError("nugget parameter must be a string or a non-negative float")
     if isinstance(nugget, str):
-        if nugget not in ("adaptive", "fit"):
-            raise ValueError("nugget must be a string set to 'adaptive', 'fit', or a float")
+        if nugget not in ("adaptive", "fit", "pivot"):
+            raise ValueError("nugget must be a string set to 'adaptive', 'fit', 'pivot', or a float")
         return getattr(LibGPGPU.nugget_type, nugget), 0.
     if nugget < 0.:
         raise ValueError("nugget parameter must be non-negative")
@@ -257,6 +258,8 @@ class GaussianProcessGPU(object):
 
     @property
     def nugget(self):
+        if self.nugget_type == "pivot":
+            return None                # GPParams.nugget, GPParams.py:444-445: no nugget with pivoting
         return self._densegp_gpu.get_nugget_size()
 
     @nugget.setter
@@ -281,6 +284,16 @@ class GaussianProcessGPU(object):
         out = np.zeros((self.n, self.n))
         self._densegp_gpu.get_cholesky_lower(out)
         return np.tril(out.T)
+
+    @property
+    def P(self):
+        """pivot order of the current fit (``Kinv.P`` of the CPU class with ``nugget="pivot"``): K[P][:, P] = L L^T"""
+        return self._densegp_gpu.get_pivot()[0]
+
+    @property
+    def pivot_rank(self):
+        """number of pivots the last pivoted factorisation accepted (n unless design points repeat)"""
+        return self._densegp_gpu.get_pivot()[1]
 
     @property
     def Kinv_t(self):
@@ -341,7 +354,7 @@ class GaussianProcessGPU(object):
             # CPU-class feature (GaussianProcess.py:899-911): (m, m) covariance, nugget on the diagonal, not clipped
             means, cov = np.zeros(m), np.zeros((m, m))
             self._densegp_gpu.predict_full_cov(testing, means, cov)
-            if include_nugget:
+            if include_nugget and self.nugget_type != "pivot":      # GaussianProcess.py:904
                 cov[np.diag_indices(m)] += self.nugget
             derivs = None
             if deriv:
@@ -362,7 +375,7 @@ class GaussianProcessGPU(object):
             if deriv:
                 self._densegp_gpu.predict_deriv(chunk, derivs[lo:lo + step])
         if unc:
-            if include_nugget:
+            if include_nugget and self.nugget_type != "pivot":      # GaussianProcess.py:915
                 variances += self.nugget
             np.maximum(variances, 0., out=variances)      # CPU oracle clips, GaussianProcess.py:918-920
         return PredictResult(mean=means, unc=variances, deriv=derivs)

@@ -39,6 +39,8 @@ class MultiOutputGP_GPU(object):
             nugtype, nugsize = LibGPGPU.nugget_type(0), 0.
         elif nugget == "fit":
             nugtype, nugsize = LibGPGPU.nugget_type(1), 0.
+        elif nugget == "pivot":
+            nugtype, nugsize = LibGPGPU.nugget_type(3), 0.
         elif isinstance(nugget, float):
             if nugget < 0.:
                 raise ValueError("nugget parameter must be non-negative")

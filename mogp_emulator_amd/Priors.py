@@ -16,7 +16,7 @@ from .libgpgpu import InvGammaPrior as _NativeInvGamma
 from .libgpgpu import LogNormalPrior as _NativeLogNormal
 from .libgpgpu import WeakPrior
 
-NUGGET_TYPES = ("fit", "adaptive", "fixed")
+NUGGET_TYPES = ("fit", "adaptive", "fixed", "pivot")
 
 
 def input_spacing(column):

@@ -87,6 +87,8 @@ SIGNATURES = {
     "mogp_densegp_get_invQ": (c_int, [c_void_p, c_double_p]),
     "mogp_densegp_get_invQt": (c_int, [c_void_p, c_double_p]),
     "mogp_densegp_get_cholesky_lower": (c_int, [c_void_p, c_double_p]),
+    "mogp_densegp_get_pivot": (c_int, [c_void_p, c_int_p, c_int_p]),
+    "mogp_pivot_cholesky": (c_int, [c_double_p, c_int, c_double_p, c_int_p, c_int_p]),
     "mogp_densegp_get_nugget_size": (c_double, [c_void_p]),
     "mogp_densegp_set_nugget_size": (c_int, [c_void_p, c_double]),
     "mogp_densegp_get_nugget_type": (c_int, [c_void_p]),

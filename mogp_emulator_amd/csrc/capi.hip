@@ -272,6 +272,10 @@ int mogp_densegp_get_K(mogp_densegp* h, double* out) { GUARD(h->eng->get_K(h->id
 int mogp_densegp_get_invQ(mogp_densegp* h, double* out) { GUARD(h->eng->get_invQ(h->idx, out)); }
 int mogp_densegp_get_invQt(mogp_densegp* h, double* out) { GUARD(h->eng->get_invQt(h->idx, out)); }
 int mogp_densegp_get_cholesky_lower(mogp_densegp* h, double* out) { GUARD(h->eng->get_chol(h->idx, out)); }
+int mogp_densegp_get_pivot(mogp_densegp* h, int* P_out, int* rank_out) { GUARD(h->eng->get_pivot(h->idx, P_out, rank_out)); }
+int mogp_pivot_cholesky(const double* A, int n, double* L_out, int* P_out, int* rank_out) {
+  GUARD(Engine::pivot_cholesky(A, n, L_out, P_out, rank_out));
+}
 double mogp_densegp_get_nugget_size(const mogp_densegp* h) { return h->eng->nugget_size(h->idx); }
 int mogp_densegp_set_nugget_size(mogp_densegp* h, double v) {
   GPState& g = h->eng->gp[h->idx];
@@ -282,7 +286,7 @@ int mogp_densegp_set_nugget_size(mogp_densegp* h, double v) {
 int mogp_densegp_get_nugget_type(const mogp_densegp* h) { return h->eng->gp[h->idx].nug_type; }
 int mogp_densegp_set_nugget_type(mogp_densegp* h, int t) {
   GUARD({
-    if (t < 0 || t > 2) throw std::runtime_error("Unrecognized nugget_type");
+    if (t < 0 || t > 3) throw std::runtime_error("Unrecognized nugget_type");
     GPState& g = h->eng->gp[h->idx];
     if (t != g.nug_type) {
       g.nug_type = t;

@@ -26,6 +26,9 @@ struct GPState {
   bool factored = false;         // A holds L (and y) for `data`
   bool linv = false, kinv = false;
   double nugget_used = 0.;       // value actually added to the diagonal in the last factorisation
+  // nugget="pivot": the factor in A, alpha, L^-1, K^-1 and this emulator's copy of the inputs are in pivoted order
+  bool permuted = false;
+  int rank = 0;                  // pivots accepted by the last pivoted factorisation (n = full rank)
   std::vector<double> beta;      // analytic mean coefficients (q), GaussianProcess.py:669-670
   std::vector<double> LA;        // q x q lower Cholesky factor of A = H^T K^-1 H + B^-1
   // informative mean priors beta ~ N(b, B) of the analytic mean (Priors.py:423-581); empty = weak
@@ -89,6 +92,10 @@ class Engine {
   void get_invQ(int i, double* out);
   void get_invQt(int i, double* out);
   void get_chol(int i, double* out);
+  // pivot order P of the last fit (A[P][:, P] = L L^T, ChoInvPivot.P); identity for the other nugget types
+  void get_pivot(int i, int* perm_out, int* rank_out);
+  // pivot_cholesky(A) of linalg/cholesky.py:284-327 for an arbitrary symmetric matrix (host buffers, row-major)
+  static void pivot_cholesky(const double* A, int n, double* L_out, int* P_out, int* rank_out);
 
   // multi-start MAP fit of emulators `ids` in lock-step (fitting.hpp:61-128)
   void fit_map(const std::vector<int>& ids, int n_tries, const double* theta0, int theta0_len);
@@ -108,6 +115,10 @@ class Engine {
   void upload_params(const std::vector<int>& ids);
   void upload_idx(const std::vector<int>& ids);
   void factorize(const std::vector<int>& ids, std::vector<int>& info);
+  void factorize_blocked(const std::vector<int>& ids, std::vector<int>& info);
+  void factorize_pivot(const std::vector<int>& ids, std::vector<int>& info);
+  void ensure_pivot_buffers();
+  void unpermute(int i, double* vec) const;          // vec (n) from pivoted to training order, in place
   void panel(const BatchView& v, int o, int w, hipStream_t st);
   void ensure_linv(const std::vector<int>& ids);
   void ensure_kinv(const std::vector<int>& ids);
@@ -120,6 +131,10 @@ class Engine {
   int *dInfo = nullptr, *dIdx = nullptr;
   double* dLpack = nullptr;
   double *dH = nullptr, *dZ = nullptr, *dM = nullptr, *dGram = nullptr;
+  // nugget="pivot": per-emulator inputs in pivot order (B*n*D), pivot order (B*n), rank (B), scratch (B*2*NP)
+  double *dXp = nullptr, *dPivWork = nullptr;
+  int *dPerm = nullptr, *dRank = nullptr;
+  std::vector<int> hPerm;
   std::vector<double> hH;        // q x n design-matrix columns      // packed transposed diagonal block + reciprocal diagonal (potf2 -> trsm)
   std::vector<double> hP;
   // predict scratch

@@ -122,7 +122,7 @@ Engine::Engine(const double* X, int n_, int D_, const double* targets, int B_, u
   if (D > MAX_D)
     throw std::runtime_error("at most " + std::to_string(MAX_D) + " input dimensions are supported by the device kernels (" +
                              std::to_string(D) + " given): the per-tile copy of the inputs must fit the 160 KB LDS");
-  if (nug_type < 0 || nug_type > 2) throw std::runtime_error("Unrecognized nugget_type");
+  if (nug_type < 0 || nug_type > 3) throw std::runtime_error("Unrecognized nugget_type");
   for (int d : mean.dims)
     if (d >= D) throw std::runtime_error("Dimension index must be less than " + std::to_string(D));
   NP = roundup(n + R, TILE);
@@ -189,7 +189,8 @@ Engine::Engine(const double* X, int n_, int D_, const double* targets, int B_, u
 Engine::~Engine() {
   for (void* p : {(void*)dX, (void*)dP, (void*)dT, (void*)dA, (void*)dLinv, (void*)dKinv, (void*)dAlpha, (void*)dLogdet, (void*)dYty,
                   (void*)dGradOut, (void*)dGradPartial, (void*)dInfo, (void*)dIdx, (void*)dXs, (void*)dKs, (void*)dMean, (void*)dVar,
-                  (void*)dVarPartial, (void*)dDeriv, (void*)dLpack, (void*)dH, (void*)dZ, (void*)dM, (void*)dGram})
+                  (void*)dVarPartial, (void*)dDeriv, (void*)dLpack, (void*)dH, (void*)dZ, (void*)dM, (void*)dGram, (void*)dXp, (void*)dPivWork,
+                  (void*)dPerm, (void*)dRank})
     if (p) hipFree(p);
   for (auto& kv : cholGraphs) hipGraphExecDestroy(kv.second);
   for (auto st : gstreams) hipStreamDestroy(st);
@@ -211,7 +212,7 @@ double Engine::nugget_size(int i) const {
 BatchView Engine::view(int nb) const {
   BatchView v;
   v.n = n; v.D = D; v.NP = NP; v.LD = LD; v.MS = MS; v.PS = PS; v.kernel_type = device_kernel();
-  v.X = dX; v.P = dP; v.T = dT; v.A = dA; v.Linv = dLinv; v.Kinv = dKinv; v.alpha = dAlpha;
+  v.X = dXp ? dXp : dX; v.XS = dXp ? (size_t)n * D : 0; v.P = dP; v.T = dT; v.A = dA; v.Linv = dLinv; v.Kinv = dKinv; v.alpha = dAlpha;
   v.idx = dIdx; v.nb = nb;
   v.R = R; v.RA = RA; v.H = dH; v.Z = (R > 1) ? dZ : dAlpha;
   return v;
@@ -307,7 +308,76 @@ void Engine::panel(const BatchView& v, int o, int w, hipStream_t st) {
 // while the main stream applies panel k to the rest of the trailing matrix (U_b).  The
 // latency-bound panel kernels (potf2 / trsm, few workgroups) thereby run underneath the MFMA
 // trailing update instead of in front of it.
+void Engine::ensure_pivot_buffers() {
+  if (dXp) return;
+  dPerm = dalloc<int>((size_t)B * n);
+  dRank = dalloc<int>(B);
+  dPivWork = dalloc<double>((size_t)B * 2 * NP);
+  hPerm.resize((size_t)B * n);
+  for (int i = 0; i < B; ++i)
+    for (int k = 0; k < n; ++k) hPerm[(size_t)i * n + k] = k;
+  double* xp = dalloc<double>((size_t)B * n * D);
+  for (int i = 0; i < B; ++i)
+    HIPCK(hipMemcpyAsync(xp + (size_t)i * n * D, dX, (size_t)n * D * sizeof(double), hipMemcpyDeviceToDevice, stream));
+  HIPCK(hipStreamSynchronize(stream));
+  dXp = xp;
+}
+
+// nugget="pivot" (cholesky_factor(K, nugget, "pivot"), linalg/cholesky.py:182-184): K without nugget, factored with
+// diagonal pivoting; afterwards the emulator's inputs are held in pivot order, so that every later kernel (prediction,
+// gradient, L^-1, K^-1) works on an ordinary lower-triangular factor of k(Xp, Xp) and never sees the permutation.
+void Engine::factorize_pivot(const std::vector<int>& ids, std::vector<int>& info) {
+  const int nb = (int)ids.size();
+  ensure_pivot_buffers();
+  for (int i : ids) gp[i].nugget_used = 0.;
+  upload_idx(ids);
+  upload_params(ids);
+  BatchView v = view(nb);
+  v.X = dX;          // the covariance is built in training order; the interchanges happen inside the factorisation
+  v.XS = 0;
+  launch_cov_build(v, stream);
+  launch_pstrf(v, dPerm, dRank, dInfo, dPivWork, stream);
+  launch_permute_rows(v, dX, dPerm, dXp, stream);
+  std::vector<int> rank(B, 0), inf(B, 0);
+  HIPCK(hipMemcpyAsync(inf.data(), dInfo, B * sizeof(int), hipMemcpyDeviceToHost, stream));
+  HIPCK(hipMemcpyAsync(rank.data(), dRank, B * sizeof(int), hipMemcpyDeviceToHost, stream));
+  HIPCK(hipMemcpyAsync(hPerm.data(), dPerm, hPerm.size() * sizeof(int), hipMemcpyDeviceToHost, stream));
+  HIPCK(hipStreamSynchronize(stream));
+  HIPCK(hipGetLastError());
+  if (info.size() != (size_t)B) info.assign(B, 0);
+  for (int i : ids) {
+    info[i] = inf[i];
+    gp[i].rank = rank[i];
+    gp[i].permuted = true;
+  }
+}
+
 void Engine::factorize(const std::vector<int>& ids, std::vector<int>& info) {
+  std::vector<int> piv, rest;
+  for (int i : ids) (gp[i].nug_type == NUG_PIVOT ? piv : rest).push_back(i);
+  if (piv.empty()) {
+    // an emulator that was pivoted earlier goes back to training order
+    for (int i : rest)
+      if (gp[i].permuted) {
+        HIPCK(hipMemcpyAsync(dXp + (size_t)i * n * D, dX, (size_t)n * D * sizeof(double), hipMemcpyDeviceToDevice, stream));
+        for (int k = 0; k < n; ++k) hPerm[(size_t)i * n + k] = k;
+        gp[i].permuted = false;
+        gp[i].rank = 0;
+      }
+    factorize_blocked(rest, info);
+    return;
+  }
+  std::vector<int> tmp;
+  if (!rest.empty()) {
+    factorize(rest, tmp);
+    info = tmp;
+  } else {
+    info.assign(B, 0);
+  }
+  factorize_pivot(piv, info);
+}
+
+void Engine::factorize_blocked(const std::vector<int>& ids, std::vector<int>& info) {
   const int nb = (int)ids.size();
   upload_idx(ids);
   upload_params(ids);
@@ -1154,6 +1224,20 @@ void Engine::loo_variance(int i, double* out) {
   HIPCK(hipMemcpyAsync(out, tmp, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, stream));
   HIPCK(hipStreamSynchronize(stream));
   hipFree(tmp);
+  unpermute(i, out);
+}
+
+void Engine::unpermute(int i, double* vec) const {
+  if (!gp[i].permuted) return;
+  const int* P = hPerm.data() + (size_t)i * n;
+  std::vector<double> tmp(vec, vec + n);
+  for (int k = 0; k < n; ++k) vec[P[k]] = tmp[k];
+}
+
+void Engine::get_pivot(int i, int* perm_out, int* rank_out) {
+  if (!gp[i].factored) throw std::runtime_error("emulator has not been fit");
+  for (int k = 0; k < n; ++k) perm_out[k] = gp[i].permuted ? hPerm[(size_t)i * n + k] : k;
+  if (rank_out) *rank_out = gp[i].permuted ? gp[i].rank : n;
 }
 
 void Engine::get_K(int i, double* out) {
@@ -1161,7 +1245,10 @@ void Engine::get_K(int i, double* out) {
   double* tmp = dalloc<double>((size_t)n * n);
   std::vector<int> ids{i};
   upload_params(ids);
-  launch_cov_full(view(1), i, tmp, stream);
+  BatchView v = view(1);
+  v.X = dX;          // training order, also for a pivoted emulator
+  v.XS = 0;
+  launch_cov_full(v, i, tmp, stream);
   HIPCK(hipMemcpyAsync(out, tmp, (size_t)n * n * sizeof(double), hipMemcpyDeviceToHost, stream));
   HIPCK(hipStreamSynchronize(stream));
   hipFree(tmp);
@@ -1175,11 +1262,49 @@ void Engine::get_invQ(int i, double* out) {
   HIPCK(hipMemcpyAsync(out, tmp, (size_t)n * n * sizeof(double), hipMemcpyDeviceToHost, stream));
   HIPCK(hipStreamSynchronize(stream));
   hipFree(tmp);
+  if (gp[i].permuted) {          // K^-1 of the pivoted matrix back to training order
+    const int* P = hPerm.data() + (size_t)i * n;
+    std::vector<double> t(out, out + (size_t)n * n);
+    for (int a = 0; a < n; ++a)
+      for (int b = 0; b < n; ++b) out[(size_t)P[a] * n + P[b]] = t[(size_t)a * n + b];
+  }
 }
 
 void Engine::get_invQt(int i, double* out) {
   if (!gp[i].factored) throw std::runtime_error("emulator has not been fit");
   HIPCK(hipMemcpy(out, dAlpha + (size_t)i * RA * LD, n * sizeof(double), hipMemcpyDeviceToHost));
+  unpermute(i, out);
+}
+
+void Engine::pivot_cholesky(const double* Ain, int n, double* L_out, int* P_out, int* rank_out) {
+  if (n < 1) throw std::runtime_error("A must have shape (n,n)");
+  // _check_cholesky_inputs, linalg/cholesky.py:196-222
+  for (int i = 0; i < n; ++i) {
+    if (!(Ain[(size_t)i * n + i] > 0.)) throw std::runtime_error("not pd: non-positive diagonal elements");
+    for (int j = 0; j < i; ++j) {
+      const double a = Ain[(size_t)i * n + j], b = Ain[(size_t)j * n + i];
+      if (!(std::fabs(a - b) <= 1e-7 * std::fabs(b))) throw std::runtime_error("A must be symmetric");
+    }
+  }
+  const size_t bytes = (size_t)n * n * sizeof(double);
+  double* dA_ = dalloc<double>((size_t)n * n);
+  double* dW = dalloc<double>((size_t)2 * n);
+  int* dI = dalloc<int>((size_t)n + 2);
+  BatchView v{};
+  v.n = n; v.D = 1; v.NP = n; v.LD = n; v.MS = (size_t)n * n; v.PS = 0; v.kernel_type = 0;
+  v.A = dA_; v.R = 0; v.RA = 0; v.idx = nullptr; v.nb = 1;
+  HIPCK(hipMemcpy(dA_, Ain, bytes, hipMemcpyHostToDevice));
+  launch_pstrf(v, dI, dI + n, dI + n + 1, dW, nullptr);
+  std::vector<int> hi((size_t)n + 2);
+  HIPCK(hipMemcpy(hi.data(), dI, hi.size() * sizeof(int), hipMemcpyDeviceToHost));
+  HIPCK(hipMemcpy(L_out, dA_, bytes, hipMemcpyDeviceToHost));
+  hipFree(dA_); hipFree(dW); hipFree(dI);
+  if (hi[n + 1] != 0) throw std::runtime_error("not pd: no positive pivot");
+  for (int i = 0; i < n; ++i) {
+    P_out[i] = hi[i];
+    for (int j = i + 1; j < n; ++j) L_out[(size_t)i * n + j] = 0.;
+  }
+  if (rank_out) *rank_out = hi[n];
 }
 
 void Engine::get_chol(int i, double* out) {

@@ -11,7 +11,7 @@
 namespace mogp {
 
 enum { PRIOR_INVGAMMA = 0, PRIOR_GAMMA = 1, PRIOR_LOGNORMAL = 2, PRIOR_WEAK = 3 };
-enum { NUG_ADAPTIVE = 0, NUG_FIT = 1, NUG_FIXED = 2 };
+enum { NUG_ADAPTIVE = 0, NUG_FIT = 1, NUG_FIXED = 2, NUG_PIVOT = 3 };
 
 struct Prior {
   int type = PRIOR_WEAK;

@@ -127,8 +127,8 @@ __global__ __launch_bounds__(256) void cov_build_kernel(BatchView v, int nt, int
   const double* T = v.T + (size_t)emu * n;
   double* si = sm;
   double* sj = sm + 64 * D;
-  stage_rows(v.X, n, D, i0, si);
-  stage_rows(v.X, n, D, j0, sj);
+  stage_rows(v.X + (size_t)emu * v.XS, n, D, i0, si);
+  stage_rows(v.X + (size_t)emu * v.XS, n, D, j0, sj);
   __syncthreads();
   const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
   double kv[4][4];
@@ -210,7 +210,7 @@ __global__ __launch_bounds__(256) void cross_cov_mean_kernel(BatchView v, const 
     const int j0 = tj * 64;
     __syncthreads();
     if (j0 < n) {
-      stage_rows(v.X, n, D, j0, sj);
+      stage_rows(v.X + (size_t)emu * v.XS, n, D, j0, sj);
       for (int e = threadIdx.x; e < R * 64; e += 256) {
         const int c = e >> 6, jj = e & 63;
         const double* src = (c == 0) ? alpha0 : Zr + (size_t)c * ld;
@@ -284,7 +284,7 @@ __global__ __launch_bounds__(256) void predict_deriv_kernel(BatchView v, const d
   const int row = threadIdx.x >> 2, part = threadIdx.x & 3;     // phase 2 mapping
   for (int j0 = 0; j0 < n; j0 += 64) {
     __syncthreads();
-    stage_rows(v.X, n, D, j0, sj);
+    stage_rows(v.X + (size_t)emu * v.XS, n, D, j0, sj);
     __syncthreads();
     // KT < 2: G = 2 sigma^2 dk/dr2 alpha_j;  product kernel: G = 2 sigma^2 k alpha_j and the per-dimension
     // factor (dm52/dr2)/m52 of dimension d is applied in the contraction below
@@ -351,8 +351,8 @@ __global__ __launch_bounds__(256) void grad_kernel(BatchView v, int ntiles, doub
   double* si = sm;
   double* sj = sm + 64 * D;
   double* wsum = sm + 128 * D;        // [4 waves][D+3]
-  stage_rows(v.X, n, D, i0, si);
-  stage_rows(v.X, n, D, j0, sj);
+  stage_rows(v.X + (size_t)emu * v.XS, n, D, i0, si);
+  stage_rows(v.X + (size_t)emu * v.XS, n, D, j0, sj);
   __syncthreads();
   const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;

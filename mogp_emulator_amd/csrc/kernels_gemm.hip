@@ -209,8 +209,8 @@ __global__ __launch_bounds__(256, (FUSE ? 3 : 2)) void update_kernel(BatchView v
     const int n = v.n, D = v.D;
     double* si = smem;
     double* sj = smem + 64 * D;
-    stage_rows(v.X, n, D, i0, si);                 // the main loop ended on a barrier: smem is free
-    stage_rows(v.X, n, D, j0, sj);
+    stage_rows(v.X + (size_t)emu * v.XS, n, D, i0, si);                 // the main loop ended on a barrier: smem is free
+    stage_rows(v.X + (size_t)emu * v.XS, n, D, j0, sj);
     __syncthreads();
     const double* P = v.P + (size_t)emu * v.PS;
     const double* T = v.T + (size_t)emu * n;

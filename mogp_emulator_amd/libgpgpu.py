@@ -10,6 +10,8 @@ The exported names, argument orders, in-place output-buffer conventions and the
 
 No CPU fallback exists here: import fails if the shared library is missing.
 """
+import ctypes
+
 import numpy as np
 
 from . import _capi
@@ -23,7 +25,7 @@ __all__ = [
     "GPParameters", "DenseGP_GPU", "MultiOutputGP_GPU", "GPPriors",
     "WeakPrior", "InvGammaPrior", "GammaPrior", "LogNormalPrior",
     "BaseTransform", "CovTransform", "CorrTransform",
-    "SquaredExponentialKernel", "Matern52Kernel", "set_fit_options", "set_device", "device_count",
+    "SquaredExponentialKernel", "Matern52Kernel", "set_fit_options", "set_device", "device_count", "pivot_cholesky",
 ]
 
 
@@ -69,7 +71,8 @@ def _make_enum(name, members):
 # SURVEY 8f row 4); the uniform kernels share one correlation length over all inputs (n_corr = 1).
 kernel_type = _make_enum("kernel_type", [("SquaredExponential", 0), ("Matern52", 1), ("ProductMat52", 2),
                                          ("UniformSqExp", 3), ("UniformMat52", 4)])
-nugget_type = _make_enum("nugget_type", [("adaptive", 0), ("fit", 1), ("fixed", 2)])
+# 3: nugget="pivot" of the CPU class (GPParams.py:185-186), not in the reference's GPU enum (types.hpp:29-35)
+nugget_type = _make_enum("nugget_type", [("adaptive", 0), ("fit", 1), ("fixed", 2), ("pivot", 3)])
 prior_type = _make_enum("prior_type", [("InvGamma", 0), ("Gamma", 1), ("LogNormal", 2), ("Weak", 3)])
 
 
@@ -629,6 +632,14 @@ class DenseGP_GPU(object):
     def get_cholesky_lower(self, result):
         self._fill_nn(_lib.mogp_densegp_get_cholesky_lower, result, "get_cholesky_lower")
 
+    def get_pivot(self):
+        """(P, rank) of the current fit: K[P][:, P] = L L^T (ChoInvPivot.P, linalg/cholesky.py:82-104); the identity and
+        n unless the nugget type is ``pivot``."""
+        P = np.zeros(self.n(), dtype=np.int32)
+        rank = ctypes.c_int(0)
+        check(_lib.mogp_densegp_get_pivot(self._h, iptr(P), ctypes.byref(rank)))
+        return P, rank.value
+
     def get_invQt(self, invQt_h):
         _outbuf(invQt_h, "invQt_h")
         if invQt_h.size < self.n():
@@ -816,6 +827,20 @@ def fit_GP_MAP(gp, n_tries=15, theta0=()):
     else:
         raise TypeError("fit_GP_MAP(): incompatible function arguments")
     return gp
+
+
+def pivot_cholesky(A):
+    """(L, P, rank) = pivoted Cholesky of a symmetric matrix with positive diagonal, computed on the device with the
+    semantics of linalg/cholesky.py:284-327 (LAPACK dpstrf; skipped rows get the decreasing replacement diagonal)."""
+    A = _f64(np.asarray(A, dtype=np.float64))
+    if A.ndim != 2 or A.shape[0] != A.shape[1]:
+        raise ValueError("A must have shape (n,n)")
+    n = A.shape[0]
+    L = np.zeros((n, n))
+    P = np.zeros(n, dtype=np.int32)
+    rank = ctypes.c_int(0)
+    check(_lib.mogp_pivot_cholesky(dptr(A), n, dptr(L), iptr(P), ctypes.byref(rank)))
+    return L, P, rank.value
 
 
 # --------------------------------------------------------------------------------------

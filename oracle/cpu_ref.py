@@ -224,10 +224,44 @@ def jit_cholesky(A, maxtries=5):
     raise linalg.LinAlgError("not positive definite, even with jitter.")
 
 
+class PivotFactor(object):
+    """ChoInvPivot, linalg/cholesky.py:82-165: the factor of A[P][:, P] and the pivot order P."""
+
+    def __init__(self, L, P):
+        self.L, self.P = L, np.asarray(P)
+        self.shape = L.shape
+
+    def inverse_order(self):
+        """_pivot_transpose, linalg/cholesky.py:330-357."""
+        Pt = np.empty_like(self.P)
+        Pt[self.P] = np.arange(len(self.P))
+        return Pt
+
+
+def pivot_cholesky(A):
+    """linalg/cholesky.py:284-327: LAPACK dpstrf (lower); the rows the factorisation skipped as collinear keep
+    whatever dpstrf left in them below the diagonal, and their diagonal entries are replaced by
+    L[rank-1, rank-1] / ((rank+1)(rank+2)...(i+1)), so that logdet and the triangular solves stay defined."""
+    A = _check_cholesky_inputs(A)
+    A = np.ascontiguousarray(A)
+    L, P, rank, info = lapack.dpstrf(A, lower=1)
+    L = np.tril(L)
+    if info < 0:
+        raise linalg.LinAlgError("Illegal value in covariance matrix")
+    n = A.shape[0]
+    idx = np.arange(rank, n)
+    divs = np.cumprod(np.arange(rank + 1, n + 1, dtype=np.float64))
+    L[idx, idx] = L[rank - 1, rank - 1] / divs
+    return L, P - 1, rank
+
+
 def cholesky_factor(A, nugget, nugget_type):
-    """linalg/cholesky.py:168-193 (without the "pivot" branch - out of scope)."""
+    """linalg/cholesky.py:168-193."""
     if nugget_type == "adaptive":
         L, nugget = jit_cholesky(A)
+    elif nugget_type == "pivot":
+        L, P, _ = pivot_cholesky(A)
+        L = PivotFactor(L, P)
     elif nugget_type in ("fit", "fixed"):
         A = A + nugget * np.eye(A.shape[0])
         L = fixed_cholesky(A)
@@ -237,19 +271,27 @@ def cholesky_factor(A, nugget, nugget_type):
 
 
 def cho_solve_L(L, b):
-    """ChoInv.solve, linalg/cholesky.py:22-42."""
+    """ChoInv.solve, linalg/cholesky.py:22-42; ChoInvPivot.solve :105-133."""
+    if isinstance(L, PivotFactor):
+        if L.shape == (1, 1):
+            return b / L.L[0, 0] ** 2
+        return cho_solve((L.L, True), b[L.P])[L.inverse_order()]
     if L.shape == (1, 1):
         return b / L[0, 0] ** 2
     return cho_solve((L, True), b)
 
 
 def solve_L(L, b):
-    """ChoInv.solve_L, linalg/cholesky.py:44-65: L^-1 b."""
+    """ChoInv.solve_L, linalg/cholesky.py:44-65: L^-1 b; ChoInvPivot.solve_L :135-165: L^-1 b[P]."""
+    if isinstance(L, PivotFactor):
+        return linalg.solve_triangular(L.L, b[L.P], lower=True)
     return linalg.solve_triangular(L, b, lower=True)
 
 
 def logdet_L(L):
     """ChoInv.logdet, linalg/cholesky.py:67-79."""
+    if isinstance(L, PivotFactor):
+        L = L.L
     return 2.0 * np.sum(np.log(np.diag(L)))
 
 
@@ -362,7 +404,7 @@ class GPRef(object):
         self.n, self.D = self.X.shape
         self.kernel = kernel
         if isinstance(nugget, str):
-            assert nugget in ("adaptive", "fit")
+            assert nugget in ("adaptive", "fit", "pivot")
             self.nugget_type, self.nugget = nugget, None
         else:
             assert float(nugget) >= 0.
@@ -455,12 +497,12 @@ class GPRef(object):
             sigma_2 = np.exp(self.theta[self.nc])
             if full_cov:
                 Kss = sigma_2 * kernel_f(testing, testing, self.theta[:self.nc], self.kernel)
-                if include_nugget:
+                if include_nugget and self.nugget_type != "pivot":       # GaussianProcess.py:904,915
                     Kss = Kss + np.eye(testing.shape[0]) * self.nugget
                 Linv_Ktest = solve_L(self.L, Ktest)
                 var = Kss - np.dot(Linv_Ktest.T, Linv_Ktest)
             else:
-                if include_nugget:
+                if include_nugget and self.nugget_type != "pivot":       # GaussianProcess.py:904,915
                     sigma_2 = sigma_2 + self.nugget
                 var = np.maximum(sigma_2 - np.sum(Ktest * Kinv_Ktest, axis=0), 0.)
         d = None
@@ -596,13 +638,13 @@ class GPRefMean(GPRef):
             sigma_2 = np.exp(self.theta[self.nc])
             if full_cov:                                                                 # :899-911
                 Kss = sigma_2 * kernel_f(testing, testing, self.theta[:self.nc], self.kernel)
-                if include_nugget:
+                if include_nugget and self.nugget_type != "pivot":       # GaussianProcess.py:904,915
                     Kss = Kss + np.eye(testing.shape[0]) * self.nugget
                 Linv_Ktest = solve_L(self.L, Ktest)
                 LAinv_R = solve_L(self.LA, Rm)
                 var = Kss - np.dot(Linv_Ktest.T, Linv_Ktest) + np.dot(LAinv_R.T, LAinv_R)
                 return mu, var, None
-            if include_nugget:
+            if include_nugget and self.nugget_type != "pivot":       # GaussianProcess.py:904,915
                 sigma_2 = sigma_2 + self.nugget
             var = np.maximum(sigma_2 - np.sum(Ktest * Kinv_Ktest, axis=0) + np.sum(Rm * cho_solve_L(self.LA, Rm), axis=0), 0.)
         return mu, var, None

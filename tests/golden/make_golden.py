@@ -58,7 +58,68 @@ def run_gp(X, t, kernel, nugget, theta, Xs, priors="weak"):
     return gp, out
 
 
+def pivot_section():
+    """---- 15. nugget="pivot": pivoted Cholesky (linalg/cholesky.py:82-165, 284-327), SURVEY 8f row 4 ----"""
+    from mogp_emulator.linalg.cholesky import pivot_cholesky
+    out = {}
+    # the two matrices of tests/test_linalg.py:156-188 and a larger rank-deficient one
+    rng = np.random.default_rng(1515)
+    G = rng.normal(size=(12, 7))
+    mats = {"wiki": np.array([[4., 12., -16.], [12., 37., -43.], [-16., -43., 98.]]),
+            "collinear": np.array([[1., 1., 1.e-6], [1., 1., 1.e-6], [1.e-6, 1.e-6, 1.]]),
+            "gram_rank7": G @ G.T + 0.0}
+    for tag, A in mats.items():
+        L, P = pivot_cholesky(np.copy(A))
+        out["mat_%s_A" % tag], out["mat_%s_L" % tag], out["mat_%s_P" % tag] = A, L, np.asarray(P, dtype=np.int64)
+    # the three-point emulator of tests/test_GaussianProcess.py:397-415, 1120-1143
+    x2, y2 = np.array([1., 2., 4.]), np.array([1., 2., 1.])
+    gp = GaussianProcess(x2, y2, nugget="pivot")
+    gp.theta = np.zeros(2)
+    xpred = np.linspace(0., 5.)
+    mean, var, _ = gp.predict(xpred)
+    out.update(three_x=x2, three_y=y2, three_xpred=xpred, three_L=gp.Kinv.L, three_P=np.asarray(gp.Kinv.P, dtype=np.int64),
+               three_Kinv_t=gp.Kinv_t, three_mean=mean, three_var=var, three_logpost=np.array(gp.current_logpost))
+    # emulators: full rank, and with repeated design points (rank-deficient K)
+    X, T, Xs = synth(15, 40, 3, 1, 30)
+    t = T[0] + 0.5 + 1.2 * X[:, 0]
+    Xd = np.vstack([X[:7], X[3:4], X[7:25], X[11:12], X[20:21], X[25:]])          # rows 3, 11, 20 repeated
+    td_same = np.concatenate([t[:7], t[3:4], t[7:25], t[11:12], t[20:21], t[25:]])  # ... with the same targets
+    td_diff = td_same.copy()
+    td_diff[[7, 26, 27]] += np.array([0.05, -0.03, 0.02])                           # ... with different targets
+    out.update(X=X, t=t, Xs=Xs, Xd=Xd, td_same=td_same, td_diff=td_diff)
+    for tag, (XX, tt) in {"full": (X, t), "dupsame": (Xd, td_same), "dupdiff": (Xd, td_diff)}.items():
+        for kern in KERNELS:
+            for mtag, formula in (("zero", None), ("lin", "x[0]")):
+                theta = np.array([3.0, 2.5, 3.5, 0.2])      # short length scales: only the repeats make K singular
+                gp = GaussianProcess(XX, tt, mean=formula, kernel=KERNELS[kern](), nugget="pivot", priors=weak(3, "pivot"))
+                gp.fit(theta)
+                pre = "%s_%s_%s_" % (tag, kern, mtag)
+                out[pre + "theta"] = theta
+                out[pre + "logpost"] = np.array(gp.current_logpost)
+                out[pre + "grad"] = gp.logpost_deriv(theta)
+                out[pre + "L"] = gp.Kinv.L
+                out[pre + "P"] = np.asarray(gp.Kinv.P, dtype=np.int64)
+                out[pre + "Kinv_t"] = gp.Kinv_t
+                out[pre + "Kinv_t_mean"] = gp.Kinv_t_mean
+                out[pre + "beta"] = np.array(gp.theta.mean)
+                mean, var, deriv = gp.predict(Xs)
+                out[pre + "mean"], out[pre + "var"] = mean, var
+                out[pre + "var_nonug"] = gp.predict(Xs, include_nugget=False)[1]
+                out[pre + "cov"] = gp.predict(Xs, full_cov=True)[1]
+                out[pre + "nugget_is_none"] = np.array(gp.nugget is None)
+    # fit_GP_MAP with pivoting on the full-rank set (end point only: optimiser trajectories are not pinned)
+    np.random.seed(1515)
+    gp = GaussianProcess(X, t, nugget="pivot")
+    gp = fit_GP_MAP(gp, n_tries=3)
+    out["map_theta"] = gp.theta.get_data()
+    out["map_logpost"] = np.array(gp.current_logpost)
+    np.savez_compressed(os.path.join(HERE, "pivot.npz"), **out)
+
+
 def main():
+    if sys.argv[1:] == ["pivot"]:
+        pivot_section()
+        return
     # ---- 1. the 2x3 fixture of tests/test_GaussianProcess.py:16-22, 556 ------------------------
     X = np.array([[1., 2., 3.], [4., 5., 6.]])
     t = np.array([2., 4.])
@@ -365,6 +426,7 @@ def main():
                 out[pre + "var"] = var
                 out[pre + "cov_full"] = gp.predict(Xs, full_cov=True)[1]
     np.savez_compressed(os.path.join(HERE, "meanpriors.npz"), **out)
+    pivot_section()
     print("golden vectors written to", HERE)
 
 

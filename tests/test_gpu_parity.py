@@ -290,7 +290,7 @@ def test_error_behaviour_matches_reference():
     with pytest.raises(ValueError):
         M.GaussianProcessGPU(X, T[0], kernel="RationalQuadratic")
     with pytest.raises(ValueError):
-        M.GaussianProcessGPU(X, T[0], nugget="pivot")
+        M.GaussianProcessGPU(X, T[0], nugget="nonsense")
 
 
 def test_predict_chunking_ragged_and_single_point():

@@ -130,8 +130,9 @@ def test_interpret_nugget_and_coercion():
     assert interpret_nugget("fit") == (LibGPGPU.nugget_type.fit, 0.)
     assert interpret_nugget(1e-4) == (LibGPGPU.nugget_type.fixed, 1e-4)
     assert interpret_nugget(1) == (LibGPGPU.nugget_type.fixed, 1.)
+    assert interpret_nugget("pivot") == (LibGPGPU.nugget_type.pivot, 0.)     # CPU-class mode, GPParams.py:185-186
     with pytest.raises(ValueError):
-        interpret_nugget("pivot")
+        interpret_nugget("nonsense")
     with pytest.raises(ValueError):
         interpret_nugget(-1.)
     with pytest.raises(TypeError):

@@ -367,3 +367,83 @@ def test_informative_mean_priors_vs_reference(tag, kern, mode):
     assert_allclose(mu, g[pre + "mean"], rtol=1e-7, atol=1e-8)
     assert_allclose(var, g[pre + "var"], rtol=1e-6, atol=1e-9)
     assert_allclose(gp.predict(g["Xs"], full_cov=True)[1], g[pre + "cov_full"], rtol=1e-6, atol=1e-7 * np.abs(g[pre + "cov_full"]).max())
+
+
+# ---- nugget="pivot" (SURVEY 8f row 4): pivoted Cholesky, linalg/cholesky.py:82-165, 284-327 -------------------------
+PIVOT_SETS = {"full": ("X", "t"), "dupsame": ("Xd", "td_same"), "dupdiff": ("Xd", "td_diff")}
+PIVOT_REPEATS = ((3, 7), (12, 26), (21, 27))       # rows of Xd that are the same design point
+
+
+def collapse_repeats(alpha):
+    """With identical targets on a repeated point only the SUM of the two weights is determined (the split between them is
+    rounding noise over the replacement diagonal, in the reference as well); predictions depend on the sum alone."""
+    a = np.array(alpha, dtype=float)
+    for keep, drop in PIVOT_REPEATS:
+        a[keep] += a[drop]
+    return np.delete(a, [d for _, d in PIVOT_REPEATS])
+
+
+def test_pivot_cholesky_known_answers():
+    # literals of the reference's tests/test_linalg.py:156-188
+    L, P, rank = R.pivot_cholesky(np.array([[4., 12., -16.], [12., 37., -43.], [-16., -43., 98.]]))
+    assert_allclose(L, [[9.899494936611665, 0., 0.], [-4.3436559415745055, 4.258245303082538, 0.],
+                        [-1.616244071283537, 1.1693999481734827, 0.1423336335961131]])
+    assert list(P) == [2, 1, 0] and rank == 3
+    L, P, rank = R.pivot_cholesky(np.array([[1., 1., 1.e-6], [1., 1., 1.e-6], [1.e-6, 1.e-6, 1.]]))
+    assert_allclose(L, [[1., 0., 0.], [9.9999999999999995e-07, 9.9999999999949996e-01, 0.], [1., 0., 3.3333333333316667e-01]])
+    assert list(P) == [0, 2, 1] and rank == 2
+    g = load_golden("pivot.npz")
+    for tag in ("wiki", "collinear", "gram_rank7"):
+        L, P, _ = R.pivot_cholesky(g["mat_%s_A" % tag])
+        assert_allclose(L, g["mat_%s_L" % tag], rtol=1e-12, atol=1e-14)
+        assert list(P) == list(g["mat_%s_P" % tag])
+
+
+def test_pivot_three_point_emulator():
+    # tests/test_GaussianProcess.py:397-415, 1120-1143: pivoting re-orders [1, 2, 4] into [1, 4, 2]
+    g = load_golden("pivot.npz")
+    gp = R.GPRef(g["three_x"], g["three_y"], nugget="pivot")
+    lp = gp.fit(np.zeros(2))
+    assert list(gp.L.P) == [0, 2, 1]
+    assert_allclose(gp.L.L, g["three_L"], rtol=1e-13)
+    assert_allclose(gp.Kinv_t, g["three_Kinv_t"], rtol=1e-12)
+    straight = R.GPRef(np.array([1., 4., 2.]), np.array([1., 1., 2.]), nugget=0.)
+    straight.fit(np.zeros(2))
+    assert_allclose(straight.L, gp.L.L, rtol=1e-13)
+    mu, var, _ = gp.predict(g["three_xpred"].reshape(-1, 1))
+    assert_allclose(mu, g["three_mean"], rtol=1e-10, atol=1e-13)
+    assert_allclose(var, g["three_var"], rtol=1e-9, atol=1e-12)
+
+
+@pytest.mark.parametrize("tag", list(PIVOT_SETS))
+@pytest.mark.parametrize("kern", KERNELS)
+@pytest.mark.parametrize("mtag", ["zero", "lin"])
+def test_pivot_emulators_vs_reference(tag, kern, mtag):
+    g = load_golden("pivot.npz")
+    X, t = g[PIVOT_SETS[tag][0]], g[PIVOT_SETS[tag][1]]
+    pre = "%s_%s_%s_" % (tag, kern, mtag)
+    theta = g[pre + "theta"]
+    gp = R.GPRef(X, t, kernel=kern, nugget="pivot") if mtag == "zero" else R.GPRefMean(X, t, [(0, 1)], True, kernel=kern, nugget="pivot")
+    lp = gp.fit(theta)
+    assert list(gp.L.P) == list(g[pre + "P"])
+    assert_allclose(gp.L.L, g[pre + "L"], rtol=1e-9, atol=1e-12)
+    # Different targets on a repeated point put weights of +-1e11..1e12 on the pair (an O(0.01) residual over a 1e-6
+    # replacement diagonal, twice): every other weight and the predictive mean then carry that scale's rounding noise, in
+    # the reference as much as here, so those comparisons are relative to the largest weight.
+    scale = max(1., float(np.max(np.abs(g[pre + "Kinv_t"]))))
+    noise = 1e-14 * scale if tag == "dupdiff" else 0.
+    assert_allclose(lp, g[pre + "logpost"], rtol=1e-9 if tag != "dupdiff" else 1e-6)
+    if tag == "dupsame":
+        assert_allclose(collapse_repeats(gp.Kinv_t), collapse_repeats(g[pre + "Kinv_t"]), rtol=1e-6, atol=1e-8)
+    else:
+        assert_allclose(gp.Kinv_t, g[pre + "Kinv_t"], rtol=1e-7, atol=1e-9 + noise)
+    if tag != "dupdiff":      # there the gradient is an O(1) remainder of terms of size scale^2: noise, not a value to match
+        assert_allclose(gp.logpost_deriv(theta), g[pre + "grad"], rtol=1e-6, atol=1e-7)
+    mu, var, _ = gp.predict(g["Xs"])
+    assert_allclose(mu, g[pre + "mean"], rtol=1e-7, atol=1e-8 + noise)
+    assert_allclose(var, g[pre + "var"], rtol=1e-6, atol=1e-9)
+    assert_allclose(gp.predict(g["Xs"], include_nugget=False)[1], g[pre + "var_nonug"], rtol=1e-6, atol=1e-9)   # no nugget to add
+    assert_allclose(gp.predict(g["Xs"], full_cov=True)[1], g[pre + "cov"], rtol=1e-6, atol=1e-8)
+    if mtag == "lin":
+        assert_allclose(gp.beta, g[pre + "beta"], rtol=1e-7, atol=noise)
+    assert bool(g[pre + "nugget_is_none"]) and gp.nugget is None
