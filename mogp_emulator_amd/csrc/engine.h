@@ -28,6 +28,7 @@ struct GPState {
   double nugget_used = 0.;       // value actually added to the diagonal in the last factorisation
   // nugget="pivot": the factor in A, alpha, L^-1, K^-1 and this emulator's copy of the inputs are in pivoted order
   bool permuted = false;
+  bool kinv_split = false;       // rank < n: Kinv was formed without the rows of L^-1 of the skipped pivots (kept in w2)
   int rank = 0;                  // pivots accepted by the last pivoted factorisation (n = full rank)
   std::vector<double> beta;      // analytic mean coefficients (q), GaussianProcess.py:669-670
   std::vector<double> LA;        // q x q lower Cholesky factor of A = H^T K^-1 H + B^-1
@@ -121,7 +122,7 @@ class Engine {
   void unpermute(int i, double* vec) const;          // vec (n) from pivoted to training order, in place
   void panel(const BatchView& v, int o, int w, hipStream_t st);
   void ensure_linv(const std::vector<int>& ids);
-  void ensure_kinv(const std::vector<int>& ids);
+  void ensure_kinv(const std::vector<int>& ids, bool for_gradient = false);
   BatchView view(int nb) const;
   void set_theta(int i, const double* theta);
   void ensure_predict_scratch(int nb, int MC);
@@ -135,6 +136,8 @@ class Engine {
   double *dXp = nullptr, *dPivWork = nullptr;
   int *dPerm = nullptr, *dRank = nullptr;
   std::vector<int> hPerm;
+  std::map<int, double*> w2;     // emulator -> (n - rank) x LD rows of L^-1 of the skipped pivots (gradient path)
+  void drop_w2(int i);
   std::vector<double> hH;        // q x n design-matrix columns      // packed transposed diagonal block + reciprocal diagonal (potf2 -> trsm)
   std::vector<double> hP;
   // predict scratch

@@ -192,6 +192,7 @@ Engine::~Engine() {
                   (void*)dVarPartial, (void*)dDeriv, (void*)dLpack, (void*)dH, (void*)dZ, (void*)dM, (void*)dGram, (void*)dXp, (void*)dPivWork,
                   (void*)dPerm, (void*)dRank})
     if (p) hipFree(p);
+  for (auto& kv : w2) hipFree(kv.second);
   for (auto& kv : cholGraphs) hipGraphExecDestroy(kv.second);
   for (auto st : gstreams) hipStreamDestroy(st);
   if (evReady) hipEventDestroy(evReady);
@@ -312,7 +313,7 @@ void Engine::ensure_pivot_buffers() {
   if (dXp) return;
   dPerm = dalloc<int>((size_t)B * n);
   dRank = dalloc<int>(B);
-  dPivWork = dalloc<double>((size_t)B * 2 * NP);
+  dPivWork = dalloc<double>((size_t)B * pstrf_work_doubles(NP));
   hPerm.resize((size_t)B * n);
   for (int i = 0; i < B; ++i)
     for (int k = 0; k < n; ++k) hPerm[(size_t)i * n + k] = k;
@@ -336,9 +337,40 @@ void Engine::factorize_pivot(const std::vector<int>& ids, std::vector<int>& info
   v.X = dX;          // the covariance is built in training order; the interchanges happen inside the factorisation
   v.XS = 0;
   launch_cov_build(v, stream);
-  launch_pstrf(v, dPerm, dRank, dInfo, dPivWork, stream);
-  launch_permute_rows(v, dX, dPerm, dXp, stream);
+  launch_pstrf_begin(v, dPerm, dRank, dInfo, dPivWork, stream);
   std::vector<int> rank(B, 0), inf(B, 0);
+  std::vector<int> active(ids), stopped;
+  for (int k0 = 0; k0 < n && !active.empty(); k0 += NBI) {
+    const bool first_half = (k0 % TILE) == 0;
+    launch_pstrf_panel(v, k0, std::min(NBI, n - k0), dPerm, dRank, dPivWork, stream);
+    HIPCK(hipMemcpyAsync(rank.data(), dRank, B * sizeof(int), hipMemcpyDeviceToHost, stream));
+    HIPCK(hipStreamSynchronize(stream));
+    std::vector<int> still;
+    for (int i : active) {
+      if (rank[i] < 0) still.push_back(i);
+      else if (rank[i] < n) stopped.push_back(i);
+    }
+    if (still.size() != active.size()) {
+      active.swap(still);
+      if (active.empty()) break;
+      upload_idx(active);
+      v = view((int)active.size());
+      v.X = dX;
+      v.XS = 0;
+    }
+    // rank-64 update of everything to the right of the panel (the 128-wide tiles start at multiples of 128)
+    if (first_half) launch_update_narrow(v, k0 + NBI, k0, k0 + NBI, stream);
+    launch_update_trailing(v, first_half ? k0 + TILE : k0 + NBI, k0, k0 + NBI, stream);
+  }
+  if (!stopped.empty()) {
+    upload_idx(stopped);
+    BatchView t = view((int)stopped.size());
+    launch_pstrf_tail(t, dPerm, dRank, dX, nullptr, stream);
+  }
+  upload_idx(ids);
+  v = view(nb);
+  launch_pstrf_end(v, stream);
+  launch_permute_rows(v, dX, dPerm, dXp, stream);
   HIPCK(hipMemcpyAsync(inf.data(), dInfo, B * sizeof(int), hipMemcpyDeviceToHost, stream));
   HIPCK(hipMemcpyAsync(rank.data(), dRank, B * sizeof(int), hipMemcpyDeviceToHost, stream));
   HIPCK(hipMemcpyAsync(hPerm.data(), dPerm, hPerm.size() * sizeof(int), hipMemcpyDeviceToHost, stream));
@@ -582,7 +614,8 @@ void Engine::factorize_blocked(const std::vector<int>& ids, std::vector<int>& in
       auto it = cholGraphs.find(key);
       if (it == cholGraphs.end()) {
         if (cholGraphs.size() >= 32) {                       // bounded cache (optimiser rounds shrink the active set)
-          for (auto& kv : cholGraphs) hipGraphExecDestroy(kv.second);
+          for (auto& kv : w2) hipFree(kv.second);
+  for (auto& kv : cholGraphs) hipGraphExecDestroy(kv.second);
           cholGraphs.clear();
         }
         hipGraph_t graph = nullptr;
@@ -919,24 +952,65 @@ void Engine::ensure_linv(const std::vector<int>& ids) {
   }
 }
 
-void Engine::ensure_kinv(const std::vector<int>& ids) {
+void Engine::drop_w2(int i) {
+  auto it = w2.find(i);
+  if (it == w2.end()) return;
+  hipFree(it->second);
+  w2.erase(it);
+}
+
+// for_gradient: an emulator whose pivoted factorisation skipped rows gets K^-1 WITHOUT the rows of L^-1 of the skipped
+// pivots (they go to w2 and enter the gradient through launch_grad_lowrank, see kernels_cov.hip); otherwise the full K^-1.
+void Engine::ensure_kinv(const std::vector<int>& ids, bool for_gradient) {
   ensure_linv(ids);
   std::vector<int> need;
-  for (int i : ids)
-    if (!gp[i].kinv) need.push_back(i);
+  for (int i : ids) {
+    const bool deficient = gp[i].permuted && gp[i].rank < n;
+    const bool want_split = for_gradient && deficient;
+    if (!gp[i].kinv || gp[i].kinv_split != want_split) need.push_back(i);
+  }
   if (need.empty()) return;
+  const size_t rowb = (size_t)LD * sizeof(double), wb = (size_t)n * sizeof(double);
+  std::vector<int> split;
+  for (int i : need)
+    if (for_gradient && gp[i].permuted && gp[i].rank < n) {
+      const int m = n - gp[i].rank;
+      drop_w2(i);
+      double* buf = dalloc<double>((size_t)m * LD);
+      w2[i] = buf;
+      double* rows = dLinv + (size_t)i * MS + (size_t)gp[i].rank * LD;
+      HIPCK(hipMemcpy2DAsync(buf, rowb, rows, rowb, wb, m, hipMemcpyDeviceToDevice, stream));
+      HIPCK(hipMemset2DAsync(rows, rowb, 0, wb, m, stream));
+      split.push_back(i);
+    }
   upload_idx(need);
   BatchView v = view((int)need.size());
   launch_kinv(v, stream);
-  for (int i : need) gp[i].kinv = true;
+  for (int i : split) {
+    double* rows = dLinv + (size_t)i * MS + (size_t)gp[i].rank * LD;
+    HIPCK(hipMemcpy2DAsync(rows, rowb, w2[i], rowb, wb, n - gp[i].rank, hipMemcpyDeviceToDevice, stream));
+  }
+  for (int i : need) {
+    gp[i].kinv = true;
+    gp[i].kinv_split = false;
+  }
+  for (int i : split) gp[i].kinv_split = true;
 }
 
 void Engine::grad_current(const std::vector<int>& ids, double* grad, int grad_ld) {
   if (ids.empty()) return;
-  ensure_kinv(ids);
+  ensure_kinv(ids, true);
   upload_idx(ids);
   BatchView v = view((int)ids.size());
   launch_grad(v, dGradPartial, dGradOut, stream);
+  for (int i : ids)
+    if (gp[i].kinv_split) {
+      const int m = n - gp[i].rank;
+      double* part = dalloc<double>((size_t)m * ((n + 127) / 128) * (D + 1));
+      launch_grad_lowrank(v, i, w2.at(i), m, part, dGradOut, stream);
+      HIPCK(hipStreamSynchronize(stream));
+      hipFree(part);
+    }
   const int NQ = D + 3;
   std::vector<double> out((size_t)B * NQ);
   HIPCK(hipMemcpyAsync(out.data(), dGradOut, out.size() * sizeof(double), hipMemcpyDeviceToHost, stream));
@@ -965,6 +1039,7 @@ void Engine::grad_current(const std::vector<int>& ids, double* grad, int grad_ld
       // densegp_gpu.hpp:734-747: -(d mean / d beta)^T alpha
       std::vector<double> a(n), md((size_t)nm * n);
       HIPCK(hipMemcpy(a.data(), dAlpha + (size_t)i * RA * LD, n * sizeof(double), hipMemcpyDeviceToHost));
+      unpermute(i, a.data());              // the mean derivatives below are in training order
       mean.mean_deriv(hX.data(), n, D, g.meanp.data(), nm, md.data());
       for (int p = 0; p < nm; ++p) {
         double s = 0.;
@@ -1256,7 +1331,7 @@ void Engine::get_K(int i, double* out) {
 
 void Engine::get_invQ(int i, double* out) {
   std::vector<int> ids{i};
-  ensure_kinv(ids);
+  ensure_kinv(ids, false);
   double* tmp = dalloc<double>((size_t)n * n);
   launch_extract(dKinv + (size_t)i * MS, LD, n, tmp, 2, stream);
   HIPCK(hipMemcpyAsync(out, tmp, (size_t)n * n * sizeof(double), hipMemcpyDeviceToHost, stream));
@@ -1286,19 +1361,38 @@ void Engine::pivot_cholesky(const double* Ain, int n, double* L_out, int* P_out,
       if (!(std::fabs(a - b) <= 1e-7 * std::fabs(b))) throw std::runtime_error("A must be symmetric");
     }
   }
-  const size_t bytes = (size_t)n * n * sizeof(double);
-  double* dA_ = dalloc<double>((size_t)n * n);
-  double* dW = dalloc<double>((size_t)2 * n);
+  // padded copy: NP x NP with the identity beyond n, so that the blocked trailing update can be used as it is
+  const int NPp = roundup(n, TILE);
+  std::vector<double> hA((size_t)NPp * NPp, 0.);
+  for (int i = 0; i < NPp; ++i) {
+    if (i < n) std::memcpy(hA.data() + (size_t)i * NPp, Ain + (size_t)i * n, (size_t)n * sizeof(double));
+    else hA[(size_t)i * NPp + i] = 1.0;
+  }
+  double* dA_ = dalloc<double>(hA.size());
+  double* dA0 = dalloc<double>((size_t)n * n);
+  double* dW = dalloc<double>(pstrf_work_doubles(NPp));
   int* dI = dalloc<int>((size_t)n + 2);
   BatchView v{};
-  v.n = n; v.D = 1; v.NP = n; v.LD = n; v.MS = (size_t)n * n; v.PS = 0; v.kernel_type = 0;
+  v.n = n; v.D = 1; v.NP = NPp; v.LD = NPp; v.MS = (size_t)NPp * NPp; v.PS = 0; v.kernel_type = 0;
   v.A = dA_; v.R = 0; v.RA = 0; v.idx = nullptr; v.nb = 1;
-  HIPCK(hipMemcpy(dA_, Ain, bytes, hipMemcpyHostToDevice));
-  launch_pstrf(v, dI, dI + n, dI + n + 1, dW, nullptr);
+  HIPCK(hipMemcpy(dA_, hA.data(), hA.size() * sizeof(double), hipMemcpyHostToDevice));
+  HIPCK(hipMemcpy(dA0, Ain, (size_t)n * n * sizeof(double), hipMemcpyHostToDevice));
+  launch_pstrf_begin(v, dI, dI + n, dI + n + 1, dW, nullptr);
+  int rk = -1;
+  for (int k0 = 0; k0 < n; k0 += NBI) {
+    const bool first_half = (k0 % TILE) == 0;
+    launch_pstrf_panel(v, k0, std::min(NBI, n - k0), dI, dI + n, dW, nullptr);
+    HIPCK(hipMemcpy(&rk, dI + n, sizeof(int), hipMemcpyDeviceToHost));
+    if (rk >= 0) break;
+    if (first_half) launch_update_narrow(v, k0 + NBI, k0, k0 + NBI, nullptr);
+    launch_update_trailing(v, first_half ? k0 + TILE : k0 + NBI, k0, k0 + NBI, nullptr);
+  }
+  launch_pstrf_tail(v, dI, dI + n, nullptr, dA0, nullptr);
   std::vector<int> hi((size_t)n + 2);
   HIPCK(hipMemcpy(hi.data(), dI, hi.size() * sizeof(int), hipMemcpyDeviceToHost));
-  HIPCK(hipMemcpy(L_out, dA_, bytes, hipMemcpyDeviceToHost));
-  hipFree(dA_); hipFree(dW); hipFree(dI);
+  HIPCK(hipMemcpy(hA.data(), dA_, hA.size() * sizeof(double), hipMemcpyDeviceToHost));
+  hipFree(dA_); hipFree(dA0); hipFree(dW); hipFree(dI);
+  for (int i = 0; i < n; ++i) std::memcpy(L_out + (size_t)i * n, hA.data() + (size_t)i * NPp, (size_t)n * sizeof(double));
   if (hi[n + 1] != 0) throw std::runtime_error("not pd: no positive pivot");
   for (int i = 0; i < n; ++i) {
     P_out[i] = hi[i];

@@ -516,6 +516,105 @@ int grad_num_tiles(int n) {
   return nt * (nt + 1) / 2;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Gradient terms of the rows of L^-1 that belong to SKIPPED pivots (nugget="pivot" with repeated design points).
+// Those rows w are ~ (e_i' - e_i) / d with a replacement diagonal d ~ 1e-6: their contribution w w^T to K^-1 has entries
+// ~ 1/d^2 that cancel against identical entries of dK only AFTER the multiplication, which costs ~ eps / d^2 ~ 1e-3 of
+// absolute accuracy in sum_ij (K^-1)_ij dK_ij.  So K^-1 is formed without these rows and their share is added as
+//      sum_k  w_k^T dK_p w_k ,   u = dK_p w_k first:
+// inside u the identical entries of dK meet the +-1/d pair of w and cancel before anything is amplified (the order in
+// which the reference's cho_solve-based logdet_deriv, linalg_utils.py:170-198, effectively works).
+//   grid (i-blocks of 128 rows, skipped rows); W2: m x LD rows of L^-1; part[(k * nblk + iblk) * (D+1) + p]
+// ---------------------------------------------------------------------------------------------
+constexpr int LOWRANK_THREADS = 128, LOWRANK_CHUNK = 8;
+template <int KT>
+__global__ __launch_bounds__(LOWRANK_THREADS) void grad_lowrank_kernel(BatchView v, int emu, const double* __restrict__ W2, int nblk,
+                                                                        double* __restrict__ part) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  __shared__ double red[LOWRANK_THREADS];
+  const int n = v.n, D = v.D, ld = v.LD;
+  const int k = blockIdx.y, tid = threadIdx.x, i = blockIdx.x * LOWRANK_THREADS + tid;
+  const double* X = v.X + (size_t)emu * v.XS;
+  const double* P = v.P + (size_t)emu * v.PS;
+  const double* w = W2 + (size_t)k * ld;
+  const double sig2 = P[D];
+  double* sxi = sm;                                  // [d][tid]
+  for (int d = 0; d < D; ++d) sxi[d * LOWRANK_THREADS + tid] = (i < n) ? X[(size_t)i * D + d] : 0.0;
+  const double wi = (i < n) ? w[i] : 0.0;
+  for (int pc = 0; pc <= D; pc += LOWRANK_CHUNK) {
+    double acc[LOWRANK_CHUNK];
+#pragma unroll
+    for (int c = 0; c < LOWRANK_CHUNK; ++c) acc[c] = 0.0;
+    for (int j = 0; j < n; ++j) {
+      const double* xj = X + (size_t)j * D;
+      const double wj = w[j];
+      double g, kv;                                  // sigma^2 dk/dr2 (product kernel: sigma^2 k), sigma^2 k
+      if (KT < 2) {
+        double r2 = 0.0;
+        for (int d = 0; d < D; ++d) {
+          const double df = sxi[d * LOWRANK_THREADS + tid] - xj[d];
+          r2 = __builtin_fma(P[d] * df, df, r2);
+        }
+        g = sig2 * kern_dr2<KT>(r2);
+        kv = sig2 * kern_val<KT>(r2);
+      } else {
+        double kk = 1.0, ssum = 0.0;
+        for (int d = 0; d < D; ++d) {
+          const double df = sxi[d * LOWRANK_THREADS + tid] - xj[d];
+          const double r2 = P[d] * df * df;
+          const double sd = sqrt(5.0 * r2);
+          kk *= 1.0 + sd + (5.0 / 3.0) * r2;
+          ssum += sd;
+        }
+        kv = sig2 * (kk * exp(-ssum));
+        g = kv;
+      }
+#pragma unroll
+      for (int c = 0; c < LOWRANK_CHUNK; ++c) {
+        const int p = pc + c;
+        if (p < D) {
+          const double df = sxi[p * LOWRANK_THREADS + tid] - xj[p];
+          const double t = (KT < 2) ? g * (P[p] * df * df) : g * mat52_dlog(P[p] * df * df) * (P[p] * df * df);
+          acc[c] = __builtin_fma(t, wj, acc[c]);
+        } else if (p == D) {
+          acc[c] = __builtin_fma(kv, wj, acc[c]);
+        }
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < LOWRANK_CHUNK; ++c) {
+      const int p = pc + c;
+      if (p > D) break;
+      red[tid] = wi * acc[c];
+      __syncthreads();
+      for (int h = LOWRANK_THREADS / 2; h > 0; h >>= 1) {
+        if (tid < h) red[tid] += red[tid + h];
+        __syncthreads();
+      }
+      if (tid == 0) part[((size_t)k * nblk + blockIdx.x) * (D + 1) + p] = red[0];
+      __syncthreads();
+    }
+  }
+}
+
+// out[emu][p] += 0.5 * sum of the partials, p <= D (fixed summation order)
+__global__ void grad_lowrank_finish_kernel(int D, int count, const double* __restrict__ part, double* __restrict__ out) {
+  const int p = threadIdx.x;
+  if (p > D) return;
+  double s = 0.0;
+  for (int e = 0; e < count; ++e) s += part[(size_t)e * (D + 1) + p];
+  out[p] += 0.5 * s;
+}
+
+void launch_grad_lowrank(const BatchView& v, int emu, const double* W2, int m, double* part, double* out, hipStream_t s) {
+  const int nblk = (v.n + LOWRANK_THREADS - 1) / LOWRANK_THREADS;
+  const size_t sm = (size_t)v.D * LOWRANK_THREADS * sizeof(double);
+#define CALL(K) hipLaunchKernelGGL((grad_lowrank_kernel<K>), dim3(nblk, m), dim3(LOWRANK_THREADS), sm, s, v, emu, W2, nblk, part)
+  KT_DISPATCH(v.kernel_type, CALL);
+#undef CALL
+  hipLaunchKernelGGL(grad_lowrank_finish_kernel, dim3(1), dim3(128), 0, s, v.D, nblk * m, part, out + (size_t)emu * (v.D + 3));
+}
+
 void launch_grad(const BatchView& v, double* partial, double* out, hipStream_t s) {
   const int ntiles = grad_num_tiles(v.n);
   const size_t sm = (size_t)(128 * v.D + 4 * (v.D + 3)) * sizeof(double);

@@ -1,95 +1,173 @@
-// Pivoted Cholesky for nugget="pivot" (linalg/cholesky.py:284-327, which calls LAPACK dpstrf; with the block size
-// reference LAPACK selects for it that is the unblocked dpstf2): a left-looking column algorithm with diagonal pivoting.
+// Pivoted Cholesky for nugget="pivot" (linalg/cholesky.py:284-327, which calls LAPACK dpstrf): diagonal pivoting,
 //
 //   per column j:   w_i   = a_ii - sum_{k<j} l_ik^2 for the remaining rows, p = first arg max_i w_i
 //                   stop when w_p <= n * eps * max_i a_ii  (rank = j)
 //                   interchange rows / columns j <-> p, l_jj = sqrt(w_p)
 //                   l_ij  = (a_ij - sum_{k<j} l_ik l_jk) / l_jj      for every row below (including the right-hand-side rows)
 //
-// The pivot of step j depends on column j-1, so the n steps are sequential and the work per step is a matrix-vector
-// product: this is HBM/L2-bound BLAS-2 work (8 n^3 / 6 bytes per emulator), not MFMA work, and one workgroup of sixteen
-// waves runs a whole emulator -- the batch over emulators is what fills the chip.  Rows are contiguous (row-major lower
-// triangle), so each wave owns rows and its lanes stride along k: every load instruction moves full 512-byte lines.
+// organised like LAPACK's blocked dpstrf: block columns of 64.  Inside a block the pivot of step j depends on column
+// j-1, so the steps are sequential and each is a matrix-vector product over the block's columns only (BLAS-2, one
+// workgroup of sixteen waves per emulator: rows are contiguous, each wave owns sixteen rows at a time and its 64 lanes
+// take one column each, so every load instruction moves one full 512-byte line and a wave has sixteen of them in flight);
+// after the block, the rank-64 update of everything to its right is the MFMA update of the blocked Cholesky
+// (launch_update_narrow / launch_update_trailing), which also keeps the diagonal that the next block's pivot search
+// reads up to date.  The host drops an emulator from the batch when its factorisation stops early.
 //
-// Rank-deficient case, as the reference has it: the rows that were never chosen keep the (interchanged) input entries
-// below the diagonal and get the diagonal l_{r-1,r-1} / ((r+1)(r+2)...(i+1)); the forward substitution of the
-// right-hand-side rows is continued through that block so that rows n.. of A hold L^-1 [t, H] for the complete factor.
+// Rank-deficient case, with the semantics of the unblocked dpstf2 (what LAPACK runs for n up to its block size; beyond
+// that the content of the skipped block depends on the LAPACK build's internal blocking and is not a defined result):
+// the rows that were never chosen hold the interchanged INPUT entries below the diagonal and the diagonal
+// l_{r-1,r-1} / ((r+1)(r+2)...(i+1)); the forward substitution of the right-hand-side rows is continued through that
+// block so that rows n.. of A hold L^-1 [t, H] for the complete factor.
 #include <cfloat>
 #include <cmath>
 #include "launch.h"
+#include "cov_dev.h"
 
 namespace mogp {
 
 constexpr int PSTRF_THREADS = 1024;
-constexpr int PSTRF_ROWS = 4;        // rows per wave in flight in the matrix-vector product
+constexpr int PSTRF_ROWS = 16;        // (rows16_sum is written for exactly sixteen)
+//       // rows per wave in flight in the matrix-vector product (rows are 16 KB apart: latency bound)
 
+// Sum over the 64 lanes, returned in every lane.  DPP moves inside the rows of 16 lanes (full-rate VALU, no LDS
+// crossbar: the __shfl_xor butterfly cost ~1800 cycles per matrix row and bounded the whole panel kernel), then the four
+// row totals through v_readlane.
+template <int CTRL>
+__device__ __forceinline__ double dpp_add(double x) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, 0xF, 0xF, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, 0xF, 0xF, true);
+  return x + __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ double wave_sum(double x) {
-#pragma unroll
-  for (int off = 32; off; off >>= 1) x += __shfl_xor(x, off);
-  return x;
+  x = dpp_add<0xB1>(x);     // quad_perm:[1,0,3,2]
+  x = dpp_add<0x4E>(x);     // quad_perm:[2,3,0,1]
+  x = dpp_add<0x141>(x);    // row_half_mirror
+  x = dpp_add<0x140>(x);    // row_mirror
+  const int lo = __double2loint(x), hi = __double2hiint(x);
+  const double r0 = __hiloint2double(__builtin_amdgcn_readlane(hi, 0), __builtin_amdgcn_readlane(lo, 0));
+  const double r1 = __hiloint2double(__builtin_amdgcn_readlane(hi, 16), __builtin_amdgcn_readlane(lo, 16));
+  const double r2 = __hiloint2double(__builtin_amdgcn_readlane(hi, 32), __builtin_amdgcn_readlane(lo, 32));
+  const double r3 = __hiloint2double(__builtin_amdgcn_readlane(hi, 48), __builtin_amdgcn_readlane(lo, 48));
+  return (r0 + r1) + (r2 + r3);
 }
 
-__global__ __launch_bounds__(PSTRF_THREADS) void pstrf_kernel(BatchView v, int* __restrict__ perm, int* __restrict__ rank_out,
-                                                               int* __restrict__ info, double* __restrict__ work) {
-  __shared__ double s_val[PSTRF_THREADS / 64];
-  __shared__ int s_idx[PSTRF_THREADS / 64];
-  __shared__ double s_piv;
-  __shared__ int s_p;
-  const int emu = v.idx ? v.idx[blockIdx.x] : blockIdx.x;
-  const int n = v.n, ld = v.LD, nr = v.n + v.R;
-  double* A = v.A + (size_t)emu * v.MS;
-  double* dots = work + (size_t)emu * 2 * v.NP;      // sum_k l_ik^2 so far
-  double* diag = dots + v.NP;                         // diagonal of the (interchanged) input matrix
-  int* P = perm + (size_t)emu * n;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = PSTRF_THREADS / 64;
-
-  // block-wide "first arg max" of (val, idx); NaN never wins; idx = n when nothing does
-  auto arg_max = [&](double bv, int bi) {
+// Sixteen per-row partial sums per lane -> the sixteen row totals, total of row (lane >> 2) in every lane: a
+// reduce-scatter (each exchange halves the number of values a lane carries) instead of sixteen butterflies.  The two
+// cross-row exchanges are gfx950's v_permlane32_swap / v_permlane16_swap, the rest DPP moves inside the rows of 16 lanes.
+// 63 instead of ~400 VALU instructions per sixteen rows -- the butterflies were what bounded the panel kernel.
+__device__ __forceinline__ double comb32(double a, double b) {      // lanes 0-31: a.lo + a.hi halves, lanes 32-63: b's
+  const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+  const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+  return __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
+}
+__device__ __forceinline__ double comb16(double a, double b) {      // rows (of 16 lanes) 0, 2: a's row pairs, rows 1, 3: b's
+  const auto lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+  const auto hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+  return __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
+}
+template <int CTRL>
+__device__ __forceinline__ double comb_dpp(double a, double b, bool upper) {   // lower partner keeps a, upper partner keeps b
+  const double keep = upper ? b : a, send = upper ? a : b;
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(send), CTRL, 0xF, 0xF, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(send), CTRL, 0xF, 0xF, true);
+  return keep + __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double rows16_sum(const double (&s)[16], int lane) {
+  double t[8], w[4];
 #pragma unroll
-    for (int off = 32; off; off >>= 1) {
-      const double ov = __shfl_down(bv, off);
-      const int oi = __shfl_down(bi, off);
-      if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
-    }
-    if (lane == 0) { s_val[wave] = bv; s_idx[wave] = bi; }
-    __syncthreads();
-    if (tid == 0) {
-      for (int w = 1; w < nw; ++w)
-        if (s_val[w] > bv || (s_val[w] == bv && s_idx[w] < bi)) { bv = s_val[w]; bi = s_idx[w]; }
-      s_piv = bv;
-      s_p = bi;
-    }
-    __syncthreads();
-  };
+  for (int u = 0; u < 8; ++u) t[u] = comb32(s[u], s[u + 8]);           // lane bit 5 <-> row bit 3
+#pragma unroll
+  for (int u = 0; u < 4; ++u) w[u] = comb16(t[u], t[u + 4]);           // lane bit 4 <-> row bit 2
+  const bool b3 = lane & 8, b2 = lane & 4;
+  const double z0 = comb_dpp<0x128>(w[0], w[2], b3), z1 = comb_dpp<0x128>(w[1], w[3], b3);   // row_ror:8, lane bit 3 <-> row bit 1
+  double y = comb_dpp<0x141>(z0, z1, b2);                              // row_half_mirror, lane bit 2 <-> row bit 0
+  y = dpp_add<0xB1>(y);
+  return dpp_add<0x4E>(y);
+}
 
+// block-wide "first arg max" of (val, idx) over PSTRF_THREADS threads; NaN never wins; idx = none when nothing does
+struct ArgMax {
+  double val;
+  int idx;
+};
+__device__ __forceinline__ ArgMax block_arg_max(double bv, int bi, double* s_val, int* s_idx) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = PSTRF_THREADS / 64;
+#pragma unroll
+  for (int off = 32; off; off >>= 1) {
+    const double ov = __shfl_down(bv, off);
+    const int oi = __shfl_down(bi, off);
+    if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+  }
+  __syncthreads();                      // the previous round's readers are done with s_val / s_idx
+  if (lane == 0) { s_val[wave] = bv; s_idx[wave] = bi; }
+  __syncthreads();
+  if (tid == 0) {
+    for (int w = 1; w < nw; ++w)
+      if (s_val[w] > bv || (s_val[w] == bv && s_idx[w] < bi)) { bv = s_val[w]; bi = s_idx[w]; }
+    s_val[nw] = bv;
+    s_idx[nw] = bi;
+  }
+  __syncthreads();
+  return ArgMax{s_val[nw], s_idx[nw]};
+}
+
+__device__ __forceinline__ double* pstrf_work(double* work, const BatchView& v, int emu) { return work + (size_t)emu * pstrf_work_doubles(v.NP); }
+
+// rank[emu] = -1 (running), perm = identity, stopping threshold from the largest diagonal entry
+__global__ __launch_bounds__(PSTRF_THREADS) void pstrf_begin_kernel(BatchView v, int* __restrict__ perm, int* __restrict__ rank,
+                                                                     int* __restrict__ info, double* __restrict__ work) {
+  __shared__ double s_val[PSTRF_THREADS / 64 + 1];
+  __shared__ int s_idx[PSTRF_THREADS / 64 + 1];
+  const int emu = v.idx ? v.idx[blockIdx.x] : blockIdx.x;
+  const int n = v.n, ld = v.LD;
+  const double* A = v.A + (size_t)emu * v.MS;
+  int* P = perm + (size_t)emu * n;
   double bv = -INFINITY;
   int bi = n;
-  for (int i = tid; i < n; i += PSTRF_THREADS) {
+  for (int i = threadIdx.x; i < n; i += PSTRF_THREADS) {
     const double d = A[(size_t)i * ld + i];
-    dots[i] = 0.0;
-    diag[i] = d;
     P[i] = i;
     if (d > bv) { bv = d; bi = i; }
   }
-  arg_max(bv, bi);
-  const double amax = s_piv;
-  if (s_p >= n || !(amax > 0.0)) {          // dpstf2: largest diagonal entry <= 0 or NaN -> rank 0, info 1
-    if (tid == 0) { rank_out[emu] = 0; info[emu] = 1; }
-    return;
+  const ArgMax m = block_arg_max(bv, bi, s_val, s_idx);
+  if (threadIdx.x == 0) {
+    const bool bad = m.idx >= n || !(m.val > 0.0);      // dpstf2: largest diagonal entry <= 0 or NaN -> rank 0, info 1
+    rank[emu] = bad ? 0 : -1;
+    info[emu] = bad ? 1 : 0;
+    pstrf_work(work, v, emu)[2 * v.NP] = n * (0.5 * DBL_EPSILON) * m.val;     // tol < 0: N * DLAMCH('Epsilon') * max diagonal
   }
-  const double dstop = n * (0.5 * DBL_EPSILON) * amax;     // tol < 0: N * DLAMCH('Epsilon') * max diagonal
+}
 
-  int r = n;
-  for (int j = 0; j < n; ++j) {
-    bv = -INFINITY;
-    bi = n;
+// columns [k0, k0 + jb), jb <= 64, of every running emulator in the launch
+__global__ __launch_bounds__(PSTRF_THREADS) void pstrf_panel_kernel(BatchView v, int k0, int jb, int* __restrict__ perm,
+                                                                     int* __restrict__ rank, double* __restrict__ work) {
+  __shared__ double s_val[PSTRF_THREADS / 64 + 1];
+  __shared__ int s_idx[PSTRF_THREADS / 64 + 1];
+  const int emu = v.idx ? v.idx[blockIdx.x] : blockIdx.x;
+  if (rank[emu] >= 0) return;
+  const int n = v.n, ld = v.LD, nr = v.n + v.R;
+  double* A = v.A + (size_t)emu * v.MS;
+  double* dots = pstrf_work(work, v, emu);          // sum over the block's columns of l_ik^2
+  double* diag = dots + v.NP;                       // diagonal as the earlier blocks' updates left it
+  const double dstop = dots[2 * v.NP];
+  int* P = perm + (size_t)emu * n;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = PSTRF_THREADS / 64;
+  for (int i = k0 + tid; i < n; i += PSTRF_THREADS) {
+    dots[i] = 0.0;
+    diag[i] = A[(size_t)i * ld + i];
+  }
+  __syncthreads();
+  int r = -1;
+  for (int j = k0; j < k0 + jb; ++j) {
+    double bv = -INFINITY;
+    int bi = n;
     for (int i = j + tid; i < n; i += PSTRF_THREADS) {
       const double w = diag[i] - dots[i];
       if (w > bv) { bv = w; bi = i; }
     }
-    arg_max(bv, bi);
-    const double piv = s_piv;
-    const int p = s_p;
+    const ArgMax m = block_arg_max(bv, bi, s_val, s_idx);
+    const double piv = m.val;
+    const int p = m.idx;
     if (p >= n || !(piv > dstop)) { r = j; break; }
     double* rj = A + (size_t)j * ld;
     if (p != j) {
@@ -105,7 +183,8 @@ __global__ __launch_bounds__(PSTRF_THREADS) void pstrf_kernel(BatchView v, int* 
       }
       if (tid == 0) {
         double t = dots[j]; dots[j] = dots[p]; dots[p] = t;
-        t = diag[j]; diag[j] = diag[p]; diag[p] = t;
+        rp[p] = diag[j];                   // the diagonal entries change places as well (a_jj itself becomes l_jj below)
+        diag[p] = diag[j];
         const int q = P[j]; P[j] = P[p]; P[p] = q;
       }
     }
@@ -121,19 +200,20 @@ __global__ __launch_bounds__(PSTRF_THREADS) void pstrf_kernel(BatchView v, int* 
         row[u] = A + (size_t)min(i0 + u, nr - 1) * ld;
         s[u] = 0.0;
       }
-      for (int k = lane; k < j; k += 64) {
-        const double x = rj[k];
+      {
+        // at most 63 earlier columns in this launch: one predicated load per row, all of them in flight together
+        const int ka = k0 + lane;
+        const bool pa = ka < j;
+        const double xa = pa ? rj[ka] : 0.0;
+        double va[PSTRF_ROWS];
 #pragma unroll
-        for (int u = 0; u < PSTRF_ROWS; ++u) s[u] = __builtin_fma(row[u][k], x, s[u]);
-      }
-      double mine = 0.0;
+        for (int u = 0; u < PSTRF_ROWS; ++u) va[u] = pa ? row[u][ka] : 0.0;
 #pragma unroll
-      for (int u = 0; u < PSTRF_ROWS; ++u) {
-        const double t = wave_sum(s[u]);
-        if (lane == u) mine = t;
+        for (int u = 0; u < PSTRF_ROWS; ++u) s[u] = va[u] * xa;
       }
-      const int i = i0 + lane;
-      if (lane < PSTRF_ROWS && i < nr) {
+      const double mine = rows16_sum(s, lane);          // total of row i0 + (lane >> 2)
+      const int i = i0 + (lane >> 2);
+      if ((lane & 3) == 0 && i < nr) {
         double* c = A + (size_t)i * ld + j;
         const double val = (*c - mine) * inv;
         *c = val;
@@ -142,36 +222,91 @@ __global__ __launch_bounds__(PSTRF_THREADS) void pstrf_kernel(BatchView v, int* 
     }
     __syncthreads();
   }
+  if (tid == 0) {
+    if (r >= 0) rank[emu] = r;
+    else if (k0 + jb >= n) rank[emu] = n;
+  }
+}
 
-  if (r < n) {
-    __syncthreads();
-    if (tid == 0) {
-      // linalg/cholesky.py:321-325: L[i][i] = L[r-1][r-1] / cumprod(r+1 .. i+1)
-      const double d = A[(size_t)(r - 1) * ld + (r - 1)];
-      double div = 1.0;
-      for (int i = r; i < n; ++i) {
-        div *= (double)(i + 1);
-        A[(size_t)i * ld + i] = d / div;
-      }
+// sigma^2 k(x_a, x_b) with the operation order of the covariance build (cov_dev.h pair_kval)
+__device__ __forceinline__ double cov_pair_global(const BatchView& v, const double* __restrict__ X, const double* __restrict__ P, int a, int b) {
+  const int D = v.D;
+  const double* xa = X + (size_t)a * D;
+  const double* xb = X + (size_t)b * D;
+  if (v.kernel_type < 2) {
+    double r2 = 0.0;
+    for (int d = 0; d < D; ++d) {
+      const double df = xa[d] - xb[d];
+      r2 = __builtin_fma(P[d] * df, df, r2);
     }
-    __syncthreads();
-    // forward substitution of the right-hand-side rows through the columns that were not factored: one wave per row,
-    // sequential in j (column j needs the row's entries of all earlier columns)
-    if (wave < v.R) {
-      double* row = A + (size_t)(n + wave) * ld;
-      for (int j = r; j < n; ++j) {
-        const double* rj = A + (size_t)j * ld;
-        double s = 0.0;
-        for (int k = lane; k < j; k += 64) s = __builtin_fma(row[k], rj[k], s);
-        s = wave_sum(s);
-        if (lane == 0) row[j] = (row[j] - s) / rj[j];
-        __threadfence_block();
-      }
+    return P[D] * (v.kernel_type == 0 ? kern_val<0>(r2) : kern_val<1>(r2));
+  }
+  double k = 1.0, ssum = 0.0;
+  for (int d = 0; d < D; ++d) {
+    const double df = xa[d] - xb[d];
+    const double r2 = P[d] * df * df;
+    const double sd = sqrt(5.0 * r2);
+    k *= 1.0 + sd + (5.0 / 3.0) * r2;
+    ssum += sd;
+  }
+  return P[D] * (k * exp(-ssum));
+}
+
+// Emulators whose factorisation stopped at rank r < n: put the input entries back into the block that was skipped (the
+// trailing updates of the completed block columns have touched it), set its replacement diagonal, and take the
+// right-hand-side rows through it.  A0 != null: the input matrix (n x n, row-major) instead of the kernel function.
+__global__ __launch_bounds__(PSTRF_THREADS) void pstrf_tail_kernel(BatchView v, const int* __restrict__ perm, const int* __restrict__ rank,
+                                                                    const double* __restrict__ X0, const double* __restrict__ A0) {
+  const int emu = v.idx ? v.idx[blockIdx.x] : blockIdx.x;
+  const int n = v.n, ld = v.LD, r = rank[emu];
+  if (r <= 0 || r >= n) return;
+  double* A = v.A + (size_t)emu * v.MS;
+  const int* P = perm + (size_t)emu * n;
+  const double* prm = v.P ? v.P + (size_t)emu * v.PS : nullptr;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int m = n - r;
+  for (long e = tid; e < (long)m * m; e += PSTRF_THREADS) {
+    const int i = r + (int)(e / m), j = r + (int)(e % m);
+    if (j >= i) continue;
+    A[(size_t)i * ld + j] = A0 ? A0[(size_t)P[i] * n + P[j]] : cov_pair_global(v, X0, prm, P[i], P[j]);
+  }
+  for (int e = tid; e < v.R * m; e += PSTRF_THREADS) {
+    const int c = e / m, j = r + e % m;
+    A[(size_t)(n + c) * ld + j] = (c == 0) ? v.T[(size_t)emu * n + P[j]] : v.H[(size_t)(c - 1) * n + P[j]];
+  }
+  if (tid == 0) {
+    // linalg/cholesky.py:321-325: L[i][i] = L[r-1][r-1] / cumprod(r+1 .. i+1)
+    const double d = A[(size_t)(r - 1) * ld + (r - 1)];
+    double div = 1.0;
+    for (int i = r; i < n; ++i) {
+      div *= (double)(i + 1);
+      A[(size_t)i * ld + i] = d / div;
     }
   }
-  // the right-hand-side rows close the augmented factor like the blocked path does: diagonal sqrt(PAD_BIG), zeros between
-  if (tid < v.R) A[(size_t)(n + tid) * ld + (n + tid)] = sqrt(PAD_BIG);
-  if (tid == 0) { rank_out[emu] = r; info[emu] = 0; }
+  __syncthreads();
+  // one wave per right-hand-side row, sequential in j (column j needs the row's entries of all earlier columns)
+  if (wave < v.R) {
+    double* row = A + (size_t)(n + wave) * ld;
+    for (int j = r; j < n; ++j) {
+      const double* rj = A + (size_t)j * ld;
+      double s = 0.0;
+      for (int k = lane; k < j; k += 64) s = __builtin_fma(row[k], rj[k], s);
+      s = wave_sum(s);
+      if (lane == 0) row[j] = (row[j] - s) / rj[j];
+      __threadfence_block();
+    }
+  }
+}
+
+// the right-hand-side rows close the augmented factor like the blocked path does: diagonal sqrt(PAD_BIG), zeros between
+__global__ void pstrf_end_kernel(BatchView v) {
+  const int emu = v.idx ? v.idx[blockIdx.x] : blockIdx.x;
+  double* A = v.A + (size_t)emu * v.MS;
+  const int R = v.R, n = v.n;
+  for (int e = threadIdx.x; e < R * R; e += blockDim.x) {
+    const int a = e / R, b = e % R;
+    if (b <= a) A[(size_t)(n + a) * v.LD + n + b] = (a == b) ? sqrt(PAD_BIG) : 0.0;
+  }
 }
 
 __global__ __launch_bounds__(256) void permute_rows_kernel(BatchView v, const double* __restrict__ X, const int* __restrict__ perm,
@@ -184,8 +319,20 @@ __global__ __launch_bounds__(256) void permute_rows_kernel(BatchView v, const do
   Xp[(size_t)emu * n * D + e] = X[(size_t)perm[(size_t)emu * n + pos] * D + d];
 }
 
-void launch_pstrf(const BatchView& v, int* perm, int* rank, int* info, double* work, hipStream_t s) {
-  hipLaunchKernelGGL(pstrf_kernel, dim3(v.nb), dim3(PSTRF_THREADS), 0, s, v, perm, rank, info, work);
+void launch_pstrf_begin(const BatchView& v, int* perm, int* rank, int* info, double* work, hipStream_t s) {
+  hipLaunchKernelGGL(pstrf_begin_kernel, dim3(v.nb), dim3(PSTRF_THREADS), 0, s, v, perm, rank, info, work);
+}
+
+void launch_pstrf_panel(const BatchView& v, int k0, int jb, int* perm, int* rank, double* work, hipStream_t s) {
+  hipLaunchKernelGGL(pstrf_panel_kernel, dim3(v.nb), dim3(PSTRF_THREADS), 0, s, v, k0, jb, perm, rank, work);
+}
+
+void launch_pstrf_tail(const BatchView& v, const int* perm, const int* rank, const double* X0, const double* A0, hipStream_t s) {
+  hipLaunchKernelGGL(pstrf_tail_kernel, dim3(v.nb), dim3(PSTRF_THREADS), 0, s, v, perm, rank, X0, A0);
+}
+
+void launch_pstrf_end(const BatchView& v, hipStream_t s) {
+  if (v.R > 0) hipLaunchKernelGGL(pstrf_end_kernel, dim3(v.nb), dim3(64), 0, s, v);
 }
 
 void launch_permute_rows(const BatchView& v, const double* X, const int* perm, double* Xp, hipStream_t s) {
