@@ -221,6 +221,14 @@ def main():
         libgpgpu.fit_GP_MAP(mo, 1, theta)
         extras["fit_GP_MAP_s_64_emulators_1_start_maxiter30"] = time.perf_counter() - t0
         extras["fit_GP_MAP_all_fit"] = len(mo.get_unfitted_indices()) == 0
+        # nugget="pivot" (SURVEY 8f row 4): the same 64 fits through the pivoted Cholesky (2000 sequential pivot steps each)
+        gpp = M.MultiOutputGP_GPU(X, T, kernel=args.kernel, nugget="pivot", priors=GPPriors(n_corr=d, nugget_type="pivot"))
+        gpp._mogp_gpu.eval(thetas, grad=False)
+        t0 = time.perf_counter()
+        fp, _, okp = gpp._mogp_gpu.eval(thetas, grad=False)
+        extras["pivot_fits_per_s"] = B / (time.perf_counter() - t0)
+        assert okp.all()
+        del gpp
 
     # per-kernel device times from HIP events on the launch stream
     kern = {}

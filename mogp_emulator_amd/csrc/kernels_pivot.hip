@@ -98,17 +98,17 @@ __device__ __forceinline__ ArgMax block_arg_max(double bv, int bi, double* s_val
     const int oi = __shfl_down(bi, off);
     if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
   }
-  __syncthreads();                      // the previous round's readers are done with s_val / s_idx
+  // (the callers have a barrier between the reads below and the next call's writes)
   if (lane == 0) { s_val[wave] = bv; s_idx[wave] = bi; }
   __syncthreads();
-  if (tid == 0) {
-    for (int w = 1; w < nw; ++w)
-      if (s_val[w] > bv || (s_val[w] == bv && s_idx[w] < bi)) { bv = s_val[w]; bi = s_idx[w]; }
-    s_val[nw] = bv;
-    s_idx[nw] = bi;
+  bv = s_val[0];
+  bi = s_idx[0];
+  for (int w = 1; w < nw; ++w) {
+    const double ov = s_val[w];
+    const int oi = s_idx[w];
+    if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
   }
-  __syncthreads();
-  return ArgMax{s_val[nw], s_idx[nw]};
+  return ArgMax{bv, bi};
 }
 
 __device__ __forceinline__ double* pstrf_work(double* work, const BatchView& v, int emu) { return work + (size_t)emu * pstrf_work_doubles(v.NP); }
@@ -158,16 +158,20 @@ __global__ __launch_bounds__(PSTRF_THREADS) void pstrf_panel_kernel(BatchView v,
   }
   __syncthreads();
   int r = -1;
-  for (int j = k0; j < k0 + jb; ++j) {
+  // pivot candidate of the first column; for the later columns it comes out of the previous column's epilogue
+  ArgMax cur;
+  {
     double bv = -INFINITY;
     int bi = n;
-    for (int i = j + tid; i < n; i += PSTRF_THREADS) {
+    for (int i = k0 + tid; i < n; i += PSTRF_THREADS) {
       const double w = diag[i] - dots[i];
       if (w > bv) { bv = w; bi = i; }
     }
-    const ArgMax m = block_arg_max(bv, bi, s_val, s_idx);
-    const double piv = m.val;
-    const int p = m.idx;
+    cur = block_arg_max(bv, bi, s_val, s_idx);
+  }
+  for (int j = k0; j < k0 + jb; ++j) {
+    const double piv = cur.val;
+    const int p = cur.idx;
     if (p >= n || !(piv > dstop)) { r = j; break; }
     double* rj = A + (size_t)j * ld;
     if (p != j) {
@@ -192,6 +196,8 @@ __global__ __launch_bounds__(PSTRF_THREADS) void pstrf_panel_kernel(BatchView v,
     if (tid == 0) rj[j] = ajj;
     __syncthreads();
     const double inv = 1.0 / ajj;            // dpstf2 scales the column by the reciprocal
+    double bv = -INFINITY;                   // this thread's candidate for the next pivot (rows in increasing order)
+    int bi = n;
     for (int i0 = j + 1 + wave * PSTRF_ROWS; i0 < nr; i0 += nw * PSTRF_ROWS) {
       const double* row[PSTRF_ROWS];
       double s[PSTRF_ROWS];
@@ -199,6 +205,14 @@ __global__ __launch_bounds__(PSTRF_THREADS) void pstrf_panel_kernel(BatchView v,
       for (int u = 0; u < PSTRF_ROWS; ++u) {
         row[u] = A + (size_t)min(i0 + u, nr - 1) * ld;
         s[u] = 0.0;
+      }
+      const int i = i0 + (lane >> 2);
+      const bool owner = (lane & 3) == 0 && i < nr;          // this lane finishes row i
+      double* c = A + (size_t)min(i, nr - 1) * ld + j;
+      double cold = 0.0, dold = 0.0, gold = 0.0;
+      if (owner) {
+        cold = *c;
+        if (i < n) { dold = dots[i]; gold = diag[i]; }
       }
       {
         // at most 63 earlier columns in this launch: one predicated load per row, all of them in flight together
@@ -212,15 +226,18 @@ __global__ __launch_bounds__(PSTRF_THREADS) void pstrf_panel_kernel(BatchView v,
         for (int u = 0; u < PSTRF_ROWS; ++u) s[u] = va[u] * xa;
       }
       const double mine = rows16_sum(s, lane);          // total of row i0 + (lane >> 2)
-      const int i = i0 + (lane >> 2);
-      if ((lane & 3) == 0 && i < nr) {
-        double* c = A + (size_t)i * ld + j;
-        const double val = (*c - mine) * inv;
+      if (owner) {
+        const double val = (cold - mine) * inv;
         *c = val;
-        if (i < n) dots[i] += val * val;
+        if (i < n) {
+          const double dn = dold + val * val;
+          dots[i] = dn;
+          const double w = gold - dn;
+          if (w > bv) { bv = w; bi = i; }
+        }
       }
     }
-    __syncthreads();
+    cur = block_arg_max(bv, bi, s_val, s_idx);          // its barrier also closes the column
   }
   if (tid == 0) {
     if (r >= 0) rank[emu] = r;
