@@ -888,7 +888,9 @@ void Engine::eval(const std::vector<int>& ids, const std::vector<const double*>&
       }
     }
     g.has_data = fine;
-    g.factored = fine;
+    // a pivoted factor stays inspectable (get_cholesky_lower / get_pivot, the reference's Kinv.L / Kinv.P) when the
+    // log-posterior over its tiny replacement diagonal is not finite
+    g.factored = fine || (good[i] && g.nug_type == NUG_PIVOT);
     g.logpost = val;
     if (f) f[k] = val;
     if (ok) ok[k] = fine ? 1 : 0;

@@ -237,3 +237,45 @@ def test_gradient_with_repeated_points_vs_oracle(kern):
     resid = L @ L.T @ Kinv[np.ix_(P, P)] - np.eye(n0 + 3)
     assert np.abs(resid).max() < 1e-4
     assert_allclose(gp.logpost_deriv(theta), grad, rtol=1e-12)           # and back to the gradient's reduced form
+
+
+def test_emulators_of_one_batch_stop_at_different_panels():
+    # numerically rank-deficient K (long length scales): every emulator of the batch stops at its own rank, some inside
+    # the first 64-column panel, some several panels later, some never -- the host drops them from the batch one by one
+    rng = np.random.default_rng(5)
+    n, d, B = 100, 2, 10
+    X = rng.random((n, d))
+    scales = np.array([-6., -4., -3., -2., -1., 0., 1., 2., 4., 6.])       # corr_raw: length = exp(-corr_raw / 2)
+    thetas = np.stack([np.array([s, s, 0.0]) for s in scales])
+    T = np.stack([np.sin(2 * X[:, 0] + k) + X[:, 1] for k in range(B)])
+    mo = M.MultiOutputGP_GPU(X, T, kernel="SquaredExponential", nugget="pivot", priors=weak(d))
+    f, _, ok = mo._mogp_gpu.eval(thetas, grad=False)
+    # With dozens of skipped rows the replacement diagonal d / ((r+1)...(i+1)) is ~1e-100 and the log-posterior is not
+    # finite -- in the reference as well (the oracle gives nan for the same emulators); the factor itself is defined.
+    assert ok[-2:].all() and not ok[:5].any()
+    ranks = []
+    for k in range(B):
+        native = mo._mogp_gpu.emulator(k)
+        P, rank = native.get_pivot()
+        ranks.append(rank)
+        assert sorted(P) == list(range(n))
+        Lt = np.zeros((n, n)); native.get_cholesky_lower(Lt)
+        L = np.tril(Lt.T)
+        sig2 = np.exp(thetas[k][d])
+        K = sig2 * R.kernel_f(X, X, thetas[k][:d], R.SQEXP)
+        Kp = K[np.ix_(P, P)]
+        # the accepted pivots reproduce the leading block, and what is left of the diagonal is below LAPACK's threshold
+        assert_allclose(L[:rank, :rank] @ L[:rank, :rank].T, Kp[:rank, :rank], atol=1e-9 * sig2)
+        left = np.diag(Kp)[rank:] - np.sum(L[rank:, :rank] ** 2, axis=1)
+        assert np.all(left <= 10 * n * 1.2e-16 * sig2 + 1e-13)
+        _, _, rr = R.pivot_cholesky(K)
+        assert abs(rank - rr) <= 2
+        if rank < n:
+            d_ = np.diag(L)
+            assert_allclose(d_[rank:], d_[rank - 1] / np.cumprod(np.arange(rank + 1, n + 1, dtype=float)), rtol=1e-13)
+    assert ranks[0] < 64 < ranks[6] and ranks[-1] == n and len(set(ranks)) >= 5
+    # and the batch gives what each emulator gives alone
+    for k in (8, 9):
+        gp = M.GaussianProcessGPU(X, T[k], nugget="pivot", priors=weak(d))
+        assert_allclose(gp.logposterior(thetas[k]), f[k], rtol=1e-12)
+        assert gp.pivot_rank == ranks[k]
