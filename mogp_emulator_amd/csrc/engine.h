@@ -142,6 +142,9 @@ class Engine {
   std::vector<double> hP;
   // predict scratch
   double *dXs = nullptr, *dKs = nullptr, *dMean = nullptr, *dVar = nullptr, *dVarPartial = nullptr, *dDeriv = nullptr;
+  double* dKs2 = nullptr;        // second cross-covariance buffer: the next chunk is built while the current one is consumed
+  size_t capKs2 = 0;
+  hipEvent_t evKsReady[2] = {}, evKsFree[2] = {};
   size_t capXs = 0, capKs = 0, capMean = 0, capVar = 0, capVarPartial = 0, capDeriv = 0;
   std::mt19937_64 rng;
 };

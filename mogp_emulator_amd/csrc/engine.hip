@@ -188,11 +188,13 @@ Engine::Engine(const double* X, int n_, int D_, const double* targets, int B_, u
 
 Engine::~Engine() {
   for (void* p : {(void*)dX, (void*)dP, (void*)dT, (void*)dA, (void*)dLinv, (void*)dKinv, (void*)dAlpha, (void*)dLogdet, (void*)dYty,
-                  (void*)dGradOut, (void*)dGradPartial, (void*)dInfo, (void*)dIdx, (void*)dXs, (void*)dKs, (void*)dMean, (void*)dVar,
+                  (void*)dGradOut, (void*)dGradPartial, (void*)dInfo, (void*)dIdx, (void*)dXs, (void*)dKs, (void*)dKs2, (void*)dMean, (void*)dVar,
                   (void*)dVarPartial, (void*)dDeriv, (void*)dLpack, (void*)dH, (void*)dZ, (void*)dM, (void*)dGram, (void*)dXp, (void*)dPivWork,
                   (void*)dPerm, (void*)dRank})
     if (p) hipFree(p);
   for (auto& kv : w2) hipFree(kv.second);
+  for (auto e : evKsReady) if (e) hipEventDestroy(e);
+  for (auto e : evKsFree) if (e) hipEventDestroy(e);
   for (auto& kv : cholGraphs) hipGraphExecDestroy(kv.second);
   for (auto st : gstreams) hipStreamDestroy(st);
   if (evReady) hipEventDestroy(evReady);
@@ -615,6 +617,8 @@ void Engine::factorize_blocked(const std::vector<int>& ids, std::vector<int>& in
       if (it == cholGraphs.end()) {
         if (cholGraphs.size() >= 32) {                       // bounded cache (optimiser rounds shrink the active set)
           for (auto& kv : w2) hipFree(kv.second);
+  for (auto e : evKsReady) if (e) hipEventDestroy(e);
+  for (auto e : evKsFree) if (e) hipEventDestroy(e);
   for (auto& kv : cholGraphs) hipGraphExecDestroy(kv.second);
           cholGraphs.clear();
         }
@@ -1085,14 +1089,50 @@ void Engine::predict(const std::vector<int>& ids, const double* Xs, int m, bool 
     ld = m;
   }
   const int MPtot = roundup(m, 128);
-  long MC = (long)(6.0e9 / ((double)nb * LD * 8.0)) / 128 * 128;
+  // Experiment (MOGP_PV_OVERLAP=1, off): the cross-covariance build is HBM-write bound and the variance GEMM MFMA bound, so
+  // with two half-size buffers the build of chunk c+1 can run on the look-ahead stream underneath the GEMM of chunk c.
+  // Measured at 64 x n=2000 x m=10^4: predict 45.9 -> 46.5 ms -- the GEMM slows down by as much as the build hides
+  // (20.9 ms per 5632 points -> 11.3 ms per 2560 points, 61.3 -> 56.6 TFLOP/s).
+  static const bool want_overlap = [] { const char* e = getenv("MOGP_PV_OVERLAP"); return e && e[0] == '1'; }();
+  const double budget = 6.0e9;
+  long MC = (long)(budget / ((double)nb * LD * 8.0)) / 128 * 128;
   MC = std::max<long>(128, std::min<long>(MC, MPtot));
+  const bool overlap = vars && want_overlap && MPtot > 2 * 128 && (long)MPtot * nb * LD * 8.0 > 1.0e9;
+  if (overlap) {
+    long half = (long)(0.5 * budget / ((double)nb * LD * 8.0)) / 128 * 128;
+    half = std::max<long>(128, half);
+    const long nch = std::max<long>(2, (MPtot + half - 1) / half);
+    MC = roundup((int)((MPtot / 128 + nch - 1) / nch), 1) * 128;          // equal chunks
+  }
   if (vars) ensure_predict_scratch(nb, (int)MC);
-  for (int c0 = 0; c0 < m; c0 += (int)MC) {
-    const int mc = std::min<int>((int)MC, m - c0);
-    const int MPc = roundup(mc, 128);
-    launch_cross_cov_mean(v, dXsrc + (size_t)c0 * D, mc, MPc, vars ? dKs : nullptr, dm + c0, (int)ld, stream);
-    if (vars) launch_predict_var(v, dKs, mc, MPc, dVarPartial, dv + c0, (int)ld, stream);
+  if (overlap) {
+    grow(dKs2, capKs2, (size_t)nb * MC * LD);
+    for (int b = 0; b < 2; ++b) {
+      if (!evKsReady[b]) HIPCK(hipEventCreateWithFlags(&evKsReady[b], hipEventDisableTiming));
+      if (!evKsFree[b]) HIPCK(hipEventCreateWithFlags(&evKsFree[b], hipEventDisableTiming));
+    }
+    HIPCK(hipEventRecord(evReady, stream));                 // X* upload, L^-1
+    HIPCK(hipStreamWaitEvent(pstream, evReady, 0));
+    int c = 0;
+    for (int c0 = 0; c0 < m; c0 += (int)MC, ++c) {
+      const int mc = std::min<int>((int)MC, m - c0);
+      const int MPc = roundup(mc, 128);
+      const int b = c & 1;
+      double* buf = b ? dKs2 : dKs;
+      if (c >= 2) HIPCK(hipStreamWaitEvent(pstream, evKsFree[b], 0));
+      launch_cross_cov_mean(v, dXsrc + (size_t)c0 * D, mc, MPc, buf, dm + c0, (int)ld, pstream);
+      HIPCK(hipEventRecord(evKsReady[b], pstream));
+      HIPCK(hipStreamWaitEvent(stream, evKsReady[b], 0));
+      launch_predict_var(v, buf, mc, MPc, dVarPartial, dv + c0, (int)ld, stream);
+      HIPCK(hipEventRecord(evKsFree[b], stream));
+    }
+  } else {
+    for (int c0 = 0; c0 < m; c0 += (int)MC) {
+      const int mc = std::min<int>((int)MC, m - c0);
+      const int MPc = roundup(mc, 128);
+      launch_cross_cov_mean(v, dXsrc + (size_t)c0 * D, mc, MPc, vars ? dKs : nullptr, dm + c0, (int)ld, stream);
+      if (vars) launch_predict_var(v, dKs, mc, MPc, dVarPartial, dv + c0, (int)ld, stream);
+    }
   }
   if (derivs) {
     grow(dDeriv, capDeriv, (size_t)nb * m * D);
