@@ -279,3 +279,25 @@ def test_emulators_of_one_batch_stop_at_different_panels():
         gp = M.GaussianProcessGPU(X, T[k], nugget="pivot", priors=weak(d))
         assert_allclose(gp.logposterior(thetas[k]), f[k], rtol=1e-12)
         assert gp.pivot_rank == ranks[k]
+
+
+def test_multioutput_fit_GP_MAP_with_pivoting():
+    # the multi-start optimiser runs its starts on a replica engine: the pivot mode has to travel with it
+    g = load_golden("pivot.npz")
+    X, t = g["X"], g["t"]
+    T = np.stack([t, 2.0 * t - 0.3, np.cos(3 * X[:, 1]) + t, t[::-1].copy()])
+    LibGPGPU.set_fit_options(max_iter=200, ftol=1e-9, gtol=1e-6, seed=11)
+    mo = M.MultiOutputGP_GPU(X, T, nugget="pivot")                        # default priors, as the golden single-output fit
+    mo = M.fit_GP_MAP(mo, n_tries=6)
+    assert mo.get_indices_not_fit() == []
+    lp = [em.current_logpost for em in mo.emulators]
+    assert np.all(np.isfinite(lp))
+    assert lp[0] <= float(g["map_logpost"]) + 1e-4 * abs(float(g["map_logpost"]))
+    # the optimum of every output is a stationary point of its own objective, evaluated independently of the batch
+    for k in range(4):
+        th = mo.emulators[k].theta.get_data()
+        single = M.GaussianProcessGPU(X, T[k], nugget="pivot")
+        assert_allclose(single.logposterior(th), lp[k], rtol=1e-10)
+        assert np.abs(single.logpost_deriv(th)).max() < 2e-2 * max(1., abs(lp[k]))
+    mean, var, _ = mo.predict(g["Xs"])
+    assert np.all(np.isfinite(mean)) and np.all(var >= 0.)
