@@ -115,8 +115,12 @@ class Engine {
  private:
   void upload_params(const std::vector<int>& ids);
   void upload_idx(const std::vector<int>& ids);
-  void factorize(const std::vector<int>& ids, std::vector<int>& info);
-  void factorize_blocked(const std::vector<int>& ids, std::vector<int>& info);
+  // defer_info: leave the status words on the device (the caller reads them together with its own results: one
+  // synchronisation per evaluation instead of two)
+  void factorize(const std::vector<int>& ids, std::vector<int>& info, bool defer_info = false);
+  void factorize_blocked(const std::vector<int>& ids, std::vector<int>& info, bool defer_info);
+  void read_info(std::vector<int>& info, bool defer_info);
+  std::vector<int> idx_on_device;          // what dIdx holds (upload_idx skips an identical list)
   void factorize_pivot(const std::vector<int>& ids, std::vector<int>& info);
   void ensure_pivot_buffers();
   void unpermute(int i, double* vec) const;          // vec (n) from pivoted to training order, in place

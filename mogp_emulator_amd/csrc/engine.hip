@@ -222,8 +222,10 @@ BatchView Engine::view(int nb) const {
 }
 
 void Engine::upload_idx(const std::vector<int>& ids) {
+  if (ids == idx_on_device) return;      // the optimiser and the benchmark evaluate the same list again and again
   HIPCK(hipMemcpyAsync(dIdx, ids.data(), ids.size() * sizeof(int), hipMemcpyHostToDevice, stream));
   HIPCK(hipStreamSynchronize(stream));   // ids may be a temporary
+  idx_on_device = ids;
 }
 
 void Engine::set_mean_priors(int i, int q_in, const double* b, const double* Binv, const double* Binvb, double logdetB) {
@@ -386,7 +388,7 @@ void Engine::factorize_pivot(const std::vector<int>& ids, std::vector<int>& info
   }
 }
 
-void Engine::factorize(const std::vector<int>& ids, std::vector<int>& info) {
+void Engine::factorize(const std::vector<int>& ids, std::vector<int>& info, bool defer_info) {
   std::vector<int> piv, rest;
   for (int i : ids) (gp[i].nug_type == NUG_PIVOT ? piv : rest).push_back(i);
   if (piv.empty()) {
@@ -398,7 +400,7 @@ void Engine::factorize(const std::vector<int>& ids, std::vector<int>& info) {
         gp[i].permuted = false;
         gp[i].rank = 0;
       }
-    factorize_blocked(rest, info);
+    factorize_blocked(rest, info, defer_info);
     return;
   }
   std::vector<int> tmp;
@@ -411,7 +413,15 @@ void Engine::factorize(const std::vector<int>& ids, std::vector<int>& info) {
   factorize_pivot(piv, info);
 }
 
-void Engine::factorize_blocked(const std::vector<int>& ids, std::vector<int>& info) {
+void Engine::read_info(std::vector<int>& info, bool defer_info) {
+  if (defer_info) return;
+  info.assign(B, 0);
+  HIPCK(hipMemcpyAsync(info.data(), dInfo, B * sizeof(int), hipMemcpyDeviceToHost, stream));
+  HIPCK(hipStreamSynchronize(stream));
+  HIPCK(hipGetLastError());
+}
+
+void Engine::factorize_blocked(const std::vector<int>& ids, std::vector<int>& info, bool defer_info) {
   const int nb = (int)ids.size();
   upload_idx(ids);
   upload_params(ids);
@@ -605,10 +615,7 @@ void Engine::factorize_blocked(const std::vector<int>& ids, std::vector<int>& in
         for (int i = 0; i < 5; ++i) launch2(chain_op(0, cols[k], i), update_piece(1, cols[k], i));
         for (int i = 0; i < 5; ++i) launch2(chain_op(1, cols[k], i), (k + 1 < K) ? update_piece(0, cols[k + 1], i) : none);
       }
-      info.assign(B, 0);
-      HIPCK(hipMemcpyAsync(info.data(), dInfo, B * sizeof(int), hipMemcpyDeviceToHost, stream));
-      HIPCK(hipStreamSynchronize(stream));
-      HIPCK(hipGetLastError());
+      read_info(info, defer_info);
       return;
     }
     if (want_graph && !prof_is_on()) {
@@ -616,10 +623,7 @@ void Engine::factorize_blocked(const std::vector<int>& ids, std::vector<int>& in
       auto it = cholGraphs.find(key);
       if (it == cholGraphs.end()) {
         if (cholGraphs.size() >= 32) {                       // bounded cache (optimiser rounds shrink the active set)
-          for (auto& kv : w2) hipFree(kv.second);
-  for (auto e : evKsReady) if (e) hipEventDestroy(e);
-  for (auto e : evKsFree) if (e) hipEventDestroy(e);
-  for (auto& kv : cholGraphs) hipGraphExecDestroy(kv.second);
+          for (auto& kv : cholGraphs) hipGraphExecDestroy(kv.second);
           cholGraphs.clear();
         }
         hipGraph_t graph = nullptr;
@@ -635,10 +639,7 @@ void Engine::factorize_blocked(const std::vector<int>& ids, std::vector<int>& in
     } else {
       issue();
     }
-    info.assign(B, 0);
-    HIPCK(hipMemcpyAsync(info.data(), dInfo, B * sizeof(int), hipMemcpyDeviceToHost, stream));
-    HIPCK(hipStreamSynchronize(stream));
-    HIPCK(hipGetLastError());
+    read_info(info, defer_info);
     return;
   }
   HIPCK(hipMemsetAsync(dInfo, 0, B * sizeof(int), stream));
@@ -674,10 +675,7 @@ void Engine::factorize_blocked(const std::vector<int>& ids, std::vector<int>& in
       if (j > 0 && j + 1 < K) launch_update_wide(v, o + TILE, 0, o, stream);   // panels < j -> column j+1 (K = o), under panel j
     }
     HIPCK(hipStreamWaitEvent(stream, evPanel[K - 1], 0));
-    info.assign(B, 0);
-    HIPCK(hipMemcpyAsync(info.data(), dInfo, B * sizeof(int), hipMemcpyDeviceToHost, stream));
-    HIPCK(hipStreamSynchronize(stream));
-    HIPCK(hipGetLastError());
+    read_info(info, defer_info);
     return;
   }
   std::vector<int> starts;
@@ -712,10 +710,7 @@ void Engine::factorize_blocked(const std::vector<int>& ids, std::vector<int>& in
       launch_update_trailing(v, o + w, o, o + w, stream);   // (empty unless padding rows remain)
     }
   }
-  info.assign(B, 0);
-  HIPCK(hipMemcpyAsync(info.data(), dInfo, B * sizeof(int), hipMemcpyDeviceToHost, stream));
-  HIPCK(hipStreamSynchronize(stream));
-  HIPCK(hipGetLastError());
+  read_info(info, defer_info);
 }
 
 void Engine::eval(const std::vector<int>& ids, const std::vector<const double*>& thetas, bool want_grad, double* f, double* grad,
@@ -727,19 +722,57 @@ void Engine::eval(const std::vector<int>& ids, const std::vector<const double*>&
     GPState& g = gp[ids[k]];
     g.nugget_used = (g.nug_type == NUG_FIXED) ? g.nug_size : (g.nug_type == NUG_FIT ? std::exp(g.data[NC + 1]) : 0.0);
   }
+  // One synchronisation per evaluation: the factorisation leaves its status words on the device, log-det / Gram / alpha
+  // (and L^-1 on the gradient path) are launched right behind it, and everything is read back together.  An emulator
+  // whose factorisation failed has produced garbage there -- it is either retried (adaptive jitter) or reported.
+  std::vector<double> logdet(B, 0.), gram((size_t)B * RMAX * RMAX, 0.);
+  auto after_factor = [&](const std::vector<int>& list, std::vector<int>* info_out) {
+    for (int i : list) gp[i].factored = true;                // provisional (ensure_linv checks it)
+    upload_idx(list);
+    BatchView v = view((int)list.size());
+    launch_logdet(v, dLogdet, dGram, stream);
+    if (want_grad) {
+      // gradient path: L^-1 is needed anyway, so K^-1 [t, H] = L^-T Y is one fully parallel gemv with it
+      ensure_linv(list);
+      upload_idx(list);
+      v = view((int)list.size());
+      launch_alpha_from_linv(v, stream);
+    } else {
+      launch_backsolve(v, stream);
+    }
+    std::vector<double> ld(B), gr(gram.size());
+    if (info_out) {
+      info_out->assign(B, 0);
+      HIPCK(hipMemcpyAsync(info_out->data(), dInfo, B * sizeof(int), hipMemcpyDeviceToHost, stream));
+    }
+    HIPCK(hipMemcpyAsync(ld.data(), dLogdet, B * sizeof(double), hipMemcpyDeviceToHost, stream));
+    HIPCK(hipMemcpyAsync(gr.data(), dGram, gr.size() * sizeof(double), hipMemcpyDeviceToHost, stream));
+    HIPCK(hipStreamSynchronize(stream));
+    HIPCK(hipGetLastError());
+    for (int i : list) {
+      logdet[i] = ld[i];
+      std::memcpy(gram.data() + (size_t)i * RMAX * RMAX, gr.data() + (size_t)i * RMAX * RMAX, sizeof(double) * RMAX * RMAX);
+    }
+  };
   std::vector<int> info;
-  factorize(ids, info);
+  bool has_pivot = false;
+  for (int i : ids) has_pivot = has_pivot || gp[i].nug_type == NUG_PIVOT;
+  factorize(ids, info, !has_pivot);                          // (the pivoted path reads its status after every panel anyway)
+  after_factor(ids, has_pivot ? nullptr : &info);
   std::vector<char> good(B, 0);
   std::vector<int> failed;
   for (int i : ids) {
     if (info[i] == 0) good[i] = 1;
-    else failed.push_back(i);
+    else {
+      failed.push_back(i);
+      gp[i].factored = gp[i].linv = gp[i].kinv = false;
+    }
   }
   // adaptive jitter ladder: linalg/cholesky.py:268-279 -- jitter = mean(diag K) * 1e-6, x10 per try, 5 tries.
   // diag K = sigma^2 k(0) = sigma^2 exactly, so mean(diag K) = sigma^2.
   std::vector<double> jitter(B, 0.);
   {
-    std::vector<int> retry;
+    std::vector<int> retry, recovered;
     for (int i : failed)
       if (gp[i].nug_type == NUG_ADAPTIVE) {
         jitter[i] = std::exp(gp[i].data[NC]) * 1e-6;
@@ -759,6 +792,7 @@ void Engine::eval(const std::vector<int>& ids, const std::vector<const double*>&
         if (info[i] == 0) {
           good[i] = 1;
           gp[i].nug_size = jitter[i];
+          recovered.push_back(i);
         } else {
           jitter[i] *= 10;
           still.push_back(i);
@@ -766,28 +800,14 @@ void Engine::eval(const std::vector<int>& ids, const std::vector<const double*>&
       }
       retry.swap(still);
     }
+    if (!recovered.empty()) after_factor(recovered, nullptr);
   }
   std::vector<int> okids;
   for (int i : ids)
     if (good[i]) okids.push_back(i);
-  std::vector<double> logdet(B, 0.), gram((size_t)B * RMAX * RMAX, 0.);
-  for (int i : ids) gp[i].factored = good[i] != 0;
-  if (!okids.empty()) {
-    upload_idx(okids);
-    BatchView v = view((int)okids.size());
-    launch_logdet(v, dLogdet, dGram, stream);
-    if (want_grad) {
-      // gradient path: L^-1 is needed anyway, so K^-1 [t, H] = L^-T Y is one fully parallel gemv with it
-      ensure_linv(okids);
-      upload_idx(okids);
-      v = view((int)okids.size());
-      launch_alpha_from_linv(v, stream);
-    } else {
-      launch_backsolve(v, stream);
-    }
-    HIPCK(hipMemcpyAsync(logdet.data(), dLogdet, B * sizeof(double), hipMemcpyDeviceToHost, stream));
-    HIPCK(hipMemcpyAsync(gram.data(), dGram, gram.size() * sizeof(double), hipMemcpyDeviceToHost, stream));
-    HIPCK(hipStreamSynchronize(stream));
+  for (int i : ids) {
+    gp[i].factored = good[i] != 0;
+    if (!good[i]) gp[i].linv = gp[i].kinv = false;
   }
   std::vector<double> hM;
   if (R > 1) hM.assign((size_t)B * (RMAX + 1) * RMAX, 0.);
