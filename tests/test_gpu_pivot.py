@@ -301,3 +301,26 @@ def test_multioutput_fit_GP_MAP_with_pivoting():
         assert np.abs(single.logpost_deriv(th)).max() < 2e-2 * max(1., abs(lp[k]))
     mean, var, _ = mo.predict(g["Xs"])
     assert np.all(np.isfinite(mean)) and np.all(var >= 0.)
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 63, 64, 65, 127, 128, 129])
+def test_pivot_tiny_and_block_edge_sizes_vs_oracle(n):
+    rng = np.random.default_rng(400 + n)
+    d, m = 2, 17
+    X, Xs = rng.random((n, d)), rng.random((m, d))
+    if n >= 63:
+        X[n - 1] = X[0]                                                   # one repeated point straddling the panel edge
+    t = np.sin(3 * X[:, 0]) + X[:, 1]
+    theta = np.array([5.0, 4.5, 0.2])
+    gp = M.GaussianProcessGPU(X, t, kernel="Matern52", nugget="pivot", priors=weak(d))
+    ref = R.GPRef(X, t, kernel="Matern52", nugget="pivot")
+    assert_allclose(gp.logposterior(theta), ref.fit(theta), rtol=1e-9)
+    gp.fit(theta)
+    assert gp.pivot_rank == (n - 1 if n >= 63 else n)
+    mu, var, _ = gp.predict(Xs)
+    rmu, rvar, _ = ref.predict(Xs)
+    assert_allclose(mu, rmu, rtol=1e-7, atol=1e-9)
+    assert_allclose(var, rvar, rtol=1e-6, atol=1e-9)
+    if n <= 64:                                                           # (unblocked LAPACK: the whole factor is defined)
+        assert_allclose(gp.L, ref.L.L, rtol=1e-8, atol=1e-11)
+        assert_allclose(gp.logpost_deriv(theta), ref.logpost_deriv(theta), rtol=1e-5, atol=1e-6)
