@@ -400,7 +400,7 @@ int mogp_mogp_fit(mogp_mogp* h, const double* thetas, int n_rows, int n_cols) {
     std::vector<int> ok(e->B);
     if (mogp_mogp_eval(h, thetas, n_rows, n_cols, nullptr, nullptr, ok.data())) throw std::runtime_error(g_err);
     for (int i = 0; i < e->B; ++i)
-      if (!ok[i]) {
+      if (!ok[i] && !(e->gp[i].nug_type == NUG_PIVOT && e->gp[i].factored)) {
         if (e->gp[i].nug_type == NUG_ADAPTIVE) throw std::runtime_error("All attempts at factorization failed. Last return code 1");
         throw std::runtime_error("Unable to factorize matrix using selected nugget type");
       }

@@ -911,10 +911,12 @@ void Engine::eval(const std::vector<int>& ids, const std::vector<const double*>&
         if (!std::isfinite(val)) fine = false;
       }
     }
-    g.has_data = fine;
-    // a pivoted factor stays inspectable (get_cholesky_lower / get_pivot, the reference's Kinv.L / Kinv.P) when the
-    // log-posterior over its tiny replacement diagonal is not finite
-    g.factored = fine || (good[i] && g.nug_type == NUG_PIVOT);
+    // nugget="pivot": the reference never fails a fit whose pivoted factorisation exists; with many skipped rows the
+    // log-posterior over the tiny replacement diagonal is inf / nan there as well, and the emulator is left "fit" with
+    // that value (garbage in, garbage out) instead of raising.  ok[] still reports it, so the optimiser steps away.
+    const bool pivot_kept = good[i] && g.nug_type == NUG_PIVOT;
+    g.has_data = fine || pivot_kept;
+    g.factored = fine || pivot_kept;
     g.logpost = val;
     if (f) f[k] = val;
     if (ok) ok[k] = fine ? 1 : 0;
@@ -950,7 +952,7 @@ void Engine::fit_one(int i, const double* theta, int len) {
   std::vector<int> ids{i};
   std::vector<const double*> th{theta};
   eval(ids, th, false, &f, nullptr, 0, &ok);
-  if (!ok) {
+  if (!ok && !(gp[i].nug_type == NUG_PIVOT && gp[i].factored)) {
     if (gp[i].nug_type == NUG_ADAPTIVE) throw std::runtime_error("All attempts at factorization failed. Last return code 1");
     throw std::runtime_error("Unable to factorize matrix using selected nugget type");
   }

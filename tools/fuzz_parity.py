@@ -1,0 +1,88 @@
+"""Randomised differential test: device path (through the C ABI) against the oracle over random shapes, kernels, nugget
+types and mean functions.  Prints every mismatch; exit code 1 if any.  Usage: python tools/fuzz_parity.py [cases] [seed]"""
+import sys, os
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import mogp_emulator_amd as M
+from mogp_emulator_amd import LibGPGPU
+from mogp_emulator_amd.Priors import GPPriors
+from oracle import cpu_ref as R
+
+cases = int(sys.argv[1]) if len(sys.argv) > 1 else 120
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 2024)
+KERNELS = ["SquaredExponential", "Matern52", "ProductMat52", "UniformSqExp", "UniformMat52"]
+bad = 0
+
+
+def close(tag, a, b, rtol, atol, ctx):
+    global bad
+    a, b = np.asarray(a, dtype=float), np.asarray(b, dtype=float)
+    if a.shape != b.shape or not np.allclose(a, b, rtol=rtol, atol=atol):
+        bad += 1
+        err = np.abs(a - b).max() if a.shape == b.shape else float("nan")
+        print("MISMATCH %-8s max abs err %.3e (scale %.3e)  %s" % (tag, err, np.abs(b).max() if b.size else 0., ctx), flush=True)
+
+
+for case in range(cases):
+    n = int(rng.choice([1, 2, 5, 17, 63, 64, 65, 100, 127, 128, 129, 200, 257, 400]))
+    D = int(rng.integers(1, 9))
+    B = int(rng.choice([1, 1, 2, 3, 8, 9]))
+    m = int(rng.choice([1, 7, 64, 130]))
+    kern = KERNELS[int(rng.integers(0, 5))]
+    nug_kind = ["fixed", "fit", "adaptive", "pivot"][int(rng.integers(0, 4))]
+    mean_kind = ["none", "const", "lin"][int(rng.integers(0, 3))] if n > 3 else "none"
+    X = rng.random((n, D)); Xs = rng.random((m, D))
+    T = np.stack([np.sin(3 * X[:, 0] + k) + 0.3 * X[:, -1] ** 2 + 0.05 * rng.normal(size=n) + k for k in range(B)])
+    nc = 1 if kern.startswith("Uniform") else D
+    # short length scales and a healthy nugget keep cond(K) moderate, so that the tolerances below mean something
+    corr = rng.uniform(3.0, 5.0, size=nc)
+    theta = np.r_[corr, rng.uniform(-0.5, 0.5)]
+    nug_arg = {"fixed": 1e-4, "fit": "fit", "adaptive": "adaptive", "pivot": "pivot"}[nug_kind]
+    if nug_kind == "fit":
+        theta = np.r_[theta, np.log(1e-4)]
+    terms = {"none": None, "const": [], "lin": [(0, 1)]}[mean_kind]
+    kw = {}
+    if terms is not None:
+        kw = dict(mean=LibGPGPU.PolyMeanFunc(terms) if terms else LibGPGPU.ConstMeanFunc(), analytic_mean=True)
+    ctx = "case %d: n=%d D=%d B=%d m=%d %s nugget=%s mean=%s" % (case, n, D, B, m, kern, nug_kind, mean_kind)
+    try:
+        mo = M.MultiOutputGP_GPU(X, T, kernel=kern, nugget=nug_arg, priors=GPPriors(n_corr=nc, nugget_type=nug_kind), **kw)
+        thetas = np.tile(theta, (B, 1)) + 0.05 * rng.normal(size=(B, theta.size)) * (np.arange(theta.size) < nc)
+        f, g, ok = mo._mogp_gpu.eval(thetas, grad=True)
+        mo.fit(thetas)
+        mean, var, deriv = mo.predict(Xs)
+        cov = mo.predict(Xs[:min(m, 9)], full_cov=True, deriv=False)[1] if m > 1 else None
+    except Exception as e:          # noqa
+        bad += 1
+        print("EXCEPTION %r  %s" % (e, ctx), flush=True)
+        continue
+    for k in range(B):
+        rk = dict(kernel=kern, nugget=nug_arg)
+        ref = R.GPRef(X, T[k], **rk) if terms is None else R.GPRefMean(X, T[k], terms, True, **rk)
+        try:
+            lp = ref.fit(thetas[k])
+        except (ValueError, FloatingPointError, np.linalg.LinAlgError):
+            continue                # the reference semantics give inf / nan here (dozens of skipped pivots): nothing to compare
+        if not np.isfinite(lp):
+            continue
+        if nug_kind == "adaptive" and ref.nugget > 0:
+            continue                # jitter ladder engaged: values depend on where exactly LAPACK gave up
+        Lf = ref.L.L if isinstance(ref.L, R.PivotFactor) else ref.L
+        dg = np.abs(np.diag(Lf))
+        cond = float((dg.max() / dg.min()) ** 2)              # lower bound of cond(K): scales every tolerance
+        amp = max(1., cond * 1e-6)
+        if cond > 1e8:          # (the diagonal ratio is only a lower bound of cond(K))
+            continue                # zero-nugget matrix, D = 1, dense points: the quadratic form ~1e8+ carries cond * eps
+        c2 = ctx + " cond>=%.1e" % cond
+        close("logpost", f[k], lp, 1e-8 * amp, 1e-8 * amp, c2)
+        close("grad", g[k], ref.logpost_deriv(thetas[k]), 1e-5 * amp, 1e-6 * amp * max(1., np.abs(g[k]).max()), c2)
+        rmu, rvar, rder = ref.predict(Xs, deriv=(terms is None))
+        close("mean", mean[k], rmu, 1e-6 * amp, 1e-7 * amp, c2)
+        close("var", var[k], rvar, 1e-5 * amp, 1e-8 * amp, c2)
+        if terms is None:
+            close("deriv", deriv[k], rder, 1e-5 * amp, 1e-6 * amp, c2)
+        if cov is not None:
+            close("fullcov", cov[k], ref.predict(Xs[:min(m, 9)], full_cov=True)[1], 1e-5 * amp, 1e-8 * amp, c2)
+print("%d cases, %d mismatches" % (cases, bad))
+sys.exit(1 if bad else 0)
