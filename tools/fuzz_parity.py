@@ -31,7 +31,9 @@ for case in range(cases):
     m = int(rng.choice([1, 7, 64, 130]))
     kern = KERNELS[int(rng.integers(0, 5))]
     nug_kind = ["fixed", "fit", "adaptive", "pivot"][int(rng.integers(0, 4))]
-    mean_kind = ["none", "const", "lin"][int(rng.integers(0, 3))] if n > 3 else "none"
+    # none / analytic (coefficients integrated out, CPU-class semantics) / theta_* (coefficients are hyper-parameters, the
+    # reference GPU class's semantics) / fixed value
+    mean_kind = ["none", "const", "lin", "theta_const", "theta_lin", "fixed"][int(rng.integers(0, 6))] if n > 3 else "none"
     X = rng.random((n, D)); Xs = rng.random((m, D))
     T = np.stack([np.sin(3 * X[:, 0] + k) + 0.3 * X[:, -1] ** 2 + 0.05 * rng.normal(size=n) + k for k in range(B)])
     nc = 1 if kern.startswith("Uniform") else D
@@ -41,10 +43,19 @@ for case in range(cases):
     nug_arg = {"fixed": 1e-4, "fit": "fit", "adaptive": "adaptive", "pivot": "pivot"}[nug_kind]
     if nug_kind == "fit":
         theta = np.r_[theta, np.log(1e-4)]
-    terms = {"none": None, "const": [], "lin": [(0, 1)]}[mean_kind]
+    terms = {"none": None, "const": [], "lin": [(0, 1)]}.get(mean_kind)
     kw = {}
+    beta_theta = None                   # mean coefficients carried in theta (reference GPU semantics)
+    Hx = Hs = None
     if terms is not None:
         kw = dict(mean=LibGPGPU.PolyMeanFunc(terms) if terms else LibGPGPU.ConstMeanFunc(), analytic_mean=True)
+    elif mean_kind in ("theta_const", "theta_lin"):
+        tt = [] if mean_kind == "theta_const" else [(0, 1)]
+        kw = dict(mean=LibGPGPU.PolyMeanFunc(tt) if tt else LibGPGPU.ConstMeanFunc())
+        Hx, Hs = R.design_matrix(X, tt, True), R.design_matrix(Xs, tt, True)
+        beta_theta = rng.normal(size=(B, Hx.shape[1]))
+    elif mean_kind == "fixed":
+        kw = dict(mean=LibGPGPU.FixedMeanFunc(0.7))
     # hyper-parameter priors: weak, or a random proper prior per parameter (Priors.py:842-1128)
     PRI = {"invgamma": InvGammaPrior, "gamma": GammaPrior, "lognormal": LogNormalPrior}
     proper = bool(rng.integers(0, 2))
@@ -74,8 +85,9 @@ for case in range(cases):
     try:
         mo = M.MultiOutputGP_GPU(X, T, kernel=kern, nugget=nug_arg, priors=gpri, **kw)
         thetas = np.tile(theta, (B, 1)) + 0.05 * rng.normal(size=(B, theta.size)) * (np.arange(theta.size) < nc)
-        f, g, ok = mo._mogp_gpu.eval(thetas, grad=True)
-        mo.fit(thetas)
+        full = thetas if beta_theta is None else np.hstack([beta_theta, thetas])
+        f, g, ok = mo._mogp_gpu.eval(full, grad=True)
+        mo.fit(full)
         mean, var, deriv = mo.predict(Xs)
         cov = mo.predict(Xs[:min(m, 9)], full_cov=True, deriv=False)[1] if m > 1 else None
     except Exception as e:          # noqa
@@ -84,7 +96,12 @@ for case in range(cases):
         continue
     for k in range(B):
         rk = dict(kernel=kern, nugget=nug_arg, priors=rpri)
-        ref = R.GPRef(X, T[k], **rk) if terms is None else R.GPRefMean(X, T[k], terms, True, mean_prior=mean_prior, **rk)
+        tk = T[k]
+        if beta_theta is not None:
+            tk = T[k] - Hx @ beta_theta[k]
+        elif mean_kind == "fixed":
+            tk = T[k] - 0.7
+        ref = R.GPRef(X, tk, **rk) if terms is None else R.GPRefMean(X, tk, terms, True, mean_prior=mean_prior, **rk)
         try:
             lp = ref.fit(thetas[k])
         except (ValueError, FloatingPointError, AssertionError, np.linalg.LinAlgError):
@@ -101,8 +118,17 @@ for case in range(cases):
             continue                # zero-nugget matrix, D = 1, dense points: the quadratic form ~1e8+ carries cond * eps
         c2 = ctx + " cond>=%.1e" % cond
         close("logpost", f[k], lp, 1e-8 * amp, 1e-8 * amp, c2)
-        close("grad", g[k], ref.logpost_deriv(thetas[k]), 1e-5 * amp, 1e-6 * amp * max(1., np.abs(g[k]).max()), c2)
+        rgrad = ref.logpost_deriv(thetas[k])
+        if beta_theta is not None:          # d/d beta of the objective: -(d mean / d beta)^T K^-1 (t - m), densegp_gpu.hpp:734-747
+            rgrad = np.r_[-Hx.T @ ref.Kinv_t, rgrad]
+        close("grad", g[k], rgrad, 1e-5 * amp, 1e-6 * amp * max(1., np.abs(g[k]).max()), c2)
         rmu, rvar, rder = ref.predict(Xs, deriv=(terms is None))
+        if beta_theta is not None:
+            rmu = rmu + Hs @ beta_theta[k]
+            if mean_kind == "theta_lin":
+                rder = rder.copy(); rder[:, 0] += beta_theta[k][1]
+        elif mean_kind == "fixed":
+            rmu = rmu + 0.7
         close("mean", mean[k], rmu, 1e-6 * amp, 1e-7 * amp, c2)
         close("var", var[k], rvar, 1e-5 * amp, 1e-8 * amp, c2)
         if terms is None:
