@@ -11,6 +11,7 @@ from oracle import cpu_ref as R
 
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 120
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 2024)
+LARGE = len(sys.argv) > 3 and sys.argv[3] == "large"       # several block columns, both Cholesky schedules
 KERNELS = ["SquaredExponential", "Matern52", "ProductMat52", "UniformSqExp", "UniformMat52"]
 bad = 0
 
@@ -25,9 +26,9 @@ def close(tag, a, b, rtol, atol, ctx):
 
 
 for case in range(cases):
-    n = int(rng.choice([1, 2, 5, 17, 63, 64, 65, 100, 127, 128, 129, 200, 257, 400]))
-    D = int(rng.integers(1, 9))
-    B = int(rng.choice([1, 1, 2, 3, 8, 9]))
+    n = int(rng.choice([513, 700, 1025, 1300, 1536]) if LARGE else rng.choice([1, 2, 5, 17, 63, 64, 65, 100, 127, 128, 129, 200, 257, 400]))
+    D = int(rng.integers(2, 9)) if LARGE else int(rng.integers(1, 9))
+    B = int(rng.choice([1, 2, 3, 17]) if LARGE else rng.choice([1, 1, 2, 3, 8, 9]))
     m = int(rng.choice([1, 7, 64, 130]))
     kern = KERNELS[int(rng.integers(0, 5))]
     nug_kind = ["fixed", "fit", "adaptive", "pivot"][int(rng.integers(0, 4))]
@@ -94,7 +95,7 @@ for case in range(cases):
         bad += 1
         print("EXCEPTION %r  %s" % (e, ctx), flush=True)
         continue
-    for k in range(B):
+    for k in (range(B) if not LARGE else sorted(set([0, B - 1]))):
         rk = dict(kernel=kern, nugget=nug_arg, priors=rpri)
         tk = T[k]
         if beta_theta is not None:
