@@ -6,8 +6,8 @@ mogp_emulator_amd -- MI355X (gfx950) native fit + predict backend for mogp_emula
   libgpgpu.py      drop-in for the reference's pybind11 module `libgpgpu`
   LibGPGPU.py, GaussianProcessGPU.py, MultiOutputGP_GPU.py, fitting.py, Priors.py, Kernel.py
                    host-side mirrors of the reference's GPU-facing Python interface
-  HistoryMatching.py, SequentialDesign.py
-                   consumers of the batched prediction (implausibility, MICE scoring), fused on the device
+  HistoryMatching.py, SequentialDesign.py, validation.py
+                   consumers of the batched prediction (implausibility, MICE scoring, validation errors)
   dist.py          one-process-per-GPU sharding of emulators + single gather (torch.distributed/RCCL)
 """
 from .LibGPGPU import HAVE_LIBGPGPU, gpu_usable            # noqa: F401
@@ -20,5 +20,6 @@ if HAVE_LIBGPGPU:
     from .Priors import GPPriors, MeanPriors, InvGammaPrior, GammaPrior, LogNormalPrior, WeakPrior   # noqa: F401
     from .HistoryMatching import HistoryMatching                           # noqa: F401
     from .SequentialDesign import MICEFastGP, mice_criterion               # noqa: F401
+    from . import validation                                                # noqa: F401
 
 __version__ = "0.1.0"

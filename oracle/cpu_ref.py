@@ -728,3 +728,32 @@ def mice_criterion_ref(gp, candidates, nugget_s=1.):
         unc1 = gp.predict(candidates[c], unc=True)[1]
         out[c] = unc1[0] / mice_fast_predict_ref(fast, c)[0]
     return out
+
+
+# ----------------------------------------------------------------------------
+# validation.py: errors on a validation set from the predictions
+# ----------------------------------------------------------------------------
+
+def standard_errors_ref(target, mean, var):
+    """StandardErrors.__call__, validation.py:367-398: errors in order of decreasing predictive variance."""
+    P = np.argsort(var)[::-1]
+    return ((mean - target) / np.sqrt(var))[P], P
+
+
+def pivoted_errors_ref(target, mean, cov):
+    """PivotErrors.__call__, validation.py:401-441: cholesky_factor(cov, 0., "pivot") then ChoInvPivot.solve_L."""
+    L, P, _ = pivot_cholesky(cov)
+    return linalg.solve_triangular(L, (mean - target)[P], lower=True), P
+
+
+def mahalanobis_ref(target, mean, cov, n_train=None, n_mean=0, scaled=False):
+    """mahalanobis, validation.py:8-95 (one emulator): sum of squared pivoted errors; scaled by the mean and standard
+    deviation of F(n_valid, n_train - n_mean - 2) with scale n_valid (generate_mahal_dist, :98-135)."""
+    from scipy.stats import f
+    err, _ = pivoted_errors_ref(target, mean, cov)
+    M = float(np.sum(err ** 2))
+    if scaled:
+        nv = len(target)
+        mu, var = f(dfn=nv, dfd=n_train - n_mean - 2, scale=nv).stats()
+        M = (M - mu) / np.sqrt(var)
+    return M

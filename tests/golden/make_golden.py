@@ -116,9 +116,48 @@ def pivot_section():
     np.savez_compressed(os.path.join(HERE, "pivot.npz"), **out)
 
 
+def validation_section():
+    """---- 16. validation.py (consumer of predict(full_cov=True)): standard / pivoted errors, Mahalanobis ----"""
+    from mogp_emulator.validation import mahalanobis, standard_errors, pivoted_errors, generate_mahal_dist
+    X, T, Xv = synth(16, 60, 2, 3, 25)
+    rng = np.random.default_rng(1616)
+    w = rng.normal(size=(3, 2))
+    Tv = np.stack([np.sin(2 * np.pi * Xv @ w_k / np.sqrt(2)) + 0.1 * (Xv ** 2) @ np.abs(w_k) for w_k in w]) + 0.02 * rng.normal(size=(3, 25))
+    out = dict(X=X, T=T, Xv=Xv, Tv=Tv)
+    for kern in KERNELS:
+        for mode, nugget in (("fixed", 1.e-4), ("fit", "fit")):
+            theta = [2.5, 3.0, 0.1] + ([np.log(3.e-4)] if mode == "fit" else [])
+            nt = nugget if isinstance(nugget, str) else "fixed"
+            pre = "%s_%s_" % (kern, mode)
+            out[pre + "theta"] = np.array(theta)
+            gp = GaussianProcess(X, T[0], kernel=KERNELS[kern](), nugget=nugget, priors=weak(2, nt))
+            gp.fit(np.array(theta))
+            e, P = standard_errors(gp, Xv, Tv[0])
+            out[pre + "std_err"], out[pre + "std_P"] = e, np.asarray(P, dtype=np.int64)
+            e, P = pivoted_errors(gp, Xv, Tv[0])
+            out[pre + "piv_err"], out[pre + "piv_P"] = e, np.asarray(P, dtype=np.int64)
+            out[pre + "mahal"] = np.array(mahalanobis(gp, Xv, Tv[0]))
+            out[pre + "mahal_scaled"] = np.array(mahalanobis(gp, Xv, Tv[0], scaled=True))
+            d = generate_mahal_dist(gp, Xv)
+            out[pre + "dist_args"] = np.array([d.kwds["dfn"], d.kwds["dfd"], d.kwds["scale"]], dtype=float)
+            mo = MultiOutputGP(X, T, kernel=KERNELS[kern](), nugget=nugget, priors=weak(2, nt))
+            for em in mo.emulators:
+                em.fit(np.array(theta))
+            se = standard_errors(mo, Xv, Tv)
+            pe = pivoted_errors(mo, Xv, Tv)
+            out[pre + "mo_std_err"] = np.stack([x[0] for x in se]); out[pre + "mo_std_P"] = np.stack([np.asarray(x[1], dtype=np.int64) for x in se])
+            out[pre + "mo_piv_err"] = np.stack([x[0] for x in pe]); out[pre + "mo_piv_P"] = np.stack([np.asarray(x[1], dtype=np.int64) for x in pe])
+            out[pre + "mo_mahal"] = np.array(mahalanobis(mo, Xv, Tv))
+            out[pre + "mo_mahal_scaled"] = np.array(mahalanobis(mo, Xv, Tv, scaled=True))
+    np.savez_compressed(os.path.join(HERE, "validation.npz"), **out)
+
+
 def main():
     if sys.argv[1:] == ["pivot"]:
         pivot_section()
+        return
+    if sys.argv[1:] == ["validation"]:
+        validation_section()
         return
     # ---- 1. the 2x3 fixture of tests/test_GaussianProcess.py:16-22, 556 ------------------------
     X = np.array([[1., 2., 3.], [4., 5., 6.]])
@@ -427,6 +466,7 @@ def main():
                 out[pre + "cov_full"] = gp.predict(Xs, full_cov=True)[1]
     np.savez_compressed(os.path.join(HERE, "meanpriors.npz"), **out)
     pivot_section()
+    validation_section()
     print("golden vectors written to", HERE)
 
 

@@ -447,3 +447,30 @@ def test_pivot_emulators_vs_reference(tag, kern, mtag):
     if mtag == "lin":
         assert_allclose(gp.beta, g[pre + "beta"], rtol=1e-7, atol=noise)
     assert bool(g[pre + "nugget_is_none"]) and gp.nugget is None
+
+
+# ---- validation.py: standard / pivoted errors and the Mahalanobis distance -------------------------
+@pytest.mark.parametrize("kern", KERNELS)
+@pytest.mark.parametrize("mode", ["fixed", "fit"])
+def test_validation_errors_vs_reference(kern, mode):
+    g = load_golden("validation.npz")
+    pre = "%s_%s_" % (kern, mode)
+    theta = g[pre + "theta"]
+    nug = {"fixed": 1.e-4, "fit": "fit"}[mode]
+    for k in range(3):
+        gp = R.GPRef(g["X"], g["T"][k], kernel=kern, nugget=nug)
+        gp.fit(theta)
+        mu, var, _ = gp.predict(g["Xv"])
+        cov = gp.predict(g["Xv"], full_cov=True)[1]
+        e, P = R.standard_errors_ref(g["Tv"][k], mu, var)
+        assert list(P) == list(g[pre + "mo_std_P"][k])
+        assert_allclose(e, g[pre + "mo_std_err"][k], rtol=1e-6, atol=1e-8)
+        e, P = R.pivoted_errors_ref(g["Tv"][k], mu, cov)
+        assert list(P) == list(g[pre + "mo_piv_P"][k])
+        assert_allclose(e, g[pre + "mo_piv_err"][k], rtol=1e-6, atol=1e-7)
+        assert_allclose(R.mahalanobis_ref(g["Tv"][k], mu, cov), g[pre + "mo_mahal"][k], rtol=1e-7)
+        assert_allclose(R.mahalanobis_ref(g["Tv"][k], mu, cov, n_train=60, n_mean=0, scaled=True), g[pre + "mo_mahal_scaled"][k], rtol=1e-7)
+        if k == 0:       # the single-emulator entry points give the same numbers
+            assert_allclose(e, g[pre + "piv_err"], rtol=1e-6, atol=1e-7)
+            assert_allclose(g[pre + "mahal"], g[pre + "mo_mahal"][0], rtol=1e-12)
+    assert list(g[pre + "dist_args"]) == [25., 58., 25.]
