@@ -78,3 +78,58 @@ def test_argument_checks_follow_the_reference():
         V.generate_mahal_dist(3.0, g["Xv"])
     with pytest.raises(ValueError):
         V.compute_errors(gp, g["Xv"], g["Tv"][0], "nonsense")
+
+
+# ---- the reference's own cases (tests/test_validation.py:8-175): predictions replaced by fixed numbers, so that only the
+# ---- error definitions and the (device) pivoted factorisation of the 3 x 3 covariance are exercised -------------------
+targets1 = np.array([0.5, 2.1, 2.8])
+targets2 = np.array([2.5, 2.9, 3.5])
+mean1 = np.array([1.0, 2.0, 3.0])
+mean2 = np.array([2.0, 3.0, 4.0])
+err1, err2 = mean1 - targets1, mean2 - targets2
+unc1 = np.array([[0.1, 0.05, 0.02], [0.05, 0.2, 0.01], [0.02, 0.01, 0.15]])
+idx1 = np.array([1, 2, 0])
+
+
+def mock_predict(self, testing, unc=True, deriv=False, include_nugget=True, full_cov=False):
+    return M.PredictResult(mean=mean1, unc=unc1 if full_cov else np.diag(unc1), deriv=None)
+
+
+def mock_predict_mogp(self, testing, unc=True, deriv=False, include_nugget=True, full_cov=False, **kw):
+    return M.PredictResult(mean=np.vstack([mean1, mean2]), unc=np.stack([unc1] * 2) if full_cov else np.vstack([np.diag(unc1)] * 2),
+                           deriv=None)
+
+
+def test_reference_cases_single(monkeypatch):
+    monkeypatch.setattr(M.GaussianProcessGPU, "predict", mock_predict)
+    x = np.reshape(mean1, (-1, 1))
+    gp = M.GaussianProcessGPU(x, targets1, nugget=0.0)
+    e, P = V.standard_errors(gp, x, targets1)
+    assert_allclose(e, err1[idx1] / np.sqrt(np.diag(unc1)[idx1]))
+    assert np.array_equal(P, idx1)
+    e, P = V.pivoted_errors(gp, x, targets1)
+    A = np.linalg.cholesky(unc1[idx1][:, idx1])
+    assert_allclose(e, np.linalg.solve(A, err1[idx1]), rtol=1e-12)
+    assert np.array_equal(P, idx1)
+    M_expect = np.dot(err1, np.linalg.solve(unc1, err1))
+    assert_allclose(V.mahalanobis(gp, x, targets1), M_expect, rtol=1e-12)
+    monkeypatch.setattr("scipy.stats._distn_infrastructure.rv_generic.stats", lambda *a, **k: (2.0, 3.0))
+    assert_allclose(V.mahalanobis(gp, x, targets1, scaled=True), (M_expect - 2.0) / np.sqrt(3.0), rtol=1e-12)
+
+
+def test_reference_cases_multi_output(monkeypatch):
+    monkeypatch.setattr(M.MultiOutputGP_GPU, "predict", mock_predict_mogp)
+    x = np.reshape(mean1, (-1, 1))
+    T = np.vstack([targets1, targets2])
+    gp = M.MultiOutputGP_GPU(x, T, nugget=0.0)
+    for e, want in zip(V.standard_errors(gp, x, T), [err1[idx1] / np.sqrt(np.diag(unc1))[idx1], err2[idx1] / np.sqrt(np.diag(unc1))[idx1]]):
+        assert_allclose(e[0], want)
+        assert np.array_equal(e[1], idx1)
+    A = np.linalg.cholesky(unc1[idx1][:, idx1])
+    for e, er in zip(V.pivoted_errors(gp, x, T), [err1, err2]):
+        assert_allclose(e[0], np.linalg.solve(A, er[idx1]), rtol=1e-12)
+        assert np.array_equal(e[1], idx1)
+    M_expect = np.array([np.dot(er, np.linalg.solve(unc1, er)) for er in (err1, err2)])
+    assert_allclose(V.mahalanobis(gp, x, T), M_expect, rtol=1e-12)
+    monkeypatch.setattr("scipy.stats._distn_infrastructure.rv_generic.stats", lambda *a, **k: (2.0, 3.0))
+    assert_allclose(V.mahalanobis(gp, x, T, scaled=True), (M_expect - 2.0) / np.sqrt(3.0), rtol=1e-12)
