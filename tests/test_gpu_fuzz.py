@@ -1,4 +1,4 @@
-"""Randomised differential test of the device path against the oracle (tools/fuzz_parity.py): random shapes around the
+"""Randomised differential test of the device path against the oracle (tests/tools/fuzz_parity.py): random shapes around the
 tile edges, the five kernels, the four nugget types, zero / analytic constant / analytic linear mean, 1-9 outputs."""
 import os
 import subprocess
@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 @pytest.mark.parametrize("seed", [11, 12])
 def test_random_configurations_match_the_oracle(seed):
-    out = subprocess.run([sys.executable, "-W", "ignore", os.path.join(ROOT, "tools", "fuzz_parity.py"), "70", str(seed)],
+    out = subprocess.run([sys.executable, "-W", "ignore", os.path.join(ROOT, "tests", "tools", "fuzz_parity.py"), "70", str(seed)],
                          capture_output=True, text=True, timeout=500)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
     assert "70 cases, 0 mismatches" in out.stdout

@@ -2,7 +2,7 @@
 types and mean functions.  Prints every mismatch; exit code 1 if any.  Usage: python tools/fuzz_parity.py [cases] [seed]"""
 import sys, os
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import mogp_emulator_amd as M
 from mogp_emulator_amd import LibGPGPU

@@ -1,7 +1,7 @@
 """Stage-by-stage check of the HIP path against the oracle (development aid; prints max errors)."""
 import os, sys, time
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from mogp_emulator_amd import _capi as C
 from oracle import cpu_ref as R

@@ -2,7 +2,7 @@
 MFMA path (nugget fixed) on the device and LAPACK dpstrf on the host (oracle, one emulator)."""
 import os, sys, time
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import mogp_emulator_amd as M
 from mogp_emulator_amd.Priors import GPPriors

@@ -1,7 +1,7 @@
 """Shapes far from the benchmark configurations: many small emulators, a long prediction sweep, n just above tile edges."""
 import os, sys, time
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import mogp_emulator_amd as M
 from mogp_emulator_amd.Priors import GPPriors
