@@ -229,6 +229,27 @@ def main():
         extras["pivot_fits_per_s"] = B / (time.perf_counter() - t0)
         assert okp.all()
         del gpp
+        # the one benchmark the reference publishes a figure for: its tsunami data (210 simulations, 14 inputs, 64 outputs;
+        # tests/golden/tsunamidata.npz is the reference's data file), fit_GP_MAP with the default 15 starts --
+        # "roughly 1 second per emulator" on one core of a quad-core laptop (benchmarks/benchmark_tsunami.py:9-11)
+        try:
+            ts = np.load(os.path.join(ROOT, "tests", "golden", "tsunamidata.npz"))
+            libgpgpu.set_fit_options(max_iter=200, ftol=1e-9, gtol=1e-6, seed=1)
+            best = None
+            for _ in range(2):
+                gpt = M.MultiOutputGP_GPU(ts["inputs"], ts["targets"])
+                t0 = time.perf_counter()
+                gpt = M.fit_GP_MAP(gpt)
+                dt = time.perf_counter() - t0
+                best = dt if best is None else min(best, dt)
+            extras["tsunami_benchmark"] = {"n_emulators": int(ts["targets"].shape[0]), "n": int(ts["inputs"].shape[0]),
+                                           "d": int(ts["inputs"].shape[1]), "n_tries": 15, "fit_GP_MAP_s": best,
+                                           "s_per_emulator": best / ts["targets"].shape[0],
+                                           "all_fit": gpt.get_indices_not_fit() == [],
+                                           "reference_published_s_per_emulator": 1.0}
+            del gpt
+        except OSError:
+            pass
 
     # per-kernel device times from HIP events on the launch stream
     kern = {}
