@@ -474,3 +474,19 @@ def test_validation_errors_vs_reference(kern, mode):
             assert_allclose(e, g[pre + "piv_err"], rtol=1e-6, atol=1e-7)
             assert_allclose(g[pre + "mahal"], g[pre + "mo_mahal"][0], rtol=1e-12)
     assert list(g[pre + "dist_args"]) == [25., 58., 25.]
+
+
+def test_tsunami_reference_optimum_is_reproduced_by_the_oracle():
+    # the reference's own benchmark data (benchmarks/tsunamidata.npz -> tests/golden/tsunamidata.npz) and its MAP fits
+    data, g = load_golden("tsunamidata.npz"), load_golden("tsunami_fit.npz")
+    X = data["inputs"]
+    from mogp_emulator_amd.Priors import GPPriors, InvGammaPrior
+    dp = GPPriors.default_priors(X, X.shape[1], "adaptive")
+    corr = [R.Prior("invgamma", p.shape, p.scale) if isinstance(p, InvGammaPrior) else R.Prior() for p in dp.corr]
+    for k in range(4):
+        gp = R.GPRef(X, data["targets"][k], nugget="adaptive", priors=R.GPPriorsRef(X.shape[1], "adaptive", corr=corr))
+        assert_allclose(gp.fit(g["theta"][k]), g["logpost"][k], rtol=1e-9)
+        assert np.abs(gp.logpost_deriv(g["theta"][k])).max() < 1e-2        # a stationary point of the oracle's objective too
+        mu, var, _ = gp.predict(g["Xs"])
+        assert_allclose(mu, g["mean"][k], rtol=1e-6, atol=1e-8)
+        assert_allclose(var, g["var"][k], rtol=1e-5, atol=1e-10)

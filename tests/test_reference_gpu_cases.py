@@ -15,6 +15,7 @@ from mogp_emulator_amd import LibGPGPU
 from mogp_emulator_amd.LibGPGPU import kernel_type
 from mogp_emulator_amd.Priors import GPPriors
 from oracle import cpu_ref as R
+from conftest import load_golden
 
 pytestmark = pytest.mark.gpu
 
@@ -332,3 +333,20 @@ def test_history_matching_sanity_checks_GPU(capsys):
     hm = M.HistoryMatching()
     hm.set_gp(gp)
     assert hm.gp is gp
+
+
+def test_tsunami_benchmark_reaches_the_reference_optima():
+    # benchmarks/benchmark_tsunami.py on the reference's data file: default priors, adaptive nugget, 15 starts.  The
+    # golden optima come from the reference's own fit_GP_MAP (tests/golden/make_golden.py, section 17).
+    data, g = load_golden("tsunamidata.npz"), load_golden("tsunami_fit.npz")
+    LibGPGPU.set_fit_options(max_iter=200, ftol=1e-9, gtol=1e-6, seed=5)
+    mo = M.MultiOutputGP_GPU(data["inputs"], data["targets"][:4])
+    mo = M.fit_GP_MAP(mo)
+    assert mo.get_indices_not_fit() == []
+    lp = np.array([em.current_logpost for em in mo.emulators])
+    assert_allclose(lp, g["logpost"], rtol=1e-6)
+    th = np.stack([em.theta.get_data() for em in mo.emulators])
+    assert_allclose(th, g["theta"], atol=2e-3)
+    mean, var, _ = mo.predict(g["Xs"])
+    assert_allclose(mean, g["mean"], rtol=1e-3, atol=1e-5)
+    assert_allclose(var, g["var"], rtol=2e-2, atol=1e-8)
