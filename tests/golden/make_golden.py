@@ -168,7 +168,45 @@ def tsunami_section():
                         Xs=Xs, mean=mean, var=var)
 
 
+def branin_pivot_section():
+    """---- 18. the reference's pivot benchmark (benchmarks/benchmark_pivot.py): 2-D Branin function on Latin-hypercube
+    designs with one duplicated point, MAP fits with nugget="adaptive" and nugget="pivot", accuracy on random test points ----"""
+    from mogp_emulator import LatinHypercubeDesign, MonteCarloDesign
+    from scipy.stats import uniform
+
+    def branin(x):
+        x1, x2 = x[:, 0], x[:, 1]
+        a, b, c, r, s, t = 1., 5.1 / 4. / np.pi ** 2, 5. / np.pi, 6., 10., 1. / 8. / np.pi
+        return a * (x2 - b * x1 ** 2 + c * x1 - r) ** 2 + s * (1. - t) * np.cos(x1) + s
+
+    space = [uniform(loc=-5., scale=15.).ppf, uniform(loc=0., scale=15.).ppf]
+    np.random.seed(1818)
+    out = {}
+    testing = MonteCarloDesign(space).sample(100)
+    out["testing"], out["test_targets"] = testing, branin(testing)
+    for n_sim in (5, 10, 15, 20, 25, 30):
+        X = LatinHypercubeDesign(space).sample(n_sim)
+        X = np.vstack([X, X[:1]])
+        t = branin(X)
+        pre = "n%d_" % n_sim
+        out[pre + "X"], out[pre + "t"] = X, t
+        for tag in ("adaptive", "pivot"):
+            gp = fit_GP_MAP(GaussianProcess(X, t, nugget=tag))
+            if gp.theta.get_data() is None:
+                continue
+            mean, var, _ = gp.predict(testing, deriv=False, unc=True)
+            out[pre + tag + "_theta"] = gp.theta.get_data()
+            out[pre + tag + "_logpost"] = np.array(gp.current_logpost)
+            out[pre + tag + "_mean"], out[pre + tag + "_var"] = mean, var
+            if tag == "pivot":
+                out[pre + "pivot_P"] = np.asarray(gp.Kinv.P, dtype=np.int64)
+    np.savez_compressed(os.path.join(HERE, "branin_pivot.npz"), **out)
+
+
 def main():
+    if sys.argv[1:] == ["branin"]:
+        branin_pivot_section()
+        return
     if sys.argv[1:] == ["tsunami"]:
         tsunami_section()
         return
@@ -487,6 +525,7 @@ def main():
     pivot_section()
     validation_section()
     tsunami_section()
+    branin_pivot_section()
     print("golden vectors written to", HERE)
 
 

@@ -324,3 +324,32 @@ def test_pivot_tiny_and_block_edge_sizes_vs_oracle(n):
     if n <= 64:                                                           # (unblocked LAPACK: the whole factor is defined)
         assert_allclose(gp.L, ref.L.L, rtol=1e-8, atol=1e-11)
         assert_allclose(gp.logpost_deriv(theta), ref.logpost_deriv(theta), rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("n_sim", [5, 10, 15, 20, 25, 30])
+def test_branin_pivot_benchmark_of_the_reference(n_sim):
+    # benchmarks/benchmark_pivot.py: Latin-hypercube design of the 2-D Branin function with ONE DUPLICATED POINT (the use
+    # case of nugget="pivot"); golden = the reference's own MAP fit and its predictions at 100 random test points
+    g = load_golden("branin_pivot.npz")
+    pre = "n%d_" % n_sim
+    X, t, Xs, ys = g[pre + "X"], g[pre + "t"], g["testing"], g["test_targets"]
+    th_ref, lp_ref = g[pre + "pivot_theta"], float(g[pre + "pivot_logpost"])
+    gp = M.GaussianProcessGPU(X, t, nugget="pivot")                       # default priors, as the benchmark
+    # 1. at the reference's optimum: same objective, same skipped point, same predictions
+    assert_allclose(gp.logposterior(th_ref), lp_ref, rtol=1e-8)
+    gp.fit(th_ref)
+    assert gp.pivot_rank == n_sim
+    assert set(gp.P[-1:]) <= {0, n_sim}                                   # one of the two copies of the repeated point is skipped
+    mean, var, _ = gp.predict(Xs, deriv=False)
+    assert_allclose(mean, g[pre + "pivot_mean"], rtol=1e-6, atol=1e-6 * np.abs(ys).max())
+    assert_allclose(var, g[pre + "pivot_var"], rtol=1e-5, atol=1e-8 * np.abs(g[pre + "pivot_var"]).max() + 1e-10)
+    # 2. the device optimiser on the same data ends at the same level and predicts as well (with a skipped point the
+    #    gradient of the reference formulation is not exactly the derivative of its objective -- the trace term runs over
+    #    (L L^T)^-1 of the patched factor -- so two optimisers stop a few 1e-4 apart)
+    LibGPGPU.set_fit_options(max_iter=300, ftol=1e-9, gtol=1e-6, seed=3)
+    fit = M.fit_GP_MAP(M.GaussianProcessGPU(X, t, nugget="pivot"), n_tries=15)
+    assert fit.current_logpost <= lp_ref + 1e-3 * abs(lp_ref)
+    norm = ys.max() - ys.min()
+    rmse_ref = np.sqrt(np.mean((g[pre + "pivot_mean"] - ys) ** 2)) / norm
+    rmse = np.sqrt(np.mean((fit.predict(Xs, deriv=False)[0] - ys) ** 2)) / norm
+    assert rmse <= 1.5 * rmse_ref + 1e-3
