@@ -1116,7 +1116,7 @@ void Engine::predict(const std::vector<int>& ids, const double* Xs, int m, bool 
   // Measured at 64 x n=2000 x m=10^4: predict 45.9 -> 46.5 ms -- the GEMM slows down by as much as the build hides
   // (20.9 ms per 5632 points -> 11.3 ms per 2560 points, 61.3 -> 56.6 TFLOP/s).
   static const bool want_overlap = [] { const char* e = getenv("MOGP_PV_OVERLAP"); return e && e[0] == '1'; }();
-  const double budget = 6.0e9;
+  static const double budget = [] { const char* e = getenv("MOGP_KS_BUDGET_GB"); return (e ? atof(e) : 6.0) * 1e9; }();   // cross-covariance chunk
   long MC = (long)(budget / ((double)nb * LD * 8.0)) / 128 * 128;
   MC = std::max<long>(128, std::min<long>(MC, MPtot));
   const bool overlap = vars && want_overlap && MPtot > 2 * 128 && (long)MPtot * nb * LD * 8.0 > 1.0e9;
