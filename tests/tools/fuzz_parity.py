@@ -120,15 +120,22 @@ for case in range(cases):
             continue
         if nug_kind == "adaptive" and ref.nugget > 0:
             continue                # jitter ladder engaged: values depend on where exactly LAPACK gave up
-        Lf = ref.L.L if isinstance(ref.L, R.PivotFactor) else ref.L
-        dg = np.abs(np.diag(Lf))
-        if n_rep:
-            dg = dg[:n - n_rep]     # (the replacement diagonal of the skipped rows is not a measure of conditioning)
-        cond = float((dg.max() / dg.min()) ** 2)              # lower bound of cond(K): scales every tolerance
-        amp = max(1., cond * 1e-5)
-        if cond > 1e8:          # (the diagonal ratio is only a lower bound of cond(K))
-            continue                # zero-nugget matrix, D = 1, dense points: the quadratic form ~1e8+ carries cond * eps
-        c2 = ctx + " cond>=%.1e" % cond
+        # 2-norm condition number of the matrix that was factorised (its leading block of accepted pivots when design points
+        # repeat): every tolerance below scales with it
+        Kn = ref.get_K_matrix() + (ref.nugget or 0.) * np.eye(n)
+        ev = np.sort(np.linalg.eigvalsh(Kn))[::-1]
+        cond = float(ev[0] / max(ev[n - n_rep - 1], 1e-300))
+        amp = max(1., cond * 1e-7)
+        if n_rep >= 2:
+            # the second skipped row divides (rounding residue of the first / its replacement diagonal) x (an entry of the
+            # skipped block) by a replacement diagonal that is another factor (r + 2) smaller: the reference's own values
+            # carry that amplified residue, and for n > 64 the entry itself depends on the LAPACK build
+            amp *= 1e3
+            if cond > 1e8:
+                continue            # ... and at this conditioning the amplified residue IS the value (log-posteriors of 1e6)
+        if cond > 1e11:
+            continue                # zero-nugget matrix at the edge of fp64: the quadratic form carries cond * eps
+        c2 = ctx + " cond=%.1e" % cond
         close("logpost", f[k], lp, 1e-8 * amp, 1e-8 * amp, c2)
         if n_rep and n > 64:
             # beyond LAPACK's block size the skipped block of the oracle's factor depends on the LAPACK build and the trace
