@@ -110,13 +110,14 @@ def interpret_nugget(nugget):
 
 
 def _native_prior(prior):
-    if isinstance(prior, InvGammaPrior):
-        return (LibGPGPU.prior_type.InvGamma, [prior.shape, prior.scale])
-    if isinstance(prior, GammaPrior):
-        return (LibGPGPU.prior_type.Gamma, [prior.shape, prior.scale])
-    if isinstance(prior, LogNormalPrior):
-        return (LibGPGPU.prior_type.LogNormal, [prior.shape, prior.scale])
-    if prior is None or (isinstance(prior, WeakPrior) and not isinstance(prior, PriorDist)):
+    """(prior_type, [shape, scale]) of a ``Priors.*`` object or of one of the native prior objects ``LibGPGPU``
+    re-exports (bindings.cu:458-545); only an actual weak prior -- never an unrecognised subclass -- maps to Weak."""
+    for host_cls, native_cls, kind in ((InvGammaPrior, LibGPGPU.InvGammaPrior, LibGPGPU.prior_type.InvGamma),
+                                       (GammaPrior, LibGPGPU.GammaPrior, LibGPGPU.prior_type.Gamma),
+                                       (LogNormalPrior, LibGPGPU.LogNormalPrior, LibGPGPU.prior_type.LogNormal)):
+        if isinstance(prior, (host_cls, native_cls)):
+            return (kind, [float(prior.shape), float(prior.scale)])
+    if prior is None or type(prior) in (WeakPrior, LibGPGPU.WeakPrior):
         return (LibGPGPU.prior_type.Weak, [0., 0.])
     raise TypeError("Unknown prior type {} for C++/GPU implementation".format(type(prior)))
 
@@ -390,13 +391,16 @@ class GaussianProcessGPU(object):
     def __getstate__(self):
         th = self.theta
         theta = np.concatenate([th.get_mean(), th.get_data()]) if th.data_has_been_set() else None
+        # the CURRENT nugget setting (the ``nugget`` setter may have changed it since construction); the mean function
+        # pickles as its constructor arguments (libgpgpu.*MeanFunc.__reduce__)
+        nugget_size = self._densegp_gpu.get_nugget_size() if self.nugget_type == "fixed" else 0.
         return dict(inputs=self._inputs, targets=self._targets, max_batch_size=self._max_batch_size,
-                    kernel=self.kernel, nugget_type=self.nugget_type, nugget_size=self._init_nugget_size,
-                    priors=self._priors_arg, theta=theta)
+                    kernel=self.kernel, nugget_type=self.nugget_type, nugget_size=nugget_size,
+                    priors=self._priors_arg, theta=theta, mean=self.mean, analytic_mean=self._analytic_mean)
 
     def __setstate__(self, state):
         nugget = state["nugget_size"] if state["nugget_type"] == "fixed" else state["nugget_type"]
-        self.__init__(state["inputs"], state["targets"], kernel=state["kernel"], priors=state["priors"], nugget=nugget,
-                      max_batch_size=state["max_batch_size"])
+        self.__init__(state["inputs"], state["targets"], mean=state.get("mean"), kernel=state["kernel"], priors=state["priors"],
+                      nugget=nugget, max_batch_size=state["max_batch_size"], analytic_mean=state.get("analytic_mean", False))
         if state["theta"] is not None:
             self.fit(state["theta"])

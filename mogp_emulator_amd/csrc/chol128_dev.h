@@ -1,0 +1,337 @@
+// 128 x 128 diagonal block of the blocked Cholesky, factored by ONE 256-thread workgroup entirely on the matrix cores.
+// Replaces the diagonal-block share of cusolverDnDpotrf (densegp_gpu.hpp:451-474) / LAPACK dpotrf
+// (linalg/cholesky.py:225-232).
+//
+// The block is an 8 x 8 grid of 16 x 16 sub-blocks.  Its lower triangle lives in REGISTERS for the whole kernel, in
+// the fp64 MFMA accumulator layout (lane = (rg, cl) = (lane>>4, lane&15), register q: element [rg + 4q][cl]): wave w
+// owns the block rows w and 7-w (nine sub-blocks); off-diagonal sub-blocks are held transposed.  Sub-blocks are loaded
+// from global memory straight into that layout (no staging pass, no barrier before the first column step), finished
+// columns of L leave for global memory as they are produced; LDS only carries them to the other waves (operands of
+// the rank-16 updates) together with the next diagonal sub-block.
+//
+// One column step j of block step b is a rank-1 update, and a rank-1 update of a SYMMETRIC accumulator needs no data
+// movement on this layout: row j of the diagonal sub-block sits in register j>>2 of the 16 lanes with rg == j&3,
+// indexed by cl -- exactly where the MFMA expects k-slice j&3 of both its A and its B operand.  So
+//     v  = (rg == j&3 && cl >= j) ? D[j][cl] * rsqrt(D[j][j]) : 0        (column j of L, zero in the other k-slices)
+//     D  = mfma(-v, v, D)                                                 (D -= v v^T)
+// and for a sub-block below it, held transposed (T[c][x] = A[16r + x][16b + c]):
+//     u  = (rg == j&3) ? T[j][cl] * rsqrt(D[j][j]) : 0                    (column j of the L sub-block)
+//     T  = mfma(-v, u, T)                                                 (T -= v u^T)
+// The same sweep applied to an identity block yields inv(L_bb)^T, which the MFMA panel solve below the block wants.
+// Every wave factors its own copy of the diagonal sub-block (identical arithmetic, so nothing is exchanged inside a
+// block step) and carries two transposed sub-blocks through the 16 steps: three independent MFMAs per step, straight-line
+// code.  The panel below the diagonal sub-block is thereby solved by the same backward-stable recurrence as dpotf2 /
+// dtrsm.  The pivot of step j+1 does not wait for the MFMA of step j: d' = D[j+1][j+1] - v[j+1]^2 is formed from two
+// v_readlane and one FMA, so the dependent chain per column is readlane -> fma -> v_rsq_f64 + 5 FMAs -> multiply
+// (~200 cycles; a dependent fp64 MFMA alone costs ~150).  Between block steps: one barrier, the rank-16 update of the
+// owned trailing sub-blocks (independent accumulators interleaved), the owner publishes the next diagonal sub-block,
+// one barrier.
+//
+// Measured on MI355X (tools/chol128_probe.hip): see DESIGN.md section 3.  History: lane = row with pivots and multipliers
+// by v_readlane, 2 x 64 dependent column steps and a global-memory round trip between the halves: 58 us; first MFMA
+// version (LDS-staged load / store phases at one CU's ~10 B/cycle, MFMA results read back after every instruction): 57 us.
+#pragma once
+#include "launch.h"
+
+namespace mogp {
+
+typedef double c128_v2d __attribute__((ext_vector_type(2)));
+typedef double c128_v4d __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ double readlane_f64(double x, int srclane) {
+  int lo = __double2loint(x), hi = __double2hiint(x);
+  lo = __builtin_amdgcn_readlane(lo, srclane);
+  hi = __builtin_amdgcn_readlane(hi, srclane);
+  return __hiloint2double(hi, lo);
+}
+
+// 1/sqrt(d) on the critical path of every column: v_rsq_f64 (2^29 ulp, i.e. ~2^-23 relative) and ONE third-order
+// correction.  With E = 1 - d r0^2 (|E| ~ 2^-22):  d^-1/2 = r0 (1 - E)^-1/2 = r0 (1 + E/2 + 3E^2/8 + O(E^3)); the
+// neglected term is ~2^-67.  Five dependent operations instead of the eight of two coupled Goldschmidt steps; the
+// result is within ~1 ulp (the probe compares the factor with a host Cholesky).
+__device__ __forceinline__ double rsqrt_fast(double d) {
+  const double r0 = __builtin_amdgcn_rsq(d);
+  const double t = d * r0;
+  const double E = __builtin_fma(-t, r0, 1.0);
+  const double p = __builtin_fma(0.375, E, 0.5);
+  return __builtin_fma(r0, E * p, r0);
+}
+
+// optional cycle stamps for tools/chol128_probe.hip (compiled out of the library)
+#ifdef C128_PROFILE
+#define C128_STAMP(i) do { if (threadIdx.x == 0 && c128_stamps) c128_stamps[blockIdx.x * 32 + (i)] = __builtin_readcyclecounter(); } while (0)
+#if C128_PROFILE > 1
+#define C128_STAMPW(i) do { if ((threadIdx.x & 63) == 0 && c128_stamps) c128_stamps[2048 + (blockIdx.x * 4 + (threadIdx.x >> 6)) * 64 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define C128_STAMPW(i) do { } while (0)
+#endif
+__device__ unsigned long long* c128_stamps = nullptr;
+#else
+#define C128_STAMP(i) do { } while (0)
+#define C128_STAMPW(i) do { } while (0)
+#endif
+
+constexpr int C128_LD = 130;                                  // LDS row stride (doubles): conflict-free ds_read_b64 in both MFMA layouts
+constexpr int C128_LDS_DOUBLES = 128 * C128_LD + 256 + 4 * 256;   // columns of L + published diagonal sub-block + inverse staging
+
+// Pack written for the panel solve below the block (trsm128_dev), per emulator:
+//   [PACK128_LT  + c * 128 + r]            = L[r][c]                    (transposed, so that lanes run over rows)
+//   [PACK128_INV + b * 256 + k * 16 + i]   = inv(L_bb)[i][k]            (the eight 16 x 16 diagonal sub-blocks)
+constexpr int PACK128_LT = 0;
+constexpr int PACK128_INV = 128 * 128;
+constexpr int PACK128_STRIDE = PACK128_INV + 8 * 256;
+
+// 16 column steps of one block step.  All accumulators are held NEGATED (Dn = -D, ...), so that every update is a
+// plain accumulate and every sign rides on a free source modifier of a VALU multiply:
+//   Dn = this wave's copy of the diagonal sub-block (symmetric), Xn / Yn = two sub-blocks carried along in transposed
+//   form (a panel sub-block below the diagonal one, minus the identity for the inverse, or zeros).
+// Returns the columns of L (Lv: diagonal sub-block; UX / UY: columns of the solved X / Y) as lane (rg, cl), register
+// s = column rg + 4s, row cl.  NSLOT = 1: only Xn is carried.  A pivot that is not > 0 (or NaN / Inf) is recorded in
+// `fail` (first one wins) and the factorisation runs on with garbage -- the caller discards the emulator.
+template <int NSLOT>
+__device__ __forceinline__ void c128_column_steps(c128_v4d& Dn, c128_v4d& Xn, c128_v4d& Yn, c128_v4d& Lv, c128_v4d& UX, c128_v4d& UY, double& rs_last,
+                                                  int rg, int cl) {
+  // A wave issues in order and has its SIMD to itself, so every VALU instruction counts (~20 per step) and the order
+  // written here is the order that matters (pinned for the scheduler by the sched_group_barrier pattern below): the
+  // MFMA on the diagonal sub-block first, the reciprocal square root of the NEXT pivot -- which does not depend on it --
+  // underneath, then the two carried sub-blocks, and only then the accumulator is read back for the next step.
+  //   * one lane mask per step: nrs = (rg == j&3) ? -rs : 0 scales row j of all three accumulators.  Entries cl < j of
+  //     the diagonal sub-block's row are already eliminated (rounding residue); they only touch dead rows / columns
+  //     and are cleared once per block step by the caller, not per step.
+  //   * no pivot test: a pivot <= 0, NaN or Inf turns rs into NaN (v_rsq_f64 of 0 / negative / Inf, then 0 x Inf), and
+  //     NaN then reaches every later pivot; the caller tests the last rs of the block.
+  double d = -readlane_f64(Dn[0], 0);
+  double rs = rsqrt_fast(d);
+  double vv = Dn[0] * ((rg == 0) ? -rs : 0.0);
+  {
+    const double m = -readlane_f64(Dn[0], 1) * rs;
+    d = __builtin_fma(-m, m, -readlane_f64(Dn[0], 17));
+  }
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const int q = j & 3, reg = j >> 2;
+    const double nrs = (rg == q) ? -rs : 0.0;              // of step j
+    Dn = __builtin_amdgcn_mfma_f64_16x16x4f64(vv, vv, Dn, 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (j < 15) rs = rsqrt_fast(d);                        // of step j + 1; independent of the MFMA above
+    const double ux = Xn[reg] * nrs;                       // Xn as the MFMA of step j - 1 left it (issued a whole step ago)
+    __builtin_amdgcn_sched_barrier(0);
+    Xn = __builtin_amdgcn_mfma_f64_16x16x4f64(vv, ux, Xn, 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    Lv[reg] += vv;                                         // vv, ux, uy are exact zeros outside the lanes rg == q
+    UX[reg] += ux;
+    if (NSLOT > 1) {
+      const double uy = Yn[reg] * nrs;
+      __builtin_amdgcn_sched_barrier(0);
+      Yn = __builtin_amdgcn_mfma_f64_16x16x4f64(vv, uy, Yn, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      UY[reg] += uy;
+    }
+    if (j < 15) {
+      // by now the MFMA on Dn has retired (one or two MFMA issue slots later): read it back for step j + 1
+      const int jn = j + 1, qn = jn & 3, rn = jn >> 2;
+      vv = Dn[rn] * ((rg == qn) ? -rs : 0.0);              // column jn of L: row jn of D / sqrt(pivot)
+      if (jn < 15) {
+        // pivot after next, D[jn+1][jn+1] - L[jn+1][jn]^2, from two v_readlane and two FMAs: the MFMA of step jn is not waited for
+        const double m = -readlane_f64(Dn[rn], 16 * qn + jn + 1) * rs;
+        d = __builtin_fma(-m, m, -readlane_f64(Dn[(jn + 1) >> 2], 16 * ((jn + 1) & 3) + jn + 1));
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  rs_last = rs;
+}
+
+// A: origin of the 128 x 128 block (row stride ld); only its lower triangle is read.  On return A holds L (upper
+// triangle of the two 64 x 64 diagonal tiles zeroed), pk the pack above, *info_slot = c0 + 1 if it was 0 and the block is not
+// positive definite (the failing column inside the block is not recorded: the engine only tests for non-zero).  All 256 threads must call; lds: C128_LDS_DOUBLES doubles.
+__device__ __forceinline__ void chol128_dev(double* __restrict__ A, int ld, double* __restrict__ pk, int* info_slot, int c0, double* lds) {
+  const int t = threadIdx.x, lane = t & 63;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int rg = lane >> 4, cl = lane & 15;
+  double* S = lds;                           // finished columns of L, row-major image of the block
+  double* Dbuf = lds + 128 * C128_LD;        // next diagonal sub-block (negated), accumulator layout
+  double* Ibuf = Dbuf + 256;                 // 4 x 256: per-wave staging of an inverted diagonal sub-block
+  const int r1 = w, r2 = 7 - w;
+  const c128_v4d zero4 = {0., 0., 0., 0.};
+  C128_STAMP(0);
+  // sub-block (r, k), k < r, transposed and negated: register q = -A[16r + cl][16k + rg + 4q]
+  auto load_off = [&](int r, int k) {
+    c128_v4d x;
+    const double* p = A + (size_t)(16 * r + cl) * ld + 16 * k + rg;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) x[q] = -p[4 * q];
+    return x;
+  };
+  // diagonal sub-block (r, r), both triangles, mirrored from the lower one, negated
+  auto load_diag = [&](int r) {
+    c128_v4d x;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int i = rg + 4 * q, hi = i > cl ? i : cl, lo = i > cl ? cl : i;
+      x[q] = -A[(size_t)(16 * r + hi) * ld + 16 * r + lo];
+    }
+    return x;
+  };
+  c128_v4d Dn = load_diag(0);
+  c128_v4d R1[4], R2[8];                     // R1[k] = -(sub-block (r1, k)), R2[k] = -(sub-block (r2, k)); block column 0 first
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    R1[k] = zero4;
+    if (k < r1) R1[k] = load_off(r1, k);
+    else if (k == r1 && k > 0) R1[k] = load_diag(r1);
+    R2[k] = load_off(r2, k);                 // r2 >= 4 > k
+  }
+#pragma unroll
+  for (int k = 4; k < 8; ++k) {
+    R2[k] = zero4;
+    if (k < r2) R2[k] = load_off(r2, k);
+    else if (k == r2) R2[k] = load_diag(r2);
+  }
+  // zeros above the diagonal inside the two 64 x 64 diagonal tiles (three sub-blocks per wave)
+#pragma unroll
+  for (int k = 1; k < 8; ++k) {
+    const c128_v2d z2 = {0., 0.};
+    if (k > r1 && k <= 3) {
+      double* p = A + (size_t)(16 * r1 + cl) * ld + 16 * k + 4 * rg;
+      *reinterpret_cast<c128_v2d*>(p) = z2;
+      *reinterpret_cast<c128_v2d*>(p + 2) = z2;
+    }
+    if (k > r2) {
+      double* p = A + (size_t)(16 * r2 + cl) * ld + 16 * k + 4 * rg;
+      *reinterpret_cast<c128_v2d*>(p) = z2;
+      *reinterpret_cast<c128_v2d*>(p + 2) = z2;
+    }
+  }
+  c128_v4d nident;                           // minus the identity, transposed layout (symmetric)
+#pragma unroll
+  for (int q = 0; q < 4; ++q) nident[q] = (rg + 4 * q == cl) ? -1.0 : 0.0;
+  double rs_last = 1.0;
+#pragma unroll
+  for (int b = 0; b < 8; ++b) {
+    const bool p1 = r1 > b, p2 = r2 > b;     // the wave owns a sub-block below diagonal sub-block b in block row r1 / r2
+    // the inverse of the diagonal sub-block rides along in a wave that has a free slot
+    const bool inv = (b < 3) ? (w == 0) : ((b == 3) ? (w == 3) : (r2 == b));
+    if (r2 >= b) {
+      if (b > 0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) Dn[q] = Dbuf[(rg + 4 * q) * 16 + cl];
+      }
+      c128_v4d Lv = zero4, UX = zero4, UY = zero4;
+      C128_STAMPW(4 * b);
+      if (b < 4) {
+        // two slots: X = sub-block (r1, b) -- or the inverse where r1 <= b --, Y = sub-block (r2, b)
+        c128_v4d X = zero4;
+        if (b < 3 && p1) X = R1[b < 3 ? b : 0];
+        if (inv) X = nident;                 // (inv implies !p1)
+        c128_v4d Y = R2[b];                  // r2 >= 4 > b
+        c128_column_steps<2>(Dn, X, Y, Lv, UX, UY, rs_last, rg, cl);
+      } else {
+        // one slot: sub-block (r2, b), or the inverse in the wave that owns the diagonal sub-block
+        c128_v4d X = p2 ? R2[b] : nident, Y = zero4;
+        c128_column_steps<1>(Dn, X, Y, Lv, UX, UY, rs_last, rg, cl);
+        UY = UX;                             // uniform naming below: UY belongs to block row r2
+      }
+      C128_STAMPW(4 * b + 1);
+      // finished columns into the LDS image: lane (rg, cl), register s = L[16r + cl][16b + rg + 4s]
+      auto put = [&](int r, const c128_v4d& U) {
+        double* ps = S + (16 * r + cl) * C128_LD + 16 * b + rg;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) ps[4 * s] = U[s];
+      };
+      if (r1 == b || r2 == b) {
+        // the strict upper triangle of the diagonal sub-block as exact zeros (see c128_column_steps)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) Lv[q] = (cl >= rg + 4 * q) ? Lv[q] : 0.0;
+        put(b, Lv);
+      }
+      if (b < 3 && p1) put(r1, UX);
+      if (p2) put(r2, UY);
+      if (inv) {
+        // columns of inv(L_bb)^T: lane (rg, cl), register s = inv(L_bb)[rg + 4s][cl]; pack order [k = cl][i = rg + 4s];
+        // through a wave-private LDS stage so that it leaves as two fully coalesced 1 KB stores
+        const c128_v4d& UI = (b < 4) ? UX : UY;
+        double* stage = Ibuf + 256 * w;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) stage[cl * 16 + rg + 4 * s] = UI[s];
+        __builtin_amdgcn_wave_barrier();
+        double* pi = pk + PACK128_INV + b * 256;
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+          *reinterpret_cast<c128_v2d*>(pi + 128 * h + 2 * lane) = *reinterpret_cast<const c128_v2d*>(stage + 128 * h + 2 * lane);
+      }
+    }
+    C128_STAMPW(4 * b + 2);
+    __syncthreads();
+    C128_STAMPW(4 * b + 3);
+    C128_STAMP(2 + 2 * b);
+    // block column b of L leaves the LDS image as full 128-byte row segments: A (row-major) and the transposed pack.
+    // All LDS reads first, then the stores (fire and forget: they drain underneath the MFMAs below).
+    {
+      const int nrows = 128 - 16 * b;
+      c128_v2d ca[4], ct[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (32 * i < nrows) {
+          const int row = 16 * b + (t >> 3) + 32 * i, rc = row < 128 ? row : 127;
+          ca[i] = *reinterpret_cast<const c128_v2d*>(S + rc * C128_LD + 16 * b + 2 * (t & 7));
+          const int r = 16 * b + 2 * (t & 15) + 32 * i, rr = r < 128 ? r : 126, c = 16 * b + (t >> 4);
+          ct[i][0] = S[rr * C128_LD + c];
+          ct[i][1] = S[(rr + 1) * C128_LD + c];
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (32 * i < nrows) {
+          const int row = 16 * b + (t >> 3) + 32 * i;
+          if (row < 128) *reinterpret_cast<c128_v2d*>(A + (size_t)row * ld + 16 * b + 2 * (t & 7)) = ca[i];
+          const int r = 16 * b + 2 * (t & 15) + 32 * i, c = 16 * b + (t >> 4);
+          if (r < 128) *reinterpret_cast<c128_v2d*>(pk + PACK128_LT + c * 128 + r) = ct[i];
+        }
+      }
+    }
+    if (b == 7) break;
+    // rank-16 update of the owned sub-blocks to the right of block column b.  Branch-free: sub-blocks the wave does
+    // not own (k > r) are updated with a zero operand, so that no control flow touches an accumulator; with k == r the
+    // A operand is the wave's own panel sub-block, i.e. the symmetric update of the diagonal sub-block.
+    {
+      double bo1[4], bo2[4];
+      const double* pb1 = S + (16 * r1 + cl) * C128_LD + 16 * b + rg;
+      const double* pb2 = S + (16 * r2 + cl) * C128_LD + 16 * b + rg;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        bo1[s] = pb1[4 * s];
+        bo2[s] = pb2[4 * s];
+      }
+#pragma unroll
+      for (int k = b + 1; k < 8; ++k) {
+        const double* pa = S + (16 * k + cl) * C128_LD + 16 * b + rg;
+        double ak[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) ak[s] = pa[4 * s];
+        if (k < 4) {
+#pragma unroll
+          for (int s = 0; s < 4; ++s) R1[k < 4 ? k : 0] = __builtin_amdgcn_mfma_f64_16x16x4f64(k <= r1 ? ak[s] : 0.0, bo1[s], R1[k < 4 ? k : 0], 0, 0, 0);
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) R2[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(k <= r2 ? ak[s] : 0.0, bo2[s], R2[k], 0, 0, 0);
+      }
+    }
+    // the owner of the next diagonal sub-block publishes it
+    {
+      const bool own = (b + 1 < 4) ? (r1 == b + 1) : (r2 == b + 1);
+      const c128_v4d Dnext = (b + 1 < 4) ? R1[b + 1 < 4 ? b + 1 : 0] : R2[b + 1];
+      if (own) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) Dbuf[(rg + 4 * q) * 16 + cl] = Dnext[q];
+      }
+    }
+    __syncthreads();
+    C128_STAMP(3 + 2 * b);
+  }
+  // wave 0 took part in every block step: its last reciprocal square root is NaN iff some pivot was not a positive finite number
+  if (w == 0 && lane == 0 && !(rs_last > 0.0) && *info_slot == 0) *info_slot = c0 + 1;
+  C128_STAMP(18);
+}
+
+}  // namespace mogp

@@ -107,10 +107,8 @@ class Engine {
   hipStream_t pstream = nullptr;     // look-ahead stream: panel factorisations
   std::vector<hipEvent_t> evPanel, evUpd;
   std::vector<hipStream_t> gstreams;  // extra streams for independent emulator groups
-  std::map<long, hipGraphExec_t> cholGraphs;   // captured left-looking factorisation per (batch size, group count)
   hipEvent_t evReady = nullptr;
   hipEvent_t evGroup[15] = {};
-  std::vector<hipEvent_t> evAlt;      // update-slot hand-over events of the alternating two-group schedule
 
  private:
   void upload_params(const std::vector<int>& ids);
@@ -146,9 +144,6 @@ class Engine {
   std::vector<double> hP;
   // predict scratch
   double *dXs = nullptr, *dKs = nullptr, *dMean = nullptr, *dVar = nullptr, *dVarPartial = nullptr, *dDeriv = nullptr;
-  double* dKs2 = nullptr;        // second cross-covariance buffer: the next chunk is built while the current one is consumed
-  size_t capKs2 = 0;
-  hipEvent_t evKsReady[2] = {}, evKsFree[2] = {};
   size_t capXs = 0, capKs = 0, capMean = 0, capVar = 0, capVarPartial = 0, capDeriv = 0;
   std::mt19937_64 rng;
 };

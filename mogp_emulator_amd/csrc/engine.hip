@@ -175,7 +175,7 @@ Engine::Engine(const double* X, int n_, int D_, const double* targets, int B_, u
   dYty = dalloc<double>(B);
   dInfo = dalloc<int>(B);
   dIdx = dalloc<int>(B);
-  dLpack = dalloc<double>((size_t)B * std::max(lpack_doubles_per_emulator(), lpack128_doubles_per_emulator()));
+  dLpack = dalloc<double>((size_t)B * lpack128_doubles_per_emulator());
   hP.assign((size_t)B * PS, 0.);
   HIPCK(hipMemcpy(dX, hX.data(), hX.size() * sizeof(double), hipMemcpyHostToDevice));
   // residual targets for parameter-free means are fixed once
@@ -188,18 +188,14 @@ Engine::Engine(const double* X, int n_, int D_, const double* targets, int B_, u
 
 Engine::~Engine() {
   for (void* p : {(void*)dX, (void*)dP, (void*)dT, (void*)dA, (void*)dLinv, (void*)dKinv, (void*)dAlpha, (void*)dLogdet, (void*)dYty,
-                  (void*)dGradOut, (void*)dGradPartial, (void*)dInfo, (void*)dIdx, (void*)dXs, (void*)dKs, (void*)dKs2, (void*)dMean, (void*)dVar,
+                  (void*)dGradOut, (void*)dGradPartial, (void*)dInfo, (void*)dIdx, (void*)dXs, (void*)dKs, (void*)dMean, (void*)dVar,
                   (void*)dVarPartial, (void*)dDeriv, (void*)dLpack, (void*)dH, (void*)dZ, (void*)dM, (void*)dGram, (void*)dXp, (void*)dPivWork,
                   (void*)dPerm, (void*)dRank})
     if (p) hipFree(p);
   for (auto& kv : w2) hipFree(kv.second);
-  for (auto e : evKsReady) if (e) hipEventDestroy(e);
-  for (auto e : evKsFree) if (e) hipEventDestroy(e);
-  for (auto& kv : cholGraphs) hipGraphExecDestroy(kv.second);
   for (auto st : gstreams) hipStreamDestroy(st);
   if (evReady) hipEventDestroy(evReady);
   for (auto e : evGroup) if (e) hipEventDestroy(e);
-  for (auto e : evAlt) hipEventDestroy(e);
   for (auto e : evPanel) hipEventDestroy(e);
   for (auto e : evUpd) hipEventDestroy(e);
   if (pstream) hipStreamDestroy(pstream);
@@ -287,24 +283,14 @@ static void update_column_block(const BatchView& v, int c, int k0, int k1, hipSt
 }
 
 void Engine::panel(const BatchView& v, int o, int w, hipStream_t st) {
-  // 128 x 128 diagonal block + 128-wide panel solve in two launches (default); MOGP_P128=0: the recursive 64-wide chain
-  // potf2 -> trsm -> 64-wide update -> potf2 -> trsm (five launches, the 64-wide update is a memory-bound pass at ~20 TF)
-  static const bool p128 = [] { const char* e = getenv("MOGP_P128"); return !e || e[0] != '0'; }();
-  if (w == TILE && p128) {
-    launch_panel128(v, o, dInfo, dLpack, st);
+  if (w == TILE) {
+    launch_panel128(v, o, dInfo, dLpack, st);      // 128 x 128 diagonal block + 128-wide panel solve
     return;
   }
-  if (w == NBI) {
-    launch_potf2(v, o, dInfo, dLpack, st);
-    launch_trsm(v, o, o + NBI, dLpack, st);
-    return;
-  }
-  int h = NBI;                       // largest power of two below w (w is 128 or a multiple of 128)
+  int h = TILE;                      // largest power of two below w (w is a multiple of 128)
   while (2 * h < w) h *= 2;
   panel(v, o, h, st);
-  if (h == NBI) launch_update_narrow(v, o + h, o, o + h, st);
-  else
-    for (int c = o + h; c < o + w; c += TILE) update_column_block(v, c, o, o + h, st);
+  for (int c = o + h; c < o + w; c += TILE) update_column_block(v, c, o, o + h, st);
   panel(v, o + h, w - h, st);
 }
 
@@ -445,199 +431,43 @@ void Engine::factorize_blocked(const std::vector<int>& ids, std::vector<int>& in
     // two streams is on the device side (kernel-boundary cache maintenance of one queue hits the kernels
     // of the others), not host launch overhead.  Graph replay is kept as an option, off by default.
     static const long tail_threshold = [] { const char* e = getenv("MOGP_TAIL"); return e ? atol(e) : 1100L; }();
-    static const bool fuse_potf2 = [] { const char* e = getenv("MOGP_FUSE_POTF2"); return e && e[0] == '1'; }();
     static const int want_groups = [] { const char* e = getenv("MOGP_GROUPS"); return e ? std::max(1, atoi(e)) : 2; }();
-    static const bool want_graph = [] { const char* e = getenv("MOGP_GRAPH"); return e && e[0] == '1'; }();
     const int G = std::min(want_groups, std::max(1, nb / 8));
     while ((int)gstreams.size() < G - 1) {
       hipStream_t st;
       HIPCK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
       gstreams.push_back(st);
     }
-    // Experiment (MOGP_FUSEK=1): the long-K update of block column j is the first kernel to touch its tiles, so it can
-    // generate their covariance entries itself and the K build shrinks to the first block column.  Bit-identical, but
-    // measured slower (6.00 -> 6.05 ms; single stream 6.07 -> 6.18 ms): the per-entry distance + exp in the epilogue of
-    // the MFMA kernel costs more than the 0.3 ms K build and the read of C it saves.
-    static const bool fuse_k = [] { const char* e = getenv("MOGP_FUSEK"); return e && e[0] == '1'; }();
-    static const bool pair = [] { const char* e = getenv("MOGP_PAIR"); return !e || e[0] != '0'; }();
-    bool gen_cov = fuse_k && pair && !fuse_potf2;
-    for (int o = TILE; o < n + R && gen_cov; o += TILE)
-      if ((long)((nb + G - 1) / G) * ((NP - o) / TILE) >= tail_threshold) gen_cov = false;      // a wide-tile update would be used
-    auto issue = [&]() {
-      HIPCK(hipMemsetAsync(dInfo, 0, B * sizeof(int), stream));
-      launch_cov_build(v, stream, gen_cov ? TILE : 0);
-      HIPCK(hipEventRecord(evReady, stream));
-      std::vector<BatchView> gv(G, v);
-      std::vector<hipStream_t> gs(G, stream);
-      for (int g = 0; g < G; ++g) {
-        const int lo = (int)((long)nb * g / G), hi = (int)((long)nb * (g + 1) / G);
-        gv[g].idx = dIdx + lo;
-        gv[g].nb = hi - lo;
-        if (g > 0) {
-          gs[g] = gstreams[g - 1];
-          HIPCK(hipStreamWaitEvent(gs[g], evReady, 0));
-        }
+    HIPCK(hipMemsetAsync(dInfo, 0, B * sizeof(int), stream));
+    launch_cov_build(v, stream);
+    HIPCK(hipEventRecord(evReady, stream));
+    std::vector<BatchView> gv(G, v);
+    std::vector<hipStream_t> gs(G, stream);
+    for (int g = 0; g < G; ++g) {
+      const int lo = (int)((long)nb * g / G), hi = (int)((long)nb * (g + 1) / G);
+      gv[g].idx = dIdx + lo;
+      gv[g].nb = hi - lo;
+      if (g > 0) {
+        gs[g] = gstreams[g - 1];
+        HIPCK(hipStreamWaitEvent(gs[g], evReady, 0));
       }
-      // MOGP_ALT=1 (two groups): the long updates of the two groups strictly alternate (each waits for the other
-      // group's previous update), so a group's panel chain always runs under the other group's update
-      static const bool alternate = [] { const char* e = getenv("MOGP_ALT"); return e && e[0] == '1'; }();
-      const bool alt = alternate && G == 2;
-      size_t nev = 0;
-      hipEvent_t prev_update = nullptr;
-      auto next_event = [&]() {
-        if (nev == evAlt.size()) {
-          hipEvent_t e;
-          HIPCK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-          evAlt.push_back(e);
-        }
-        return evAlt[nev++];
-      };
-      for (int o = 0; o < n + R; o += TILE)
-        for (int g = 0; g < G; ++g) {
-          if (alt && prev_update) HIPCK(hipStreamWaitEvent(gs[g], prev_update, 0));
-          if (o > 0) {
-            // with fewer than ~4 128-tiles per CU (always true at n=2000 x 64, measured 7.6 vs 8.3 ms) use
-            // 64x64 tiles: 4x the workgroups, 3 resident per CU, better balance and latency hiding
-            const long tiles128 = (long)gv[g].nb * ((NP - o) / TILE);
-            if (tiles128 >= tail_threshold) launch_update_wide(gv[g], o, 0, o, gs[g]);
-            else {
-              if (fuse_potf2) {
-                // experiment (MOGP_FUSE_POTF2=1): the diagonal tile's workgroup factors D1 / D2 itself.  Measured
-                // SLOWER (7.5 -> 8.0..8.5 ms): the potf2 wave's 128+ live VGPRs set the register allocation of the
-                // whole update kernel (86 -> 168/255), costing a resident workgroup per CU or spilling.
-                launch_update_narrow_potf2(gv[g], o, 0, o, dInfo, dLpack, gs[g]);          // + potf2(o)
-                launch_update_narrow(gv[g], o + NBI, 0, o, gs[g]);
-                launch_trsm(gv[g], o, o + NBI, dLpack, gs[g]);
-                launch_update_narrow_potf2(gv[g], o + NBI, o, o + NBI, dInfo, dLpack, gs[g]);   // + potf2(o+64)
-                launch_trsm(gv[g], o + NBI, o + TILE, dLpack, gs[g]);
-                continue;
-              }
-              // both 64-wide halves of the block column in one launch (measured 7.56 -> 6.84 ms: the partially
-              // filled last round of workgroups is paid once instead of twice)
-              if (pair) launch_update_narrow_pair(gv[g], o, 0, o, gs[g], gen_cov);
-              else {
-                launch_update_narrow(gv[g], o, 0, o, gs[g]);
-                launch_update_narrow(gv[g], o + NBI, 0, o, gs[g]);
-              }
-            }
-          }
-          if (alt) {
-            // the "update slot" of this group ends here (at o = 0: after its first panel, which offsets the groups)
-            if (o == 0) panel(gv[g], o, TILE, gs[g]);
-            prev_update = next_event();
-            HIPCK(hipEventRecord(prev_update, gs[g]));
-            if (o == 0) continue;
-          }
-          panel(gv[g], o, TILE, gs[g]);
-        }
-      for (int g = 1; g < G; ++g) {
-        HIPCK(hipEventRecord(evGroup[g - 1], gs[g]));
-        HIPCK(hipStreamWaitEvent(stream, evGroup[g - 1], 0));
-      }
-    };
-    // Role-fused software pipeline (experiment, MOGP_FUSED=1): two emulator groups in anti-phase; every launch
-    // carries one panel-chain kernel of one group (potf2 / trsm / 64-wide update: few workgroups, latency
-    // bound) and a slice of the other group's long-K update (MFMA bound) as two jobs of ONE kernel, so they
-    // overlap by construction.  Bit-identical results, but measured SLOWER than two free-running streams
-    // (64 x n=2000: 6.07 ms two streams; fused 11.4 ms with the update cut in 5 slices, 7.9 ms in 2, 7.5 ms
-    // uncut): a slice can never finish faster than one long-K tile (27-55 us), and the half-batch panel
-    // kernels then run alone on the machine, one after the other, in a single stream.
-    static const bool want_fused = [] { const char* e = getenv("MOGP_FUSED"); return e && e[0] == '1'; }();
-    if (want_fused && nb >= 16 && !fuse_potf2 && (long)(nb / 2) * (NP / TILE) < tail_threshold) {
-      static const std::vector<double> weights = [] {
-        std::vector<double> w{32., 13., 10., 32., 13.};
-        if (const char* e = getenv("MOGP_FUSEW")) {
-          std::vector<double> u;
-          for (const char* p = e; *p;) {
-            u.push_back(atof(p));
-            while (*p && *p != ',') ++p;
-            if (*p == ',') ++p;
-          }
-          if (u.size() == 5) w = u;
-        }
-        return w;
-      }();
-      HIPCK(hipMemsetAsync(dInfo, 0, B * sizeof(int), stream));
-      launch_cov_build(v, stream);
-      const int off[2] = {0, nb / 2}, cnt[2] = {nb / 2, nb - nb / 2};
-      auto job = [&](int role, int g, int per_emu, int c0, int k0, int k1, int nt, int tile0, int r0) {
-        FusedJob j{};
-        j.role = role; j.idx_off = off[g]; j.nb = cnt[g]; j.per_emu = per_emu;
-        j.c0 = c0; j.k0 = k0; j.k1 = k1; j.nt = nt; j.tile0 = tile0; j.r0 = r0;
-        j.wg_count = (per_emu > 0) ? cnt[g] * per_emu : 0;
-        return j;
-      };
-      auto chain_op = [&](int g, int o, int i) {
-        switch (i) {
-          case 0: return job(ROLE_POTF2, g, 1, o, 0, 0, 0, 0, 0);
-          case 1: return job(ROLE_TRSM, g, (NP - o - NBI) / 64, o, 0, 0, 0, 0, o + NBI);
-          case 2: return job(ROLE_UPDATE, g, (NP - o - NBI) / 64, o + NBI, o, o + NBI, (NP - o - NBI) / 64, 0, 0);
-          case 3: return job(ROLE_POTF2, g, (o + NBI < NP) ? 1 : 0, o + NBI, 0, 0, 0, 0, 0);
-          default: return job(ROLE_TRSM, g, (NP - o - TILE) / 64, o + NBI, 0, 0, 0, 0, o + TILE);
-        }
-      };
-      // slice i (of 5) of the block-column update of group g at column o; i < 0: the whole update
-      auto update_piece = [&](int g, int o, int i) {
-        const int nt = (NP - o) / 64, ntiles = std::max(0, 2 * nt - 1);
-        int t0 = 0, t1 = ntiles;
-        if (i >= 0) {
-          double tot = 0., acc0 = 0.;
-          for (double x : weights) tot += x;
-          for (int q = 0; q < i; ++q) acc0 += weights[q];
-          t0 = (int)std::lround(ntiles * acc0 / tot);
-          t1 = (i == 4) ? ntiles : (int)std::lround(ntiles * (acc0 + weights[i]) / tot);
-        }
-        return job(ROLE_UPDATE, g, t1 - t0, o, 0, o, nt, t0, 0);
-      };
-      auto launch2 = [&](FusedJob a, FusedJob b) {
-        FusedArgs fa{};
-        if (a.wg_count == 0) std::swap(a, b);
-        if (a.wg_count == 0) return;
-        a.wg_begin = 0;
-        fa.job[0] = a;
-        fa.njobs = 1;
-        int total = a.wg_count;
-        if (b.wg_count > 0) {
-          b.wg_begin = roundup(a.wg_count, 8);
-          fa.job[1] = b;
-          fa.njobs = 2;
-          total = b.wg_begin + b.wg_count;
-        }
-        launch_fused_step(v, fa, total, dInfo, dLpack, stream);
-      };
-      std::vector<int> cols;
-      for (int o = 0; o < n + R; o += TILE) cols.push_back(o);
-      const int K = (int)cols.size();
-      const FusedJob none{};
-      for (int i = 0; i < 5; ++i) launch2(chain_op(0, cols[0], i), chain_op(1, cols[0], i));   // first panel: both groups
-      if (K > 1) launch2(update_piece(0, cols[1], -1), none);                                    // offsets the groups by half a period
-      for (int k = 1; k < K; ++k) {
-        for (int i = 0; i < 5; ++i) launch2(chain_op(0, cols[k], i), update_piece(1, cols[k], i));
-        for (int i = 0; i < 5; ++i) launch2(chain_op(1, cols[k], i), (k + 1 < K) ? update_piece(0, cols[k + 1], i) : none);
-      }
-      read_info(info, defer_info);
-      return;
     }
-    if (want_graph && !prof_is_on()) {
-      const long key = (long)nb * 64 + G;
-      auto it = cholGraphs.find(key);
-      if (it == cholGraphs.end()) {
-        if (cholGraphs.size() >= 32) {                       // bounded cache (optimiser rounds shrink the active set)
-          for (auto& kv : cholGraphs) hipGraphExecDestroy(kv.second);
-          cholGraphs.clear();
+    for (int o = 0; o < n + R; o += TILE)
+      for (int g = 0; g < G; ++g) {
+        if (o > 0) {
+          // with fewer than ~4 128-tiles per CU (always true at n=2000 x 64, measured 7.6 vs 8.3 ms) use
+          // 64x64 tiles: 4x the workgroups, 3 resident per CU, better balance and latency hiding; both 64-wide
+          // halves of the block column go in one launch (7.56 -> 6.84 ms: the partially filled last round of
+          // workgroups is paid once instead of twice)
+          const long tiles128 = (long)gv[g].nb * ((NP - o) / TILE);
+          if (tiles128 >= tail_threshold) launch_update_wide(gv[g], o, 0, o, gs[g]);
+          else launch_update_narrow_pair(gv[g], o, 0, o, gs[g]);
         }
-        hipGraph_t graph = nullptr;
-        hipGraphExec_t exec = nullptr;
-        HIPCK(hipStreamBeginCapture(stream, hipStreamCaptureModeRelaxed));
-        issue();
-        HIPCK(hipStreamEndCapture(stream, &graph));
-        HIPCK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
-        HIPCK(hipGraphDestroy(graph));
-        it = cholGraphs.emplace(key, exec).first;
+        panel(gv[g], o, TILE, gs[g]);
       }
-      HIPCK(hipGraphLaunch(it->second, stream));
-    } else {
-      issue();
+    for (int g = 1; g < G; ++g) {
+      HIPCK(hipEventRecord(evGroup[g - 1], gs[g]));
+      HIPCK(hipStreamWaitEvent(stream, evGroup[g - 1], 0));
     }
     read_info(info, defer_info);
     return;
@@ -1111,50 +941,15 @@ void Engine::predict(const std::vector<int>& ids, const double* Xs, int m, bool 
     ld = m;
   }
   const int MPtot = roundup(m, 128);
-  // Experiment (MOGP_PV_OVERLAP=1, off): the cross-covariance build is HBM-write bound and the variance GEMM MFMA bound, so
-  // with two half-size buffers the build of chunk c+1 can run on the look-ahead stream underneath the GEMM of chunk c.
-  // Measured at 64 x n=2000 x m=10^4: predict 45.9 -> 46.5 ms -- the GEMM slows down by as much as the build hides
-  // (20.9 ms per 5632 points -> 11.3 ms per 2560 points, 61.3 -> 56.6 TFLOP/s).
-  static const bool want_overlap = [] { const char* e = getenv("MOGP_PV_OVERLAP"); return e && e[0] == '1'; }();
   static const double budget = [] { const char* e = getenv("MOGP_KS_BUDGET_GB"); return (e ? atof(e) : 6.0) * 1e9; }();   // cross-covariance chunk
   long MC = (long)(budget / ((double)nb * LD * 8.0)) / 128 * 128;
   MC = std::max<long>(128, std::min<long>(MC, MPtot));
-  const bool overlap = vars && want_overlap && MPtot > 2 * 128 && (long)MPtot * nb * LD * 8.0 > 1.0e9;
-  if (overlap) {
-    long half = (long)(0.5 * budget / ((double)nb * LD * 8.0)) / 128 * 128;
-    half = std::max<long>(128, half);
-    const long nch = std::max<long>(2, (MPtot + half - 1) / half);
-    MC = roundup((int)((MPtot / 128 + nch - 1) / nch), 1) * 128;          // equal chunks
-  }
   if (vars) ensure_predict_scratch(nb, (int)MC);
-  if (overlap) {
-    grow(dKs2, capKs2, (size_t)nb * MC * LD);
-    for (int b = 0; b < 2; ++b) {
-      if (!evKsReady[b]) HIPCK(hipEventCreateWithFlags(&evKsReady[b], hipEventDisableTiming));
-      if (!evKsFree[b]) HIPCK(hipEventCreateWithFlags(&evKsFree[b], hipEventDisableTiming));
-    }
-    HIPCK(hipEventRecord(evReady, stream));                 // X* upload, L^-1
-    HIPCK(hipStreamWaitEvent(pstream, evReady, 0));
-    int c = 0;
-    for (int c0 = 0; c0 < m; c0 += (int)MC, ++c) {
-      const int mc = std::min<int>((int)MC, m - c0);
-      const int MPc = roundup(mc, 128);
-      const int b = c & 1;
-      double* buf = b ? dKs2 : dKs;
-      if (c >= 2) HIPCK(hipStreamWaitEvent(pstream, evKsFree[b], 0));
-      launch_cross_cov_mean(v, dXsrc + (size_t)c0 * D, mc, MPc, buf, dm + c0, (int)ld, pstream);
-      HIPCK(hipEventRecord(evKsReady[b], pstream));
-      HIPCK(hipStreamWaitEvent(stream, evKsReady[b], 0));
-      launch_predict_var(v, buf, mc, MPc, dVarPartial, dv + c0, (int)ld, stream);
-      HIPCK(hipEventRecord(evKsFree[b], stream));
-    }
-  } else {
-    for (int c0 = 0; c0 < m; c0 += (int)MC) {
-      const int mc = std::min<int>((int)MC, m - c0);
-      const int MPc = roundup(mc, 128);
-      launch_cross_cov_mean(v, dXsrc + (size_t)c0 * D, mc, MPc, vars ? dKs : nullptr, dm + c0, (int)ld, stream);
-      if (vars) launch_predict_var(v, dKs, mc, MPc, dVarPartial, dv + c0, (int)ld, stream);
-    }
+  for (int c0 = 0; c0 < m; c0 += (int)MC) {
+    const int mc = std::min<int>((int)MC, m - c0);
+    const int MPc = roundup(mc, 128);
+    launch_cross_cov_mean(v, dXsrc + (size_t)c0 * D, mc, MPc, vars ? dKs : nullptr, dm + c0, (int)ld, stream);
+    if (vars) launch_predict_var(v, dKs, mc, MPc, dVarPartial, dv + c0, (int)ld, stream);
   }
   if (derivs) {
     grow(dDeriv, capDeriv, (size_t)nb * m * D);

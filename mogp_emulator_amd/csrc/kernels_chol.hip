@@ -1,15 +1,9 @@
-// Panel kernels of the blocked right-looking Cholesky, the triangular solves and the
-// triangular-inverse leaf.  These replace cusolverDnDpotrf / Dpotrs as used by the reference
-// (densegp_gpu.hpp:451-474, 576-591) and the cub log-diagonal reduction (util.cu:38-49).
-//
-// Numerics: the factorisation itself uses exact substitution inside every 64-wide panel
-// (no inverted diagonal blocks), i.e. the same backward-stable recurrence as LAPACK dpotrf /
-// dtrsm.  A pivot that is not > 0 (or is NaN) marks the emulator as failed (info = 1-based
-// column), which is what drives the adaptive-nugget ladder (linalg/cholesky.py:234-281).
+// Log-determinant, triangular solves, the triangular-inverse leaf and small consumers of the factor.  These replace
+// cusolverDnDpotrs as used by the reference (densegp_gpu.hpp:576-591) and the cub log-diagonal reduction
+// (util.cu:38-49).  The factorisation kernels themselves live in kernels_gemm.hip / chol128_dev.h / trsm_dev.h.
 #include <cstdlib>
 #include "launch.h"
-#include "potf2_dev.h"
-#include "trsm_dev.h"
+#include "chol128_dev.h"
 
 namespace mogp {
 
@@ -17,108 +11,6 @@ typedef double v2d __attribute__((ext_vector_type(2)));
 typedef double v4d __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ int slot_emu(const int* idx, int z) { return idx ? idx[z] : z; }
-
-// ---------------------------------------------------------------------------------------------
-// potf2: unblocked Cholesky of the 64x64 diagonal block at (c0, c0): ONE wave per emulator, lane i
-// owns row i in registers (fully unrolled, compile-time register indices).  Per column j the pivot
-// is broadcast with v_readlane, the scaled column goes through a 512-byte LDS line and is re-read
-// by every lane as broadcast operands of the rank-1 update (63-j independent FMAs per lane).
-// ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void potf2_kernel(BatchView v, int c0, int* __restrict__ info, double* __restrict__ Lpack) {
-  __shared__ __attribute__((aligned(16))) double lds[POTF2_LDS_DOUBLES];
-  const int emu = slot_emu(v.idx, blockIdx.x);
-  const int ld = v.LD;
-  double* A = v.A + (size_t)emu * v.MS + (size_t)c0 * ld + c0;
-  const int lane = threadIdx.x;
-  // coalesced block load: 2 full 512-byte rows per load instruction into the LDS image
-  {
-    const int half = lane >> 5, part = lane & 31;
-#pragma unroll 8
-    for (int q = 0; q < 32; ++q) {
-      const int r = 2 * q + half;
-      const v2d w = *reinterpret_cast<const v2d*>(A + (size_t)r * ld + 2 * part);
-      lds[r * 65 + 2 * part] = w[0];
-      lds[r * 65 + 2 * part + 1] = w[1];
-    }
-  }
-  __builtin_amdgcn_wave_barrier();
-  potf2_wave(lds, lds + 64 * 65, A, ld, Lpack + (size_t)emu * PACK_STRIDE, info + emu, c0);
-}
-
-// four-wave version (potf2_block_dev): lane = row, wave = 16-column block
-__global__ __launch_bounds__(256) void potf2_block_kernel(BatchView v, int c0, int* __restrict__ info, double* __restrict__ Lpack) {
-  __shared__ __attribute__((aligned(16))) double lds[POTF2B_LDS_DOUBLES];
-  const int emu = slot_emu(v.idx, blockIdx.x);
-  double* A = v.A + (size_t)emu * v.MS + (size_t)c0 * v.LD + c0;
-  potf2_block_dev(A, v.LD, Lpack + (size_t)emu * PACK_STRIDE, info + emu, c0, lds);
-}
-
-// ---------------------------------------------------------------------------------------------
-// Panel TRSM: rows [r0, NP) of the column block [c0, c0+64):  X * L_kk^T = A_panel, one thread per
-// row, right-looking (column oriented) substitution so the 63-c updates of step c are independent
-// FMAs; L_kk^T and the reciprocal diagonal (as optimised BLAS trsm kernels use) arrive as scalar
-// operands from Lpack.
-// ---------------------------------------------------------------------------------------------
-// The 2016 broadcast operands per row come from an LDS copy of Lpack and are read as 16-byte
-// aligned pairs (ds_read_b128: half the LDS cycles of ds_read2_b64, which is what bounds this
-// kernel: 8 waves per CU each re-read the whole block).  SMEM operands were tried and lost: scalar
-// loads return out of order, so every batch waits lgkmcnt(0) and exposes a full L2 round trip.
-// one row per thread (two rows per thread spill: 2 x 64 doubles + operands > 256 VGPRs);
-// TRSM_THREADS = 256 for big batches, 64 when a launch would otherwise have < 256 workgroups (single large matrix)
-template <int TRSM_THREADS>
-__global__ __launch_bounds__(TRSM_THREADS) void trsm_kernel(BatchView v, int c0, int r0, const double* __restrict__ Lpack) {
-  __shared__ __attribute__((aligned(16))) double LT[PACK_STRIDE];
-  const int emu = slot_emu(v.idx, blockIdx.y);
-  const int ld = v.LD;
-  double* A = v.A + (size_t)emu * v.MS;
-  const v2d* src = reinterpret_cast<const v2d*>(Lpack + (size_t)emu * PACK_STRIDE);
-  for (int e = threadIdx.x; e < PACK_STRIDE / 2; e += TRSM_THREADS) reinterpret_cast<v2d*>(LT)[e] = src[e];
-  __syncthreads();
-  const int row = r0 + blockIdx.x * TRSM_THREADS + threadIdx.x;
-  if (row >= v.NP) return;
-  double* arow = A + (size_t)row * ld + c0;
-  double x[64];
-#pragma unroll
-  for (int q = 0; q < 32; ++q) {
-    const v2d w = *reinterpret_cast<const v2d*>(arow + 2 * q);
-    x[2 * q] = w[0];
-    x[2 * q + 1] = w[1];
-  }
-#pragma unroll
-  for (int c = 0; c < 64; ++c) {
-    x[c] *= LT[4096 + c];
-    const double xc = x[c];
-#pragma unroll
-    for (int q0 = (c + 1) & ~1; q0 < 64; q0 += 2) {
-      const v2d lv = *reinterpret_cast<const v2d*>(LT + c * 64 + q0);
-      if (q0 > c) x[q0] = __builtin_fma(-xc, lv[0], x[q0]);
-      x[q0 + 1] = __builtin_fma(-xc, lv[1], x[q0 + 1]);
-    }
-  }
-#pragma unroll
-  for (int q = 0; q < 32; ++q) {
-    v2d w;
-    w[0] = x[2 * q];
-    w[1] = x[2 * q + 1];
-    *reinterpret_cast<v2d*>(arow + 2 * q) = w;
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
-// Panel TRSM on the matrix cores.  Each wave owns a 16-row slab B (16 x 64) of the panel and solves
-// X L_kk^T = B in the transposed form  X^T = L_kk^-1 B^T  by block forward substitution over the four
-// 16-column blocks:
-//     T_b = B_b^T - sum_{a<b} L_ba X_a^T ,   X_b^T = inv(L_bb) T_b        (v_mfma_f64_16x16x4)
-// The transposed form chains without any LDS transpose: an MFMA result (lane holds rows g+4r, g = lane>>4,
-// column lane&15) is used directly as the B operand of the next MFMA with the k index running over g+4r,
-// and the A operand (L_ba or inv(L_bb), element [lane&15][g+4r]) is fetched with the same k mapping.
-// 40 dependent MFMAs per wave instead of 2016 LDS-fed FMAs per row; rows/16 waves per emulator.
-// ---------------------------------------------------------------------------------------------
-template <bool STAGED>
-__global__ __launch_bounds__(256) void trsm_mfma_kernel(BatchView v, int c0, int r0, const double* __restrict__ Lpack) {
-  __shared__ __attribute__((aligned(16))) double stage[STAGED ? 4 * TRSM_STAGE : 2];
-  trsm_mfma_dev(v, c0, r0, Lpack, slot_emu(v.idx, blockIdx.y), blockIdx.x, STAGED ? stage : nullptr);
-}
 
 // ---------------------------------------------------------------------------------------------
 // logdet = 2 sum_{i<n} log L_ii ;  yty = sum_{c<n} L[n,c]^2   (row n of the factor holds y^T)
@@ -518,33 +410,6 @@ __global__ void extract_kernel(const double* __restrict__ src, int NP, int n, do
 }
 
 // =============================================================================================
-void launch_potf2(const BatchView& v, int c0, int* info, double* Lpack, hipStream_t s) {
-  static const bool one_wave = [] { const char* e = getenv("MOGP_POTF2"); return e && e[0] == '1'; }();   // 1: single-wave kernel
-  if (!one_wave) {
-    hipLaunchKernelGGL(potf2_block_kernel, dim3(v.nb), dim3(256), 0, s, v, c0, info, Lpack);
-    return;
-  }
-  hipLaunchKernelGGL(potf2_kernel, dim3(v.nb), dim3(64), 0, s, v, c0, info, Lpack);
-}
-
-void launch_trsm(const BatchView& v, int c0, int r0, const double* Lpack, hipStream_t s) {
-  const int rows = v.NP - r0;
-  if (rows <= 0) return;
-  static const bool mfma = [] { const char* e = getenv("MOGP_TRSM"); return !e || e[0] != '0'; }();   // 0: per-row substitution kernels
-  if (mfma) {
-    static const bool staged = [] { const char* e = getenv("MOGP_TRSM_STAGE"); return !e || e[0] != '0'; }();
-    if (staged) hipLaunchKernelGGL(trsm_mfma_kernel<true>, dim3(rows / 64, v.nb), dim3(256), 0, s, v, c0, r0, Lpack);
-    else hipLaunchKernelGGL(trsm_mfma_kernel<false>, dim3(rows / 64, v.nb), dim3(256), 0, s, v, c0, r0, Lpack);
-    return;
-  }
-  if ((long)v.nb * ((rows + 255) / 256) >= 256)
-    hipLaunchKernelGGL(trsm_kernel<256>, dim3((rows + 255) / 256, v.nb), dim3(256), 0, s, v, c0, r0, Lpack);
-  else
-    hipLaunchKernelGGL(trsm_kernel<64>, dim3((rows + 63) / 64, v.nb), dim3(64), 0, s, v, c0, r0, Lpack);
-}
-
-size_t lpack_doubles_per_emulator() { return PACK_STRIDE; }
-
 void launch_logdet(const BatchView& v, double* logdet, double* gram, hipStream_t s) {
   hipLaunchKernelGGL(logdet_kernel, dim3(v.nb), dim3(256), 0, s, v, logdet, gram);
 }

@@ -103,23 +103,15 @@ __device__ __forceinline__ void micro_k(const double* si, const double* sj, cons
 // fused on the diagonal, the targets laid into row n and identity padding beyond.
 // ---------------------------------------------------------------------------------------------
 template <int KT>
-__global__ __launch_bounds__(256) void cov_build_kernel(BatchView v, int nt, int ncol) {
+__global__ __launch_bounds__(256) void cov_build_kernel(BatchView v) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int z = blockIdx.y;
   const int emu = slot_emu2(v.idx, z);
-  int tile = blockIdx.x;
-  int ti, tj;
-  if (ncol > 0) {
-    // only the first ncol tile columns: tile = tj * nt + ti, lower part (ti >= tj)
-    tj = tile / nt;
-    ti = tile % nt;
-    if (ti < tj) return;
-  } else {
-    ti = (int)((sqrt(8.0 * tile + 1.0) - 1.0) * 0.5);
-    while (ti * (ti + 1) / 2 > tile) --ti;
-    while ((ti + 1) * (ti + 2) / 2 <= tile) ++ti;
-    tj = tile - ti * (ti + 1) / 2;
-  }
+  const int tile = blockIdx.x;
+  int ti = (int)((sqrt(8.0 * tile + 1.0) - 1.0) * 0.5);
+  while (ti * (ti + 1) / 2 > tile) --ti;
+  while ((ti + 1) * (ti + 2) / 2 <= tile) ++ti;
+  const int tj = tile - ti * (ti + 1) / 2;
   const int i0 = ti * 64, j0 = tj * 64;
   const int n = v.n, D = v.D, ld = v.LD;
   const double* P = v.P + (size_t)emu * v.PS;
@@ -464,18 +456,16 @@ __global__ __launch_bounds__(256) void grad_finish_kernel(BatchView v, int ntile
     if ((kt) == 0) { CALL(0); } else if ((kt) == 1) { CALL(1); } else { CALL(2); } \
   } while (0)
 
-void launch_cov_build(const BatchView& v, hipStream_t s, int first_cols) {
+void launch_cov_build(const BatchView& v, hipStream_t s) {
   const int nt = v.NP / 64;
-  const int ncol = std::min(nt, first_cols / 64);
-  const int ntiles = ncol > 0 ? ncol * nt : nt * (nt + 1) / 2;
+  const int ntiles = nt * (nt + 1) / 2;
   const size_t sm = (size_t)128 * v.D * sizeof(double);
   prof_begin("cov_build", s);
-#define CALL(K) hipLaunchKernelGGL((cov_build_kernel<K>), dim3(ntiles, v.nb), dim3(256), sm, s, v, nt, ncol)
+#define CALL(K) hipLaunchKernelGGL((cov_build_kernel<K>), dim3(ntiles, v.nb), dim3(256), sm, s, v)
   KT_DISPATCH(v.kernel_type, CALL);
 #undef CALL
   // algorithmic bytes: lower triangle written once (4 n^2) + X read once per emulator
-  const double cols = ncol > 0 ? 64.0 * ncol : 0.5 * v.NP;
-  prof_end("cov_build", s, 0., (double)v.nb * (8.0 * cols * (double)v.NP + 8.0 * v.n * v.D));
+  prof_end("cov_build", s, 0., (double)v.nb * (4.0 * (double)v.NP * (double)v.NP + 8.0 * v.n * v.D));
 }
 
 // prior covariance of the test points for every slot: out (nb, m, m) = sigma^2 k(Xs, Xs)

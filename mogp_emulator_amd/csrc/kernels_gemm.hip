@@ -22,9 +22,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include "launch.h"
-#include "potf2_dev.h"
 #include "trsm_dev.h"
-#include "cov_dev.h"
 
 namespace mogp {
 
@@ -171,12 +169,8 @@ __device__ __forceinline__ void decode_block(int nb, int ntiles, int& z, int& ti
 //   TRI = true : lower-triangular tile set over rows/cols [c0, NP)  (WT = 4)
 //   TRI = false: single tile column [c0, c0+BM), rows [c0, NP)     (WT = 2, "narrow" update)
 // ---------------------------------------------------------------------------------------------
-// KF >= 0: the tile is touched for the first time by this launch (left-looking long-K pass, k0 = 0), so its covariance
-// entries are generated here (kernel type KF, same arithmetic as cov_build_kernel) instead of being written by the K
-// build and read back: C = K(x_i, x_j) - acc.  Saves the K write and the C read of everything but the first block column.
-template <int WT, bool TRI, bool FUSE, int KF = -1>
-__global__ __launch_bounds__(256, (FUSE ? 3 : 2)) void update_kernel(BatchView v, int c0, int k0, int k1, int nt, int ntiles, int* __restrict__ info,
-                                                        double* __restrict__ Lpack) {
+template <int WT, bool TRI>
+__global__ __launch_bounds__(256, 2) void update_kernel(BatchView v, int c0, int k0, int k1, int nt, int ntiles) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   using C = Cfg<WT>;
   int z, tile;
@@ -203,122 +197,13 @@ __global__ __launch_bounds__(256, (FUSE ? 3 : 2)) void update_kernel(BatchView v
   const int i0 = c0 + ti * C::BM, j0 = c0 + tj * C::BM;
   v4d acc[WT][WT];
   gemm_mainloop<WT, true, true>(A + (size_t)i0 * ld + k0, ld, A + (size_t)j0 * ld + k0, ld, (k1 - k0) / BK, acc, smem);
-  // FUSE (64x64 tiles only): the workgroup that owns the diagonal tile keeps its updated block in LDS
-  // and one of its waves factors it right away (potf2), hidden under the rest of this launch.
-  if (KF >= 0) {
-    const int n = v.n, D = v.D;
-    double* si = smem;
-    double* sj = smem + 64 * D;
-    stage_rows(v.X + (size_t)emu * v.XS, n, D, i0, si);                 // the main loop ended on a barrier: smem is free
-    stage_rows(v.X + (size_t)emu * v.XS, n, D, j0, sj);
-    __syncthreads();
-    const double* P = v.P + (size_t)emu * v.PS;
-    const double* T = v.T + (size_t)emu * n;
-    const double sig2 = P[D], nug = P[D + 1];
-    for_each_acc<WT>(acc, [&](int r, int c, double x) {
-      const int i = i0 + r, j = j0 + c;
-      const double sk = (i < n && j < n) ? sig2 * pair_kval<(KF < 0 ? 0 : KF)>(si, sj, P, D, r, c) : 0.0;
-      A[(size_t)i * ld + j] = cov_entry(v, T, i, j, sk, nug) - x;
-    });
-    return;
-  }
-  const bool fuse_tile = FUSE && WT == 2 && tile == 0;
   for_each_acc<WT>(acc, [&](int r, int c, double x) {
-    double* p = A + (size_t)(i0 + r) * ld + (j0 + c);
-    const double nv = *p - x;
-    *p = nv;
-    if (fuse_tile) smem[r * 65 + c] = nv;
-  });
-  if (fuse_tile) {
-    __syncthreads();
-    if (threadIdx.x < 64)
-      potf2_wave(smem, smem + 64 * 65, A + (size_t)i0 * ld + j0, ld, Lpack + (size_t)emu * PACK_STRIDE, info + emu, c0);
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
-// Role-fused factorisation step.  Kernels of different HIP streams overlap poorly on this stack, but
-// workgroups of ONE launch run concurrently by construction: a launch carries up to two jobs for two
-// disjoint emulator groups -- a slice of the long-K MFMA update of one group and one latency-bound
-// panel kernel (potf2 / MFMA trsm / 64-wide update) of the other -- so the panel chain of a group is
-// hidden under the other group's update (engine.hip, schedule "fused").
-// ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void update_tile64_dev(const BatchView& v, int emu, int c0, int k0, int k1, int nt, int tile, double* smem) {
-  int ti, tj;
-  if (tile < nt) {
-    ti = tile;
-    tj = 0;
-  } else {
-    ti = tile - nt + 1;
-    tj = 1;
-  }
-  double* A = v.A + (size_t)emu * v.MS;
-  const int ld = v.LD;
-  const int i0 = c0 + ti * 64, j0 = c0 + tj * 64;
-  v4d acc[2][2];
-  gemm_mainloop<2, true, true>(A + (size_t)i0 * ld + k0, ld, A + (size_t)j0 * ld + k0, ld, (k1 - k0) / BK, acc, smem);
-  for_each_acc<2>(acc, [&](int r, int c, double x) {
     double* p = A + (size_t)(i0 + r) * ld + (j0 + c);
     *p -= x;
   });
 }
 
-__global__ __launch_bounds__(256, 2) void fused_step_kernel(BatchView v, FusedArgs fa, int* __restrict__ info, double* __restrict__ Lpack) {
-  extern __shared__ __attribute__((aligned(16))) double smem[];
-  const int j = (fa.njobs > 1 && (int)blockIdx.x >= fa.job[1].wg_begin) ? 1 : 0;
-  const FusedJob& job = fa.job[j];
-  const int local = blockIdx.x - job.wg_begin;
-  if (local >= job.wg_count) return;                    // padding between jobs
-  const int* idx = v.idx + job.idx_off;
-  int z, part;
-  if ((job.nb & 7) == 0) {                              // same XCD-aware decode as decode_block (wg_begin is a multiple of 8)
-    const int xcd = local & 7, w = local >> 3;
-    z = (w / job.per_emu) * 8 + xcd;
-    part = w % job.per_emu;
-  } else {
-    z = local / job.per_emu;
-    part = local % job.per_emu;
-  }
-  if (z >= job.nb) return;
-  const int emu = idx[z];
-  if (job.role == ROLE_UPDATE) {
-    update_tile64_dev(v, emu, job.c0, job.k0, job.k1, job.nt, job.tile0 + part, smem);
-  } else if (job.role == ROLE_TRSM) {
-    trsm_mfma_dev(v, job.c0, job.r0, Lpack, emu, part);
-  } else {                                               // ROLE_POTF2: four-wave block potf2
-    double* A = v.A + (size_t)emu * v.MS + (size_t)job.c0 * v.LD + job.c0;
-    potf2_block_dev(A, v.LD, Lpack + (size_t)emu * PACK_STRIDE, info + emu, job.c0, smem);
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
-// 128 x 128 diagonal block in ONE launch (one workgroup per emulator): potf2(D1) -> L21 = A21 L11^-T (MFMA block
-// substitution, 4 waves x 16 rows) -> D2 -= L21 L21^T (64 x 64 x 64 on the MFMA main loop) -> potf2(D2).  Replaces the
-// diagonal-block share of four dependent launches (potf2, trsm, 64-wide update, potf2); the rows below are solved by
-// trsm128_kernel in one pass over the 128-wide panel.
-// ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 2) void potf2_128_kernel(BatchView v, int c0, int* __restrict__ info, double* __restrict__ Lpack128) {
-  extern __shared__ __attribute__((aligned(16))) double smem[];
-  const int emu = slot_to_emu(v.idx, blockIdx.x);
-  const int ld = v.LD;
-  double* A = v.A + (size_t)emu * v.MS;
-  double* pk = Lpack128 + (size_t)emu * PACK128_STRIDE;
-  potf2_block_dev(A + (size_t)c0 * ld + c0, ld, pk, info + emu, c0, smem);
-  __syncthreads();
-  trsm_mfma_pk(v, c0, c0 + 64, pk, emu, 0);
-  __syncthreads();
-  {
-    // L21^T for trsm128: thread (row q, 16-column group w)
-    const int q = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const double* src = A + (size_t)(c0 + 64 + q) * ld + c0 + 16 * w;
-#pragma unroll
-    for (int c = 0; c < 16; ++c) pk[2 * PACK_STRIDE + (16 * w + c) * 64 + q] = src[c];
-  }
-  update_tile64_dev(v, emu, c0 + 64, c0, c0 + 64, 1, 0, smem);
-  __syncthreads();
-  potf2_block_dev(A + (size_t)(c0 + 64) * ld + c0 + 64, ld, pk + PACK_STRIDE, info + emu, c0 + 64, smem);
-}
-
+// 128-wide panel solve below a factored 128 x 128 diagonal block (trsm_dev.h): one wave per 16-row slab
 __global__ __launch_bounds__(256) void trsm128_kernel(BatchView v, int c0, int r0, const double* __restrict__ Lpack128) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int emu = slot_to_emu(v.idx, blockIdx.y);
@@ -699,36 +584,20 @@ static int padded_grid(int nb, int ntiles) { return ((nb & 7) == 0) ? nb * ntile
 void launch_update_narrow(const BatchView& v, int c0, int k0, int k1, hipStream_t s) {
   const int nt = (v.NP - c0) / 64;
   if (nt <= 0) return;
-  hipLaunchKernelGGL((update_kernel<2, false, false>), dim3(padded_grid(v.nb, nt)), dim3(256), smem_bytes<2>(), s, v, c0, k0, k1, nt, nt, (int*)nullptr,
-                     (double*)nullptr);
+  hipLaunchKernelGGL((update_kernel<2, false>), dim3(padded_grid(v.nb, nt)), dim3(256), smem_bytes<2>(), s, v, c0, k0, k1, nt, nt);
 }
 
 // two adjacent 64-wide block columns [c0, c0+128) in ONE launch (2 nt - 1 lower tiles): twice the workgroups per
 // launch, so the last partially filled round of workgroups costs half as much as with two launches
-void launch_update_narrow_pair(const BatchView& v, int c0, int k0, int k1, hipStream_t s, bool generate_cov) {
+void launch_update_narrow_pair(const BatchView& v, int c0, int k0, int k1, hipStream_t s) {
   const int nt = (v.NP - c0) / 64;
   if (nt <= 0) return;
   const int ntiles = std::max(1, 2 * nt - 1);
-  const dim3 grid(padded_grid(v.nb, ntiles));
-  if (generate_cov) {
-    const size_t sm = std::max(smem_bytes<2>(), (size_t)128 * v.D * sizeof(double));
-    if (v.kernel_type == 0) hipLaunchKernelGGL((update_kernel<2, false, false, 0>), grid, dim3(256), sm, s, v, c0, k0, k1, nt, ntiles, (int*)nullptr, (double*)nullptr);
-    else if (v.kernel_type == 1) hipLaunchKernelGGL((update_kernel<2, false, false, 1>), grid, dim3(256), sm, s, v, c0, k0, k1, nt, ntiles, (int*)nullptr, (double*)nullptr);
-    else hipLaunchKernelGGL((update_kernel<2, false, false, 2>), grid, dim3(256), sm, s, v, c0, k0, k1, nt, ntiles, (int*)nullptr, (double*)nullptr);
-    return;
-  }
-  hipLaunchKernelGGL((update_kernel<2, false, false>), grid, dim3(256), smem_bytes<2>(), s, v, c0, k0, k1, nt, ntiles, (int*)nullptr, (double*)nullptr);
-}
-
-// 64-wide block-column update whose diagonal-tile workgroup also factors the 64x64 block at (c0, c0)
-void launch_update_narrow_potf2(const BatchView& v, int c0, int k0, int k1, int* info, double* Lpack, hipStream_t s) {
-  const int nt = (v.NP - c0) / 64;
-  if (nt <= 0) return;
-  const size_t sm = std::max(smem_bytes<2>(), (size_t)POTF2_LDS_DOUBLES * sizeof(double));
   const double m = (double)(v.NP - c0);
-  prof_begin("update_wide", s);
-  hipLaunchKernelGGL((update_kernel<2, false, true>), dim3(padded_grid(v.nb, nt)), dim3(256), sm, s, v, c0, k0, k1, nt, nt, info, Lpack);
-  prof_end("update_wide", s, (double)v.nb * (m * 64.0 - 64.0 * 64.0 / 2.0) * 2.0 * (k1 - k0), 0.);
+  prof_begin("chol_update", s);
+  hipLaunchKernelGGL((update_kernel<2, false>), dim3(padded_grid(v.nb, ntiles)), dim3(256), smem_bytes<2>(), s, v, c0, k0, k1, nt, ntiles);
+  // algorithmic flops: the lower part of the m x 128 block column, 2 flops per multiply-add
+  prof_end("chol_update", s, (double)v.nb * (m * 128.0 - 128.0 * 128.0 / 2.0) * 2.0 * (k1 - k0), (double)v.nb * (16.0 * m * 128.0 + 8.0 * (m + 128.0) * (k1 - k0)));
 }
 
 // one 128-wide block column [c0, c0+128), rows [c0, NP) (inner update of the recursive panel)
@@ -736,11 +605,10 @@ void launch_update_wide(const BatchView& v, int c0, int k0, int k1, hipStream_t 
   const int nt = (v.NP - c0) / 128;
   if (nt <= 0) return;
   const double m = (double)(v.NP - c0);
-  prof_begin("update_wide", s);
-  hipLaunchKernelGGL((update_kernel<4, false, false>), dim3(padded_grid(v.nb, nt)), dim3(256), smem_bytes<4>(), s, v, c0, k0, k1, nt, nt, (int*)nullptr,
-                     (double*)nullptr);
+  prof_begin("chol_update", s);
+  hipLaunchKernelGGL((update_kernel<4, false>), dim3(padded_grid(v.nb, nt)), dim3(256), smem_bytes<4>(), s, v, c0, k0, k1, nt, nt);
   // algorithmic flops of the block-column update (lower part): (m*128 - 128*128/2) * 2 * K / 2 ... count m*128*K*2 minus the upper half of the diagonal tile
-  prof_end("update_wide", s, (double)v.nb * (m * 128.0 - 128.0 * 128.0 / 2.0) * 2.0 * (k1 - k0), (double)v.nb * (16.0 * m * 128.0 + 8.0 * (m + 128.0) * (k1 - k0)));
+  prof_end("chol_update", s, (double)v.nb * (m * 128.0 - 128.0 * 128.0 / 2.0) * 2.0 * (k1 - k0), (double)v.nb * (16.0 * m * 128.0 + 8.0 * (m + 128.0) * (k1 - k0)));
 }
 
 void launch_update_trailing(const BatchView& v, int c0, int k0, int k1, hipStream_t s) {
@@ -752,8 +620,7 @@ void launch_update_trailing(const BatchView& v, int c0, int k0, int k1, hipStrea
   static const bool w8 = [] { const char* e = getenv("MOGP_TRI_WAVES"); return !e || atoi(e) != 4; }();   // 4: 2 x 2-wave kernel
   if (w8) hipLaunchKernelGGL(update_tri8_kernel, dim3(padded_grid(v.nb, ntiles)), dim3(512), smem_bytes<4>(), s, v, c0, k0, k1, ntiles);
   else
-    hipLaunchKernelGGL((update_kernel<4, true, false>), dim3(padded_grid(v.nb, ntiles)), dim3(256), smem_bytes<4>(), s, v, c0, k0, k1, nt, ntiles,
-                       (int*)nullptr, (double*)nullptr);
+    hipLaunchKernelGGL((update_kernel<4, true>), dim3(padded_grid(v.nb, ntiles)), dim3(256), smem_bytes<4>(), s, v, c0, k0, k1, nt, ntiles);
   // algorithmic: lower half of an m x m rank-(k1-k0) update = m^2 (k1-k0) flops; bytes: read+write C lower half + panel
   prof_end("syrk_trailing", s, (double)v.nb * m * m * (k1 - k0), (double)v.nb * (8.0 * m * m + 8.0 * m * (k1 - k0)));
 }
@@ -764,17 +631,17 @@ void launch_trtri_merges(const BatchView& v, hipStream_t s) {
     const int nodes = (v.NP + 2 * h - 1) / (2 * h);
     if (h == 64 || wt == 2) {
       const int tpd = h / 64;
+      // algorithmic flops per node: two triangular-times-dense products of size h, h^3 flops each (h^3 / 2 multiply-adds)
       if (h > 64) prof_begin("trtri_merge", s);
       hipLaunchKernelGGL((trtri_merge_kernel<2, 0>), dim3(padded_grid(v.nb, tpd * tpd * nodes)), dim3(256), smem_bytes<2>(), s, v, h, tpd, nodes);
       hipLaunchKernelGGL((trtri_merge_kernel<2, 1>), dim3(padded_grid(v.nb, tpd * tpd * nodes)), dim3(256), smem_bytes<2>(), s, v, h, tpd, nodes);
-      if (h > 64) prof_end("trtri_merge", s, (double)v.nb * nodes * 2.0 * h * h * h / 2.0, 0.);
+      if (h > 64) prof_end("trtri_merge", s, (double)v.nb * nodes * 2.0 * h * h * h, 0.);
     } else {
       const int tpd = h / 128;
       prof_begin("trtri_merge", s);
       hipLaunchKernelGGL((trtri_merge_kernel<4, 0>), dim3(padded_grid(v.nb, tpd * tpd * nodes)), dim3(256), smem_bytes<4>(), s, v, h, tpd, nodes);
       hipLaunchKernelGGL((trtri_merge_kernel<4, 1>), dim3(padded_grid(v.nb, tpd * tpd * nodes)), dim3(256), smem_bytes<4>(), s, v, h, tpd, nodes);
-      // algorithmic flops: two triangular-times-square products of size h per node = 2 * h^3 / 2 * 2 flops... = 2 h^3
-      prof_end("trtri_merge", s, (double)v.nb * nodes * 2.0 * h * h * h / 2.0, 0.);
+      prof_end("trtri_merge", s, (double)v.nb * nodes * 2.0 * h * h * h, 0.);
     }
   }
 }
@@ -809,21 +676,13 @@ void launch_predict_var(const BatchView& v, const double* Ks, int m, int MP, dou
   hipLaunchKernelGGL(predict_var_finish_kernel, dim3((m + 255) / 256, v.nb), dim3(256), 0, s, v, partial, m, MP, nti, var, var_ld);
 }
 
-size_t lpack128_doubles_per_emulator() { return PACK128_STRIDE; }
-
-// factor the 128 x 128 diagonal block at c0 and solve the panel rows [c0 + 128, NP) below it
-void launch_panel128(const BatchView& v, int c0, int* info, double* Lpack128, hipStream_t s) {
-  const size_t sm = std::max(smem_bytes<2>(), (size_t)POTF2B_LDS_DOUBLES * sizeof(double));
-  hipLaunchKernelGGL(potf2_128_kernel, dim3(v.nb), dim3(256), sm, s, v, c0, info, Lpack128);
+void launch_trsm128(const BatchView& v, int c0, const double* Lpack128, hipStream_t s) {
   const int rows = v.NP - c0 - 128;
-  if (rows > 0)
-    hipLaunchKernelGGL(trsm128_kernel, dim3(rows / 64, v.nb), dim3(256), 4 * TRSM128_STAGE * sizeof(double), s, v, c0, c0 + 128, (const double*)Lpack128);
-}
-
-void launch_fused_step(const BatchView& v, const FusedArgs& fa, int total_wgs, int* info, double* Lpack, hipStream_t s) {
-  if (total_wgs <= 0) return;
-  const size_t sm = std::max(smem_bytes<2>(), (size_t)POTF2B_LDS_DOUBLES * sizeof(double));
-  hipLaunchKernelGGL(fused_step_kernel, dim3(total_wgs), dim3(256), sm, s, v, fa, info, Lpack);
+  if (rows <= 0) return;
+  prof_begin("chol_trsm128", s);
+  hipLaunchKernelGGL(trsm128_kernel, dim3(rows / 64, v.nb), dim3(256), 4 * TRSM128_STAGE * sizeof(double), s, v, c0, c0 + 128, Lpack128);
+  // rows x 128 triangular solve: rows * 128^2 flops; the panel is read and written once
+  prof_end("chol_trsm128", s, (double)v.nb * rows * 128.0 * 128.0, (double)v.nb * 2.0 * 8.0 * rows * 128.0);
 }
 
 // cov (nb, m, m) holds K** on entry and the predictive covariance (without nugget) on return; V is nb*NP*MP scratch

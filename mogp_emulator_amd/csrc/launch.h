@@ -21,7 +21,7 @@ constexpr int TILE = 128;       // MFMA macro tile / padding granule
 // The covariance kernels stage two 64-row blocks of X (and, for predict_deriv, a 64 x 65 work tile and a 64 x D
 // accumulator) in LDS: (192 D + 4160) doubles <= 160 KB  ->  D <= 85.
 constexpr int MAX_D = 80;
-constexpr int NBI = 64;         // inner panel width (potf2 / trsm / trtri leaf)
+constexpr int NBI = 64;         // pivoted-Cholesky panel width / trtri leaf
 constexpr double PAD_BIG = 1e300;
 constexpr int RMAX = 8;         // max right-hand-side rows (targets + up to 7 mean-function columns)
 
@@ -48,8 +48,7 @@ struct BatchView {
 };
 
 // --- covariance build ---------------------------------------------------------------------
-// first_cols > 0: only the tile columns [0, first_cols/64) (the rest is generated by the first update that touches it)
-void launch_cov_build(const BatchView& v, hipStream_t s, int first_cols = 0);
+void launch_cov_build(const BatchView& v, hipStream_t s);
 // full symmetric K (no nugget) for get_K: out (n,n) for one emulator
 void launch_cov_full(const BatchView& v, int emu, double* out, hipStream_t s);
 // leave-one-out predictive variance 1/[K^-1]_ii of every training input (needs Linv): out[slot*out_ld + i]
@@ -65,35 +64,15 @@ void launch_cov_self_batch(const BatchView& v, const double* Xs, int m, double* 
 void launch_predict_fullcov(const BatchView& v, const double* Ks, int m, int MP, double* V, double* cov, hipStream_t s);
 
 // --- blocked Cholesky ---------------------------------------------------------------------
-// potf2 of the 64x64 diagonal block at c0; info[emu] = first failing (1-based) column or 0
-void launch_potf2(const BatchView& v, int c0, int* info, double* Lpack, hipStream_t s);
-size_t lpack_doubles_per_emulator();   // scratch written by potf2, read by trsm
-size_t lpack128_doubles_per_emulator();
-// 128 x 128 diagonal block (potf2 + trsm + update + potf2 in one workgroup per emulator) and the panel below it
+size_t lpack128_doubles_per_emulator();   // scratch written by the diagonal-block kernel, read by the panel solve
+// 128 x 128 diagonal block at c0 (one workgroup per emulator, chol128_dev.h) and the 128-wide panel below it (MFMA block
+// substitution); info[emu] = first failing (1-based) column or 0
 void launch_panel128(const BatchView& v, int c0, int* info, double* Lpack128, hipStream_t s);
-// rows [r0, NP) of column block [c0, c0+64): X L_kk^T = A
-void launch_trsm(const BatchView& v, int c0, int r0, const double* Lpack, hipStream_t s);
 // C[i,j] -= sum_{k in [k0,k1)} A[i,k] A[j,k] for the 64-wide column block [c0,c0+64), rows [c0, NP)
 void launch_update_narrow(const BatchView& v, int c0, int k0, int k1, hipStream_t s);
-// same, and the diagonal-tile workgroup then factors the 64x64 block at (c0,c0) (fused potf2)
-void launch_update_narrow_potf2(const BatchView& v, int c0, int k0, int k1, int* info, double* Lpack, hipStream_t s);
-// same for a 128-wide column block (MFMA 128x128 tiles)
-// Role-fused step launch: up to two jobs over disjoint emulator groups (see kernels_gemm.hip)
-enum { ROLE_UPDATE = 0, ROLE_POTF2 = 1, ROLE_TRSM = 2 };
-struct FusedJob {
-  int role;
-  int wg_begin, wg_count;   // workgroup range of the job inside the launch (wg_begin is a multiple of 8)
-  int idx_off, nb;          // emulator group: idx[idx_off .. idx_off + nb)
-  int per_emu;              // workgroups per emulator (tiles of this slice / row blocks / 1)
-  int c0, k0, k1, nt, tile0, r0;
-};
-struct FusedArgs {
-  FusedJob job[2];
-  int njobs;
-};
-void launch_fused_step(const BatchView& v, const FusedArgs& fa, int total_wgs, int* info, double* Lpack, hipStream_t s);
-// generate_cov: the launch is the first to touch its tiles and builds their covariance entries itself (k0 must be 0)
-void launch_update_narrow_pair(const BatchView& v, int c0, int k0, int k1, hipStream_t s, bool generate_cov = false);
+// the two 64-wide halves of the 128-wide column block [c0, c0+128) in one launch of 64 x 64 tiles
+void launch_update_narrow_pair(const BatchView& v, int c0, int k0, int k1, hipStream_t s);
+// same for a 128-wide column block with 128 x 128 tiles
 void launch_update_wide(const BatchView& v, int c0, int k0, int k1, hipStream_t s);
 // trailing lower-triangular update, rows/cols [c0, NP), k in [k0,k1) (c0 multiple of 128)
 void launch_update_trailing(const BatchView& v, int c0, int k0, int k1, hipStream_t s);

@@ -146,19 +146,30 @@ class BaseMeanFunc(object):
         return self._call(_lib.mogp_meanfunc_mean_inputderiv, xs, params, lambda m, D: (D, m))
 
 
+# the native handle never travels: a pickled mean function is rebuilt from its constructor arguments
 class ZeroMeanFunc(BaseMeanFunc):
     def __init__(self):
         self._h = _lib.mogp_meanfunc_zero()
 
+    def __reduce__(self):
+        return (ZeroMeanFunc, ())
+
 
 class FixedMeanFunc(BaseMeanFunc):
     def __init__(self, value):
-        self._h = _lib.mogp_meanfunc_fixed(float(value))
+        self._value = float(value)
+        self._h = _lib.mogp_meanfunc_fixed(self._value)
+
+    def __reduce__(self):
+        return (FixedMeanFunc, (self._value,))
 
 
 class ConstMeanFunc(BaseMeanFunc):
     def __init__(self):
         self._h = _lib.mogp_meanfunc_const()
+
+    def __reduce__(self):
+        return (ConstMeanFunc, ())
 
 
 class PolyMeanFunc(BaseMeanFunc):
@@ -167,6 +178,9 @@ class PolyMeanFunc(BaseMeanFunc):
         self._dims = np.ascontiguousarray(dp[:, 0])
         self._pows = np.ascontiguousarray(dp[:, 1])
         self._h = _lib.mogp_meanfunc_poly(iptr(self._dims), iptr(self._pows), int(dp.shape[0]))
+
+    def __reduce__(self):
+        return (PolyMeanFunc, (np.stack([self._dims, self._pows], axis=1).tolist(),))
 
 
 # --------------------------------------------------------------------------------------
