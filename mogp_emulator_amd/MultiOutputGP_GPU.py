@@ -100,6 +100,26 @@ class MultiOutputGP_GPU(object):
     def fit(self, thetas):
         self._mogp_gpu.fit(np.asarray(thetas, dtype=np.float64))
 
+    def fit_record(self):
+        """Per-emulator fit results in one place -- what one rank contributes to the single gather of a sharded fit
+        (dist.ShardedMultiOutputGP; fitting.hpp:111-117): fit status, current log-posterior, nugget in use and
+        theta = [mean parameters, correlation / covariance (/ nugget) parameters]; None / nan where not fit."""
+        ok, logpost, nugget, theta = [], [], [], []
+        for i in range(self.n_emulators):
+            em = self._mogp_gpu.emulator(i)
+            fitted = bool(em.theta_fit_status())
+            ok.append(fitted)
+            nugget.append(float(em.get_nugget_size()))
+            if fitted:
+                th = em.get_theta()
+                vec = np.concatenate([th.get_mean(), th.get_data()])
+                theta.append(vec)
+                logpost.append(float(em.get_logpost(vec)))          # cached: theta is the current one
+            else:
+                theta.append(None)
+                logpost.append(np.nan)
+        return {"fit_ok": ok, "logpost": logpost, "nugget": nugget, "theta": theta}
+
     def fit_emulator(self, index, theta):
         self._mogp_gpu.fit_emulator(index, np.asarray(theta, dtype=np.float64))
 

@@ -71,8 +71,13 @@ __device__ unsigned long long* c128_stamps = nullptr;
 #define C128_STAMPW(i) do { } while (0)
 #endif
 
-constexpr int C128_LD = 130;                                  // LDS row stride (doubles): conflict-free ds_read_b64 in both MFMA layouts
-constexpr int C128_LDS_DOUBLES = 128 * C128_LD + 256 + 4 * 256;   // columns of L + published diagonal sub-block + inverse staging
+// LDS: the 16 finished columns of the current block step (128 rows, row stride 18 doubles: conflict-free ds_read_b64 in
+// both MFMA operand layouts; the two barriers of a block step separate its readers from the next step's writers) + the
+// published diagonal sub-block + the inverse staging: 22.5 KB, so that the workgroup fits next to the three resident
+// workgroups per CU of a concurrent MFMA update kernel (the first version kept the whole 128 x 130 image, 143 KB, and
+// waited for entire CUs to drain: 34 -> 80-105 us under a trailing update).
+constexpr int C128_LD = 18;
+constexpr int C128_LDS_DOUBLES = 128 * C128_LD + 256 + 256;
 
 // Pack written for the panel solve below the block (trsm128_dev), per emulator:
 //   [PACK128_LT  + c * 128 + r]            = L[r][c]                    (transposed, so that lanes run over rows)
@@ -149,11 +154,11 @@ __device__ __forceinline__ void chol128_dev(double* __restrict__ A, int ld, doub
   const int t = threadIdx.x, lane = t & 63;
   const int w = __builtin_amdgcn_readfirstlane(t >> 6);
   const int rg = lane >> 4, cl = lane & 15;
-  double* S = lds;                           // finished columns of L, row-major image of the block
   double* Dbuf = lds + 128 * C128_LD;        // next diagonal sub-block (negated), accumulator layout
-  double* Ibuf = Dbuf + 256;                 // 4 x 256: per-wave staging of an inverted diagonal sub-block
+  double* Ibuf = Dbuf + 256;                 // staging of the inverted diagonal sub-block (one wave per block step)
   const int r1 = w, r2 = 7 - w;
   const c128_v4d zero4 = {0., 0., 0., 0.};
+  __builtin_amdgcn_s_setprio(3);             // latency-bound chain: issue ahead of the MFMA waves of a concurrent update kernel
   C128_STAMP(0);
   // sub-block (r, k), k < r, transposed and negated: register q = -A[16r + cl][16k + rg + 4q]
   auto load_off = [&](int r, int k) {
@@ -212,6 +217,7 @@ __device__ __forceinline__ void chol128_dev(double* __restrict__ A, int ld, doub
     const bool p1 = r1 > b, p2 = r2 > b;     // the wave owns a sub-block below diagonal sub-block b in block row r1 / r2
     // the inverse of the diagonal sub-block rides along in a wave that has a free slot
     const bool inv = (b < 3) ? (w == 0) : ((b == 3) ? (w == 3) : (r2 == b));
+    double* Sb = lds;                                      // this block step's 16 columns of L: [row][column in block]
     if (r2 >= b) {
       if (b > 0) {
 #pragma unroll
@@ -235,7 +241,7 @@ __device__ __forceinline__ void chol128_dev(double* __restrict__ A, int ld, doub
       C128_STAMPW(4 * b + 1);
       // finished columns into the LDS image: lane (rg, cl), register s = L[16r + cl][16b + rg + 4s]
       auto put = [&](int r, const c128_v4d& U) {
-        double* ps = S + (16 * r + cl) * C128_LD + 16 * b + rg;
+        double* ps = Sb + (16 * r + cl) * C128_LD + rg;
 #pragma unroll
         for (int s = 0; s < 4; ++s) ps[4 * s] = U[s];
       };
@@ -251,7 +257,7 @@ __device__ __forceinline__ void chol128_dev(double* __restrict__ A, int ld, doub
         // columns of inv(L_bb)^T: lane (rg, cl), register s = inv(L_bb)[rg + 4s][cl]; pack order [k = cl][i = rg + 4s];
         // through a wave-private LDS stage so that it leaves as two fully coalesced 1 KB stores
         const c128_v4d& UI = (b < 4) ? UX : UY;
-        double* stage = Ibuf + 256 * w;
+        double* stage = Ibuf;
 #pragma unroll
         for (int s = 0; s < 4; ++s) stage[cl * 16 + rg + 4 * s] = UI[s];
         __builtin_amdgcn_wave_barrier();
@@ -274,10 +280,10 @@ __device__ __forceinline__ void chol128_dev(double* __restrict__ A, int ld, doub
       for (int i = 0; i < 4; ++i) {
         if (32 * i < nrows) {
           const int row = 16 * b + (t >> 3) + 32 * i, rc = row < 128 ? row : 127;
-          ca[i] = *reinterpret_cast<const c128_v2d*>(S + rc * C128_LD + 16 * b + 2 * (t & 7));
-          const int r = 16 * b + 2 * (t & 15) + 32 * i, rr = r < 128 ? r : 126, c = 16 * b + (t >> 4);
-          ct[i][0] = S[rr * C128_LD + c];
-          ct[i][1] = S[(rr + 1) * C128_LD + c];
+          ca[i] = *reinterpret_cast<const c128_v2d*>(Sb + rc * C128_LD + 2 * (t & 7));
+          const int r = 16 * b + 2 * (t & 15) + 32 * i, rr = r < 128 ? r : 126;
+          ct[i][0] = Sb[rr * C128_LD + (t >> 4)];
+          ct[i][1] = Sb[(rr + 1) * C128_LD + (t >> 4)];
         }
       }
 #pragma unroll
@@ -296,8 +302,8 @@ __device__ __forceinline__ void chol128_dev(double* __restrict__ A, int ld, doub
     // A operand is the wave's own panel sub-block, i.e. the symmetric update of the diagonal sub-block.
     {
       double bo1[4], bo2[4];
-      const double* pb1 = S + (16 * r1 + cl) * C128_LD + 16 * b + rg;
-      const double* pb2 = S + (16 * r2 + cl) * C128_LD + 16 * b + rg;
+      const double* pb1 = Sb + (16 * r1 + cl) * C128_LD + rg;
+      const double* pb2 = Sb + (16 * r2 + cl) * C128_LD + rg;
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         bo1[s] = pb1[4 * s];
@@ -305,7 +311,7 @@ __device__ __forceinline__ void chol128_dev(double* __restrict__ A, int ld, doub
       }
 #pragma unroll
       for (int k = b + 1; k < 8; ++k) {
-        const double* pa = S + (16 * k + cl) * C128_LD + 16 * b + rg;
+        const double* pa = Sb + (16 * k + cl) * C128_LD + rg;
         double ak[4];
 #pragma unroll
         for (int s = 0; s < 4; ++s) ak[s] = pa[4 * s];

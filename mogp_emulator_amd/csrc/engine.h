@@ -130,10 +130,11 @@ class Engine {
   void ensure_predict_scratch(int nb, int MC);
 
   double *dX = nullptr, *dP = nullptr, *dT = nullptr, *dA = nullptr, *dLinv = nullptr, *dKinv = nullptr, *dAlpha = nullptr;
-  double *dLogdet = nullptr, *dYty = nullptr, *dGradOut = nullptr, *dGradPartial = nullptr;
+  double *dRes = nullptr, *hRes = nullptr;   // per emulator [log-det, status, Gram matrix]: device buffer and its pinned host mirror
+  double *dGradOut = nullptr, *dGradPartial = nullptr;
   int *dInfo = nullptr, *dIdx = nullptr;
   double* dLpack = nullptr;
-  double *dH = nullptr, *dZ = nullptr, *dM = nullptr, *dGram = nullptr;
+  double *dH = nullptr, *dZ = nullptr, *dM = nullptr;
   // nugget="pivot": per-emulator inputs in pivot order (B*n*D), pivot order (B*n), rank (B), scratch (B*2*NP)
   double *dXp = nullptr, *dPivWork = nullptr;
   int *dPerm = nullptr, *dRank = nullptr;

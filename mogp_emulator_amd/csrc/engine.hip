@@ -160,7 +160,6 @@ Engine::Engine(const double* X, int n_, int D_, const double* targets, int B_, u
   dA = dalloc<double>((size_t)B * MS);
   RA = (R > 1) ? R + 1 : 1;
   dAlpha = dalloc<double>((size_t)B * RA * LD);
-  dGram = dalloc<double>((size_t)B * RMAX * RMAX);
   if (R > 1) {
     dZ = dalloc<double>((size_t)B * R * LD);
     dM = dalloc<double>((size_t)B * (RMAX + 1) * RMAX);
@@ -171,8 +170,8 @@ Engine::Engine(const double* X, int n_, int D_, const double* targets, int B_, u
     dH = dalloc<double>(hH.size());
     HIPCK(hipMemcpy(dH, hH.data(), hH.size() * sizeof(double), hipMemcpyHostToDevice));
   }
-  dLogdet = dalloc<double>(B);
-  dYty = dalloc<double>(B);
+  dRes = dalloc<double>((size_t)B * RES_STRIDE);
+  HIPCK(hipHostMalloc(reinterpret_cast<void**>(&hRes), (size_t)B * RES_STRIDE * sizeof(double), hipHostMallocDefault));
   dInfo = dalloc<int>(B);
   dIdx = dalloc<int>(B);
   dLpack = dalloc<double>((size_t)B * lpack128_doubles_per_emulator());
@@ -187,11 +186,12 @@ Engine::Engine(const double* X, int n_, int D_, const double* targets, int B_, u
 }
 
 Engine::~Engine() {
-  for (void* p : {(void*)dX, (void*)dP, (void*)dT, (void*)dA, (void*)dLinv, (void*)dKinv, (void*)dAlpha, (void*)dLogdet, (void*)dYty,
+  for (void* p : {(void*)dX, (void*)dP, (void*)dT, (void*)dA, (void*)dLinv, (void*)dKinv, (void*)dAlpha, (void*)dRes,
                   (void*)dGradOut, (void*)dGradPartial, (void*)dInfo, (void*)dIdx, (void*)dXs, (void*)dKs, (void*)dMean, (void*)dVar,
-                  (void*)dVarPartial, (void*)dDeriv, (void*)dLpack, (void*)dH, (void*)dZ, (void*)dM, (void*)dGram, (void*)dXp, (void*)dPivWork,
+                  (void*)dVarPartial, (void*)dDeriv, (void*)dLpack, (void*)dH, (void*)dZ, (void*)dM, (void*)dXp, (void*)dPivWork,
                   (void*)dPerm, (void*)dRank})
     if (p) hipFree(p);
+  if (hRes) hipHostFree(hRes);
   for (auto& kv : w2) hipFree(kv.second);
   for (auto st : gstreams) hipStreamDestroy(st);
   if (evReady) hipEventDestroy(evReady);
@@ -412,16 +412,72 @@ void Engine::factorize_blocked(const std::vector<int>& ids, std::vector<int>& in
   upload_idx(ids);
   upload_params(ids);
   BatchView v = view(nb);
-  // schedule: 0 = left-looking (default), 2 = left-looking + two-stream look-ahead split, 1 = right-looking + look-ahead
+  // schedule: 3 = left-looking with look-ahead (default); for A/B: 0 = left-looking in two emulator groups, 1 = right-looking +
+  // look-ahead, 2 = the round-1 look-ahead split (128-wide tiles, short update on the main stream)
   static const int forced = [] {
     const char* e = getenv("MOGP_CHOL");
     if (!e) return -1;
     if (e[0] == 'r') return 1;
-    return (std::string(e) == "leftla") ? 2 : 0;
+    if (std::string(e) == "leftla") return 2;
+    return (std::string(e) == "left") ? 0 : 3;
   }();
-  // Left-looking needs enough tiles per block column to fill 256 CUs (many emulators, C2/C3/C4);
-  // a single large matrix (C5) has thousands of trailing tiles per step instead -> right-looking.
-  const int schedule = forced >= 0 ? forced : (((long)nb * (NP / TILE) >= 512) ? 0 : 1);
+  // Measured (fit, ms; look-ahead / two groups / right-looking): 8 x n=2000 1.75 / 1.97 / 1.89, 16 x 2.21 / 2.38 / 2.44,
+  // 32 x 3.32 / 3.34 / 3.65, 64 x 5.47 / 5.37 / 6.76, 16 x n=5000 18.9 / 19.8 / -, 2 x n=5000 6.59 / - / 6.42,
+  // 1 x n=16000 59.8 / - / 38.4: one matrix has too few tiles per block column for a left-looking pass (right-looking),
+  // a large batch fills the machine with the update of ONE emulator group while the other factors its panels.
+  const long tiles64 = (long)nb * (NP / 64), tiles128 = (long)nb * (NP / TILE);
+  const int schedule = forced >= 0 ? forced : (tiles64 < 256 ? 1 : (tiles128 >= 1024 ? 0 : 3));
+  if (schedule == 3) {
+    // LEFT-LOOKING WITH LOOK-AHEAD.  Block column c receives the panels 0 .. c-2 in one long-K MFMA pass U1(c) on the main
+    // stream -- every element of the trailing matrix is read-modified-written once, at the K depth where the MFMA main
+    // loop runs best -- WHILE the panel stream works on block column c-1:
+    //     panel stream (high priority):  U2(c): column c -= panel c-1 (K = 128)  ->  128 x 128 diagonal block  ->  panel solve
+    //     main stream:                   U1(c+2): column c+2 -= panels 0 .. c    (needs the panel solve of column c)
+    // The whole dependent chain of a block column (short update, diagonal block, panel solve) sits in ONE stream: a
+    // cross-stream event wait costs ~12 us on this stack when the waiter is already blocked (kernel trace), and the
+    // earlier schedules paid two of them per block column.  The main stream is one block column ahead, so its events
+    // have normally fired by the time the panel stream asks.  Replaces the two-emulator-group schedule (5.37 ms at
+    // 64 x n=2000), the right-looking schedule of small batches and of a single large matrix.
+    std::vector<int> cols;
+    for (int o = 0; o < n + R; o += TILE) cols.push_back(o);
+    const int K = (int)cols.size();
+    while ((int)evPanel.size() < K + 1) {
+      hipEvent_t a, b;
+      HIPCK(hipEventCreateWithFlags(&a, hipEventDisableTiming));
+      HIPCK(hipEventCreateWithFlags(&b, hipEventDisableTiming));
+      evPanel.push_back(a);
+      evUpd.push_back(b);
+    }
+    static const long tail_threshold = [] { const char* e = getenv("MOGP_TAIL"); return e ? atol(e) : 1100L; }();
+    auto long_update = [&](int o, int k1, hipStream_t st) {
+      // 64 x 64 tiles unless the launch has several rounds of 128 x 128 ones (measured 7.6 vs 8.3 ms at 64 x n=2000)
+      if ((long)nb * ((NP - o) / TILE) >= tail_threshold) launch_update_wide(v, o, 0, k1, st);
+      else launch_update_narrow_pair(v, o, 0, k1, st);
+    };
+    static const bool serial = [] { const char* e = getenv("MOGP_LA_SERIAL"); return e && e[0] == '1'; }();   // measurement aid: one stream
+    hipStream_t pst = serial ? stream : pstream;
+    HIPCK(hipMemsetAsync(dInfo, 0, B * sizeof(int), stream));
+    launch_cov_build(v, stream);
+    HIPCK(hipEventRecord(evReady, stream));
+    HIPCK(hipStreamWaitEvent(pst, evReady, 0));
+    for (int c = 0; c < K; ++c) {
+      const int o = cols[c];
+      if (c >= 1) {
+        if (c >= 2) HIPCK(hipStreamWaitEvent(pst, evUpd[c], 0));              // U1(c) done
+        launch_update_narrow_pair(v, o, o - TILE, o, pst);                      // U2(c): panel c-1 -> column c
+      }
+      panel(v, o, TILE, pst);
+      HIPCK(hipEventRecord(evPanel[c], pst));
+      if (c + 2 < K) {
+        HIPCK(hipStreamWaitEvent(stream, evPanel[c], 0));
+        long_update(cols[c + 2], cols[c + 1], stream);                          // U1(c+2): panels 0 .. c -> column c+2
+        HIPCK(hipEventRecord(evUpd[c + 2], stream));
+      }
+    }
+    HIPCK(hipStreamWaitEvent(stream, evPanel[K - 1], 0));
+    read_info(info, defer_info);
+    return;
+  }
   if (schedule == 0) {
     // Two independent emulator groups on separate streams (MOGP_GROUPS, default 2): while one group runs its
     // latency-bound panel kernels (potf2 / trsm: few workgroups) the other group's MFMA update fills the
@@ -510,7 +566,7 @@ void Engine::factorize_blocked(const std::vector<int>& ids, std::vector<int>& in
   }
   std::vector<int> starts;
   // outer block = K depth of the trailing update (MOGP_OUTER: 256 / 512 / 1024 -> C5 fit 45.7 / 41.7 / 44.3 ms)
-  static const int OUTERW = [] { const char* e = getenv("MOGP_OUTER"); const int w = e ? atoi(e) : 512; return (w == 256 || w == 512 || w == 1024) ? w : 512; }();
+  static const int OUTERW = [] { const char* e = getenv("MOGP_OUTER"); const int w = e ? atoi(e) : 512; return (w == 128 || w == 256 || w == 512 || w == 1024) ? w : 512; }();
   for (int o = 0; o < n + R; o += OUTERW) starts.push_back(o);
   const int K = (int)starts.size();
   while ((int)evPanel.size() < K + 1) {
@@ -560,7 +616,7 @@ void Engine::eval(const std::vector<int>& ids, const std::vector<const double*>&
     for (int i : list) gp[i].factored = true;                // provisional (ensure_linv checks it)
     upload_idx(list);
     BatchView v = view((int)list.size());
-    launch_logdet(v, dLogdet, dGram, stream);
+    launch_logdet(v, dInfo, dRes, stream);
     if (want_grad) {
       // gradient path: L^-1 is needed anyway, so K^-1 [t, H] = L^-T Y is one fully parallel gemv with it
       ensure_linv(list);
@@ -570,18 +626,16 @@ void Engine::eval(const std::vector<int>& ids, const std::vector<const double*>&
     } else {
       launch_backsolve(v, stream);
     }
-    std::vector<double> ld(B), gr(gram.size());
-    if (info_out) {
-      info_out->assign(B, 0);
-      HIPCK(hipMemcpyAsync(info_out->data(), dInfo, B * sizeof(int), hipMemcpyDeviceToHost, stream));
-    }
-    HIPCK(hipMemcpyAsync(ld.data(), dLogdet, B * sizeof(double), hipMemcpyDeviceToHost, stream));
-    HIPCK(hipMemcpyAsync(gr.data(), dGram, gr.size() * sizeof(double), hipMemcpyDeviceToHost, stream));
+    // status words, log-determinants and Gram matrices come back in ONE copy into pinned host memory
+    HIPCK(hipMemcpyAsync(hRes, dRes, (size_t)B * RES_STRIDE * sizeof(double), hipMemcpyDeviceToHost, stream));
     HIPCK(hipStreamSynchronize(stream));
     HIPCK(hipGetLastError());
+    if (info_out) info_out->assign(B, 0);
     for (int i : list) {
-      logdet[i] = ld[i];
-      std::memcpy(gram.data() + (size_t)i * RMAX * RMAX, gr.data() + (size_t)i * RMAX * RMAX, sizeof(double) * RMAX * RMAX);
+      const double* r = hRes + (size_t)i * RES_STRIDE;
+      logdet[i] = r[0];
+      if (info_out) (*info_out)[i] = (int)r[1];
+      std::memcpy(gram.data() + (size_t)i * RMAX * RMAX, r + 2, sizeof(double) * RMAX * RMAX);
     }
   };
   std::vector<int> info;

@@ -15,7 +15,9 @@ __device__ __forceinline__ int slot_emu(const int* idx, int z) { return idx ? id
 // ---------------------------------------------------------------------------------------------
 // logdet = 2 sum_{i<n} log L_ii ;  yty = sum_{c<n} L[n,c]^2   (row n of the factor holds y^T)
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void logdet_kernel(BatchView v, double* __restrict__ logdet, double* __restrict__ gram) {
+// res[emu * RES_STRIDE + ..]: [0] log-determinant, [1] factorisation status word (as a double), [2 + r * RMAX + c] Gram matrix --
+// everything the host needs after a factorisation in ONE device-to-host copy (three separate copies cost ~20 us each).
+__global__ __launch_bounds__(256) void logdet_kernel(BatchView v, const int* __restrict__ info, double* __restrict__ res) {
   __shared__ double red[256];
   const int emu = slot_emu(v.idx, blockIdx.x);
   const int ld = v.LD, R = v.R;
@@ -46,7 +48,11 @@ __global__ __launch_bounds__(256) void logdet_kernel(BatchView v, double* __rest
     return out;
   };
   const double ls = block_sum(s);
-  if (threadIdx.x == 0) logdet[emu] = 2.0 * ls;
+  double* out = res + (size_t)emu * RES_STRIDE;
+  if (threadIdx.x == 0) {
+    out[0] = 2.0 * ls;
+    out[1] = (double)info[emu];
+  }
 #pragma unroll
   for (int r = 0; r < RMAX; ++r)
 #pragma unroll
@@ -54,8 +60,8 @@ __global__ __launch_bounds__(256) void logdet_kernel(BatchView v, double* __rest
       if (r < R) {                    // uniform
         const double g = block_sum(acc[r * (r + 1) / 2 + c]);
         if (threadIdx.x == 0) {
-          gram[(size_t)emu * RMAX * RMAX + r * RMAX + c] = g;
-          gram[(size_t)emu * RMAX * RMAX + c * RMAX + r] = g;
+          out[2 + r * RMAX + c] = g;
+          out[2 + c * RMAX + r] = g;
         }
       }
     }
@@ -410,8 +416,8 @@ __global__ void extract_kernel(const double* __restrict__ src, int NP, int n, do
 }
 
 // =============================================================================================
-void launch_logdet(const BatchView& v, double* logdet, double* gram, hipStream_t s) {
-  hipLaunchKernelGGL(logdet_kernel, dim3(v.nb), dim3(256), 0, s, v, logdet, gram);
+void launch_logdet(const BatchView& v, const int* info, double* res, hipStream_t s) {
+  hipLaunchKernelGGL(logdet_kernel, dim3(v.nb), dim3(256), 0, s, v, info, res);
 }
 
 void launch_combine_rows(const BatchView& v, const double* M, hipStream_t s) {

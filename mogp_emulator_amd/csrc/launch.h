@@ -76,8 +76,10 @@ void launch_update_narrow_pair(const BatchView& v, int c0, int k0, int k1, hipSt
 void launch_update_wide(const BatchView& v, int c0, int k0, int k1, hipStream_t s);
 // trailing lower-triangular update, rows/cols [c0, NP), k in [k0,k1) (c0 multiple of 128)
 void launch_update_trailing(const BatchView& v, int c0, int k0, int k1, hipStream_t s);
-// logdet[emu] = 2 sum_{i<n} log L_ii ; gram[emu][r*R+s] = sum_{c<n} L[n+r,c] L[n+s,c]  (gram[0] = y^T y)
-void launch_logdet(const BatchView& v, double* logdet, double* gram, hipStream_t s);
+// res (indexed by emulator, RES_STRIDE doubles each): [0] = 2 sum_{i<n} log L_ii, [1] = info[emu],
+// [2 + r*RMAX + s] = sum_{c<n} L[n+r,c] L[n+s,c]  (Gram matrix of the right-hand-side rows; [2] = y^T y)
+constexpr int RES_STRIDE = 2 + RMAX * RMAX;
+void launch_logdet(const BatchView& v, const int* info, double* res, hipStream_t s);
 // alpha[c] = sum_r M[emu][c][r] Z[r], c < RA   (M: indexed by emulator, (RMAX+1) x RMAX row-major)
 void launch_combine_rows(const BatchView& v, const double* M, hipStream_t s);
 // alpha = L^-T y (y = row n of A)

@@ -478,6 +478,38 @@ class GPRef(object):
         partials -= self.priors.dlogpdtheta(self.theta)
         return partials
 
+    def logpost_deriv_chunked(self, theta, chunk_rows=128):
+        """GaussianProcess.py:711-782 at sizes where the (D, n, n) ``kernel_deriv`` tensor and the (n, n D) right-hand
+        side of ``logdet_deriv`` (linalg/linalg_utils.py:170-198) do not fit (C4: 4 GB + 4 GB, C5: 16 GB each).
+        DEVIATION, flagged as SURVEY.md section 8d allows for the memory guard: tr(K^-1 dK_p) is accumulated as
+        sum_ij [K^-1]_ij [dK_p]_ij over row blocks of dK_p, with K^-1 from LAPACK (cho_solve on the identity), instead of
+        as the trace of cho_solve on the stacked planes -- the same quantity, the per-entry arithmetic of dK_p is the
+        reference's (``kernel_deriv`` on a row block).  tests/test_oracle_golden.py pins it to ``logpost_deriv``."""
+        if self._refit(theta):
+            self.fit(theta)
+        D, n = self.nc, self.n
+        Kinv = cho_solve_L(self.L, np.eye(n))
+        a = self.Kinv_t
+        sig2 = np.exp(self.theta[D])
+        tr = np.zeros(D + 1)
+        quad = np.zeros(D + 1)
+        for lo in range(0, n, chunk_rows):
+            hi = min(lo + chunk_rows, n)
+            dK = sig2 * kernel_deriv(self.X[lo:hi], self.X, self.theta[:D], self.kernel)          # (D, rows, n)
+            Kc = self.get_cov_matrix(self.X[lo:hi]).T                                              # (rows, n), no nugget
+            W = Kinv[lo:hi]
+            for p in range(D):
+                tr[p] += np.sum(W * dK[p])
+                quad[p] += np.dot(a[lo:hi], np.dot(dK[p], a))
+            tr[D] += np.sum(W * Kc)
+            quad[D] += np.dot(a[lo:hi], np.dot(Kc, a))
+        partials = np.zeros(self.n_params)
+        partials[:D + 1] = 0.5 * (tr - quad)
+        if self.nugget_type == "fit":
+            partials[-1] = 0.5 * self.nugget * (np.trace(Kinv) - np.dot(a, a))
+        partials -= self.priors.dlogpdtheta(self.theta)
+        return partials
+
     # -- predict ------------------------------------------------------------
     def predict(self, testing, unc=True, deriv=False, include_nugget=True, full_cov=False):
         """GaussianProcess.py:818-927 (R = 0; ``full_cov`` :899-911).  ``deriv=True``

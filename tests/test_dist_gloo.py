@@ -22,6 +22,14 @@ class _LocalStub(object):
     def fit(self, thetas):
         self.fitted = np.asarray(thetas)
 
+    def fit_record(self):
+        """emulator k is 'fit' unless its first target is negative; logpost = sum(theta), nugget = 0.5 + first target"""
+        n = self.t.shape[0]
+        ok = [bool(self.fitted is not None and self.t[k, 0] >= 0.) for k in range(n)]
+        return {"fit_ok": ok, "logpost": [float(self.fitted[k].sum()) if ok[k] else np.nan for k in range(n)],
+                "nugget": [0.5 + float(self.t[k, 0]) for k in range(n)],
+                "theta": [self.fitted[k] if ok[k] else None for k in range(n)]}
+
     def predict(self, testing, deriv=False, **kw):
         s = np.asarray(testing).sum(axis=1)
         mean = self.t.sum(axis=1)[:, None] + s[None, :]
@@ -46,6 +54,17 @@ def _worker(rank, world, port, n_out, q):
     ref = _LocalStub(X, T); ref.fit(thetas)
     rm, ru, _ = ref.predict(Xs)
     ok = np.allclose(mean, rm) and np.allclose(unc, ru) and mean.shape == (n_out, 5)
+    # the fit exchange: every rank knows the record of every emulator after ONE gather
+    rec = ref.fit_record()
+    ok = ok and gp.get_indices_fit() == [k for k in range(n_out) if rec["fit_ok"][k]]
+    ok = ok and gp.get_indices_not_fit() == [k for k in range(n_out) if not rec["fit_ok"][k]]
+    ok = ok and sorted(gp.get_indices_fit() + gp.get_indices_not_fit()) == list(range(n_out))
+    for k in range(n_out):
+        ok = ok and np.isclose(gp.nuggets[k], rec["nugget"][k])
+        if rec["fit_ok"][k]:
+            ok = ok and np.array_equal(gp.theta_hat[k], thetas[k]) and np.isclose(gp.logpost[k], rec["logpost"][k])
+        else:
+            ok = ok and gp.theta_hat[k] is None and np.isnan(gp.logpost[k])
     lo, hi = shard_bounds(n_out, world, rank)
     g = gather_rows(np.arange(lo, hi, dtype=np.float64).reshape(-1, 1), n_out).numpy().ravel()
     ok = ok and np.array_equal(g, np.arange(n_out))

@@ -1,0 +1,83 @@
+"""Two ranks on ONE GPU with the real per-rank model ("1 GPU pretending to be k shards"): the emulator
+partition, the single gather of fit records (theta_hat, log-posterior, nugget, fit status) and the single gather of
+predictions, compared with the unsharded MultiOutputGP_GPU.  The process group is gloo (both ranks share device 0; RCCL
+wants one device per rank), so the payloads cross host memory -- the collective call sites are the ones bench.py uses
+with "nccl"."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _data(n_out):
+    rng = np.random.default_rng(5)
+    n, d = 300, 3
+    X = rng.uniform(0, 1, (n, d))
+    T = np.stack([np.sin(3 * X @ rng.normal(size=d)) + 0.05 * rng.normal(size=n) for _ in range(n_out)])
+    Xs = rng.uniform(0, 1, (40, d))
+    return X, T, Xs
+
+
+def _worker(rank, world, port, n_out, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    os.environ["LOCAL_RANK"] = str(rank)
+    os.environ["MOGP_CHOL"] = "left"          # one Cholesky schedule whatever the shard size: bit-for-bit comparable
+    import torch.distributed as dist
+    import mogp_emulator_amd as M
+    from mogp_emulator_amd import libgpgpu
+    from mogp_emulator_amd.dist import ShardedMultiOutputGP
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    X, T, Xs = _data(n_out)
+    libgpgpu.set_fit_options(max_iter=40, ftol=1e-9, gtol=1e-6, seed=1)
+    sh = ShardedMultiOutputGP(X, T, nugget="fit")
+    theta0 = np.array([1.0, 1.0, 1.0, 0.0, np.log(1e-3)])
+    sh.fit_GP_MAP(n_tries=1, theta0=theta0)
+    mean, unc = sh.predict(Xs)
+    q.put((rank, (sh.lo, sh.hi), sh.get_indices_fit(), sh.get_indices_not_fit(), [None if t is None else t.copy() for t in sh.theta_hat],
+           sh.logpost.copy(), sh.nuggets.copy(), mean, unc))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_out", [5, 2])
+def test_two_ranks_on_one_gpu_match_the_unsharded_model(n_out):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_out, q)) for r in range(2)]
+    for p in procs: p.start()
+    res = sorted([q.get(timeout=300) for _ in procs], key=lambda r: r[0])
+    for p in procs: p.join(timeout=60)
+    # the unsharded model, same schedule, same optimiser settings, in a third process-local engine
+    os.environ["MOGP_CHOL"] = "left"
+    import mogp_emulator_amd as M
+    from mogp_emulator_amd import libgpgpu
+    X, T, Xs = _data(n_out)
+    libgpgpu.set_fit_options(max_iter=40, ftol=1e-9, gtol=1e-6, seed=1)
+    full = M.MultiOutputGP_GPU(X, T, nugget="fit")
+    full = M.fit_GP_MAP(full, n_tries=1, theta0=np.array([1.0, 1.0, 1.0, 0.0, np.log(1e-3)]))
+    rec = full.fit_record()
+    fmean, func, _ = full.predict(Xs, deriv=False)
+    assert res[0][1][0] == 0 and res[0][1][1] == res[1][1][0] and res[1][1][1] == n_out
+    for r in res:                                   # every rank holds the records of ALL emulators
+        _, _, fit_idx, notfit_idx, theta_hat, logpost, nuggets, mean, unc = r
+        assert fit_idx == full.get_indices_fit() and notfit_idx == full.get_indices_not_fit()
+        for k in range(n_out):
+            if rec["fit_ok"][k]:
+                np.testing.assert_allclose(theta_hat[k], rec["theta"][k], rtol=1e-9, atol=1e-9)
+                np.testing.assert_allclose(logpost[k], rec["logpost"][k], rtol=1e-10)
+                np.testing.assert_allclose(nuggets[k], rec["nugget"][k], rtol=1e-9)
+            else:
+                assert theta_hat[k] is None and np.isnan(logpost[k])
+        np.testing.assert_allclose(mean, fmean, rtol=1e-8, atol=1e-10)
+        np.testing.assert_allclose(unc, func, rtol=1e-6, atol=1e-9)
+    # both ranks return the same bits
+    assert np.array_equal(res[0][7], res[1][7]) and np.array_equal(res[0][8], res[1][8])

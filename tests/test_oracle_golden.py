@@ -201,6 +201,22 @@ def test_fit_map_endpoint_vs_reference():
     assert_allclose(gp.fit(g["theta_hat"]), g["logpost_hat"], rtol=1e-10)
 
 
+@pytest.mark.parametrize("tag", ["c1_n200_d4", "n500_d10"])
+@pytest.mark.parametrize("kern", KERNELS)
+@pytest.mark.parametrize("mode", ["fixed", "fit"])
+def test_chunked_gradient_matches_the_faithful_one_and_the_reference(tag, kern, mode):
+    """GPRef.logpost_deriv_chunked (the row-blocked gradient the C4 / C5 full-size GPU tests compare with) against the
+    faithful restatement and against the gradient the reference itself produced for the same emulator."""
+    g = load_golden(tag + ".npz")
+    pre = "%s_%s_" % (kern, mode)
+    gp = R.GPRef(g["X"], g["T"][0], kernel=kern, nugget=1.e-6 if mode == "fixed" else mode)
+    theta = g[pre + "theta"]
+    full = gp.logpost_deriv(theta)
+    chunked = gp.logpost_deriv_chunked(theta, chunk_rows=37)
+    assert_allclose(chunked, full, rtol=1e-7, atol=1e-7 * np.abs(full).max())
+    assert_allclose(chunked, g[pre + "grad"], rtol=1e-7, atol=1e-7 * np.abs(full).max())
+
+
 def test_gradient_fd():
     # FD check in the style of tests/test_GaussianProcess.py:626-661
     g = load_golden("grid11.npz")

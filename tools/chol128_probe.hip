@@ -21,6 +21,8 @@ __global__ __launch_bounds__(256) void probe_kernel(double* A, int ld, size_t st
 
 int main(int argc, char** argv) {
   const int NB = argc > 1 ? atoi(argv[1]) : 64, ld = 2048;
+  const double shift = argc > 2 ? atof(argv[2]) : 8.0;      // small shift + low-rank G: ill-conditioned blocks
+  const int rank = argc > 3 ? atoi(argv[3]) : 128;
   const size_t stride = (size_t)128 * ld;
   std::vector<double> hA(NB * stride), hL(NB * stride);
   srand(1);
@@ -30,8 +32,8 @@ int main(int argc, char** argv) {
     for (auto& x : G) x = rand() / (double)RAND_MAX - 0.5;
     for (int i = 0; i < 128; ++i)
       for (int j = 0; j < 128; ++j) {
-        double s = (i == j) ? 8.0 : 0.0;
-        for (int k = 0; k < 128; ++k) s += G[i * 128 + k] * G[j * 128 + k];
+        double s = (i == j) ? shift : 0.0;
+        for (int k = 0; k < rank; ++k) s += G[i * 128 + k] * G[j * 128 + k];
         hA[b * stride + (size_t)i * ld + j] = (j <= i) ? s : 1e30;
       }
   }
@@ -54,7 +56,7 @@ int main(int argc, char** argv) {
   std::vector<double> pk((size_t)NB * PACK128_STRIDE); CK(hipMemcpy(pk.data(), dpk, pk.size() * 8, hipMemcpyDeviceToHost));
   std::vector<unsigned long long> st(2048 + NB * 4 * 64); CK(hipMemcpy(st.data(), dst, st.size() * 8, hipMemcpyDeviceToHost));
   // host check
-  double maxerr = 0., maxinv = 0., maxlt = 0.;
+  double maxerr = 0., maxinv = 0., maxlt = 0., res_dev = 0., res_host = 0.;
   for (int b = 0; b < NB; ++b) {
     std::vector<double> L(128 * 128, 0.);
     for (int j = 0; j < 128; ++j) {
@@ -74,6 +76,24 @@ int main(int argc, char** argv) {
           maxerr = std::fmax(maxerr, std::fabs(hL[b * stride + (size_t)i * ld + j] - L[i * 128 + j]));
         if (j <= i) maxlt = std::fmax(maxlt, std::fabs(pk[(size_t)b * PACK128_STRIDE + PACK128_LT + j * 128 + i] - L[i * 128 + j]));
       }
+    // backward error: max |L L^T - A| / max |A| for the device factor and for the host factor
+    {
+      double amax = 0., rd = 0., rh = 0.;
+      for (int i = 0; i < 128; ++i)
+        for (int j = 0; j <= i; ++j) {
+          double sd = 0., sh = 0.;
+          for (int k = 0; k <= j; ++k) {
+            sd += hL[b * stride + (size_t)i * ld + k] * hL[b * stride + (size_t)j * ld + k];
+            sh += L[i * 128 + k] * L[j * 128 + k];
+          }
+          const double a = hA[b * stride + (size_t)i * ld + j];
+          amax = std::fmax(amax, std::fabs(a));
+          rd = std::fmax(rd, std::fabs(sd - a));
+          rh = std::fmax(rh, std::fabs(sh - a));
+        }
+      res_dev = std::fmax(res_dev, rd / amax);
+      res_host = std::fmax(res_host, rh / amax);
+    }
     // inv check: L_bb * inv = I
     for (int bb = 0; bb < 8; ++bb)
       for (int i = 0; i < 16; ++i)
@@ -84,6 +104,7 @@ int main(int argc, char** argv) {
         }
   }
   printf("NB=%d kernel %.1f us  max|L - Lref| %.3e  max|LT - Lref| %.3e  max|L inv - I| %.3e  info[0]=%d\n", NB, best * 1e3, maxerr, maxlt, maxinv, info[0]);
+  printf("  backward error max|L L^T - A| / max|A|: device %.3e, host Cholesky %.3e\n", res_dev, res_host);
   const char* names[19] = {"start", "loaded", "b0 cols", "b0 syrk", "b1 cols", "b1 syrk", "b2 cols", "b2 syrk", "b3 cols", "b3 syrk", "b4 cols", "b4 syrk",
                            "b5 cols", "b5 syrk", "b6 cols", "b6 syrk", "b7 cols", "inverses", "stored"};
   for (int i = 1; i < 19; ++i)
