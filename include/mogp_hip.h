@@ -199,10 +199,23 @@ int mogp_fit_GP_MAP(mogp_mogp*, int n_tries, const double* theta0, int theta0_le
 /* optimiser controls (not in the reference API; defaults reproduce fitting.hpp's stop rule 1e-9) */
 int mogp_set_fit_options(int max_iter, double ftol, double gtol, unsigned long long seed);
 
+/* ---- stand-alone kernel objects: SquaredExponentialKernel / Matern52Kernel .kernel_f / kernel_deriv / kernel_inputderiv
+   (mogp_gpu/src/bindings.cu:340-361, kernel.hpp:47-107; CPU counterparts Kernel.py:99-173).
+   kernel_type as the enum above (+ 2 ProductMat52, 3 UniformSqExp, 4 UniformMat52); x1 (n1, D), x2 (n2, D) row-major;
+   params = [corr_raw.., log sigma^2] (n_corr + 1, n_corr = D or 1 for the uniform kernels).
+   what = 0: out (n1, n2)            = sigma^2 k(x1_i, x2_j)
+   what = 1: out (n_corr + 1, n1, n2) = d/d theta_p (last plane: d/d log sigma^2 = K)
+   what = 2: out (n2, n1, D)         = d/d x1_i[d]   (the flat order of the reference's CUDA kernel, kernel.cu:86-100) */
+int mogp_kernel_eval(int kernel_type, int what, const double* x1, int n1, const double* x2, int n2, int D, const double* params,
+                     int n_params, double* out);
+
 /* ---- measurement hooks (bench.py only) -------------------------------------------------- */
 /* when enabled, HIP events are recorded on the launch stream around every launch of the tagged kernels */
 int mogp_profile_enable(int on);
 int mogp_profile_reset(void);
+/* force the Cholesky schedule (0 two emulator groups, 1 right-looking, 3 look-ahead, -1 the library's choice) and / or
+   serialise it onto one stream, so that the HIP-event time of a kernel is its time alone on the device */
+int mogp_profile_schedule(int schedule, int single_stream);
 /* sums over launches since reset: total milliseconds, launch count, algorithmic flops and bytes */
 int mogp_profile_get(const char* kernel_tag, double* total_ms, long long* launches, double* alg_flops, double* alg_bytes);
 /* device memory helpers so a host program can hand device-resident buffers to the *_dev calls */

@@ -121,8 +121,10 @@ SIGNATURES = {
     "mogp_mogp_predict_variance_batch_dev": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "mogp_fit_GP_MAP": (c_int, [c_void_p, c_int, c_double_p, c_int]),
     "mogp_set_fit_options": (c_int, [c_int, c_double, c_double, c_ulonglong]),
+    "mogp_kernel_eval": (c_int, [c_int, c_int, c_double_p, c_int, c_double_p, c_int, c_int, c_double_p, c_int, c_double_p]),
     "mogp_profile_enable": (c_int, [c_int]),
     "mogp_profile_reset": (c_int, []),
+    "mogp_profile_schedule": (c_int, [c_int, c_int]),
     "mogp_profile_get": (c_int, [c_char_p, c_double_p, POINTER(c_longlong), c_double_p, c_double_p]),
     "mogp_dev_malloc": (c_void_p, [c_ulonglong]),
     "mogp_dev_free": (c_int, [c_void_p]),

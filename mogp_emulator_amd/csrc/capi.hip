@@ -42,7 +42,58 @@ static void set_priors(Engine* eng, int i, int n_corr, const int* ct, const doub
   pr.nug.type = nugt; pr.nug.shape = nugp[0]; pr.nug.scale = nugp[1];
   pr.created = true;
   eng->gp[i].pri = pr;
+  eng->gp[i].logpost_stale = true;      // the cached log-posterior was computed with the old priors
 }
+
+static void kernel_eval_impl(int kernel_type, int what, const double* x1, int n1, const double* x2, int n2, int D, const double* params,
+                             int n_params, double* out) {
+  {
+    if (kernel_type < 0 || kernel_type > 4) throw std::runtime_error("Unrecognized kernel type\n");
+    if (what < 0 || what > 2) throw std::runtime_error("kernel_eval: what must be 0 (f), 1 (deriv) or 2 (inputderiv)");
+    if (n1 < 1 || n2 < 1 || D < 1) throw std::runtime_error("kernel inputs must have shape (n, D) with n, D >= 1");
+    const bool uniform = kernel_type >= 3;
+    const int nc = uniform ? 1 : D;
+    if (n_params != nc + 1) throw std::runtime_error("Expected params list of length " + std::to_string(nc + 1));
+    const int dk = kernel_type == 3 ? 0 : (kernel_type == 4 ? 1 : kernel_type);
+    std::vector<double> P(D + 1);
+    for (int d = 0; d < D; ++d) P[d] = std::exp(params[uniform ? 0 : d]);
+    P[D] = std::exp(params[nc]);
+    const size_t planes = what == 0 ? 1 : (what == 1 ? (size_t)D + 1 : (size_t)D);
+    const size_t cnt = planes * (size_t)n1 * n2;
+    double *d1 = nullptr, *d2 = nullptr, *dP = nullptr, *dO = nullptr;
+    auto cleanup = [&]() { for (double* p : {d1, d2, dP, dO}) if (p) hipFree(p); };
+    try {
+      hip_check(hipMalloc(reinterpret_cast<void**>(&d1), (size_t)n1 * D * 8), "hipMalloc");
+      hip_check(hipMalloc(reinterpret_cast<void**>(&d2), (size_t)n2 * D * 8), "hipMalloc");
+      hip_check(hipMalloc(reinterpret_cast<void**>(&dP), P.size() * 8), "hipMalloc");
+      hip_check(hipMalloc(reinterpret_cast<void**>(&dO), cnt * 8), "hipMalloc");
+      hip_check(hipMemcpy(d1, x1, (size_t)n1 * D * 8, hipMemcpyHostToDevice), "hipMemcpy");
+      hip_check(hipMemcpy(d2, x2, (size_t)n2 * D * 8, hipMemcpyHostToDevice), "hipMemcpy");
+      hip_check(hipMemcpy(dP, P.data(), P.size() * 8, hipMemcpyHostToDevice), "hipMemcpy");
+      launch_kernel_object(dk, d1, n1, d2, n2, D, dP, what, dO, nullptr);
+      std::vector<double> tmp(cnt);
+      hip_check(hipMemcpy(tmp.data(), dO, cnt * 8, hipMemcpyDeviceToHost), "hipMemcpy");
+      hip_check(hipGetLastError(), "kernel_object_kernel");
+      if (what == 1 && uniform) {
+        // one shared length scale: d/dtheta_0 = sum of the per-dimension planes (Kernel.py:338-376); then the sigma^2 plane
+        const size_t pl = (size_t)n1 * n2;
+        for (size_t e = 0; e < pl; ++e) {
+          double s = 0.;
+          for (int d = 0; d < D; ++d) s += tmp[(size_t)d * pl + e];
+          out[e] = s;
+          out[pl + e] = tmp[(size_t)D * pl + e];
+        }
+      } else {
+        std::memcpy(out, tmp.data(), cnt * 8);
+      }
+    } catch (...) {
+      cleanup();
+      throw;
+    }
+    cleanup();
+  }
+}
+
 
 extern "C" {
 
@@ -187,7 +238,7 @@ int mogp_densegp_get_logpost(mogp_densegp* h, const double* theta, int len, doub
     const int i = h->idx;
     if (len != e->n_theta(i)) throw std::runtime_error("Shape of new GPParams object does not match existing one");
     const GPState& g = e->gp[i];
-    bool close = g.has_data && g.factored;
+    bool close = g.has_data && g.factored && !g.logpost_stale;
     if (close) {   // gpparams.hpp:204-210 test_close: ||theta - current|| < 1e-8
       double d2 = 0.;
       const int nm = e->n_mean();
@@ -279,6 +330,12 @@ int mogp_pivot_cholesky(const double* A, int n, double* L_out, int* P_out, int* 
 double mogp_densegp_get_nugget_size(const mogp_densegp* h) { return h->eng->nugget_size(h->idx); }
 int mogp_densegp_set_nugget_size(mogp_densegp* h, double v) {
   GPState& g = h->eng->gp[h->idx];
+  // a fixed nugget is part of the factored matrix: a new value invalidates the factor, alpha and the log-posterior
+  // (the reference keeps serving the stale ones, densegp_gpu.hpp:125-135); the emulator has to be fit again
+  if (g.nug_type == NUG_FIXED && v != g.nug_size) {
+    g.has_data = false;
+    g.factored = g.linv = g.kinv = false;
+  }
   g.nug_size = v;
   if (g.nug_type == NUG_FIT && !g.data.empty()) g.data[g.data.size() - 1] = v;   // gpparams.hpp:167-172
   return 0;
@@ -503,9 +560,23 @@ int mogp_set_fit_options(int max_iter, double ftol, double gtol, unsigned long l
   return 0;
 }
 
+// ---- stand-alone kernel objects (bindings.cu:340-361, kernel.hpp:47-107) --------------------------------------
+// kernel_type as in the enum (0 SqExp, 1 Matern52, 2 ProductMat52, 3 UniformSqExp, 4 UniformMat52); params = [corr_raw.., log sigma^2]
+// (n_corr + 1 entries, n_corr = 1 for the uniform kernels); what = 0 kernel_f -> out (n1, n2), 1 kernel_deriv -> out
+// (n_corr + 1, n1, n2), 2 kernel_inputderiv -> out (n2, n1, D) (the reference's flat order)
+int mogp_kernel_eval(int kernel_type, int what, const double* x1, int n1, const double* x2, int n2, int D, const double* params, int n_params,
+                     double* out) {
+  GUARD(kernel_eval_impl(kernel_type, what, x1, n1, x2, n2, D, params, n_params, out));
+}
+
 // ---- measurement hooks ----------------------------------------------------------------------------
 int mogp_profile_enable(int on) { prof_enable(on != 0); return 0; }
 int mogp_profile_reset(void) { prof_reset(); return 0; }
+int mogp_profile_schedule(int schedule, int single_stream) {
+  schedule_override().schedule = schedule;
+  schedule_override().single_stream = single_stream != 0;
+  return 0;
+}
 int mogp_profile_get(const char* tag, double* total_ms, long long* launches, double* alg_flops, double* alg_bytes) {
   return prof_get(tag, total_ms, launches, alg_flops, alg_bytes) ? 0 : 1;
 }

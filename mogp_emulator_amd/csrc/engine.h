@@ -23,6 +23,7 @@ struct GPState {
   double nug_size = 0.;          // adaptive: jitter found by the last fit; fixed: the constant
   Priors pri;
   double logpost = 0.;
+  bool logpost_stale = false;    // the priors changed since `logpost` was computed (the factorisation itself is still valid)
   bool factored = false;         // A holds L (and y) for `data`
   bool linv = false, kinv = false;
   double nugget_used = 0.;       // value actually added to the diagonal in the last factorisation
@@ -157,6 +158,14 @@ struct FitOptions {
   unsigned long long seed = 0;
 };
 FitOptions& fit_options();
+
+// measurement hooks (mogp_profile_schedule): force the Cholesky schedule / serialise it onto one stream so that the
+// HIP-event time of a kernel is its time alone on the device; -1 / false = the library's own choice
+struct ScheduleOverride {
+  int schedule = -1;       // 0 two emulator groups, 1 right-looking, 3 look-ahead
+  bool single_stream = false;
+};
+ScheduleOverride& schedule_override();
 
 void hip_check(hipError_t e, const char* what);
 void prof_enable(bool on);

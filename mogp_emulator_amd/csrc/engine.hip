@@ -19,6 +19,10 @@ FitOptions& fit_options() {
   static FitOptions o;
   return o;
 }
+ScheduleOverride& schedule_override() {
+  static ScheduleOverride o;
+  return o;
+}
 
 // ---------------------------------------------------------------------------------------------
 // profiling registry (bench.py): HIP events on the launch stream around tagged kernels
@@ -426,7 +430,8 @@ void Engine::factorize_blocked(const std::vector<int>& ids, std::vector<int>& in
   // 1 x n=16000 59.8 / - / 38.4: one matrix has too few tiles per block column for a left-looking pass (right-looking),
   // a large batch fills the machine with the update of ONE emulator group while the other factors its panels.
   const long tiles64 = (long)nb * (NP / 64), tiles128 = (long)nb * (NP / TILE);
-  const int schedule = forced >= 0 ? forced : (tiles64 < 256 ? 1 : (tiles128 >= 1024 ? 0 : 3));
+  const ScheduleOverride& ovr = schedule_override();
+  const int schedule = ovr.schedule >= 0 ? ovr.schedule : (forced >= 0 ? forced : (tiles64 < 256 ? 1 : (tiles128 >= 1024 ? 0 : 3)));
   if (schedule == 3) {
     // LEFT-LOOKING WITH LOOK-AHEAD.  Block column c receives the panels 0 .. c-2 in one long-K MFMA pass U1(c) on the main
     // stream -- every element of the trailing matrix is read-modified-written once, at the K depth where the MFMA main
@@ -454,8 +459,7 @@ void Engine::factorize_blocked(const std::vector<int>& ids, std::vector<int>& in
       if ((long)nb * ((NP - o) / TILE) >= tail_threshold) launch_update_wide(v, o, 0, k1, st);
       else launch_update_narrow_pair(v, o, 0, k1, st);
     };
-    static const bool serial = [] { const char* e = getenv("MOGP_LA_SERIAL"); return e && e[0] == '1'; }();   // measurement aid: one stream
-    hipStream_t pst = serial ? stream : pstream;
+    hipStream_t pst = ovr.single_stream ? stream : pstream;
     HIPCK(hipMemsetAsync(dInfo, 0, B * sizeof(int), stream));
     launch_cov_build(v, stream);
     HIPCK(hipEventRecord(evReady, stream));
@@ -488,7 +492,7 @@ void Engine::factorize_blocked(const std::vector<int>& ids, std::vector<int>& in
     // of the others), not host launch overhead.  Graph replay is kept as an option, off by default.
     static const long tail_threshold = [] { const char* e = getenv("MOGP_TAIL"); return e ? atol(e) : 1100L; }();
     static const int want_groups = [] { const char* e = getenv("MOGP_GROUPS"); return e ? std::max(1, atoi(e)) : 2; }();
-    const int G = std::min(want_groups, std::max(1, nb / 8));
+    const int G = ovr.single_stream ? 1 : std::min(want_groups, std::max(1, nb / 8));
     while ((int)gstreams.size() < G - 1) {
       hipStream_t st;
       HIPCK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
@@ -802,6 +806,7 @@ void Engine::eval(const std::vector<int>& ids, const std::vector<const double*>&
     g.has_data = fine || pivot_kept;
     g.factored = fine || pivot_kept;
     g.logpost = val;
+    g.logpost_stale = false;
     if (f) f[k] = val;
     if (ok) ok[k] = fine ? 1 : 0;
     if (!fine) good[i] = 0;

@@ -450,6 +450,61 @@ __global__ __launch_bounds__(256) void grad_finish_kernel(BatchView v, int ntile
   if (threadIdx.x == 0) out[(size_t)emu * NQ + p] = (p <= v.D) ? 0.5 * red[0] : red[0];
 }
 
+// ---------------------------------------------------------------------------------------------
+// Stand-alone kernel objects of the native module (bindings.cu:340-361; kernel.hpp:47-107): covariance of two point
+// sets and its derivatives into caller buffers.  mode 0: out[i*n2 + j] = sigma^2 k(x1_i, x2_j) (cov_batch, kernel.cu:55-65);
+// mode 1: out[(p*n1 + i)*n2 + j] = d/d theta_p (the CPU class's (n_params, n1, n2) order, Kernel.py:133-173; the
+// reference's CUDA kernel indexes its inputs crosswise, kernel.cu:129-141, which is only meaningful for n1 == n2);
+// mode 2: out[(j*n1 + i)*D + d] = d/d x1_i[d] (cov_deriv_x_batch, kernel.cu:86-100).  One thread per pair; P = [exp(theta_d),
+// sigma^2].  Same per-pair arithmetic as the tiled kernels (pair loop of cov_dev.h), not a hot path.
+// ---------------------------------------------------------------------------------------------
+template <int KT>
+__global__ __launch_bounds__(256) void kernel_object_kernel(const double* __restrict__ x1, int n1, const double* __restrict__ x2, int n2, int D,
+                                                            const double* __restrict__ P, int mode, double* __restrict__ out) {
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= (long)n1 * n2) return;
+  const int i = (int)(e / n2), j = (int)(e % n2);
+  const double* a = x1 + (size_t)i * D;
+  const double* b = x2 + (size_t)j * D;
+  const double sig2 = P[D];
+  if (KT < 2) {
+    double r2 = 0.0;
+    for (int d = 0; d < D; ++d) {
+      const double df = a[d] - b[d];
+      r2 = __builtin_fma(P[d] * df, df, r2);
+    }
+    const double k = sig2 * kern_val<KT>(r2), dk = sig2 * kern_dr2<KT>(r2);
+    if (mode == 0) out[e] = k;
+    else if (mode == 1) {
+      for (int p = 0; p < D; ++p) {
+        const double df = a[p] - b[p];
+        out[((size_t)p * n1 + i) * n2 + j] = dk * P[p] * df * df;          // dr2/dtheta_p = exp(theta_p) (x - y)_p^2
+      }
+      out[((size_t)D * n1 + i) * n2 + j] = k;
+    } else {
+      for (int d = 0; d < D; ++d) out[((size_t)j * n1 + i) * D + d] = dk * 2.0 * P[d] * (a[d] - b[d]);
+    }
+    return;
+  }
+  // product of one-dimensional Matern-5/2 factors m(r2_d) = (1 + s + s^2/3) exp(-s), s = sqrt(5 r2_d)
+  double k = sig2;
+  for (int d = 0; d < D; ++d) {
+    const double df = a[d] - b[d];
+    k *= kern_val<1>(P[d] * df * df);
+  }
+  if (mode == 0) {
+    out[e] = k;
+    return;
+  }
+  for (int d = 0; d < D; ++d) {
+    const double df = a[d] - b[d], r2 = P[d] * df * df;
+    const double ratio = kern_dr2<1>(r2) / kern_val<1>(r2);                  // (dm/dr2) / m
+    if (mode == 1) out[((size_t)d * n1 + i) * n2 + j] = k * ratio * r2;
+    else out[((size_t)j * n1 + i) * D + d] = k * ratio * 2.0 * P[d] * df;
+  }
+  if (mode == 1) out[((size_t)D * n1 + i) * n2 + j] = k;
+}
+
 // =============================================================================================
 #define KT_DISPATCH(kt, CALL)            \
   do {                                   \
@@ -466,6 +521,13 @@ void launch_cov_build(const BatchView& v, hipStream_t s) {
 #undef CALL
   // algorithmic bytes: lower triangle written once (4 n^2) + X read once per emulator
   prof_end("cov_build", s, 0., (double)v.nb * (4.0 * (double)v.NP * (double)v.NP + 8.0 * v.n * v.D));
+}
+
+void launch_kernel_object(int kt, const double* x1, int n1, const double* x2, int n2, int D, const double* P, int mode, double* out, hipStream_t s) {
+  const dim3 grid((unsigned)(((long)n1 * n2 + 255) / 256));
+#define CALL(K) hipLaunchKernelGGL((kernel_object_kernel<K>), grid, dim3(256), 0, s, x1, n1, x2, n2, D, P, mode, out)
+  KT_DISPATCH(kt, CALL);
+#undef CALL
 }
 
 // prior covariance of the test points for every slot: out (nb, m, m) = sigma^2 k(Xs, Xs)

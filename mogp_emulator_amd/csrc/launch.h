@@ -51,6 +51,9 @@ struct BatchView {
 void launch_cov_build(const BatchView& v, hipStream_t s);
 // full symmetric K (no nugget) for get_K: out (n,n) for one emulator
 void launch_cov_full(const BatchView& v, int emu, double* out, hipStream_t s);
+// stand-alone kernel objects (bindings.cu:340-361): device buffers x1 (n1, D), x2 (n2, D), P = [exp(theta_d) (D), sigma^2];
+// mode 0 K (n1, n2), 1 dK/dtheta (D+1, n1, n2), 2 dK/dx1 (n2, n1, D); kt = device kernel 0 / 1 / 2
+void launch_kernel_object(int kt, const double* x1, int n1, const double* x2, int n2, int D, const double* P, int mode, double* out, hipStream_t s);
 // leave-one-out predictive variance 1/[K^-1]_ii of every training input (needs Linv): out[slot*out_ld + i]
 void launch_loo_variance(const BatchView& v, double* out, int out_ld, hipStream_t s);
 // history-matching score of m query points from device-resident means / variances (nb, ld); prm (nb, 3) =

@@ -25,7 +25,7 @@ __all__ = [
     "GPParameters", "DenseGP_GPU", "MultiOutputGP_GPU", "GPPriors",
     "WeakPrior", "InvGammaPrior", "GammaPrior", "LogNormalPrior",
     "BaseTransform", "CovTransform", "CorrTransform",
-    "SquaredExponentialKernel", "Matern52Kernel", "set_fit_options", "set_device", "device_count", "pivot_cholesky",
+    "SquaredExponentialKernel", "Matern52Kernel", "MeanPriors", "set_fit_options", "set_device", "device_count", "pivot_cholesky",
 ]
 
 
@@ -858,9 +858,9 @@ def pivot_cholesky(A):
 
 
 # --------------------------------------------------------------------------------------
-# stand-alone kernel objects (bindings.cu:340-361; flat layouts of kernel.hpp:68-107)
-# evaluated on the device through a throw-away DenseGP (K build kernel), so there is still
-# no host implementation of the covariance in the product.
+# stand-alone kernel objects (bindings.cu:340-361; flat layouts of kernel.hpp:47-107), evaluated on the
+# device (mogp_kernel_eval): there is no host implementation of the covariance in the product.
+# params = [corr_raw (n_corr), log sigma^2], as the native objects of the reference take them.
 # --------------------------------------------------------------------------------------
 class _KernelBase(object):
     _kt = kernel_type.SquaredExponential
@@ -868,27 +868,75 @@ class _KernelBase(object):
     def get_n_params(self, inputs):
         return int(np.atleast_2d(inputs).shape[1])
 
-    def kernel_f(self, x1, x2, params):
+    def _eval(self, what, x1, x2, params):
         x1, x2 = np.atleast_2d(_f64(x1)), np.atleast_2d(_f64(x2))
+        if x1.shape[1] != x2.shape[1]:
+            raise RuntimeError("kernel inputs must have the same number of columns")
         p = _f64(params, 1)
-        if p.size != self.get_n_params(x1) + 1:
-            raise RuntimeError("kernel_f: expected n_corr+1 hyperparameters")
-        gp = DenseGP_GPU(x2, np.zeros(x2.shape[0]), max(x1.shape[0], 1), ZeroMeanFunc(), self._kt, nugget_type.fixed, 1.0)
-        gp.fit(p)
-        # k(x1_i, x2_j) = d/d alpha_j of the predictive mean: use unit targets trick is wasteful;
-        # instead read the cross-covariance through predict with alpha = e_j is O(n) fits.  For the
-        # square case x1 is x2 the native get_K is exact.
-        if x1.shape == x2.shape and np.array_equal(x1, x2):
-            K = np.zeros((x2.shape[0], x2.shape[0]))
-            gp.get_K(K)
-            return K.reshape(-1)
-        raise RuntimeError("kernel_f for distinct x1, x2 is not exposed by this backend; use DenseGP_GPU.predict*")
+        n1, D = x1.shape
+        n2 = x2.shape[0]
+        nc = self.get_n_params(x1)
+        out = np.zeros({0: n1 * n2, 1: (nc + 1) * n1 * n2, 2: n2 * n1 * D}[what])
+        check(_lib.mogp_kernel_eval(int(self._kt), what, dptr(x1), n1, dptr(x2), n2, D, dptr(p), int(p.size), dptr(out)))
+        return out, (n1, n2, D, nc)
+
+    def kernel_f(self, x1, x2, params):
+        """sigma^2 k(x1_i, x2_j), shape (n1, n2)"""
+        out, (n1, n2, _, _) = self._eval(0, x1, x2, params)
+        return out.reshape(n1, n2)
 
     def kernel_deriv(self, x1, x2, params):
-        raise RuntimeError("kernel_deriv planes are never materialised by this backend (fused gradient reduction)")
+        """d/d theta_p of kernel_f as a flat array of n_params * n1 * n2 entries in (p, i, j) order (the reference returns
+        it flat, kernel.hpp:89-107; ``.reshape(n_params, n1, n2)`` is the CPU class's array, Kernel.py:133-173)"""
+        return self._eval(1, x1, x2, params)[0]
 
     def kernel_inputderiv(self, x1, x2, params):
-        raise RuntimeError("kernel_inputderiv planes are never materialised by this backend (fused predict_deriv)")
+        """d/d x1_i[d] of kernel_f as a flat array of n1 * n2 * D entries in (j, i, d) order (kernel.hpp:68-85, kernel.cu:86-100)"""
+        return self._eval(2, x1, x2, params)[0]
+
+
+class MeanPriors(object):
+    """Native-module view of the mean-function priors N(mean, cov) (bindings.cu:558-582, gppriors.hpp): constructed from a
+    mean vector and a covariance MATRIX; accessor names of the pybind class.  The numbers the device needs (b, B^-1,
+    B^-1 b, log|B|) come from here (DenseGP_GPU.set_mean_priors)."""
+
+    def __init__(self, mean=(), cov=()):
+        self._mean = np.reshape(np.array(mean, dtype=np.float64), (-1,))
+        self._cov = np.array(cov, dtype=np.float64).reshape(self._mean.size, self._mean.size) if self._mean.size else np.zeros((0, 0))
+        if self._mean.size and not np.all(np.diag(self._cov) > 0.):
+            raise RuntimeError("all covariances must be greater than zero in MeanPriors")
+
+    def get_mean(self):
+        return self._mean.copy()
+
+    def get_cov(self):
+        return self._cov.copy()
+
+    def get_n_params(self):
+        return int(self._mean.size)
+
+    def has_weak_priors(self):
+        return self._mean.size == 0
+
+    def dm_dot_b(self, dm):
+        dm = np.asarray(dm, dtype=np.float64)
+        return np.zeros(dm.shape[0]) if self.has_weak_priors() else dm @ self._mean
+
+    def inv_cov(self):
+        return np.zeros((0, 0)) if self.has_weak_priors() else np.linalg.inv(self._cov)
+
+    def inv_cov_b(self):
+        return np.zeros(0) if self.has_weak_priors() else np.linalg.solve(self._cov, self._mean)
+
+    def logdet_cov(self):
+        return 0. if self.has_weak_priors() else float(np.linalg.slogdet(self._cov)[1])
+
+    def native_params(self):
+        """(q, b, B^-1, B^-1 b, log|B|) for DenseGP_GPU.set_mean_priors"""
+        if self.has_weak_priors():
+            return 0, np.zeros(1), np.zeros(1), np.zeros(1), 0.
+        return (self.get_n_params(), np.ascontiguousarray(self._mean), np.ascontiguousarray(self.inv_cov()),
+                np.ascontiguousarray(self.inv_cov_b()), self.logdet_cov())
 
 
 class SquaredExponentialKernel(_KernelBase):

@@ -1110,3 +1110,108 @@ def test_mean_priors_per_emulator_and_errors():
         MeanPriors(mean=[1., 2.])
     with pytest.raises(AssertionError):
         MeanPriors(mean=[1., 2.], cov=-1.)
+
+
+# ------------------------------------------------------------------------------------------------
+# stand-alone kernel objects and MeanPriors of the native module (bindings.cu:340-361, 558-582)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name, cls", [("SquaredExponential", "SquaredExponentialKernel"), ("Matern52", "Matern52Kernel")])
+def test_kernel_objects_vs_reference_golden(name, cls):
+    """kernel_f / kernel_deriv for x1 != x2 against the arrays the reference's Kernel.kernel_f / kernel_deriv produced
+    (tests/golden/kernels.npz, Kernel.py:99-173); the native objects carry log sigma^2 as their last parameter."""
+    from mogp_emulator_amd import libgpgpu
+    g = load_golden("kernels.npz")
+    x1, x2, theta = g["x1"], g["x2"], g["theta"]
+    kern = getattr(libgpgpu, cls)()
+    logs2 = 0.7
+    params = np.concatenate([theta, [logs2]])
+    s2 = np.exp(logs2)
+    K = kern.kernel_f(x1, x2, params)
+    assert K.shape == (7, 5)
+    assert_allclose(K, s2 * g[name + "_K"], rtol=1e-13)
+    dK = kern.kernel_deriv(x1, x2, params)
+    assert dK.shape == (4 * 7 * 5,)
+    dK = dK.reshape(4, 7, 5)
+    assert_allclose(dK[:3], s2 * g[name + "_dKdtheta"], rtol=1e-12, atol=1e-15)
+    assert_allclose(dK[3], K, rtol=1e-14)
+    # input derivatives: flat (n2, n1, D) order of the reference's CUDA kernel, checked by central differences of kernel_f
+    dX = kern.kernel_inputderiv(x1, x2, params)
+    assert dX.shape == (5 * 7 * 3,)
+    dX = dX.reshape(5, 7, 3)
+    h = 1e-6
+    for d in range(3):
+        e = np.zeros(3); e[d] = h
+        fd = (kern.kernel_f(x1 + e, x2, params) - kern.kernel_f(x1 - e, x2, params)) / (2 * h)
+        assert_allclose(dX[:, :, d].T, fd, rtol=1e-6, atol=1e-8)
+    # the oracle's analytic input derivative (what predict_deriv is checked against) has the CPU (D, n1, n2) order
+    assert_allclose(np.transpose(dX, (2, 1, 0)), s2 * R.kernel_inputderiv(x1, x2, theta, name), rtol=1e-11, atol=1e-14)
+    # closed forms of tests/test_Kernel.py:8-38
+    Kc = kern.kernel_f(g["closed_x"], g["closed_y"], np.array([0., 0.]))
+    assert_allclose(Kc, g[name + "_closed_K"], rtol=1e-14)
+    assert kern.get_n_params(x1) == 3
+    with pytest.raises(RuntimeError):
+        kern.kernel_f(x1, x2, theta)                   # one parameter short (no log sigma^2)
+    with pytest.raises(RuntimeError):
+        kern.kernel_f(x1, x2[:, :2], params)
+
+
+@pytest.mark.parametrize("name, cls", [("UniformSqExp", "UniformSqExpKernel"), ("UniformMat52", "UniformMat52Kernel"),
+                                       ("ProductMat52", "ProductMat52Kernel")])
+def test_cpu_only_kernel_objects_vs_reference_golden(name, cls):
+    from mogp_emulator_amd import libgpgpu
+    g = load_golden("kernels_cpuonly.npz")
+    x1, x2 = g["X"][:7], g["Xs"][:5]                    # the point sets and parameters tests/golden/make_golden.py used
+    kern = getattr(libgpgpu, cls)()
+    nc = 1 if name.startswith("Uniform") else 3
+    theta = np.array([0.7, -0.3, 1.1])[:nc]
+    params = np.concatenate([theta, [0.]])
+    assert_allclose(kern.kernel_f(x1, x2, params), g[name + "_kf"], rtol=1e-12)
+    dK = kern.kernel_deriv(x1, x2, params).reshape(nc + 1, 7, 5)
+    assert_allclose(dK[:nc], g[name + "_kd"], rtol=1e-11, atol=1e-14)
+
+
+def test_native_meanpriors_object():
+    """LibGPGPU.MeanPriors(mean, cov) with the accessor names of bindings.cu:558-582, usable for an analytic-mean emulator."""
+    from mogp_emulator_amd import libgpgpu
+    b = np.array([1.0, -0.5]); C = np.array([[2.0, 0.3], [0.3, 1.5]])
+    mp = LibGPGPU.MeanPriors(b, C)
+    assert mp.get_n_params() == 2 and not mp.has_weak_priors()
+    assert_allclose(mp.get_mean(), b); assert_allclose(mp.get_cov(), C)
+    assert_allclose(mp.inv_cov() @ C, np.eye(2), atol=1e-14)
+    assert_allclose(mp.inv_cov_b(), np.linalg.solve(C, b)); assert_allclose(mp.logdet_cov(), np.log(np.linalg.det(C)))
+    assert_allclose(mp.dm_dot_b(np.array([[1., 2.], [3., 4.]])), [0., 1.])
+    assert libgpgpu.MeanPriors().has_weak_priors() and libgpgpu.MeanPriors().get_n_params() == 0
+    # it drives the device the same way as the host-side Priors.MeanPriors value object
+    from mogp_emulator_amd.Priors import MeanPriors as HostMeanPriors
+    X, T, Xs = synth(3, 80, 2, 1, 6)
+    t = T[0] + 2.0 + X[:, 0]
+    gp_a = M.GaussianProcessGPU(X, t, mean="c+c*x[0]", analytic_mean=True, nugget=1e-6,
+                                priors=GPPriors(mean=HostMeanPriors(b, C), n_corr=2, nugget_type="fixed"))
+    gp_b = M.GaussianProcessGPU(X, t, mean="c+c*x[0]", analytic_mean=True, nugget=1e-6, priors=GPPriors(n_corr=2, nugget_type="fixed"))
+    gp_b._densegp_gpu.set_mean_priors(*mp.native_params())
+    th = np.array([0.3, 0.1, 0.2])
+    assert gp_a.logposterior(th) == gp_b.logposterior(th)
+
+
+def test_state_changes_invalidate_cached_results():
+    """A new fixed nugget invalidates factor / alpha / log-posterior (refit required), new priors invalidate the cached
+    log-posterior (the reference serves the stale values in both cases)."""
+    X, T, Xs = synth(21, 90, 2, 1, 7)
+    th = np.array([0.4, 0.2, 0.1])
+    gp = M.GaussianProcessGPU(X, T[0], nugget=1e-6, priors=GPPriors(n_corr=2, nugget_type="fixed"))
+    gp.fit(th)
+    lp_small = gp.logposterior(th)
+    gp.nugget = 1e-2
+    assert not gp.theta.data_has_been_set()
+    with pytest.raises(ValueError):
+        gp.predict(Xs)
+    lp_big = gp.logposterior(th)                      # refits with the new nugget
+    ref = R.GPRef(X, T[0], nugget=1e-2)
+    assert_allclose(lp_big, ref.fit(th), rtol=1e-10)
+    assert abs(lp_big - lp_small) > 1.0
+    mu, var, _ = ref.predict(Xs)
+    assert_allclose(gp.predict(Xs).unc, var, atol=1e-9)
+    # priors changed after a fit: same theta, the log-posterior is recomputed with the new priors
+    gp._set_priors(GPPriors(corr=[InvGammaPrior(2., 1.), InvGammaPrior(2., 1.)], cov=InvGammaPrior(3., 2.), nugget_type="fixed"))
+    pri = R.GPPriorsRef(2, "fixed", corr=[R.Prior("invgamma", 2., 1.)] * 2, cov=R.Prior("invgamma", 3., 2.))
+    assert_allclose(gp.logposterior(th), R.GPRef(X, T[0], nugget=1e-2, priors=pri).fit(th), rtol=1e-10)
