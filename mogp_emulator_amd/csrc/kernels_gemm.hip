@@ -183,13 +183,15 @@ __global__ __launch_bounds__(256, 2) void update_kernel(BatchView v, int c0, int
     while (ti * (ti + 1) / 2 > tile) --ti;
     while ((ti + 1) * (ti + 2) / 2 <= tile) ++ti;
     tj = tile - ti * (ti + 1) / 2;
-  } else if (tile < nt) {
+  } else if (ntiles == nt) {
     ti = tile;
     tj = 0;
   } else {
-    // pair launch (ntiles = 2 nt - 1): second tile column, rows from the diagonal tile of that column
-    ti = tile - nt + 1;
-    tj = 1;
+    // pair launch (ntiles = 2 nt - 1): tile 0 = (0, 0), then the two tiles of a row tile next to each other --
+    // (ti, 0) and (ti, 1) read the same 64 x K row panel, and as neighbours in dispatch order (same XCD) the second one
+    // finds it in L2 instead of fetching it again (the column-by-column order had nt - 1 other tiles in between)
+    ti = (tile + 1) >> 1;
+    tj = (tile > 0 && (tile & 1) == 0) ? 1 : 0;
   }
   const int emu = slot_to_emu(v.idx, z);
   double* A = v.A + (size_t)emu * v.MS;
