@@ -131,6 +131,8 @@ class Engine {
   void ensure_predict_scratch(int nb, int MC);
 
   double *dX = nullptr, *dP = nullptr, *dT = nullptr, *dA = nullptr, *dLinv = nullptr, *dKinv = nullptr, *dAlpha = nullptr;
+  int* dBsFlags = nullptr;       // hand-off flags of the one-launch back substitution (B x ceil(n/128)), compared with bs_epoch
+  int bs_epoch = 0;
   double *dRes = nullptr, *hRes = nullptr;   // per emulator [log-det, status, Gram matrix]: device buffer and its pinned host mirror
   double *dGradOut = nullptr, *dGradPartial = nullptr;
   int *dInfo = nullptr, *dIdx = nullptr;

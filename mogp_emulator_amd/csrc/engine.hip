@@ -196,6 +196,7 @@ Engine::~Engine() {
                   (void*)dPerm, (void*)dRank})
     if (p) hipFree(p);
   if (hRes) hipHostFree(hRes);
+  if (dBsFlags) hipFree(dBsFlags);
   for (auto& kv : w2) hipFree(kv.second);
   for (auto st : gstreams) hipStreamDestroy(st);
   if (evReady) hipEventDestroy(evReady);
@@ -620,7 +621,6 @@ void Engine::eval(const std::vector<int>& ids, const std::vector<const double*>&
     for (int i : list) gp[i].factored = true;                // provisional (ensure_linv checks it)
     upload_idx(list);
     BatchView v = view((int)list.size());
-    launch_logdet(v, dInfo, dRes, stream);
     if (want_grad) {
       // gradient path: L^-1 is needed anyway, so K^-1 [t, H] = L^-T Y is one fully parallel gemv with it
       ensure_linv(list);
@@ -628,8 +628,19 @@ void Engine::eval(const std::vector<int>& ids, const std::vector<const double*>&
       v = view((int)list.size());
       launch_alpha_from_linv(v, stream);
     } else {
-      launch_backsolve(v, stream);
+      // single right-hand side: the one-launch chain (MOGP_BACKSOLVE=1 / 0: per-block launches / one workgroup per emulator)
+      static const bool chain = [] { const char* e = getenv("MOGP_BACKSOLVE"); return !e; }();
+      if (chain && R == 1) {
+        if (!dBsFlags) {
+          dBsFlags = dalloc<int>((size_t)B * ((n + 127) / 128));
+          HIPCK(hipMemsetAsync(dBsFlags, 0, (size_t)B * ((n + 127) / 128) * sizeof(int), stream));
+        }
+        launch_backsolve_chain(v, dBsFlags, ++bs_epoch, dInfo, stream);
+      } else {
+        launch_backsolve(v, stream);
+      }
     }
+    launch_logdet(view((int)list.size()), dInfo, dRes, stream);      // (after the solves: it also collects the status words)
     // status words, log-determinants and Gram matrices come back in ONE copy into pinned host memory
     HIPCK(hipMemcpyAsync(hRes, dRes, (size_t)B * RES_STRIDE * sizeof(double), hipMemcpyDeviceToHost, stream));
     HIPCK(hipStreamSynchronize(stream));
