@@ -485,12 +485,9 @@ void Engine::factorize_blocked(const std::vector<int>& ids, std::vector<int>& in
   }
   if (schedule == 0) {
     // Two independent emulator groups on separate streams (MOGP_GROUPS, default 2): while one group runs its
-    // latency-bound panel kernels (potf2 / trsm: few workgroups) the other group's MFMA update fills the
-    // machine.  Measured on MI355X / ROCm 7.2 at 64 x n=2000: 1 group 6.58 ms, 2 groups 6.23 ms, 3 groups
-    // 8.3 ms, 4 groups 14.2 ms, 8 groups 19.9 ms -- identical when the whole multi-stream sequence is
-    // replayed from a captured hipGraph (MOGP_GRAPH=1: 6.51 / 6.20 / 14.4 / 20.4 ms), so the collapse beyond
-    // two streams is on the device side (kernel-boundary cache maintenance of one queue hits the kernels
-    // of the others), not host launch overhead.  Graph replay is kept as an option, off by default.
+    // latency-bound panel kernels (diagonal block / panel solve: few workgroups) the other group's MFMA update fills the
+    // machine.  More than two streams collapse (round 1, 64 x n=2000: 1 group 6.58 ms, 2 groups 6.23 ms, 3 groups 8.3 ms,
+    // 4 groups 14.2 ms -- the same when replayed from a captured hipGraph, so it is not host launch overhead).
     static const long tail_threshold = [] { const char* e = getenv("MOGP_TAIL"); return e ? atol(e) : 1100L; }();
     static const int want_groups = [] { const char* e = getenv("MOGP_GROUPS"); return e ? std::max(1, atoi(e)) : 2; }();
     const int G = ovr.single_stream ? 1 : std::min(want_groups, std::max(1, nb / 8));
