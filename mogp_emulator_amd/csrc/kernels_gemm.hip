@@ -21,6 +21,7 @@
 // predictive-variance gemm + batched dot (densegp_gpu.hpp:374-396).
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 #include "launch.h"
 #include "trsm_dev.h"
 
@@ -367,11 +368,24 @@ struct WCfg {
   static_assert(CHA >= 1 && CHB >= 1, "operand tile smaller than one chunk per thread");
 };
 
-template <int BM, int BN, int WR, int WC>
+// TRIA: the A operand is a row tile of a LOWER-TRIANGULAR matrix whose last 128 columns of the k range are its diagonal
+// block (nk_full = 16-deep k-steps before it), and rows >= a_rows of the tile are padding.  The 16-row MFMA sub-tiles are
+// then dealt to the WR wave rows round-robin (sub-tile a = i * WR + wr: every wave owns sub-tiles from the top and the
+// bottom of the tile) and a wave skips what is structurally zero:
+//   * step kd of the diagonal block only has non-zeros in sub-tiles a >= kd  (36 of the 64 (sub-tile, step) pairs);
+//   * sub-tiles that start at or below row a_rows are padding.
+// The skipped products are exact zeros.  Control flow: the k loop is cut into consecutive loops, one per set of active
+// sub-tiles [S, E) -- each one is the dense straight-line step restricted to those sub-tiles, the accumulators of the
+// others are simply not touched -- followed by a loop that only moves the wave's share of the operand tiles.  (A branch
+// around MFMA groups inside one loop costs more in register copies and exposed LDS latency than the skipped MFMAs save.)
+// Callers must not depend on the row -> accumulator map.
+template <int BM, int BN, int WR, int WC, bool TRIA = false>
 __device__ __forceinline__ void mainloop_w(const double* __restrict__ Ag, int lda, const double* __restrict__ Bg, int ldb, int nk,
-                                           v4d (&acc)[WCfg<BM, BN, WR, WC>::TI][WCfg<BM, BN, WR, WC>::TJ], double* smem) {
+                                           v4d (&acc)[WCfg<BM, BN, WR, WC>::TI][WCfg<BM, BN, WR, WC>::TJ], double* smem,
+                                           int nk_full = 0, int a_rows = BM) {
   using C = WCfg<BM, BN, WR, WC>;
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = TRIA ? __builtin_amdgcn_readfirstlane(t >> 6) : (t >> 6);
   const int wr = wave / WC, wc = wave % WC;
   const int fr = lane & 15, fk = lane >> 4;
 #pragma unroll
@@ -410,7 +424,9 @@ __device__ __forceinline__ void mainloop_w(const double* __restrict__ Ag, int ld
   loadB();
   store(smem, smem + C::OPA);
   __syncthreads();
-  for (int kt = 0; kt < nk; ++kt) {
+  // one k-step with the sub-tiles [S, E) of this wave
+  auto step = [&](int kt, auto S_, auto E_) {
+    constexpr int S = decltype(S_)::value, E = decltype(E_)::value;
     const double* sA = smem + (kt & 1) * (C::OPA + C::OPB);
     const double* sB = sA + C::OPA;
     const bool more = (kt + 1 < nk);
@@ -420,25 +436,51 @@ __device__ __forceinline__ void mainloop_w(const double* __restrict__ Ag, int ld
       loadA();
       loadB();
     }
+    if (S < E) {
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      double a[C::TI], b[C::TJ];
-      const int k = kk * 4 + fk;
+      for (int kk = 0; kk < 4; ++kk) {
+        double a[C::TI], b[C::TJ];
+        const int k = kk * 4 + fk;
 #pragma unroll
-      for (int i = 0; i < C::TI; ++i) a[i] = sA[(wr * 16 * C::TI + i * 16 + fr) * LDK + k];
+        for (int i = S; i < E; ++i) a[i] = sA[((TRIA ? i * WR + wr : wr * C::TI + i) * 16 + fr) * LDK + k];
 #pragma unroll
-      for (int j = 0; j < C::TJ; ++j) b[j] = sB[(wc * 16 * C::TJ + j * 16 + fr) * LDK + k];
+        for (int j = 0; j < C::TJ; ++j) b[j] = sB[(wc * 16 * C::TJ + j * 16 + fr) * LDK + k];
 #pragma unroll
-      for (int i = 0; i < C::TI; ++i)
+        for (int i = S; i < E; ++i)
 #pragma unroll
-        for (int j = 0; j < C::TJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < C::TJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+      }
     }
     if (more) {
       double* dA = smem + ((kt + 1) & 1) * (C::OPA + C::OPB);
       store(dA, dA + C::OPA);
     }
     __syncthreads();
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using IT = std::integral_constant<int, C::TI>;
+  int kt = 0;
+  if (!TRIA) {
+    for (; kt < nk; ++kt) step(kt, I0(), IT());
+    return;
   }
+  static_assert(!TRIA || C::TI == 4, "the phase dispatch below is written for four sub-tiles per wave");
+  // sub-tile i (a = i WR + wr) has non-zeros up to step a of the diagonal block: phase S lasts while sub-tile S is active
+  auto phases = [&](auto E_) {
+    constexpr int E = decltype(E_)::value;
+    if (E > 0) for (const int end = min(nk, nk_full + 0 * WR + wr + 1); kt < end; ++kt) step(kt, std::integral_constant<int, 0>(), E_);
+    if (E > 1) for (const int end = min(nk, nk_full + 1 * WR + wr + 1); kt < end; ++kt) step(kt, std::integral_constant<int, 1>(), E_);
+    if (E > 2) for (const int end = min(nk, nk_full + 2 * WR + wr + 1); kt < end; ++kt) step(kt, std::integral_constant<int, 2>(), E_);
+    if (E > 3) for (const int end = min(nk, nk_full + 3 * WR + wr + 1); kt < end; ++kt) step(kt, std::integral_constant<int, 3>(), E_);
+  };
+  int n_act = 0;     // sub-tiles of this wave that contain real rows
+#pragma unroll
+  for (int i = 0; i < C::TI; ++i) n_act += ((i * WR + wr) * 16 < a_rows) ? 1 : 0;
+  if (n_act == 4) phases(std::integral_constant<int, 4>());
+  else if (n_act == 3) phases(std::integral_constant<int, 3>());
+  else if (n_act == 2) phases(std::integral_constant<int, 2>());
+  else if (n_act == 1) phases(std::integral_constant<int, 1>());
+  for (; kt < nk; ++kt) step(kt, I0(), I0());
 }
 
 // f(row_in_tile, col_in_tile, value) over the accumulator fragment of mainloop_w
@@ -483,7 +525,7 @@ __global__ __launch_bounds__(512, 4) void update_tri8_kernel(BatchView v, int c0
 // VGPRs -> four waves per SIMD instead of the two of the 2 x 2 / 128-accumulator configuration):
 // 59.2 -> 61.1 TFLOP/s on 64 x n=2000 x m=10^4 (4 x 2 waves 60.7, 4 x 4 waves 57.3).
 // ---------------------------------------------------------------------------------------------
-template <int WR, int WC>
+template <int WR, int WC, bool TRI>
 __global__ __launch_bounds__(64 * WR * WC, (WR * WC >= 8 ? 4 : 2)) void predict_var_w_kernel(
     BatchView v, const double* __restrict__ Ks, int MP, int nti, int ntj, double* __restrict__ partial, int lgc) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -502,7 +544,7 @@ __global__ __launch_bounds__(64 * WR * WC, (WR * WC >= 8 ? 4 : 2)) void predict_
   const double* Li = v.Linv + (size_t)emu * v.MS;
   const double* K = Ks + (size_t)z * MP * ld;
   const int j0 = tj * 128;
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int t = threadIdx.x, lane = t & 63, wave = TRI ? __builtin_amdgcn_readfirstlane(t >> 6) : (t >> 6);
   const int wr = wave / WC, wc = wave % WC;
   const int ti_long = nti - 1 - pr, ti_short = pr;
   for (int pass = 0; pass < 2; ++pass) {
@@ -510,7 +552,9 @@ __global__ __launch_bounds__(64 * WR * WC, (WR * WC >= 8 ? 4 : 2)) void predict_
     const int ti = pass == 0 ? ti_long : ti_short;
     const int i0 = ti * 128;
     v4d acc[C::TI][C::TJ];
-    mainloop_w<128, 128, WR, WC>(Li + (size_t)i0 * ld, ld, K + (size_t)j0 * ld, ld, (i0 + 128) / BK, acc, smem);
+    // L^-1 is lower triangular and its rows >= n are padding: TRI skips the structurally zero steps (mainloop_w)
+    mainloop_w<128, 128, WR, WC, TRI>(Li + (size_t)i0 * ld, ld, K + (size_t)j0 * ld, ld,
+                                           TRI ? min(i0 + 128, (v.n + 15) & ~15) / BK : (i0 + 128) / BK, acc, smem, i0 / BK, v.n - i0);
     // column sums of squares over the tile's 128 rows: red[wr][128]
     double* red = smem;
 #pragma unroll
@@ -669,7 +713,11 @@ void launch_predict_var(const BatchView& v, const double* Ks, int m, int MP, dou
   if (waves == 8) {
     const int SC = 1 << lgc, SR = 64 >> lgc;
     const int nsup = (((nti + 1) / 2 + SR - 1) / SR) * ((ntj + SC - 1) / SC) * 64;
-    hipLaunchKernelGGL((predict_var_w_kernel<2, 4>), dim3(padded_grid(v.nb, nsup)), dim3(512), smem_bytes<4>(), s, v, Ks, MP, nti, ntj, partial, lgc);
+    static const int tri = [] { const char* e = getenv("MOGP_PV_TRI"); return e ? atoi(e) : 1; }();
+#define PV_LAUNCH(WR_, WC_, TRI_) hipLaunchKernelGGL((predict_var_w_kernel<WR_, WC_, TRI_>), dim3(padded_grid(v.nb, nsup)), dim3(512), smem_bytes<4>(), s, v, Ks, MP, nti, ntj, partial, lgc)
+    if (tri) PV_LAUNCH(2, 4, true);
+    else PV_LAUNCH(2, 4, false);
+#undef PV_LAUNCH
   } else {
     const int nsup = (((nti + 1) / 2 + 3) / 4) * ((ntj + 15) / 16) * 64;
     hipLaunchKernelGGL(predict_var_kernel<false>, dim3(padded_grid(v.nb, nsup)), dim3(256), smem_bytes<4>(), s, v, Ks, MP, nti, ntj, partial);
