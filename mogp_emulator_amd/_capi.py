@@ -12,7 +12,8 @@ from ctypes import POINTER, c_char_p, c_double, c_int, c_longlong, c_uint, c_ulo
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmogp_hip.so")
+# MOGP_LIB_PATH: another build of the same library (A/B comparisons of kernel changes, tools/ab.py)
+LIB_PATH = os.environ.get("MOGP_LIB_PATH") or os.path.join(_HERE, "libmogp_hip.so")
 
 _lib = None
 

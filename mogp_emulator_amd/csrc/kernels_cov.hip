@@ -173,13 +173,15 @@ __global__ __launch_bounds__(256) void cov_full_kernel(BatchView v, int emu, con
 // predictive mean fused: mean[z][m] = sum_j Ks[m][j] alpha_j.  One workgroup per 64 test points,
 // sweeping all training-point tiles, so the mean needs no atomics and is deterministic.
 // ---------------------------------------------------------------------------------------------
-template <int KT>
+// RB = compile-time bound of the right-hand-side rows: 1 for the plain path (8 instead of 64 accumulator registers,
+// five instead of three waves per SIMD), RMAX with an analytic mean.
+template <int KT, int RB>
 __global__ __launch_bounds__(256) void cross_cov_mean_kernel(BatchView v, const double* __restrict__ Xs, int m, int MP,
                                                            double* __restrict__ Ks, double* __restrict__ mean, int mean_ld) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int z = blockIdx.y;
   const int emu = slot_emu2(v.idx, z);
-  const int n = v.n, D = v.D, ld = v.LD, R = v.R;
+  const int n = v.n, D = v.D, ld = v.LD, R = (RB == 1) ? 1 : v.R;
   const int i0 = blockIdx.x * 64;
   const double* P = v.P + (size_t)emu * v.PS;
   const double* alpha0 = v.alpha + (size_t)emu * v.RA * ld;   // row 0: K^-1 (t - H beta)
@@ -191,9 +193,9 @@ __global__ __launch_bounds__(256) void cross_cov_mean_kernel(BatchView v, const 
   stage_rows(Xs, m, D, i0, si);
   const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
   const double sig2 = P[D];
-  double macc[RMAX][4];
+  double macc[RB][4];
 #pragma unroll
-  for (int c = 0; c < RMAX; ++c)
+  for (int c = 0; c < RB; ++c)
 #pragma unroll
     for (int a = 0; a < 4; ++a) macc[c][a] = 0.;
   double* Kz = Ks ? Ks + (size_t)z * MP * ld : nullptr;
@@ -224,7 +226,7 @@ __global__ __launch_bounds__(256) void cross_cov_mean_kernel(BatchView v, const 
         out[b] = x;
         if (j0 < n) {
 #pragma unroll
-          for (int c = 0; c < RMAX; ++c)
+          for (int c = 0; c < RB; ++c)
             if (c < R) macc[c][a] = __builtin_fma(x, sa[c * 64 + 4 * tx + b], macc[c][a]);
         }
       }
@@ -236,7 +238,7 @@ __global__ __launch_bounds__(256) void cross_cov_mean_kernel(BatchView v, const 
     }
   }
 #pragma unroll
-  for (int c = 0; c < RMAX; ++c) {
+  for (int c = 0; c < RB; ++c) {
     if (c < R) {
       __syncthreads();
 #pragma unroll
@@ -550,7 +552,11 @@ void launch_cov_full(const BatchView& v, int emu, double* out, hipStream_t s) {
 void launch_cross_cov_mean(const BatchView& v, const double* Xs, int m, int MP, double* Ks, double* mean, int mean_ld, hipStream_t s) {
   const size_t sm = (size_t)(128 * v.D + RMAX * 64 + 64 * 17) * sizeof(double);
   prof_begin("cross_cov", s);
-#define CALL(K) hipLaunchKernelGGL((cross_cov_mean_kernel<K>), dim3(MP / 64, v.nb), dim3(256), sm, s, v, Xs, m, MP, Ks, mean, mean_ld)
+#define CALL(K)                                                                                                                      \
+  do {                                                                                                                               \
+    if (v.R == 1) hipLaunchKernelGGL((cross_cov_mean_kernel<K, 1>), dim3(MP / 64, v.nb), dim3(256), sm, s, v, Xs, m, MP, Ks, mean, mean_ld);   \
+    else hipLaunchKernelGGL((cross_cov_mean_kernel<K, RMAX>), dim3(MP / 64, v.nb), dim3(256), sm, s, v, Xs, m, MP, Ks, mean, mean_ld);       \
+  } while (0)
   KT_DISPATCH(v.kernel_type, CALL);
 #undef CALL
   prof_end("cross_cov", s, 0., (double)v.nb * (8.0 * MP * (double)v.NP + 8.0 * ((double)m + v.n) * v.D));
