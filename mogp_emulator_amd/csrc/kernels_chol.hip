@@ -498,12 +498,19 @@ __global__ __launch_bounds__(256) void implausibility_kernel(int nb, const doubl
 // treat diagonal tiles of Linv as dense.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void trtri_leaf_kernel(BatchView v, const double* __restrict__ Lmat) {
+  // the 64 x 64 block goes through LDS: coalesced 512-byte rows in, and every L[c][p] of the substitution is then ONE
+  // broadcast LDS read for the whole wave (as scalar loads -- 2016 s_load per wave, returned out of order -- the kernel
+  // took 290 us for 64 emulators x n = 2000)
+  __shared__ double Ls[64 * 65];
   const int emu = __builtin_amdgcn_readfirstlane(slot_emu(v.idx, blockIdx.y));
   const int ld = v.LD;
   const int d0 = blockIdx.x * 64;
-  const double* __restrict__ L = Lmat + (size_t)emu * v.MS + (size_t)d0 * ld + d0;   // wave-uniform: scalar loads
+  const double* __restrict__ L = Lmat + (size_t)emu * v.MS + (size_t)d0 * ld + d0;
   double* Li = v.Linv + (size_t)emu * v.MS;
   const int t = threadIdx.x;
+#pragma unroll 8
+  for (int r = 0; r < 64; ++r) Ls[r * 65 + t] = L[(size_t)r * ld + t];
+  __builtin_amdgcn_wave_barrier();
   // lane t computes column t of the inverse: L z = e_t, row-oriented with 4 partial sums
   double x[64];
 #pragma unroll
@@ -511,13 +518,13 @@ __global__ __launch_bounds__(64) void trtri_leaf_kernel(BatchView v, const doubl
     double s0 = (c == t) ? 1.0 : 0.0, s1 = 0., s2 = 0., s3 = 0.;
 #pragma unroll
     for (int p = 0; p < c; ++p) {
-      const double lv = L[(size_t)c * ld + p];
+      const double lv = Ls[c * 65 + p];
       if ((p & 3) == 0) s0 = __builtin_fma(-x[p], lv, s0);
       else if ((p & 3) == 1) s1 = __builtin_fma(-x[p], lv, s1);
       else if ((p & 3) == 2) s2 = __builtin_fma(-x[p], lv, s2);
       else s3 = __builtin_fma(-x[p], lv, s3);
     }
-    x[c] = ((s0 + s1) + (s2 + s3)) / L[(size_t)c * ld + c];
+    x[c] = ((s0 + s1) + (s2 + s3)) / Ls[c * 65 + c];
   }
 #pragma unroll
   for (int i = 0; i < 64; ++i) Li[(size_t)(d0 + i) * ld + d0 + t] = x[i];
