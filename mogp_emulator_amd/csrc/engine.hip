@@ -1008,7 +1008,7 @@ void Engine::predict(const std::vector<int>& ids, const double* Xs, int m, bool 
     ld = m;
   }
   const int MPtot = roundup(m, 128);
-  static const double budget = [] { const char* e = getenv("MOGP_KS_BUDGET_GB"); return (e ? atof(e) : 6.0) * 1e9; }();   // cross-covariance chunk
+  static const double budget = [] { const char* e = getenv("MOGP_KS_BUDGET_GB"); return (e ? atof(e) : 12.0) * 1e9; }();  // cross-covariance chunk (12 GB: one chunk for 64 x n=2000 x m=10^4)
   long MC = (long)(budget / ((double)nb * LD * 8.0)) / 128 * 128;
   MC = std::max<long>(128, std::min<long>(MC, MPtot));
   if (vars) ensure_predict_scratch(nb, (int)MC);
