@@ -213,6 +213,12 @@ __global__ __launch_bounds__(256) void trsm128_kernel(BatchView v, int c0, int r
   trsm128_dev(v, c0, r0, Lpack128 + (size_t)emu * PACK128_STRIDE, emu, blockIdx.x, smem);
 }
 
+__global__ __launch_bounds__(256, 3) void trsm128_lds_kernel(BatchView v, int c0, int r0, const double* __restrict__ Lpack128) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int emu = slot_to_emu(v.idx, blockIdx.y);
+  trsm128_lds_dev(v, c0, r0, Lpack128 + (size_t)emu * PACK128_STRIDE, emu, blockIdx.x, smem);
+}
+
 // ---------------------------------------------------------------------------------------------
 // trtri merge, level h:  node q covers [base, base+2h), base = q*2h
 //   STEP 0:  T     = L21 * Linv11          (T kept in scratch at the position of block 21)
@@ -730,6 +736,9 @@ void launch_trsm128(const BatchView& v, int c0, const double* Lpack128, hipStrea
   const int rows = v.NP - c0 - 128;
   if (rows <= 0) return;
   prof_begin("chol_trsm128", s);
+  static const int lds_mode = [] { const char* e = getenv("MOGP_TRSM_LDS"); return e ? atoi(e) : 1; }();   // 0: operands through L1 (trsm128_dev)
+  if (lds_mode) hipLaunchKernelGGL(trsm128_lds_kernel, dim3(rows / 64, v.nb), dim3(256), TRSM128L_LDS * sizeof(double), s, v, c0, c0 + 128, Lpack128);
+  else
   hipLaunchKernelGGL(trsm128_kernel, dim3(rows / 64, v.nb), dim3(256), 4 * TRSM128_STAGE * sizeof(double), s, v, c0, c0 + 128, Lpack128);
   // rows x 128 triangular solve: rows * 128^2 flops; the panel is read and written once
   prof_end("chol_trsm128", s, (double)v.nb * rows * 128.0 * 128.0, (double)v.nb * 2.0 * 8.0 * rows * 128.0);

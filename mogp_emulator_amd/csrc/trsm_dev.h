@@ -60,4 +60,100 @@ __device__ __forceinline__ void trsm128_dev(const BatchView& v, int c0, int r0, 
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The same solve with the operands of the diagonal block coming out of LDS.  In trsm128_dev every MFMA fetches its A
+// operand (512 bytes of the pack) through the vector L1: 144 loads = 74 KB per 16-row slab, and with eight waves per CU
+// that is the L1's whole 64 B/clk -- the kernel is bound by operand traffic, not by the panel bytes (3.1 TB/s) or the
+// matrix pipe.  Here the four waves of a workgroup walk the eight 16-column blocks in step and share ONE image of what
+// step b needs -- row block b of L (16 x 16b entries, as [column][row]) and inv(L_bb) -- double-buffered and requested
+// a step ahead; the slab is not held in registers either: block b of it is fetched when step b needs it (two 16-byte
+// loads per lane through a 2.3 KB wave-private transposing stage) and X_b leaves the same way.  51 KB of LDS and ~130
+// VGPRs per workgroup instead of 66.5 KB / 176: three workgroups per CU instead of two.
+// ---------------------------------------------------------------------------------------------
+constexpr int TL_PK = 112 * 16 + 256;                 // row block image: A operands of the blocks a < b, then inv(L_bb)
+constexpr int TL_TS = 16 * 18;                        // one 16 x 16 block of the slab, row stride 18
+constexpr int TRSM128L_LDS = 2 * TL_PK + 4 * 2 * TL_TS;
+
+__device__ __forceinline__ void trsm128_lds_dev(const BatchView& v, int c0, int r0, const double* __restrict__ pk, int emu, int rowblock,
+                                                double* lds) {
+  const int ld = v.LD;
+  const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int g = lane >> 4, i = lane & 15;
+  double* slab = v.A + (size_t)emu * v.MS + (size_t)(r0 + rowblock * 64 + wave * 16) * ld + c0;   // 16 rows x 128 columns
+  double* pkb[2] = {lds, lds + TL_PK};
+  double* tsb[2] = {lds + 2 * TL_PK + wave * 2 * TL_TS, lds + 2 * TL_PK + wave * 2 * TL_TS + TL_TS};
+  const double* LT = pk + PACK128_LT;
+  // this lane's two 16-byte pieces of a slab block: rows q >> 3, piece q & 7 for q = lane, lane + 64
+  const int sr0 = lane >> 3, sp = (lane & 7) * 2;
+  v2d_p sl[2];
+  auto slab_request = [&](int b) {
+    sl[0] = *reinterpret_cast<const v2d_p*>(slab + (size_t)sr0 * ld + 16 * b + sp);
+    sl[1] = *reinterpret_cast<const v2d_p*>(slab + (size_t)(sr0 + 8) * ld + 16 * b + sp);
+  };
+  auto slab_deposit = [&](double* ts) {
+    *reinterpret_cast<v2d_p*>(ts + sr0 * 18 + sp) = sl[0];
+    *reinterpret_cast<v2d_p*>(ts + (sr0 + 8) * 18 + sp) = sl[1];
+  };
+  // the workgroup's share of row block b: 8 b pieces of 16 doubles [column c][rows 16b .. 16b+15], then the 256 doubles of inv(L_bb)
+  v2d_p pr[4], pinv;
+  auto pack_request = [&](int b) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int ch = t + 256 * q;
+      if (ch < 128 * b) pr[q] = *reinterpret_cast<const v2d_p*>(LT + (size_t)(ch >> 3) * 128 + 16 * b + (ch & 7) * 2);
+    }
+    if (t < 128) pinv = *reinterpret_cast<const v2d_p*>(pk + PACK128_INV + b * 256 + 2 * t);
+  };
+  auto pack_deposit = [&](int b, double* img) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int ch = t + 256 * q;
+      if (ch < 128 * b) *reinterpret_cast<v2d_p*>(img + (ch >> 3) * 16 + (ch & 7) * 2) = pr[q];
+    }
+    if (t < 128) *reinterpret_cast<v2d_p*>(img + 112 * 16 + 2 * t) = pinv;
+  };
+  pack_request(0);
+  slab_request(0);
+  pack_deposit(0, pkb[0]);
+  slab_deposit(tsb[0]);
+  __syncthreads();
+  v4d_t X[8];
+#pragma unroll
+  for (int b = 0; b < 8; ++b) {
+    const double* img = pkb[b & 1];
+    double* ts = tsb[b & 1];
+    if (b < 7) {
+      pack_request(b + 1);
+      slab_request(b + 1);
+    }
+    v4d_t T;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) T[r] = ts[i * 18 + g + 4 * r];
+#pragma unroll
+    for (int a = 0; a < b; ++a)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)      // A operand: L[16b + i][16a + g + 4r]
+        T = __builtin_amdgcn_mfma_f64_16x16x4f64(-img[(16 * a + g + 4 * r) * 16 + i], X[a][r], T, 0, 0, 0);
+    const double* inv = img + 112 * 16;
+    X[b] = (v4d_t){0., 0., 0., 0.};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) X[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(inv[(g + 4 * r) * 16 + i], T[r], X[b], 0, 0, 0);
+    // X_b leaves through the stage it came in by: full 128-byte row segments
+#pragma unroll
+    for (int r = 0; r < 4; ++r) ts[i * 18 + g + 4 * r] = X[b][r];
+    __builtin_amdgcn_wave_barrier();
+    {
+      const v2d_p o0 = *reinterpret_cast<const v2d_p*>(ts + sr0 * 18 + sp);
+      const v2d_p o1 = *reinterpret_cast<const v2d_p*>(ts + (sr0 + 8) * 18 + sp);
+      *reinterpret_cast<v2d_p*>(slab + (size_t)sr0 * ld + 16 * b + sp) = o0;
+      *reinterpret_cast<v2d_p*>(slab + (size_t)(sr0 + 8) * ld + 16 * b + sp) = o1;
+    }
+    if (b < 7) {
+      pack_deposit(b + 1, pkb[(b + 1) & 1]);
+      slab_deposit(tsb[(b + 1) & 1]);
+    }
+    __syncthreads();
+  }
+}
+
 }  // namespace mogp
