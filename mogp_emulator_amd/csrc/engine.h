@@ -131,6 +131,8 @@ class Engine {
   void ensure_predict_scratch(int nb, int MC);
 
   double *dX = nullptr, *dP = nullptr, *dT = nullptr, *dA = nullptr, *dLinv = nullptr, *dKinv = nullptr, *dAlpha = nullptr;
+  uint32_t* sigU1 = nullptr;     // signal word of the stream memory operations of the look-ahead schedule (hipMallocSignalMemory)
+  uint32_t sig_epoch = 1;
   int* dBsFlags = nullptr;       // hand-off flags of the one-launch back substitution (B x ceil(n/128)), compared with bs_epoch
   int bs_epoch = 0;
   double *dRes = nullptr, *hRes = nullptr;   // per emulator [log-det, status, Gram matrix]: device buffer and its pinned host mirror

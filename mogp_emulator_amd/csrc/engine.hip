@@ -197,6 +197,7 @@ Engine::~Engine() {
     if (p) hipFree(p);
   if (hRes) hipHostFree(hRes);
   if (dBsFlags) hipFree(dBsFlags);
+  if (sigU1) hipFree(sigU1);
   for (auto& kv : w2) hipFree(kv.second);
   for (auto st : gstreams) hipStreamDestroy(st);
   if (evReady) hipEventDestroy(evReady);
@@ -465,10 +466,34 @@ void Engine::factorize_blocked(const std::vector<int>& ids, std::vector<int>& in
     launch_cov_build(v, stream);
     HIPCK(hipEventRecord(evReady, stream));
     HIPCK(hipStreamWaitEvent(pst, evReady, 0));
+    // "U1(c) done" in front of U2(c) sits in the dependent chain although U1(c) has normally finished a block column earlier, and
+    // an event wait costs the panel stream ~11 us even then.  As a stream memory operation on one signal word (the main stream
+    // writes base + c behind U1(c), the panel stream waits for >= base + c) a satisfied wait is a memory poll: fit 1.62 -> 1.57 ms
+    // at 8 x n=2000, 2.05 -> 1.94 at 16, 3.05 -> 2.94 at 32, 1.19 -> 1.14 at 64 x n=1000.  A waiter that really has to wait is
+    // served later by the poll than by the event (n = 5000: 7.7 -> 8.0 ms at 4 emulators; the right-looking schedule, whose
+    // waits are all of that kind: 5.2 -> 5.5 ms at 2 x n=5000, 34.3 -> 35.3 at n=16000; the other direction, panel -> U1, too),
+    // so it is used up to NP = 3072 (MOGP_WAITVAL=0 / 1 forces events / memory operations).
+    static const int waitval = [] { const char* e = getenv("MOGP_WAITVAL"); return e ? atoi(e) : -1; }();
+    const bool wv = !ovr.single_stream && (waitval < 0 ? NP <= 3072 : waitval != 0);
+    if (wv && !sigU1) {
+      HIPCK(hipExtMallocWithFlags(reinterpret_cast<void**>(&sigU1), 8, hipMallocSignalMemory));
+      HIPCK(hipMemset(sigU1, 0, 8));
+    }
+    if (wv && sig_epoch > 0xF0000000u) {      // the compare is >=: start over long before the counter wraps
+      HIPCK(hipStreamSynchronize(stream));
+      HIPCK(hipStreamSynchronize(pst));
+      HIPCK(hipMemset(sigU1, 0, 8));
+      sig_epoch = 1;
+    }
+    const uint32_t sig_base = sig_epoch;
+    if (wv) sig_epoch += (uint32_t)K + 1;
     for (int c = 0; c < K; ++c) {
       const int o = cols[c];
       if (c >= 1) {
-        if (c >= 2) HIPCK(hipStreamWaitEvent(pst, evUpd[c], 0));              // U1(c) done
+        if (c >= 2) {
+          if (wv) HIPCK(hipStreamWaitValue32(pst, sigU1, sig_base + (uint32_t)c, hipStreamWaitValueGte, 0xFFFFFFFFu));
+          else HIPCK(hipStreamWaitEvent(pst, evUpd[c], 0));                     // U1(c) done
+        }
         launch_update_narrow_pair(v, o, o - TILE, o, pst);                      // U2(c): panel c-1 -> column c
       }
       panel(v, o, TILE, pst);
@@ -476,7 +501,8 @@ void Engine::factorize_blocked(const std::vector<int>& ids, std::vector<int>& in
       if (c + 2 < K) {
         HIPCK(hipStreamWaitEvent(stream, evPanel[c], 0));
         long_update(cols[c + 2], cols[c + 1], stream);                          // U1(c+2): panels 0 .. c -> column c+2
-        HIPCK(hipEventRecord(evUpd[c + 2], stream));
+        if (wv) HIPCK(hipStreamWriteValue32(stream, sigU1, sig_base + (uint32_t)(c + 2), 0));
+        else HIPCK(hipEventRecord(evUpd[c + 2], stream));
       }
     }
     HIPCK(hipStreamWaitEvent(stream, evPanel[K - 1], 0));
