@@ -474,7 +474,11 @@ void Engine::factorize_blocked(const std::vector<int>& ids, std::vector<int>& in
     // waits are all of that kind: 5.2 -> 5.5 ms at 2 x n=5000, 34.3 -> 35.3 at n=16000; the other direction, panel -> U1, too),
     // so it is used up to NP = 3072 (MOGP_WAITVAL=0 / 1 forces events / memory operations).
     static const int waitval = [] { const char* e = getenv("MOGP_WAITVAL"); return e ? atoi(e) : -1; }();
-    const bool wv = !ovr.single_stream && (waitval < 0 ? NP <= 3072 : waitval != 0);
+    static const bool can_waitval = [] {
+      int dev = 0, ok = 0;
+      return hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&ok, hipDeviceAttributeCanUseStreamWaitValue, dev) == hipSuccess && ok != 0;
+    }();
+    const bool wv = can_waitval && !ovr.single_stream && (waitval < 0 ? NP <= 3072 : waitval != 0);
     if (wv && !sigU1) {
       HIPCK(hipExtMallocWithFlags(reinterpret_cast<void**>(&sigU1), 8, hipMallocSignalMemory));
       HIPCK(hipMemset(sigU1, 0, 8));
