@@ -79,7 +79,7 @@ __device__ unsigned long long* c128_stamps = nullptr;
 constexpr int C128_LD = 18;
 constexpr int C128_LDS_DOUBLES = 128 * C128_LD + 256 + 256;
 
-// Pack written for the panel solve below the block (trsm128_dev), per emulator:
+// Pack written for the panel solve below the block (trsm128_lds_dev), per emulator:
 //   [PACK128_LT  + c * 128 + r]            = L[r][c]                    (transposed, so that lanes run over rows)
 //   [PACK128_INV + b * 256 + k * 16 + i]   = inv(L_bb)[i][k]            (the eight 16 x 16 diagonal sub-blocks)
 constexpr int PACK128_LT = 0;

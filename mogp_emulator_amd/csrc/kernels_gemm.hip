@@ -206,13 +206,7 @@ __global__ __launch_bounds__(256, 2) void update_kernel(BatchView v, int c0, int
   });
 }
 
-// 128-wide panel solve below a factored 128 x 128 diagonal block (trsm_dev.h): one wave per 16-row slab
-__global__ __launch_bounds__(256) void trsm128_kernel(BatchView v, int c0, int r0, const double* __restrict__ Lpack128) {
-  extern __shared__ __attribute__((aligned(16))) double smem[];
-  const int emu = slot_to_emu(v.idx, blockIdx.y);
-  trsm128_dev(v, c0, r0, Lpack128 + (size_t)emu * PACK128_STRIDE, emu, blockIdx.x, smem);
-}
-
+// 128-wide panel solve below a factored 128 x 128 diagonal block (trsm_dev.h): one wave per 16-row slab, four per workgroup
 __global__ __launch_bounds__(256, 3) void trsm128_lds_kernel(BatchView v, int c0, int r0, const double* __restrict__ Lpack128) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int emu = slot_to_emu(v.idx, blockIdx.y);
@@ -719,11 +713,7 @@ void launch_predict_var(const BatchView& v, const double* Ks, int m, int MP, dou
   if (waves == 8) {
     const int SC = 1 << lgc, SR = 64 >> lgc;
     const int nsup = (((nti + 1) / 2 + SR - 1) / SR) * ((ntj + SC - 1) / SC) * 64;
-    static const int tri = [] { const char* e = getenv("MOGP_PV_TRI"); return e ? atoi(e) : 1; }();
-#define PV_LAUNCH(WR_, WC_, TRI_) hipLaunchKernelGGL((predict_var_w_kernel<WR_, WC_, TRI_>), dim3(padded_grid(v.nb, nsup)), dim3(512), smem_bytes<4>(), s, v, Ks, MP, nti, ntj, partial, lgc)
-    if (tri) PV_LAUNCH(2, 4, true);
-    else PV_LAUNCH(2, 4, false);
-#undef PV_LAUNCH
+    hipLaunchKernelGGL((predict_var_w_kernel<2, 4, true>), dim3(padded_grid(v.nb, nsup)), dim3(512), smem_bytes<4>(), s, v, Ks, MP, nti, ntj, partial, lgc);
   } else {
     const int nsup = (((nti + 1) / 2 + 3) / 4) * ((ntj + 15) / 16) * 64;
     hipLaunchKernelGGL(predict_var_kernel<false>, dim3(padded_grid(v.nb, nsup)), dim3(256), smem_bytes<4>(), s, v, Ks, MP, nti, ntj, partial);
@@ -736,10 +726,7 @@ void launch_trsm128(const BatchView& v, int c0, const double* Lpack128, hipStrea
   const int rows = v.NP - c0 - 128;
   if (rows <= 0) return;
   prof_begin("chol_trsm128", s);
-  static const int lds_mode = [] { const char* e = getenv("MOGP_TRSM_LDS"); return e ? atoi(e) : 1; }();   // 0: operands through L1 (trsm128_dev)
-  if (lds_mode) hipLaunchKernelGGL(trsm128_lds_kernel, dim3(rows / 64, v.nb), dim3(256), TRSM128L_LDS * sizeof(double), s, v, c0, c0 + 128, Lpack128);
-  else
-  hipLaunchKernelGGL(trsm128_kernel, dim3(rows / 64, v.nb), dim3(256), 4 * TRSM128_STAGE * sizeof(double), s, v, c0, c0 + 128, Lpack128);
+  hipLaunchKernelGGL(trsm128_lds_kernel, dim3(rows / 64, v.nb), dim3(256), TRSM128L_LDS * sizeof(double), s, v, c0, c0 + 128, Lpack128);
   // rows x 128 triangular solve: rows * 128^2 flops; the panel is read and written once
   prof_end("chol_trsm128", s, (double)v.nb * rows * 128.0 * 128.0, (double)v.nb * 2.0 * 8.0 * rows * 128.0);
 }
