@@ -577,6 +577,15 @@ int mogp_profile_schedule(int schedule, int single_stream) {
   schedule_override().single_stream = single_stream != 0;
   return 0;
 }
+int mogp_profile_counter(const char* name, long long* out) {
+  const long long v = prof_counter(name);
+  if (v < 0 || !out) {
+    g_err = std::string("unknown counter ") + (name ? name : "(null)");
+    return 1;
+  }
+  *out = v;
+  return 0;
+}
 int mogp_profile_get(const char* tag, double* total_ms, long long* launches, double* alg_flops, double* alg_bytes) {
   return prof_get(tag, total_ms, launches, alg_flops, alg_bytes) ? 0 : 1;
 }

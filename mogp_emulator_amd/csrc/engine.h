@@ -133,6 +133,8 @@ class Engine {
   double *dX = nullptr, *dP = nullptr, *dT = nullptr, *dA = nullptr, *dLinv = nullptr, *dKinv = nullptr, *dAlpha = nullptr;
   uint32_t* sigU1 = nullptr;     // signal word of the stream memory operations of the look-ahead schedule (hipMallocSignalMemory)
   uint32_t sig_epoch = 1;
+  bool can_waitval = false;      // hipDeviceAttributeCanUseStreamWaitValue of the engine's device
+  int device = 0;                // HIP device the engine was created on
   int* dBsFlags = nullptr;       // hand-off flags of the one-launch back substitution (B x ceil(n/128)), compared with bs_epoch
   int bs_epoch = 0;
   double *dRes = nullptr, *hRes = nullptr;   // per emulator [log-det, status, Gram matrix]: device buffer and its pinned host mirror
@@ -164,7 +166,9 @@ struct FitOptions {
 FitOptions& fit_options();
 
 // measurement hooks (mogp_profile_schedule): force the Cholesky schedule / serialise it onto one stream so that the
-// HIP-event time of a kernel is its time alone on the device; -1 / false = the library's own choice
+// HIP-event time of a kernel is its time alone on the device; -1 / false = the library's own choice.
+// FOR MEASUREMENT ONLY: process-global, read by every engine at the start of a factorisation and not synchronised --
+// set it while no evaluation is in flight (bench.py does), never from a thread that races with one.
 struct ScheduleOverride {
   int schedule = -1;       // 0 two emulator groups, 1 right-looking, 3 look-ahead
   bool single_stream = false;
@@ -175,5 +179,8 @@ void hip_check(hipError_t e, const char* what);
 void prof_enable(bool on);
 void prof_reset();
 bool prof_get(const char* tag, double* ms, long long* launches, double* flops, double* bytes);
+// process-wide diagnostic counters (mogp_profile_counter): "backsolve_timeouts" = back substitutions repeated with the
+// multi-launch path after a wait of the one-launch chain timed out
+long long prof_counter(const char* name);
 
 }  // namespace mogp

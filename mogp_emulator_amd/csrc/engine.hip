@@ -1,6 +1,7 @@
 #include "engine.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -63,6 +64,11 @@ void prof_end(const char* tag, hipStream_t s, double flops, double bytes) {
   r.launches += 1;
 }
 void prof_enable(bool on) { g_prof_on = on; }
+static std::atomic<long long> g_bs_timeouts{0};
+long long prof_counter(const char* name) {
+  if (std::string(name) == "backsolve_timeouts") return g_bs_timeouts.load();
+  return -1;
+}
 bool prof_is_on() { return g_prof_on; }
 void prof_reset() {
   std::lock_guard<std::mutex> lk(g_prof_mu);
@@ -149,6 +155,12 @@ Engine::Engine(const double* X, int n_, int D_, const double* targets, int B_, u
     g.data.assign(NC + 1 + (nug_type == NUG_FIT ? 1 : 0), 0.);
     g.meanp.assign(n_mean(), 0.);
     g.beta.assign(q, 0.);
+  }
+  {
+    // stream memory operations (look-ahead schedule) are a property of the device THIS engine lives on
+    int dev = 0, ok = 0;
+    can_waitval = hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&ok, hipDeviceAttributeCanUseStreamWaitValue, dev) == hipSuccess && ok != 0;
+    device = dev;
   }
   HIPCK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
   HIPCK(hipEventCreateWithFlags(&evReady, hipEventDisableTiming));
@@ -474,10 +486,6 @@ void Engine::factorize_blocked(const std::vector<int>& ids, std::vector<int>& in
     // waits are all of that kind: 5.2 -> 5.5 ms at 2 x n=5000, 34.3 -> 35.3 at n=16000; the other direction, panel -> U1, too),
     // so it is used up to NP = 3072 (MOGP_WAITVAL=0 / 1 forces events / memory operations).
     static const int waitval = [] { const char* e = getenv("MOGP_WAITVAL"); return e ? atoi(e) : -1; }();
-    static const bool can_waitval = [] {
-      int dev = 0, ok = 0;
-      return hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&ok, hipDeviceAttributeCanUseStreamWaitValue, dev) == hipSuccess && ok != 0;
-    }();
     const bool wv = can_waitval && !ovr.single_stream && (waitval < 0 ? NP <= 3072 : waitval != 0);
     if (wv && !sigU1) {
       HIPCK(hipExtMallocWithFlags(reinterpret_cast<void**>(&sigU1), 8, hipMallocSignalMemory));
@@ -646,38 +654,58 @@ void Engine::eval(const std::vector<int>& ids, const std::vector<const double*>&
   std::vector<double> logdet(B, 0.), gram((size_t)B * RMAX * RMAX, 0.);
   auto after_factor = [&](const std::vector<int>& list, std::vector<int>* info_out) {
     for (int i : list) gp[i].factored = true;                // provisional (ensure_linv checks it)
-    upload_idx(list);
-    BatchView v = view((int)list.size());
-    if (want_grad) {
-      // gradient path: L^-1 is needed anyway, so K^-1 [t, H] = L^-T Y is one fully parallel gemv with it
-      ensure_linv(list);
-      upload_idx(list);
-      v = view((int)list.size());
-      launch_alpha_from_linv(v, stream);
-    } else {
-      // single right-hand side: the one-launch chain (MOGP_BACKSOLVE=1 / 0: per-block launches / one workgroup per emulator)
-      static const bool chain = [] { const char* e = getenv("MOGP_BACKSOLVE"); return !e; }();
-      if (chain && R == 1) {
-        if (!dBsFlags) {
-          dBsFlags = dalloc<int>((size_t)B * ((n + 127) / 128));
-          HIPCK(hipMemsetAsync(dBsFlags, 0, (size_t)B * ((n + 127) / 128) * sizeof(int), stream));
-        }
-        launch_backsolve_chain(v, dBsFlags, ++bs_epoch, dInfo, stream);
-      } else {
-        launch_backsolve(v, stream);
-      }
-    }
-    launch_logdet(view((int)list.size()), dInfo, dRes, stream);      // (after the solves: it also collects the status words)
-    // status words, log-determinants and Gram matrices come back in ONE copy into pinned host memory
-    HIPCK(hipMemcpyAsync(hRes, dRes, (size_t)B * RES_STRIDE * sizeof(double), hipMemcpyDeviceToHost, stream));
-    HIPCK(hipStreamSynchronize(stream));
-    HIPCK(hipGetLastError());
     if (info_out) info_out->assign(B, 0);
-    for (int i : list) {
-      const double* r = hRes + (size_t)i * RES_STRIDE;
-      logdet[i] = r[0];
-      if (info_out) (*info_out)[i] = (int)r[1];
-      std::memcpy(gram.data() + (size_t)i * RMAX * RMAX, r + 2, sizeof(double) * RMAX * RMAX);
+    // second pass (rare): emulators whose one-launch back substitution gave up waiting are solved again with the
+    // multi-launch path, which has no inter-workgroup waits
+    std::vector<int> todo(list);
+    for (int pass = 0; pass < 2 && !todo.empty(); ++pass) {
+      upload_idx(todo);
+      BatchView v = view((int)todo.size());
+      bool chained = false;
+      if (want_grad) {
+        // gradient path: L^-1 is needed anyway, so K^-1 [t, H] = L^-T Y is one fully parallel gemv with it
+        ensure_linv(todo);
+        upload_idx(todo);
+        v = view((int)todo.size());
+        launch_alpha_from_linv(v, stream);
+      } else {
+        // single right-hand side: the one-launch chain (MOGP_BACKSOLVE=1 / 0: per-block launches / one workgroup per emulator)
+        static const bool chain = [] { const char* e = getenv("MOGP_BACKSOLVE"); return !e; }();
+        if (chain && R == 1 && pass == 0) {
+          const size_t nfl = (size_t)B * ((n + 127) / 128);
+          if (!dBsFlags) {
+            dBsFlags = dalloc<int>(nfl + B);                 // flags, then one status word per emulator
+            HIPCK(hipMemsetAsync(dBsFlags, 0, (nfl + B) * sizeof(int), stream));
+          }
+          if (bs_epoch > 0x7FFFFF00) {                       // flags and status are compared with the epoch: start over before it wraps
+            HIPCK(hipMemsetAsync(dBsFlags, 0, (nfl + B) * sizeof(int), stream));
+            bs_epoch = 0;
+          }
+          launch_backsolve_chain(v, dBsFlags, ++bs_epoch, dBsFlags + nfl, stream);
+          chained = true;
+        } else {
+          launch_backsolve(v, stream);
+        }
+      }
+      // (after the solves: it also collects the status words)
+      launch_logdet(v, dInfo, dRes, stream, chained ? dBsFlags + (size_t)B * ((n + 127) / 128) : nullptr, bs_epoch);
+      // status words, log-determinants and Gram matrices come back in ONE copy into pinned host memory
+      HIPCK(hipMemcpyAsync(hRes, dRes, (size_t)B * RES_STRIDE * sizeof(double), hipMemcpyDeviceToHost, stream));
+      HIPCK(hipStreamSynchronize(stream));
+      HIPCK(hipGetLastError());
+      std::vector<int> again;
+      for (int i : todo) {
+        const double* r = hRes + (size_t)i * RES_STRIDE;
+        if ((int)r[1] == BACKSOLVE_TIMEOUT) {
+          again.push_back(i);
+          continue;
+        }
+        logdet[i] = r[0];
+        if (info_out) (*info_out)[i] = (int)r[1];
+        std::memcpy(gram.data() + (size_t)i * RMAX * RMAX, r + 2, sizeof(double) * RMAX * RMAX);
+      }
+      g_bs_timeouts += (long long)again.size();
+      todo.swap(again);
     }
   };
   std::vector<int> info;
@@ -1039,7 +1067,14 @@ void Engine::predict(const std::vector<int>& ids, const double* Xs, int m, bool 
   }
   const int MPtot = roundup(m, 128);
   static const double budget = [] { const char* e = getenv("MOGP_KS_BUDGET_GB"); return (e ? atof(e) : 12.0) * 1e9; }();  // cross-covariance chunk (12 GB: one chunk for 64 x n=2000 x m=10^4)
-  long MC = (long)(budget / ((double)nb * LD * 8.0)) / 128 * 128;
+  // never more than half of what the device has free right now (several engines / ranks per GPU, smaller devices);
+  // what is already allocated for the chunk counts as free
+  double cap = budget;
+  if (vars) {
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) cap = std::min(cap, 0.5 * ((double)free_b + (double)capKs * sizeof(double)));
+  }
+  long MC = (long)(cap / ((double)nb * LD * 8.0)) / 128 * 128;
   MC = std::max<long>(128, std::min<long>(MC, MPtot));
   if (vars) ensure_predict_scratch(nb, (int)MC);
   for (int c0 = 0; c0 < m; c0 += (int)MC) {

@@ -17,7 +17,10 @@ __device__ __forceinline__ int slot_emu(const int* idx, int z) { return idx ? id
 // ---------------------------------------------------------------------------------------------
 // res[emu * RES_STRIDE + ..]: [0] log-determinant, [1] factorisation status word (as a double), [2 + r * RMAX + c] Gram matrix --
 // everything the host needs after a factorisation in ONE device-to-host copy (three separate copies cost ~20 us each).
-__global__ __launch_bounds__(256) void logdet_kernel(BatchView v, const int* __restrict__ info, double* __restrict__ res) {
+// A back substitution that gave up waiting (backsolve_chain_kernel) is reported as status BACKSOLVE_TIMEOUT -- a code of its
+// own, never confused with a failed factorisation (> 0): the engine repeats the solve of that emulator with the multi-launch path.
+__global__ __launch_bounds__(256) void logdet_kernel(BatchView v, const int* __restrict__ info, double* __restrict__ res,
+                                                     const int* __restrict__ bs_status, int bs_epoch) {
   __shared__ double red[256];
   const int emu = slot_emu(v.idx, blockIdx.x);
   const int ld = v.LD, R = v.R;
@@ -51,7 +54,8 @@ __global__ __launch_bounds__(256) void logdet_kernel(BatchView v, const int* __r
   double* out = res + (size_t)emu * RES_STRIDE;
   if (threadIdx.x == 0) {
     out[0] = 2.0 * ls;
-    out[1] = (double)info[emu];
+    const int st = info[emu];
+    out[1] = (double)((st == 0 && bs_status && bs_status[emu] == bs_epoch) ? BACKSOLVE_TIMEOUT : st);
   }
 #pragma unroll
   for (int r = 0; r < RMAX; ++r)
@@ -274,15 +278,21 @@ __global__ __launch_bounds__(256) void backsolve_gemv4_kernel(BatchView v, int k
 // then, loads do not depend on alpha -- then solves its own two 64 x 64 diagonal blocks (one wave, columns of the block
 // held in LDS) and publishes.  Chunks are dispatched right to left (the rightmost chunk has no dependencies), so a
 // workgroup only ever waits for workgroups with a smaller block index: no deadlock however many are resident.
-// Hand-off without fences (MI355X_MICROARCH.md, inter-workgroup visibility): payload and flag are written with agent-scope
-// atomic stores (sc1: through to L2), drained, then the flag; the consumer polls the flag and reads the payload with
-// agent-scope atomic loads (sc1: past its own L1).  Every wait is bounded; a timeout marks the emulator as failed.
+// Hand-off (MI355X_MICROARCH.md, inter-workgroup visibility, valid form "8-byte agent atomics on both sides";
+// cdna_hip_programming.md guideline 16, recipe R1): the payload is written with agent-scope atomic stores (sc1: through to
+// L2), EVERY storing wave drains them (inline-asm s_waitcnt: the compiler may drop a builtin wait in front of a flag store),
+// a barrier, then one lane stores the flag; the consumer polls the flag relaxed and reads the payload with agent-scope
+// atomic loads (sc1: past its own L1), so no cached copy of another workgroup's alpha is ever read.
+// Forward progress is NOT assumed: in-order dispatch makes a wait short, but HIP does not promise it, so every wait is
+// bounded and a workgroup that gives up records status[emu] = epoch (a word of its own -- not the factorisation's info,
+// which would start the jitter ladder) and still publishes, so nobody behind it hangs; the engine then repeats the solve
+// of that emulator with the multi-launch path (Engine::eval, after_factor).
 // Replaces 32 launches of ~6 us each at n = 2000 (0.2 ms of a 1.7 ms fit for 8 emulators, 0.43 of 5.3 ms for 64).
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ double ld_agent(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_agent(double* p, double x) { __hip_atomic_store(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-__global__ __launch_bounds__(256) void backsolve_chain_kernel(BatchView v, int* __restrict__ flags, int epoch, int nch, int* __restrict__ info) {
+__global__ __launch_bounds__(256) void backsolve_chain_kernel(BatchView v, int* __restrict__ flags, int epoch, int nch, int* __restrict__ status, int spin_limit) {
   __shared__ double Ld[2][64 * 65];        // the two diagonal blocks of this chunk: [row][column], row stride 65
   __shared__ double w[128], xs[128];
   __shared__ v2d part[3][64];
@@ -366,8 +376,9 @@ __global__ __launch_bounds__(256) void backsolve_chain_kernel(BatchView v, int* 
     }
     if (t == 0) {
       int spins = 0;
-      while (__hip_atomic_load(fl + cc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch && ++spins < (1 << 20)) __builtin_amdgcn_s_sleep(2);
-      if (spins >= (1 << 20)) timed_out = 1;
+      bool seen = false;
+      while (!(seen = __hip_atomic_load(fl + cc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch) && spins++ < spin_limit) __builtin_amdgcn_s_sleep(2);
+      if (!seen) timed_out = 1;
     }
     __syncthreads();
     if (t < 128) xs[t] = ld_agent(alpha + 128 * cc + t);
@@ -387,7 +398,7 @@ __global__ __launch_bounds__(256) void backsolve_chain_kernel(BatchView v, int* 
   __syncthreads();
   if (t == 0) {
     __hip_atomic_store(fl + c, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (timed_out && info[emu] == 0) info[emu] = 1;
+    if (timed_out) __hip_atomic_store(status + emu, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
@@ -547,17 +558,20 @@ __global__ void extract_kernel(const double* __restrict__ src, int NP, int n, do
 }
 
 // =============================================================================================
-void launch_logdet(const BatchView& v, const int* info, double* res, hipStream_t s) {
-  hipLaunchKernelGGL(logdet_kernel, dim3(v.nb), dim3(256), 0, s, v, info, res);
+void launch_logdet(const BatchView& v, const int* info, double* res, hipStream_t s, const int* bs_status, int bs_epoch) {
+  hipLaunchKernelGGL(logdet_kernel, dim3(v.nb), dim3(256), 0, s, v, info, res, bs_status, bs_epoch);
 }
 
 void launch_combine_rows(const BatchView& v, const double* M, hipStream_t s) {
   hipLaunchKernelGGL(combine_rows_kernel, dim3((v.LD + 255) / 256, v.nb), dim3(256), 0, s, v, M);
 }
 
-void launch_backsolve_chain(const BatchView& v, int* flags, int epoch, int* info, hipStream_t s) {
+void launch_backsolve_chain(const BatchView& v, int* flags, int epoch, int* status, hipStream_t s) {
   const int nch = (v.n + 127) / 128;
-  hipLaunchKernelGGL(backsolve_chain_kernel, dim3(v.nb * nch), dim3(256), 0, s, v, flags, epoch, nch, info);
+  // MOGP_BS_SPIN: polls before a wait gives up (default 2^20, about a second); 0 makes every unsatisfied wait a timeout,
+  // which is how the GPU suite exercises the fallback
+  static const int spin_limit = [] { const char* e = getenv("MOGP_BS_SPIN"); return e ? atoi(e) : (1 << 20); }();
+  hipLaunchKernelGGL(backsolve_chain_kernel, dim3(v.nb * nch), dim3(256), 0, s, v, flags, epoch, nch, status, spin_limit);
 }
 
 void launch_backsolve(const BatchView& v, hipStream_t s) {

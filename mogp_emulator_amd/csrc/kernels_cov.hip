@@ -500,7 +500,10 @@ __global__ __launch_bounds__(256) void kernel_object_kernel(const double* __rest
   }
   for (int d = 0; d < D; ++d) {
     const double df = a[d] - b[d], r2 = P[d] * df * df;
-    const double ratio = kern_dr2<1>(r2) / kern_val<1>(r2);                  // (dm/dr2) / m
+    // (dm/dr2) / m = -(5/6) (1 + s) / (1 + s + s^2/3): the exponentials cancel, so nothing is divided by a factor that
+    // has underflowed to 0 at large distances (kern_dr2 / kern_val would give 0/0 there)
+    const double sd = sqrt(5.0 * r2);
+    const double ratio = -(5.0 / 6.0) * (1.0 + sd) / (1.0 + sd + (5.0 / 3.0) * r2);
     if (mode == 1) out[((size_t)d * n1 + i) * n2 + j] = k * ratio * r2;
     else out[((size_t)j * n1 + i) * D + d] = k * ratio * 2.0 * P[d] * df;
   }

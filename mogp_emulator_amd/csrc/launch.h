@@ -69,7 +69,9 @@ void launch_predict_fullcov(const BatchView& v, const double* Ks, int m, int MP,
 // --- blocked Cholesky ---------------------------------------------------------------------
 size_t lpack128_doubles_per_emulator();   // scratch written by the diagonal-block kernel, read by the panel solve
 // 128 x 128 diagonal block at c0 (one workgroup per emulator, chol128_dev.h) and the 128-wide panel below it (MFMA block
-// substitution); info[emu] = first failing (1-based) column or 0
+// substitution); info[emu] = 0, or c0 + 1 of the FIRST 128-wide diagonal block that met a pivot that is not a positive finite
+// number (the column inside the block is not recorded: a bad pivot turns into NaN, which reaches the block's last
+// reciprocal square root, tested once -- chol128_dev.h; the engine only tests for non-zero)
 void launch_panel128(const BatchView& v, int c0, int* info, double* Lpack128, hipStream_t s);
 // C[i,j] -= sum_{k in [k0,k1)} A[i,k] A[j,k] for the 64-wide column block [c0,c0+64), rows [c0, NP)
 void launch_update_narrow(const BatchView& v, int c0, int k0, int k1, hipStream_t s);
@@ -79,16 +81,19 @@ void launch_update_narrow_pair(const BatchView& v, int c0, int k0, int k1, hipSt
 void launch_update_wide(const BatchView& v, int c0, int k0, int k1, hipStream_t s);
 // trailing lower-triangular update, rows/cols [c0, NP), k in [k0,k1) (c0 multiple of 128)
 void launch_update_trailing(const BatchView& v, int c0, int k0, int k1, hipStream_t s);
-// res (indexed by emulator, RES_STRIDE doubles each): [0] = 2 sum_{i<n} log L_ii, [1] = info[emu],
+// res (indexed by emulator, RES_STRIDE doubles each): [0] = 2 sum_{i<n} log L_ii, [1] = info[emu] -- or BACKSOLVE_TIMEOUT when the
+// factorisation succeeded but bs_status[emu] == bs_epoch (the one-launch back substitution gave up waiting) --,
 // [2 + r*RMAX + s] = sum_{c<n} L[n+r,c] L[n+s,c]  (Gram matrix of the right-hand-side rows; [2] = y^T y)
 constexpr int RES_STRIDE = 2 + RMAX * RMAX;
-void launch_logdet(const BatchView& v, const int* info, double* res, hipStream_t s);
+constexpr int BACKSOLVE_TIMEOUT = -2;
+void launch_logdet(const BatchView& v, const int* info, double* res, hipStream_t s, const int* bs_status = nullptr, int bs_epoch = 0);
 // alpha[c] = sum_r M[emu][c][r] Z[r], c < RA   (M: indexed by emulator, (RMAX+1) x RMAX row-major)
 void launch_combine_rows(const BatchView& v, const double* M, hipStream_t s);
 // alpha = L^-T y (y = row n of A)
 void launch_backsolve(const BatchView& v, hipStream_t s);
-// the same in one launch (R == 1): flags = B * ceil(n/128) ints indexed by emulator, all != epoch on entry; info as the factorisation's
-void launch_backsolve_chain(const BatchView& v, int* flags, int epoch, int* info, hipStream_t s);
+// the same in one launch (R == 1): flags = B * ceil(n/128) ints indexed by emulator, all != epoch on entry; status[emu] = epoch
+// when a wait of that emulator's chain timed out (alpha is then unusable: repeat with launch_backsolve)
+void launch_backsolve_chain(const BatchView& v, int* flags, int epoch, int* status, hipStream_t s);
 // Pivoted Cholesky with LAPACK dpstrf semantics (nugget="pivot", linalg/cholesky.py:284-327), see kernels_pivot.hip.
 // A (K without nugget, and the right-hand-side rows) is factored in place with symmetric row/column interchanges:
 //   begin -> { panel(k0, 64 columns) -> rank-64 update of everything to its right } ... -> tail -> end

@@ -13,6 +13,15 @@ import numpy as np
 
 
 THETA_PAD = 96      # doubles reserved for theta_hat in a fit record
+REC_WIDTH = 5 + THETA_PAD   # [fit_ok, logpost, nugget, len(theta), rank_failed, theta_0 .. theta_95] = 101 doubles per emulator
+
+
+class ShardError(RuntimeError):
+    """The local work of one or more ranks raised; every rank still joined the collective (nobody hangs) and every rank
+    raises this error afterwards.  ``ranks``: the ranks that failed (as far as this rank can tell from the gather)."""
+    def __init__(self, msg, ranks=()):
+        super(ShardError, self).__init__(msg)
+        self.ranks = list(ranks)
 
 
 def shard_bounds(n_items, world_size, rank):
@@ -71,6 +80,17 @@ class ShardedMultiOutputGP(object):
     fit status of ALL emulators (``theta_hat``, ``logpost``, ``nuggets``, ``get_indices_fit()``,
     ``get_indices_not_fit()``: global emulator indices); ``predict`` ends with the single gather of
     means / variances, every rank returns the full (n_emulators, m) arrays.
+
+    Factory protocol (what a custom per-rank model must offer): ``fit(thetas)``, ``predict(testing, deriv=False, **kw)``
+    returning ``(mean, unc, deriv)`` with (n_local, m) arrays, and -- optional -- ``fit_record()`` returning
+    ``{"fit_ok", "logpost", "nugget", "theta"}`` lists of length n_local (``MultiOutputGP_GPU.fit_record``).  A model
+    without ``fit_record`` is reported through ``get_indices_fit()`` / ``get_indices_not_fit()`` alone (log-posterior,
+    nugget and theta_hat then stay nan / None).  A model that also has ``_mogp_gpu.predict_variance_batch_dev`` (the default
+    one) predicts into device buffers and the gather runs on them directly: one D2H copy of the gathered result per call.
+
+    Failure on one rank: the local work runs inside try / except and the rank ALWAYS joins the collective with an error
+    flag in its record (or payload); after the gather every rank raises ``ShardError`` -- a raising rank can therefore
+    never leave the others waiting in ``all_gather``.
     """
 
     def __init__(self, inputs, targets, factory=None, group=None, device_index=None, **kwargs):
@@ -105,41 +125,82 @@ class ShardedMultiOutputGP(object):
         self.theta_hat = [None] * self.n_emulators
 
     # -- the fit exchange -----------------------------------------------------------------------------
-    def _gather_fit_records(self):
-        """ONE collective: rows [fit_ok, logpost, nugget, n_theta, theta_0 .. theta_{P-1}] per emulator."""
-        rec = self.local.fit_record() if self.local is not None else {"fit_ok": [], "logpost": [], "nugget": [], "theta": []}
-        n_local = len(rec["fit_ok"])
+    def _local_record(self):
+        if self.local is None:
+            return {"fit_ok": [], "logpost": [], "nugget": [], "theta": []}
+        if hasattr(self.local, "fit_record"):
+            return self.local.fit_record()
+        n_local = self.hi - self.lo
+        not_fit = set(self.local.get_indices_not_fit()) if hasattr(self.local, "get_indices_not_fit") else set()
+        return {"fit_ok": [k not in not_fit for k in range(n_local)], "logpost": [np.nan] * n_local,
+                "nugget": [np.nan] * n_local, "theta": [None] * n_local}
+
+    def _gather_fit_records(self, error=None):
+        """ONE collective: rows [fit_ok, logpost, nugget, n_theta, rank_failed, theta_0 .. theta_{P-1}] per emulator.
+        ``error``: the exception the local fit raised (the rank still joins, with rank_failed = 1 in its rows)."""
+        n_local = self.hi - self.lo
         # fixed record width (equal block shapes on every rank without a second collective): the device kernels take at
-        # most 80 inputs, so theta has at most 80 + 2 data and 7 mean entries; 100 doubles per emulator is 50 KB for C3
-        width = THETA_PAD
-        assert all(t is None or len(t) <= width for t in rec["theta"])
-        block = np.zeros((n_local, 4 + width))
-        for k in range(n_local):
-            th = rec["theta"][k]
-            block[k, 0] = 1.0 if rec["fit_ok"][k] else 0.0
-            block[k, 1] = rec["logpost"][k]
-            block[k, 2] = rec["nugget"][k]
-            if th is not None:
-                block[k, 3] = len(th)
-                block[k, 4:4 + len(th)] = th
+        # most 80 inputs, so theta has at most 80 + 2 data and 7 mean entries <= THETA_PAD = 96; REC_WIDTH = 101 doubles
+        # per emulator is 52 KB for C3
+        block = np.zeros((n_local, REC_WIDTH))
+        if error is None:
+            try:
+                rec = self._local_record()
+                for k in range(n_local):
+                    th = rec["theta"][k]
+                    block[k, 0] = 1.0 if rec["fit_ok"][k] else 0.0
+                    block[k, 1] = rec["logpost"][k]
+                    block[k, 2] = rec["nugget"][k]
+                    if th is not None:
+                        if len(th) > THETA_PAD:
+                            raise ValueError("theta of %d entries does not fit the fit record (%d)" % (len(th), THETA_PAD))
+                        block[k, 3] = len(th)
+                        block[k, 5:5 + len(th)] = th
+            except Exception as exc:           # noqa: BLE001 -- the rank must reach the collective whatever happened
+                error = exc
+        if error is not None:
+            block[:] = 0.
+            block[:, 1:3] = np.nan
+            block[:, 4] = 1.0
         full = gather_rows(block, self.n_emulators, group=self.group).cpu().numpy()
         self.fit_ok = full[:, 0] > 0.5
         self.logpost = np.where(self.fit_ok, full[:, 1], np.nan)
         self.nuggets = full[:, 2].copy()
-        self.theta_hat = [full[k, 4:4 + int(full[k, 3])].copy() if self.fit_ok[k] else None for k in range(self.n_emulators)]
+        self.theta_hat = [full[k, 5:5 + int(full[k, 3])].copy() if self.fit_ok[k] and full[k, 3] > 0 else None
+                          for k in range(self.n_emulators)]
+        self._raise_if_failed(full[:, 4] > 0.5, error, "fit")
+
+    def _raise_if_failed(self, failed_rows, error, what):
+        per = -(-self.n_emulators // self.world)
+        ranks = sorted(set(int(k) // per for k in np.nonzero(failed_rows)[0]))
+        if error is not None and self.rank not in ranks:
+            ranks = sorted(ranks + [self.rank])          # a rank without emulators has no row to carry its flag
+        if ranks:
+            msg = "%s failed on rank(s) %s" % (what, ranks)
+            if error is not None:
+                msg += "; this rank (%d): %r" % (self.rank, error)
+            raise ShardError(msg, ranks) from error
 
     def fit_GP_MAP(self, fit_fn=None, **kwargs):
+        error = None
         if self.local is not None:
-            if fit_fn is None:
-                from .fitting import fit_GP_MAP as fit_fn
-            self.local = fit_fn(self.local, **kwargs)
-        self._gather_fit_records()
+            try:
+                if fit_fn is None:
+                    from .fitting import fit_GP_MAP as fit_fn
+                self.local = fit_fn(self.local, **kwargs)
+            except Exception as exc:           # noqa: BLE001
+                error = exc
+        self._gather_fit_records(error)
         return self
 
     def fit(self, thetas):
+        error = None
         if self.local is not None:
-            self.local.fit(np.asarray(thetas)[self.lo:self.hi])
-        self._gather_fit_records()
+            try:
+                self.local.fit(np.asarray(thetas)[self.lo:self.hi])
+            except Exception as exc:           # noqa: BLE001
+                error = exc
+        self._gather_fit_records(error)
 
     def get_indices_fit(self):
         return [int(k) for k in np.nonzero(self.fit_ok)[0]]
@@ -148,13 +209,56 @@ class ShardedMultiOutputGP(object):
         return [int(k) for k in np.nonzero(~self.fit_ok)[0]]
 
     # -- the predict exchange ----------------------------------------------------------------------------
-    def predict(self, testing, device=None, **kwargs):
-        m = np.atleast_2d(testing).shape[0]
-        if self.local is not None:
-            mean, unc, _ = self.local.predict(testing, deriv=False, **kwargs)
-            payload = np.stack([mean, unc if unc is not None else np.zeros_like(mean)], axis=1)   # (n_local, 2, m)
+    def _device_path(self):
+        """The default per-rank model with RCCL: predictions stay in HBM until after the gather."""
+        import torch.distributed as dist
+        mo = getattr(self.local, "_mogp_gpu", None)
+        return (dist.is_initialized() and dist.get_backend(self.group) == "nccl"
+                and (self.local is None or hasattr(mo, "predict_variance_batch_dev")))
+
+    def predict(self, testing, device=None, include_nugget=True, **kwargs):
+        """(mean, unc) of ALL emulators, (n_emulators, m) each, on every rank.  ``unc`` = predictive variance (clipped at
+        0, + nugget iff include_nugget, as MultiOutputGP_GPU.predict).  With the nccl backend and the default per-rank
+        model the local predictions are written into device buffers (``predict_variance_batch_dev``), gathered there by
+        RCCL and copied to the host once; otherwise host arrays are gathered (gloo / custom factories)."""
+        testing = np.ascontiguousarray(np.atleast_2d(np.asarray(testing, dtype=np.float64)))
+        m = testing.shape[0]
+        n_local = self.hi - self.lo
+        error = None
+        if device is None and self._device_path() and not kwargs:
+            import torch
+            dev = _collective_device(self.group)
+            payload = torch.zeros((n_local, 2, m), dtype=torch.float64, device=dev)
+            flag = torch.zeros((n_local, 1, m), dtype=torch.float64, device=dev)
+            try:
+                if self.local is not None:
+                    if len(self.local.get_indices_not_fit()) > 0:
+                        raise ValueError("Hyperparameters have not been fit for this Gaussian Process")
+                    d_x = torch.from_numpy(testing).to(dev)
+                    d_mean = torch.empty((n_local, m), dtype=torch.float64, device=dev)
+                    d_var = torch.empty((n_local, m), dtype=torch.float64, device=dev)
+                    self.local._mogp_gpu.predict_variance_batch_dev(d_x.data_ptr(), m, d_mean.data_ptr(), d_var.data_ptr())
+                    if include_nugget:
+                        d_var += torch.from_numpy(np.asarray(self.local._nuggets())).to(dev)[:, None]
+                    payload[:, 0] = d_mean
+                    payload[:, 1] = torch.clamp_min(d_var, 0.)
+            except Exception as exc:           # noqa: BLE001
+                error = exc
+                payload.zero_()
+                flag.fill_(1.)
+            full = gather_rows(torch.cat([payload, flag], dim=1), self.n_emulators, device=dev, group=self.group).cpu().numpy()
         else:
-            payload = np.zeros((0, 2, m))
-        full = gather_rows(payload, self.n_emulators, device=device, group=self.group)
-        full = full.cpu().numpy()
+            payload = np.zeros((n_local, 3, m))
+            try:
+                if self.local is not None:
+                    mean, unc, _ = self.local.predict(testing, deriv=False, include_nugget=include_nugget, **kwargs)
+                    payload[:, 0] = mean
+                    if unc is not None:
+                        payload[:, 1] = unc
+            except Exception as exc:           # noqa: BLE001
+                error = exc
+                payload[:] = 0.
+                payload[:, 2] = 1.
+            full = gather_rows(payload, self.n_emulators, device=device, group=self.group).cpu().numpy()
+        self._raise_if_failed(full[:, 2, 0] > 0.5 if m > 0 else np.zeros(self.n_emulators, bool), error, "predict")
         return full[:, 0, :], full[:, 1, :]

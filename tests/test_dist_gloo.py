@@ -87,6 +87,80 @@ def test_sharded_predict_gather_world2(n_out):
     assert bounds[0][0] == 0 and bounds[0][1] == bounds[1][0] and bounds[1][1] == n_out
 
 
+class _FailingStub(_LocalStub):
+    """raises in fit / predict on the rank that owns the emulator whose first target is the largest"""
+    def __init__(self, inputs, targets, **kw):
+        super(_FailingStub, self).__init__(inputs, targets, **kw)
+        self.bad = bool(np.any(self.t[:, 0] > 100.))
+
+    def fit(self, thetas):
+        if self.bad:
+            raise RuntimeError("boom in fit")
+        super(_FailingStub, self).fit(thetas)
+
+    def predict(self, testing, deriv=False, **kw):
+        if self.bad:
+            raise RuntimeError("boom in predict")
+        return super(_FailingStub, self).predict(testing, deriv=deriv, **kw)
+
+
+class _NoRecordStub(object):
+    """a custom per-rank model WITHOUT fit_record(): only the fit status travels"""
+    def __init__(self, inputs, targets, **kw):
+        self.t = np.asarray(targets)
+        self.done = False
+
+    def fit(self, thetas):
+        self.done = True
+
+    def get_indices_not_fit(self):
+        return [] if self.done else list(range(self.t.shape[0]))
+
+    def predict(self, testing, deriv=False, **kw):
+        s = np.asarray(testing).sum(axis=1)
+        return np.tile(s, (self.t.shape[0], 1)), np.tile(s ** 2, (self.t.shape[0], 1)), None
+
+
+def _worker_failures(rank, world, port, q):
+    from mogp_emulator_amd.dist import ShardError
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rng = np.random.default_rng(1)
+    n_out = 6
+    X = rng.normal(size=(6, 2)); T = rng.normal(size=(n_out, 6)); Xs = rng.normal(size=(5, 2))
+    T[4, 0] = 1000.                                   # emulator 4 lives on rank 1: that rank raises
+    gp = ShardedMultiOutputGP(X, T, factory=_FailingStub)
+    seen = []
+    for call in (lambda: gp.fit(rng.normal(size=(n_out, 3))), lambda: gp.predict(Xs)):
+        try:
+            call()
+            seen.append(None)
+        except ShardError as exc:                     # BOTH ranks get here: nobody is left waiting in all_gather
+            seen.append((exc.ranks, "boom" in str(exc)))
+    ok = seen[0] is not None and seen[0][0] == [1] and seen[1] is not None and seen[1][0] == [1]
+    ok = ok and (seen[0][1] == (rank == 1))           # the failing rank's message names its own exception
+    # a factory without fit_record: status only
+    gp2 = ShardedMultiOutputGP(X, T, factory=_NoRecordStub)
+    gp2.fit(np.zeros((n_out, 3)))
+    ok = ok and gp2.get_indices_fit() == list(range(n_out)) and all(t is None for t in gp2.theta_hat)
+    mean, unc = gp2.predict(Xs)
+    ok = ok and np.allclose(mean, np.tile(Xs.sum(axis=1), (n_out, 1)))
+    q.put((rank, bool(ok), seen))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_a_raising_rank_cannot_hang_the_collective_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_failures, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs: p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs: p.join(timeout=60)
+    assert all(r[1] for r in res), res
+
+
 def test_shard_bounds_cover_everything():
     for n in (1, 7, 16, 64, 65):
         for w in (1, 2, 4, 8):
