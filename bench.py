@@ -15,6 +15,9 @@ A "step" is one pass of the hot path over the rank's shard:
 `value` = fits/s over the whole job = emulators x steps / time spent in the fit phase (max over ranks);
 fit+grad/s and predict pts/s are reported next to it from the same timed steps.
 
+other_configs (N = 1): BASELINE's C4 (16 x n=5000, Matern-5/2, fitted nugget) and C5 (n=16000) timed on this GPU with their
+tagged kernels; nccl_world1 (N = 1): the two exchange payloads through RCCL in a one-rank process group; shard_sweep also
+times fit_GP_MAP with 15 concurrent starts per emulator (the workload users run at shard size).
 roofline: for the kernel with the largest share of device time; `achieved` = algorithmic flops (n^3/3 per
 Cholesky, m n^2 per predictive variance, ...) of all its launches in the timed steps / their total duration measured with
 HIP events recorded on the launch stream inside libmogp_hip.so (mogp_profile_*).  fit_roofline: the whole fit phase
@@ -81,24 +84,40 @@ def cpu_baseline(X, T, Xs, theta, nugget):
         "fit_grad_per_s": 1.0 / (t_fit + t_grad), "predict_pts_per_s": ms / t_pred,
         "host_cpus": os.cpu_count(), "affinity": len(os.sched_getaffinity(0)), "threaded_fits_per_s": 1.0 / t_fit,
     }
-    # (b) process pool, one BLAS thread per worker (~0.35 GB per worker for the (n, n, d) distance temporary);
-    # a separate script under a hard timeout so that a pool that fails to start can never wedge the bench
+    # (b) process pool, one BLAS thread per worker -- the reference's model for many outputs, Pool(processes=None) = every
+    # core (mogp_emulator/fitting.py:298, 333-335).  Two sizes: 32 workers (rounds 1-2) and ALL cores the process may run on,
+    # capped by memory (~0.35 GB per worker for the (n, n, d) distance temporary; 1 GB budgeted) -- with more workers than
+    # outputs the emulators are cycled so that every worker gets work.  A separate script under a hard timeout, so that a
+    # pool that fails to start can never wedge the bench.
+    import subprocess
+    cores = len(os.sched_getaffinity(0))
     try:
-        import subprocess
-        workers = max(1, min(T.shape[0], len(os.sched_getaffinity(0)) // 2, 32))
-        cmd = [sys.executable, os.path.join(ROOT, "oracle", "pool_fit.py"), "2", str(X.shape[0]), str(X.shape[1]),
-               str(T.shape[0]), str(workers)]
-        env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
-        res = json.loads(subprocess.run(cmd, check=True, capture_output=True, text=True, timeout=180, env=env).stdout.strip().splitlines()[-1])
-        pool_rate = res["fits"] / res["wall_s"]
-        out["pool_fits_per_s"] = pool_rate
-        out["pool_workers"] = workers
-        out["sample"] += "; process pool x%d, 1 BLAS thread each: %d fits in %.2fs (%.2fs per fit per worker)" % (
-            workers, res["fits"], res["wall_s"], res["mean_fit_s"])
-        if pool_rate > out["value"]:
-            out["value"], out["cores"] = pool_rate, workers
-    except Exception as exc:                                              # the pool is a bonus measurement
-        out["pool_error"] = repr(exc)[:200]
+        with open("/proc/meminfo") as fh:
+            avail_gb = [int(l.split()[1]) for l in fh if l.startswith("MemAvailable")][0] / 1e6
+    except Exception:
+        avail_gb = 64.0
+    all_workers = int(max(1, min(cores, avail_gb * 0.5 / 1.0)))
+    out["pool"] = []
+    for workers in sorted(set([max(1, min(T.shape[0], cores // 2, 32)), all_workers])):
+        try:
+            fits = max(T.shape[0], 2 * workers) if workers > 32 else T.shape[0]
+            cmd = [sys.executable, os.path.join(ROOT, "oracle", "pool_fit.py"), "2", str(X.shape[0]), str(X.shape[1]),
+                   str(T.shape[0]), str(workers), str(fits)]
+            env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
+            res = json.loads(subprocess.run(cmd, check=True, capture_output=True, text=True, timeout=240, env=env).stdout.strip().splitlines()[-1])
+            pool_rate = res["fits"] / res["wall_s"]
+            out["pool"].append({"workers": workers, "fits": res["fits"], "wall_s": res["wall_s"], "fits_per_s": pool_rate,
+                                "mean_fit_s_per_worker": res["mean_fit_s"]})
+            out["sample"] += "; process pool x%d, 1 BLAS thread each: %d fits in %.2fs (%.2fs per fit per worker)" % (
+                workers, res["fits"], res["wall_s"], res["mean_fit_s"])
+            if workers <= 32:
+                out["pool_fits_per_s"], out["pool_workers"] = pool_rate, workers
+            else:
+                out["pool_all_cores_fits_per_s"], out["pool_all_cores_workers"] = pool_rate, workers
+            if pool_rate > out["value"]:
+                out["value"], out["cores"] = pool_rate, workers
+        except Exception as exc:                                              # the pool is a bonus measurement
+            out["pool_error_%d" % workers] = repr(exc)[:200]
     return out, values
 
 
@@ -128,7 +147,7 @@ def parity_in_bench(mo, values, theta, Xs):
     return out
 
 
-def time_shard(M, GPPriors, cid, n, d, B, m, kernel, nugget, theta, reps):
+def time_shard(M, GPPriors, cid, n, d, B, m, kernel, nugget, theta, reps, map_starts=0, map_iters=10):
     """fit / fit+grad / predict time of ONE per-GPU shard of the multi-GPU workload (median of `reps` evaluations)."""
     X, T, Xs = synth(cid, n, d, B, m)
     nt = nugget if isinstance(nugget, str) else "fixed"
@@ -146,8 +165,117 @@ def time_shard(M, GPPriors, cid, n, d, B, m, kernel, nugget, theta, reps):
     t_fit = med(lambda it: mo.eval(th + 1e-3 * it, grad=False))
     t_fg = med(lambda it: mo.eval(th + 1e-3 * it, grad=True))
     t_pr = med(lambda it: mo.predict_variance_batch(Xs, means, vars_))
-    return {"n": n, "d": d, "emulators": B, "m": m, "kernel": kernel, "fit_ms": t_fit, "fit_grad_ms": t_fg, "predict_ms_host_buffers": t_pr,
-            "fit_ms_per_emulator": t_fit / B, "fit_TFLOPs": B * float(n) ** 3 / 3. / t_fit * 1e-9, "fit_grad_TFLOPs": B * float(n) ** 3 / t_fg * 1e-9}
+    out = {"n": n, "d": d, "emulators": B, "m": m, "kernel": kernel, "fit_ms": t_fit, "fit_grad_ms": t_fg, "predict_ms_host_buffers": t_pr,
+           "fit_ms_per_emulator": t_fit / B, "fit_TFLOPs": B * float(n) ** 3 / 3. / t_fit * 1e-9, "fit_grad_TFLOPs": B * float(n) ** 3 / t_fg * 1e-9}
+    if map_starts:
+        out.update(time_fit_map(M, X, T, kernel, nugget, map_starts, map_iters))
+    return out
+
+
+def counter(name):
+    from mogp_emulator_amd import _capi
+    v = ctypes.c_longlong()
+    _capi.load().mogp_profile_counter(name.encode(), ctypes.byref(v))
+    return int(v.value)
+
+
+def time_fit_map(M, X, T, kernel, nugget, n_tries, max_iter):
+    """The workload users run at shard size: fit_GP_MAP with `n_tries` random starts (mogp_gpu/src/fitting.hpp:61-128;
+    default priors, fixed iteration cap).  The starts of an emulator are independent, so the engine evaluates them
+    concurrently on a replica engine: a rank that holds 8 emulators factors 8 x 15 = 120 matrices per optimiser round,
+    i.e. it works in the full-batch regime of the Cholesky, not in the 8-matrix regime of a single fit(theta)."""
+    from mogp_emulator_amd import libgpgpu
+    B = T.shape[0]
+    libgpgpu.set_fit_options(max_iter=max_iter, ftol=1e-9, gtol=1e-6, seed=1)
+    gp = M.MultiOutputGP_GPU(X, T, kernel=kernel, nugget=nugget)              # default priors (SURVEY 8d)
+    e0, g0 = counter("objective_evals"), counter("gradient_evals")
+    t0 = time.perf_counter()
+    libgpgpu.fit_GP_MAP(gp._mogp_gpu, n_tries)
+    dt = time.perf_counter() - t0
+    evals = counter("objective_evals") - e0
+    res = {"fit_GP_MAP_s": dt, "fit_GP_MAP_n_tries": n_tries, "fit_GP_MAP_max_iter": max_iter,
+           "fit_GP_MAP_emulator_fits_per_s": B / dt, "fit_GP_MAP_all_fit": len(gp.get_indices_not_fit()) == 0,
+           "fit_GP_MAP_objective_evals": evals, "fit_GP_MAP_gradient_evals": counter("gradient_evals") - g0,
+           "fit_GP_MAP_objective_evals_per_s": evals / dt,
+           "fit_GP_MAP_TFLOPs": (counter("gradient_evals") - g0) * float(X.shape[0]) ** 3 / dt * 1e-12}
+    libgpgpu.set_fit_options(max_iter=200, ftol=1e-9, gtol=1e-6, seed=1)
+    return res
+
+
+def time_other_config(M, GPPriors, lib, read_kernels, tag, cid, n, d, B, m, kernel, nugget, theta, reps):
+    """One of BASELINE's other configurations (C4, C5) on this GPU: fit / fit+gradient / predict at the fixed theta of
+    SURVEY 8d, with the tagged kernels of the fit phase from HIP events (work per unit: SURVEY 8d table)."""
+    X, T, Xs = synth(cid, n, d, B, m)
+    nt = nugget if isinstance(nugget, str) else "fixed"
+    gp = M.MultiOutputGP_GPU(X, T, kernel=kernel, nugget=nugget, priors=GPPriors(n_corr=d, nugget_type=nt))
+    mo = gp._mogp_gpu
+    th = np.tile(theta, (B, 1))
+    means, vars_ = np.zeros((B, m)), np.zeros((B, m))
+
+    def med(fn, r):
+        fn(0)
+        ts = []
+        for it in range(r):
+            t0 = time.perf_counter(); fn(it + 1); ts.append(time.perf_counter() - t0)
+        return float(np.median(ts)) * 1e3
+    t_fit = med(lambda it: mo.eval(th + 1e-3 * it, grad=False), reps)
+    lib.mogp_profile_reset(); lib.mogp_profile_enable(1)
+    for it in range(2):
+        f, _, ok = mo.eval(th + 1e-3 * (it + 7), grad=False)
+    lib.mogp_profile_enable(0)
+    kern = read_kernels()
+    for v in kern.values():
+        v["ms_per_fit"] = v["ms_total"] / 2
+    t_fg = med(lambda it: mo.eval(th + 1e-3 * it, grad=True), max(1, reps - 1))
+    t_pr = med(lambda it: mo.predict_variance_batch(Xs, means, vars_), max(1, reps - 1))
+    assert ok.all() and np.all(np.isfinite(means)) and np.all(np.isfinite(vars_))
+    fit_tf, fg_tf, pv_tf = B * float(n) ** 3 / 3. / t_fit * 1e-9, B * float(n) ** 3 / t_fg * 1e-9, B * float(m) * float(n) ** 2 / t_pr * 1e-9
+    return {"config": tag, "workload": "%d outputs x n=%d x d=%d, %s, nugget %s, predict m=%d" % (B, n, d, kernel, nugget, m),
+            "fit_ms": t_fit, "fit_grad_ms": t_fg, "predict_ms_host_buffers": t_pr,
+            "fits_per_s": B / t_fit * 1e3, "fit_grad_per_s": B / t_fg * 1e3, "predict_pts_per_s": B * m / t_pr * 1e3,
+            "fit_TFLOPs": fit_tf, "fit_frac_of_fp64_mfma_peak": fit_tf / FP64_MFMA_PEAK_TF,
+            "fit_grad_TFLOPs": fg_tf, "fit_grad_frac": fg_tf / FP64_MFMA_PEAK_TF,
+            "predict_TFLOPs_m_n2": pv_tf, "predict_frac": pv_tf / FP64_MFMA_PEAK_TF,
+            "flops_per_cholesky": float(n) ** 3 / 3., "kernels_fit": kern, "logpost_checksum": float(np.sum(f))}
+
+
+def nccl_world1(mo, B, m, dev):
+    """RCCL on the one GPU this run has: a process group of ONE rank with the nccl backend, and the two real exchange
+    payloads of the multi-GPU path -- the fit records (B x 101 doubles) and the predictions (B x 2 x m doubles, device
+    resident) -- through dist.gather_rows -> all_gather_into_tensor.  Asserts the round trip is bit-exact and reports the
+    latency.  (With 8 ranks the same call moves 8 such blocks over xGMI.)"""
+    import socket
+    import torch
+    import torch.distributed as dist
+    from mogp_emulator_amd.dist import gather_rows, REC_WIDTH
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    out = {}
+    try:
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1, device_id=dev)
+        rec = torch.randn((B, REC_WIDTH), dtype=torch.float64, device=dev)
+        pred = torch.randn((B, 2, m), dtype=torch.float64, device=dev)
+        for name, payload in (("fit_records", rec), ("predictions", pred)):
+            g = gather_rows(payload, B, device=dev)                    # first call: communicator set-up
+            torch.cuda.synchronize()
+            ts = []
+            for _ in range(20):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                g = gather_rows(payload, B, device=dev)
+                torch.cuda.synchronize()
+                ts.append(time.perf_counter() - t0)
+            assert g.is_cuda and torch.equal(g, payload), name
+            out["gather_us_nccl_world1_" + name] = float(np.median(ts)) * 1e6
+            out["gather_bytes_" + name] = int(payload.numel() * 8)
+        out["gather_us_nccl_world1"] = out["gather_us_nccl_world1_predictions"]
+        out["bit_exact"] = True
+        out["backend"] = dist.get_backend()
+    except Exception as exc:                                            # reported, never fatal for the headline numbers
+        out["error"] = repr(exc)[:300]
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+    return out
 
 
 def main():
@@ -164,6 +292,7 @@ def main():
     ap.add_argument("--m", type=int, default=10000, help="prediction points per emulator")
     ap.add_argument("--kernel", default="SquaredExponential")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the C4 / C5 block (other_configs)")
     args = ap.parse_args()
 
     import torch
@@ -270,10 +399,12 @@ def main():
     extras = {}
     if rank == 0 and world == 1 and not args.no_shard_sweep and (n, d, B) == (2000, 10, 64):
         # the per-GPU shards of the 2 / 4 / 8-GPU runs of THIS workload, and of C4 (16 x n=5000 over 8 GPUs), on one GPU
-        sweep = [time_shard(M, GPPriors, 2, n, d, b, m, args.kernel, nugget, theta, 7) for b in (8, 16, 32)]
+        # (+ what users run at shard size: fit_GP_MAP with 15 concurrent starts and a fixed cap of 10 iterations)
+        sweep = [time_shard(M, GPPriors, 2, n, d, b, m, args.kernel, nugget, theta, 7, map_starts=15) for b in (8, 16, 32)]
         sweep.append(time_shard(M, GPPriors, 4, 5000, 20, 2, m, "Matern52", "fit",
                                 np.array([-2. * np.log(0.3 * np.sqrt(20))] * 20 + [0., np.log(1e-4)]), 3))
         extras["shard_sweep"] = sweep
+        extras["fit_GP_MAP_15_starts_64_emulators"] = time_fit_map(M, X, T, args.kernel, nugget, 15, 10)
     if rank == 0 and world == 1:
         means_h = np.zeros((B, m)); vars_h = np.zeros((B, m))
         mo.predict_variance_batch(Xs, means_h, vars_h)
@@ -371,6 +502,17 @@ def main():
                 kern[k]["achieved"] = v["achieved"]
                 kern[k]["note"] = "achieved = one stream (kernel alone on the device); achieved_overlapped = inside the two-stream schedule"
         kern_serial["fit_ms_single_stream"] = serial_ms
+        # BASELINE's other configurations on this GPU (VERDICT r2, row (+)2): C4 = 16 outputs, Matern-5/2 + fitted nugget,
+        # n=5000, d=20; C5 = one output, n=16000, d=8.  ~0.5 s of GPU time each.
+        if not args.no_other_configs and (n, d, B) == (2000, 10, 64):
+            extras["other_configs"] = [
+                time_other_config(M, GPPriors, lib, read_kernels, "C4", 4, 5000, 20, 16, m, "Matern52", "fit",
+                                  np.array([-2. * np.log(0.3 * np.sqrt(20))] * 20 + [0., np.log(1e-4)]), 3),
+                time_other_config(M, GPPriors, lib, read_kernels, "C5", 5, 16000, 8, 1, m, "SquaredExponential", 1e-6,
+                                  np.array([-2. * np.log(0.3 * np.sqrt(8))] * 8 + [0.]), 3)]
+        # RCCL exercised on the single GPU: the exchange payloads of the N > 1 path through a world-size-1 nccl group
+        if not dist.is_initialized():
+            extras["nccl_world1"] = nccl_world1(mo, B, m, dev)
 
     # max over ranks of every time
     times = torch.tensor([elapsed, phase["fit"], phase["fitgrad"], phase["predict"], phase["gather"]], dtype=torch.float64, device=coll_dev)

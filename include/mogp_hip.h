@@ -219,7 +219,8 @@ int mogp_profile_schedule(int schedule, int single_stream);
 /* sums over launches since reset: total milliseconds, launch count, algorithmic flops and bytes */
 int mogp_profile_get(const char* kernel_tag, double* total_ms, long long* launches, double* alg_flops, double* alg_bytes);
 /* process-wide diagnostic counters: "backsolve_timeouts" = back substitutions that were repeated with the multi-launch
-   path because a wait of the one-launch chain timed out (0 in normal operation) */
+   path because a wait of the one-launch chain timed out (0 in normal operation); "objective_evals" / "gradient_evals" =
+   emulator objective evaluations so far (all / with gradient), e.g. to turn a fit_GP_MAP wall time into evaluations/s */
 int mogp_profile_counter(const char* name, long long* out);
 /* device memory helpers so a host program can hand device-resident buffers to the *_dev calls */
 void* mogp_dev_malloc(unsigned long long bytes);

@@ -64,9 +64,12 @@ void prof_end(const char* tag, hipStream_t s, double flops, double bytes) {
   r.launches += 1;
 }
 void prof_enable(bool on) { g_prof_on = on; }
-static std::atomic<long long> g_bs_timeouts{0};
+static std::atomic<long long> g_bs_timeouts{0}, g_obj_evals{0}, g_grad_evals{0};
 long long prof_counter(const char* name) {
-  if (std::string(name) == "backsolve_timeouts") return g_bs_timeouts.load();
+  const std::string s(name ? name : "");
+  if (s == "backsolve_timeouts") return g_bs_timeouts.load();
+  if (s == "objective_evals") return g_obj_evals.load();      // emulator objective evaluations (with or without gradient)
+  if (s == "gradient_evals") return g_grad_evals.load();      // of which with gradient
   return -1;
 }
 bool prof_is_on() { return g_prof_on; }
@@ -643,6 +646,8 @@ void Engine::eval(const std::vector<int>& ids, const std::vector<const double*>&
                   int grad_ld, int* ok) {
   const int nb = (int)ids.size();
   if (nb == 0) return;
+  g_obj_evals += nb;
+  if (want_grad) g_grad_evals += nb;
   for (int k = 0; k < nb; ++k) {
     set_theta(ids[k], thetas[k]);
     GPState& g = gp[ids[k]];

@@ -55,12 +55,13 @@ def gather_rows(local, n_total, device=None, group=None):
         local_t = torch.from_numpy(np.ascontiguousarray(local))
     else:
         local_t = local.contiguous()
-    if device is None and world > 1:
+    if device is None and dist.is_initialized():
         device = _collective_device(group)
     if device is not None:
         local_t = local_t.to(device)
-    if world == 1:
+    if not dist.is_initialized():
         return local_t[:n_total]
+    # (a process group of ONE rank still goes through the collective: the same RCCL call as with 8 ranks)
     per = -(-int(n_total) // world)
     shape = (per,) + tuple(local_t.shape[1:])
     block = torch.zeros(shape, dtype=local_t.dtype, device=local_t.device)

@@ -81,3 +81,54 @@ def test_two_ranks_on_one_gpu_match_the_unsharded_model(n_out):
         np.testing.assert_allclose(unc, func, rtol=1e-6, atol=1e-9)
     # both ranks return the same bits
     assert np.array_equal(res[0][7], res[1][7]) and np.array_equal(res[0][8], res[1][8])
+
+
+def _nccl_world1_worker(port, q):
+    """ONE rank, nccl backend, on the one GPU: RCCL initialisation + all_gather_into_tensor on device memory with the real
+    payload shapes, and the device-resident predict path of ShardedMultiOutputGP (predict_variance_batch_dev -> gather ->
+    one D2H copy) against the plain model."""
+    try:
+        import torch
+        import torch.distributed as dist
+        import mogp_emulator_amd as M
+        from mogp_emulator_amd.dist import ShardedMultiOutputGP, gather_rows, REC_WIDTH
+        dev = torch.device("cuda", 0)
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1, device_id=dev)
+        assert dist.get_backend() == "nccl"
+        out = {}
+        for name, shape in (("fit_records", (64, REC_WIDTH)), ("predictions", (64, 2, 10000))):
+            payload = torch.randn(shape, dtype=torch.float64, device=dev)
+            got = gather_rows(payload, shape[0])                     # device defaults to the rank's GPU with nccl
+            torch.cuda.synchronize()
+            out[name] = bool(got.is_cuda and torch.equal(got, payload))
+        X, T, Xs = _data(5)
+        theta = np.tile(np.array([1.0, 1.0, 1.0, 0.0, np.log(1e-3)]), (5, 1))
+        sh = ShardedMultiOutputGP(X, T, nugget="fit")
+        assert sh._device_path()
+        sh.fit(theta)
+        mean, unc = sh.predict(Xs)
+        full = M.MultiOutputGP_GPU(X, T, nugget="fit")
+        full.fit(theta)
+        fmean, func, _ = full.predict(Xs, deriv=False)
+        out["predict"] = bool(np.array_equal(mean, fmean) and np.allclose(unc, func, rtol=0, atol=1e-15))
+        out["fit"] = sh.get_indices_fit() == [0, 1, 2, 3, 4] and bool(np.allclose(sh.nuggets, 1e-3))
+        m2, u2 = sh.predict(Xs, include_nugget=False)
+        f2m, f2u, _ = full.predict(Xs, deriv=False, include_nugget=False)
+        out["predict_no_nugget"] = bool(np.array_equal(m2, f2m) and np.allclose(u2, f2u, rtol=0, atol=1e-15))
+        dist.destroy_process_group()
+        q.put(out)
+    except Exception as exc:                                          # noqa: BLE001
+        import traceback
+        q.put({"error": traceback.format_exc()[-3000:]})
+
+
+def test_rccl_world1_gathers_the_real_payloads_on_device():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_nccl_world1_worker, args=(_free_port(), q))
+    p.start()
+    res = q.get(timeout=600)
+    p.join(timeout=60)
+    assert "error" not in res, res.get("error")
+    assert all(res.values()), res

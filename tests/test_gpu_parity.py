@@ -549,6 +549,46 @@ def test_cholesky_schedules_and_switches(env):
     assert out.returncode == 0 and "SWITCH-OK" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
 
 
+_BS_TIMEOUT_SCRIPT = r"""
+import sys, ctypes, numpy as np
+sys.path.insert(0, %(root)r); sys.path.insert(0, %(tests)r)
+import mogp_emulator_amd as M
+from mogp_emulator_amd import _capi
+from oracle import cpu_ref as R
+from test_gpu_parity import synth, weak
+n, d, B = 1500, 6, 5
+X, T, Xs = synth(77, n, d, B, 50)
+theta = np.array([-2. * np.log(0.3 * np.sqrt(d))] * d + [0.])
+for nugget in (1e-6, "adaptive"):
+    mo = M.MultiOutputGP_GPU(X, T, nugget=nugget, priors=weak(d, nugget))
+    f, _, ok = mo._mogp_gpu.eval(np.tile(theta, (B, 1)), grad=False)
+    assert ok.all()
+    mo.fit(np.tile(theta, (B, 1)))
+    for k in (0, B - 1):
+        ref = R.GPRef(X, T[k], nugget=nugget)
+        np.testing.assert_allclose(f[k], ref.fit(theta), rtol=1e-10)
+        np.testing.assert_allclose(mo.emulators[k].Kinv_t, ref.Kinv_t, rtol=1e-6, atol=1e-7 * np.abs(ref.Kinv_t).max())
+        # a timeout must NOT start the jitter ladder: the adaptive nugget stays what the oracle finds (0 here)
+        np.testing.assert_allclose(mo.emulators[k].nugget, ref.nugget, rtol=1e-12, atol=0)
+c = ctypes.c_longlong()
+assert _capi.load().mogp_profile_counter(b"backsolve_timeouts", ctypes.byref(c)) == 0
+print("BS-TIMEOUTS", c.value)
+"""
+
+
+def test_backsolve_chain_timeout_is_retried_not_reported_as_failure():
+    """a wait of the one-launch back substitution that gives up must not look like a failed
+    factorisation.  MOGP_BS_SPIN=0 turns every wait that is not satisfied at the first poll into a timeout; the engine has
+    to notice (status word of its own), repeat those solves with the multi-launch path and return the oracle's numbers --
+    fixed and adaptive nugget (no jitter may be added)."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = _BS_TIMEOUT_SCRIPT % {"root": root, "tests": os.path.join(root, "tests")}
+    out = subprocess.run([sys.executable, "-c", script], env=dict(os.environ, MOGP_BS_SPIN="0"), capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "BS-TIMEOUTS" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
+    assert int(out.stdout.split("BS-TIMEOUTS")[1].split()[0]) > 0, "the forced timeouts never happened: the test did not exercise the fallback"
+
+
 def test_c5_shaped_single_large_identities():
     # n = 4000, d = 8 (C5 family at a quarter size): no oracle, identities only
     n, d = 4000, 8
@@ -642,7 +682,7 @@ def test_c5_full_size_vs_oracle():
     assert 1e-10 < kappa_eps < 1e-6
     assert_allclose(lp, lp_ref, rtol=max(1e-10, 32 * kappa_eps))
     rmu, rvar, _ = ref.predict(Xs)
-    assert_allclose(mean, rmu, rtol=1e-7, atol=1e-7)
+    assert_allclose(mean, rmu, rtol=1e-7, atol=1e-9)          # (atol as in the C4 test: the means are ~0.1 - 1)
     assert_allclose(unc, rvar, atol=1e-7)
     assert_allclose(gp.Kinv_t, ref.Kinv_t, rtol=1e-5, atol=1e-5 * np.abs(ref.Kinv_t).max())
     gref = ref.logpost_deriv_chunked(theta, chunk_rows=128)
