@@ -38,4 +38,4 @@ def run(tag, cid, n, d, B, m, kernel, nugget, theta):
     print("     grad[0] analytic %.8e  FD %.8e" % (g[0, p], (fp[0] - fm[0]) / (2 * h)))
 
 if os.environ.get("ONLY","") != "C5": run("C4", 4, 5000, 20, 16, 10000, "Matern52", "fit", np.array([-2. * np.log(0.3 * np.sqrt(20))] * 20 + [0., np.log(1e-4)]))
-run("C5", 5, 16000, 8, 1, 10000, "SquaredExponential", 1e-6, np.array([-2. * np.log(0.3 * np.sqrt(8))] * 8 + [0.]))
+if os.environ.get("ONLY","") != "C4": run("C5", 5, 16000, 8, 1, 10000, "SquaredExponential", 1e-6, np.array([-2. * np.log(0.3 * np.sqrt(8))] * 8 + [0.]))
