@@ -100,7 +100,7 @@ def cpu_baseline(X, T, Xs, theta, nugget):
     out["pool"] = []
     for workers in sorted(set([max(1, min(T.shape[0], cores // 2, 32)), all_workers])):
         try:
-            fits = max(T.shape[0], 2 * workers) if workers > 32 else T.shape[0]
+            fits = max(T.shape[0], workers)
             cmd = [sys.executable, os.path.join(ROOT, "oracle", "pool_fit.py"), "2", str(X.shape[0]), str(X.shape[1]),
                    str(T.shape[0]), str(workers), str(fits)]
             env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
@@ -294,6 +294,12 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the C4 / C5 block (other_configs)")
     args = ap.parse_args()
+
+    # The contract is ONE JSON line on stdout.  RCCL (and other native libraries) print banners to the C-level stdout, which
+    # is flushed at exit, i.e. AFTER Python's: keep the real stdout aside for the JSON line and send everything else to stderr.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
 
     import torch
     import torch.distributed as dist
@@ -573,7 +579,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"], values = cpu_baseline(X, T, Xs, theta, nugget)
             out["parity_in_bench"] = parity_in_bench(mo, values, theta, Xs)
-        print(json.dumps(out))
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -24,14 +24,10 @@
 #include <type_traits>
 #include "launch.h"
 #include "trsm_dev.h"
+#include "gemm_dev.h"
 
 namespace mogp {
 
-typedef double v4d __attribute__((ext_vector_type(4)));
-typedef double v2d __attribute__((ext_vector_type(2)));
-
-constexpr int BK = 16;
-constexpr int LDK = BK + 2;
 
 template <int WT>
 struct Cfg {
@@ -350,150 +346,6 @@ __global__ __launch_bounds__(256, 2) void predict_var_kernel(BatchView v, const 
     if (threadIdx.x < 128) partial[((size_t)z * nti + ti) * MP + j0 + threadIdx.x] = red[threadIdx.x] + red[128 + threadIdx.x];
     __syncthreads();                 // red aliases the operand buffers of the next pass
   }
-}
-
-// ---------------------------------------------------------------------------------------------
-// Main loop with WR x WC waves per BM x BN block tile, both operands K-major (same LDS layout and k-step as
-// gemm_mainloop).  More, smaller wave tiles than the 2 x 2 configuration: fewer accumulator VGPRs per wave, so
-// more waves per SIMD are resident and more of the LDS / barrier latency is covered.
-//   acc[i][j]: MFMA tile rows wr*16*TI + 16 i, columns wc*16*TJ + 16 j  (TI = BM/16/WR, TJ = BN/16/WC)
-// ---------------------------------------------------------------------------------------------
-template <int BM, int BN, int WR, int WC>
-struct WCfg {
-  static constexpr int NT = 64 * WR * WC;               // threads
-  static constexpr int TI = BM / 16 / WR, TJ = BN / 16 / WC;
-  static constexpr int CHA = BM * 8 / NT, CHB = BN * 8 / NT;   // 16-byte chunks per thread per operand tile
-  static constexpr int OPA = BM * LDK, OPB = BN * LDK;
-  static constexpr int SMEM_DOUBLES = 2 * (OPA + OPB);
-  static_assert(CHA >= 1 && CHB >= 1, "operand tile smaller than one chunk per thread");
-};
-
-// TRIA: the A operand is a row tile of a LOWER-TRIANGULAR matrix whose last 128 columns of the k range are its diagonal
-// block (nk_full = 16-deep k-steps before it), and rows >= a_rows of the tile are padding.  The 16-row MFMA sub-tiles are
-// then dealt to the WR wave rows round-robin (sub-tile a = i * WR + wr: every wave owns sub-tiles from the top and the
-// bottom of the tile) and a wave skips what is structurally zero:
-//   * step kd of the diagonal block only has non-zeros in sub-tiles a >= kd  (36 of the 64 (sub-tile, step) pairs);
-//   * sub-tiles that start at or below row a_rows are padding.
-// The skipped products are exact zeros.  Control flow: the k loop is cut into consecutive loops, one per set of active
-// sub-tiles [S, E) -- each one is the dense straight-line step restricted to those sub-tiles, the accumulators of the
-// others are simply not touched -- followed by a loop that only moves the wave's share of the operand tiles.  (A branch
-// around MFMA groups inside one loop costs more in register copies and exposed LDS latency than the skipped MFMAs save.)
-// Callers must not depend on the row -> accumulator map.
-template <int BM, int BN, int WR, int WC, bool TRIA = false>
-__device__ __forceinline__ void mainloop_w(const double* __restrict__ Ag, int lda, const double* __restrict__ Bg, int ldb, int nk,
-                                           v4d (&acc)[WCfg<BM, BN, WR, WC>::TI][WCfg<BM, BN, WR, WC>::TJ], double* smem,
-                                           int nk_full = 0, int a_rows = BM) {
-  using C = WCfg<BM, BN, WR, WC>;
-  const int t = threadIdx.x, lane = t & 63;
-  const int wave = TRIA ? __builtin_amdgcn_readfirstlane(t >> 6) : (t >> 6);
-  const int wr = wave / WC, wc = wave % WC;
-  const int fr = lane & 15, fk = lane >> 4;
-#pragma unroll
-  for (int i = 0; i < C::TI; ++i)
-#pragma unroll
-    for (int j = 0; j < C::TJ; ++j) acc[i][j] = (v4d){0., 0., 0., 0.};
-  if (nk <= 0) return;
-  v2d ra[C::CHA], rb[C::CHB];
-  auto loadA = [&]() {
-#pragma unroll
-    for (int q = 0; q < C::CHA; ++q) {
-      const int c = t + C::NT * q;
-      ra[q] = *reinterpret_cast<const v2d*>(Ag + (size_t)(c >> 3) * lda + (c & 7) * 2);
-    }
-  };
-  auto loadB = [&]() {
-#pragma unroll
-    for (int q = 0; q < C::CHB; ++q) {
-      const int c = t + C::NT * q;
-      rb[q] = *reinterpret_cast<const v2d*>(Bg + (size_t)(c >> 3) * ldb + (c & 7) * 2);
-    }
-  };
-  auto store = [&](double* sA, double* sB) {
-#pragma unroll
-    for (int q = 0; q < C::CHA; ++q) {
-      const int c = t + C::NT * q;
-      *reinterpret_cast<v2d*>(sA + (c >> 3) * LDK + (c & 7) * 2) = ra[q];
-    }
-#pragma unroll
-    for (int q = 0; q < C::CHB; ++q) {
-      const int c = t + C::NT * q;
-      *reinterpret_cast<v2d*>(sB + (c >> 3) * LDK + (c & 7) * 2) = rb[q];
-    }
-  };
-  loadA();
-  loadB();
-  store(smem, smem + C::OPA);
-  __syncthreads();
-  // one k-step with the sub-tiles [S, E) of this wave
-  auto step = [&](int kt, auto S_, auto E_) {
-    constexpr int S = decltype(S_)::value, E = decltype(E_)::value;
-    const double* sA = smem + (kt & 1) * (C::OPA + C::OPB);
-    const double* sB = sA + C::OPA;
-    const bool more = (kt + 1 < nk);
-    if (more) {
-      Ag += BK;
-      Bg += BK;
-      loadA();
-      loadB();
-    }
-    if (S < E) {
-#pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {
-        double a[C::TI], b[C::TJ];
-        const int k = kk * 4 + fk;
-#pragma unroll
-        for (int i = S; i < E; ++i) a[i] = sA[((TRIA ? i * WR + wr : wr * C::TI + i) * 16 + fr) * LDK + k];
-#pragma unroll
-        for (int j = 0; j < C::TJ; ++j) b[j] = sB[(wc * 16 * C::TJ + j * 16 + fr) * LDK + k];
-#pragma unroll
-        for (int i = S; i < E; ++i)
-#pragma unroll
-          for (int j = 0; j < C::TJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
-      }
-    }
-    if (more) {
-      double* dA = smem + ((kt + 1) & 1) * (C::OPA + C::OPB);
-      store(dA, dA + C::OPA);
-    }
-    __syncthreads();
-  };
-  using I0 = std::integral_constant<int, 0>;
-  using IT = std::integral_constant<int, C::TI>;
-  int kt = 0;
-  if (!TRIA) {
-    for (; kt < nk; ++kt) step(kt, I0(), IT());
-    return;
-  }
-  static_assert(!TRIA || C::TI == 4, "the phase dispatch below is written for four sub-tiles per wave");
-  // sub-tile i (a = i WR + wr) has non-zeros up to step a of the diagonal block: phase S lasts while sub-tile S is active
-  auto phases = [&](auto E_) {
-    constexpr int E = decltype(E_)::value;
-    if (E > 0) for (const int end = min(nk, nk_full + 0 * WR + wr + 1); kt < end; ++kt) step(kt, std::integral_constant<int, 0>(), E_);
-    if (E > 1) for (const int end = min(nk, nk_full + 1 * WR + wr + 1); kt < end; ++kt) step(kt, std::integral_constant<int, 1>(), E_);
-    if (E > 2) for (const int end = min(nk, nk_full + 2 * WR + wr + 1); kt < end; ++kt) step(kt, std::integral_constant<int, 2>(), E_);
-    if (E > 3) for (const int end = min(nk, nk_full + 3 * WR + wr + 1); kt < end; ++kt) step(kt, std::integral_constant<int, 3>(), E_);
-  };
-  int n_act = 0;     // sub-tiles of this wave that contain real rows
-#pragma unroll
-  for (int i = 0; i < C::TI; ++i) n_act += ((i * WR + wr) * 16 < a_rows) ? 1 : 0;
-  if (n_act == 4) phases(std::integral_constant<int, 4>());
-  else if (n_act == 3) phases(std::integral_constant<int, 3>());
-  else if (n_act == 2) phases(std::integral_constant<int, 2>());
-  else if (n_act == 1) phases(std::integral_constant<int, 1>());
-  for (; kt < nk; ++kt) step(kt, I0(), I0());
-}
-
-// f(row_in_tile, col_in_tile, value) over the accumulator fragment of mainloop_w
-template <int WC, int TI, int TJ, typename F>
-__device__ __forceinline__ void for_each_acc_w(v4d (&acc)[TI][TJ], F f) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int wr = wave / WC, wc = wave % WC;
-#pragma unroll
-  for (int i = 0; i < TI; ++i)
-#pragma unroll
-    for (int j = 0; j < TJ; ++j)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) f(wr * 16 * TI + i * 16 + (lane >> 4) + 4 * r, wc * 16 * TJ + j * 16 + (lane & 15), acc[i][j][r]);
 }
 
 // Trailing symmetric update (lower 128 x 128 tiles over rows / columns [c0, NP)) with the 2 x 4-wave main loop:
