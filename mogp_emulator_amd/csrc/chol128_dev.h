@@ -37,6 +37,30 @@ namespace mogp {
 
 typedef double c128_v2d __attribute__((ext_vector_type(2)));
 typedef double c128_v4d __attribute__((ext_vector_type(4)));
+typedef unsigned int c128_u4 __attribute__((ext_vector_type(4)));
+
+// Write-through (sc1) 16-byte stores for data that ANOTHER workgroup of the same launch reads after a flag hand-off (the
+// one-launch Cholesky, kernels_mchol.hip): cdna_hip_programming.md guideline 16, recipe R1 -- payload stored sc1 through a
+// buffer descriptor, every storing wave drains (s_waitcnt vmcnt(0)), then one lane stores the flag.  Without SC1 the helper
+// is a plain store (separate launches: the kernel boundary publishes).
+struct Sc1Buf {
+  __amdgpu_buffer_rsrc_t rs;
+  const char* base;
+};
+__device__ __forceinline__ Sc1Buf sc1_buf(const void* base, unsigned bytes) {
+  const unsigned long long b = (unsigned long long)base;     // wave-uniform by construction: say so
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b), hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
+  void* ub = (void*)(((unsigned long long)hi << 32) | lo);
+  Sc1Buf r;
+  r.rs = __builtin_amdgcn_make_buffer_rsrc(ub, 0, bytes, 0x00020000);
+  r.base = (const char*)ub;
+  return r;
+}
+template <bool SC1>
+__device__ __forceinline__ void st16(const Sc1Buf& b, double* p, c128_v2d x) {
+  if (SC1) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(c128_u4, x), b.rs, (unsigned)((const char*)p - b.base), 0, 16);
+  else *reinterpret_cast<c128_v2d*>(p) = x;
+}
 
 __device__ __forceinline__ double readlane_f64(double x, int srclane) {
   int lo = __double2loint(x), hi = __double2hiint(x);
@@ -150,8 +174,12 @@ __device__ __forceinline__ void c128_column_steps(c128_v4d& Dn, c128_v4d& Xn, c1
 // A: origin of the 128 x 128 block (row stride ld); only its lower triangle is read.  On return A holds L (upper
 // triangle of the two 64 x 64 diagonal tiles zeroed), pk the pack above, *info_slot = c0 + 1 if it was 0 and the block is not
 // positive definite (the failing column inside the block is not recorded: the engine only tests for non-zero).  All 256 threads must call; lds: C128_LDS_DOUBLES doubles.
+// SC1_PACK: the pack is stored write-through (see st16) because the panel solves that read it belong to the same launch.
+template <bool SC1_PACK = false>
 __device__ __forceinline__ void chol128_dev(double* __restrict__ A, int ld, double* __restrict__ pk, int* info_slot, int c0, double* lds) {
-  const int t = threadIdx.x, lane = t & 63;
+  Sc1Buf pkb;
+  if (SC1_PACK) pkb = sc1_buf(pk, PACK128_STRIDE * sizeof(double));
+  const int t = mogp_tid(), lane = t & 63;
   const int w = __builtin_amdgcn_readfirstlane(t >> 6);
   const int rg = lane >> 4, cl = lane & 15;
   double* Dbuf = lds + 128 * C128_LD;        // next diagonal sub-block (negated), accumulator layout
@@ -264,7 +292,7 @@ __device__ __forceinline__ void chol128_dev(double* __restrict__ A, int ld, doub
         double* pi = pk + PACK128_INV + b * 256;
 #pragma unroll
         for (int h = 0; h < 2; ++h)
-          *reinterpret_cast<c128_v2d*>(pi + 128 * h + 2 * lane) = *reinterpret_cast<const c128_v2d*>(stage + 128 * h + 2 * lane);
+          st16<SC1_PACK>(pkb, pi + 128 * h + 2 * lane, *reinterpret_cast<const c128_v2d*>(stage + 128 * h + 2 * lane));
       }
     }
     C128_STAMPW(4 * b + 2);
@@ -292,7 +320,7 @@ __device__ __forceinline__ void chol128_dev(double* __restrict__ A, int ld, doub
           const int row = 16 * b + (t >> 3) + 32 * i;
           if (row < 128) *reinterpret_cast<c128_v2d*>(A + (size_t)row * ld + 16 * b + 2 * (t & 7)) = ca[i];
           const int r = 16 * b + 2 * (t & 15) + 32 * i, c = 16 * b + (t >> 4);
-          if (r < 128) *reinterpret_cast<c128_v2d*>(pk + PACK128_LT + c * 128 + r) = ct[i];
+          if (r < 128) st16<SC1_PACK>(pkb, pk + PACK128_LT + c * 128 + r, ct[i]);
         }
       }
     }

@@ -135,6 +135,15 @@ class Engine {
   uint32_t sig_epoch = 1;
   bool can_waitval = false;      // hipDeviceAttributeCanUseStreamWaitValue of the engine's device
   int device = 0;                // HIP device the engine was created on
+  // one-launch Cholesky (kernels_mchol.hip): task table, control words, per-column packs
+  int* dMcTable = nullptr;
+  int mc_ntasks = 0;
+  unsigned* dMcCtrl = nullptr;
+  size_t mc_ctrl_ints = 0;
+  double* dMcPacks = nullptr;
+  bool mc_used = false;          // the last factorisation of this engine went through the one-launch kernel (its abort word is live)
+  bool mc_force_legacy = false;  // transient: repeat a factorisation with a multi-launch schedule after an abort
+  int n_cu = 256;
   int* dBsFlags = nullptr;       // hand-off flags of the one-launch back substitution (B x ceil(n/128)), compared with bs_epoch
   int bs_epoch = 0;
   double *dRes = nullptr, *hRes = nullptr;   // per emulator [log-det, status, Gram matrix]: device buffer and its pinned host mirror
@@ -170,7 +179,7 @@ FitOptions& fit_options();
 // FOR MEASUREMENT ONLY: process-global, read by every engine at the start of a factorisation and not synchronised --
 // set it while no evaluation is in flight (bench.py does), never from a thread that races with one.
 struct ScheduleOverride {
-  int schedule = -1;       // 0 two emulator groups, 1 right-looking, 3 look-ahead
+  int schedule = -1;       // 0 two emulator groups, 1 right-looking, 3 look-ahead, 4 one launch (task queue)
   bool single_stream = false;
 };
 ScheduleOverride& schedule_override();

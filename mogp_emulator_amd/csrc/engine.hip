@@ -64,10 +64,11 @@ void prof_end(const char* tag, hipStream_t s, double flops, double bytes) {
   r.launches += 1;
 }
 void prof_enable(bool on) { g_prof_on = on; }
-static std::atomic<long long> g_bs_timeouts{0}, g_obj_evals{0}, g_grad_evals{0};
+static std::atomic<long long> g_bs_timeouts{0}, g_obj_evals{0}, g_grad_evals{0}, g_mc_aborts{0};
 long long prof_counter(const char* name) {
   const std::string s(name ? name : "");
   if (s == "backsolve_timeouts") return g_bs_timeouts.load();
+  if (s == "mchol_aborts") return g_mc_aborts.load();          // one-launch factorisations repeated with a multi-launch schedule
   if (s == "objective_evals") return g_obj_evals.load();      // emulator objective evaluations (with or without gradient)
   if (s == "gradient_evals") return g_grad_evals.load();      // of which with gradient
   return -1;
@@ -162,6 +163,8 @@ Engine::Engine(const double* X, int n_, int D_, const double* targets, int B_, u
   {
     // stream memory operations (look-ahead schedule) are a property of the device THIS engine lives on
     int dev = 0, ok = 0;
+    int cus = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) n_cu = cus;
     can_waitval = hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&ok, hipDeviceAttributeCanUseStreamWaitValue, dev) == hipSuccess && ok != 0;
     device = dev;
   }
@@ -212,6 +215,8 @@ Engine::~Engine() {
     if (p) hipFree(p);
   if (hRes) hipHostFree(hRes);
   if (dBsFlags) hipFree(dBsFlags);
+  for (void* p : {(void*)dMcTable, (void*)dMcCtrl, (void*)dMcPacks})
+    if (p) hipFree(p);
   if (sigU1) hipFree(sigU1);
   for (auto& kv : w2) hipFree(kv.second);
   for (auto st : gstreams) hipStreamDestroy(st);
@@ -440,6 +445,7 @@ void Engine::factorize_blocked(const std::vector<int>& ids, std::vector<int>& in
     if (!e) return -1;
     if (e[0] == 'r') return 1;
     if (std::string(e) == "leftla") return 2;
+    if (std::string(e) == "mchol") return 4;
     return (std::string(e) == "left") ? 0 : 3;
   }();
   // Measured (fit, ms; look-ahead / two groups / right-looking): 8 x n=2000 1.75 / 1.97 / 1.89, 16 x 2.21 / 2.38 / 2.44,
@@ -448,7 +454,38 @@ void Engine::factorize_blocked(const std::vector<int>& ids, std::vector<int>& in
   // a large batch fills the machine with the update of ONE emulator group while the other factors its panels.
   const long tiles64 = (long)nb * (NP / 64), tiles128 = (long)nb * (NP / TILE);
   const ScheduleOverride& ovr = schedule_override();
-  const int schedule = ovr.schedule >= 0 ? ovr.schedule : (forced >= 0 ? forced : (tiles64 < 256 ? 1 : (tiles128 >= 1024 ? 0 : 3)));
+  int schedule = ovr.schedule >= 0 ? ovr.schedule : (forced >= 0 ? forced : (tiles64 < 256 ? 1 : (tiles128 >= 1024 ? 0 : 3)));
+  // the one-launch kernel addresses an emulator's matrix through a 32-bit buffer offset; after an abort the multi-launch
+  // schedule of the same regime takes over
+  if (schedule == 4 && (mc_force_legacy || MS * sizeof(double) >= (size_t)1 << 32)) schedule = tiles64 < 256 ? 1 : (tiles128 >= 1024 ? 0 : 3);
+  mc_used = schedule == 4;
+  if (schedule == 4) {
+    // ONE LAUNCH: persistent workgroups take the tasks of all block columns from a dependency-ordered queue (kernels_mchol.hip)
+    if (!dMcTable) {
+      const std::vector<int> tb = mchol_task_table(NP);
+      mc_ntasks = (int)tb.size();
+      dMcTable = dalloc<int>(tb.size());
+      HIPCK(hipMemcpy(dMcTable, tb.data(), tb.size() * sizeof(int), hipMemcpyHostToDevice));
+      mc_ctrl_ints = mchol_ctrl_ints(NP, B);
+      dMcCtrl = dalloc<unsigned>(mc_ctrl_ints);
+      dMcPacks = dalloc<double>(mchol_pack_doubles(NP, B));
+    }
+    HIPCK(hipMemsetAsync(dInfo, 0, B * sizeof(int), stream));
+    launch_cov_build(v, stream);
+    launch_mchol(v, dMcCtrl, mc_ctrl_ints, dMcTable, mc_ntasks, dMcPacks, dInfo, n_cu, stream);
+    if (!defer_info) {
+      read_info(info, false);
+      unsigned aborted = 0;
+      HIPCK(hipMemcpy(&aborted, dMcCtrl, sizeof(unsigned), hipMemcpyDeviceToHost));
+      if (aborted) {
+        g_mc_aborts += 1;
+        mc_force_legacy = true;
+        factorize_blocked(ids, info, false);
+        mc_force_legacy = false;
+      }
+    }
+    return;
+  }
   if (schedule == 3) {
     // LEFT-LOOKING WITH LOOK-AHEAD.  Block column c receives the panels 0 .. c-2 in one long-K MFMA pass U1(c) on the main
     // stream -- every element of the trailing matrix is read-modified-written once, at the K depth where the MFMA main
@@ -693,7 +730,7 @@ void Engine::eval(const std::vector<int>& ids, const std::vector<const double*>&
         }
       }
       // (after the solves: it also collects the status words)
-      launch_logdet(v, dInfo, dRes, stream, chained ? dBsFlags + (size_t)B * ((n + 127) / 128) : nullptr, bs_epoch);
+      launch_logdet(v, dInfo, dRes, stream, chained ? dBsFlags + (size_t)B * ((n + 127) / 128) : nullptr, bs_epoch, mc_used ? dMcCtrl : nullptr);
       // status words, log-determinants and Gram matrices come back in ONE copy into pinned host memory
       HIPCK(hipMemcpyAsync(hRes, dRes, (size_t)B * RES_STRIDE * sizeof(double), hipMemcpyDeviceToHost, stream));
       HIPCK(hipStreamSynchronize(stream));
@@ -718,6 +755,19 @@ void Engine::eval(const std::vector<int>& ids, const std::vector<const double*>&
   for (int i : ids) has_pivot = has_pivot || gp[i].nug_type == NUG_PIVOT;
   factorize(ids, info, !has_pivot);                          // (the pivoted path reads its status after every panel anyway)
   after_factor(ids, has_pivot ? nullptr : &info);
+  if (!has_pivot) {
+    // the one-launch Cholesky gave up on a wait (never observed; the bound exists so that nothing can hang): its abort word
+    // came back as the status of every emulator -- factorise again with the multi-launch schedule
+    bool aborted = false;
+    for (int i : ids) aborted = aborted || info[i] == MCHOL_ABORTED;
+    if (aborted) {
+      g_mc_aborts += 1;
+      mc_force_legacy = true;
+      factorize(ids, info, true);
+      mc_force_legacy = false;
+      after_factor(ids, &info);
+    }
+  }
   std::vector<char> good(B, 0);
   std::vector<int> failed;
   for (int i : ids) {

@@ -46,7 +46,7 @@ __device__ __forceinline__ void mainloop_w(const double* __restrict__ Ag, int ld
                                            v4d (&acc)[WCfg<BM, BN, WR, WC>::TI][WCfg<BM, BN, WR, WC>::TJ], double* smem,
                                            int nk_full = 0, int a_rows = BM) {
   using C = WCfg<BM, BN, WR, WC>;
-  const int t = threadIdx.x, lane = t & 63;
+  const int t = mogp_tid(), lane = t & 63;
   const int wave = TRIA ? __builtin_amdgcn_readfirstlane(t >> 6) : (t >> 6);
   const int wr = wave / WC, wc = wave % WC;
   const int fr = lane & 15, fk = lane >> 4;
@@ -150,7 +150,7 @@ __device__ __forceinline__ void mainloop_w(const double* __restrict__ Ag, int ld
 // f(row_in_tile, col_in_tile, value) over the accumulator fragment of mainloop_w
 template <int WC, int TI, int TJ, typename F>
 __device__ __forceinline__ void for_each_acc_w(v4d (&acc)[TI][TJ], F f) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int tt = mogp_tid(), lane = tt & 63, wave = tt >> 6;
   const int wr = wave / WC, wc = wave % WC;
 #pragma unroll
   for (int i = 0; i < TI; ++i)

@@ -20,7 +20,7 @@ __device__ __forceinline__ int slot_emu(const int* idx, int z) { return idx ? id
 // A back substitution that gave up waiting (backsolve_chain_kernel) is reported as status BACKSOLVE_TIMEOUT -- a code of its
 // own, never confused with a failed factorisation (> 0): the engine repeats the solve of that emulator with the multi-launch path.
 __global__ __launch_bounds__(256) void logdet_kernel(BatchView v, const int* __restrict__ info, double* __restrict__ res,
-                                                     const int* __restrict__ bs_status, int bs_epoch) {
+                                                     const int* __restrict__ bs_status, int bs_epoch, const unsigned* __restrict__ mc_abort) {
   __shared__ double red[256];
   const int emu = slot_emu(v.idx, blockIdx.x);
   const int ld = v.LD, R = v.R;
@@ -55,7 +55,9 @@ __global__ __launch_bounds__(256) void logdet_kernel(BatchView v, const int* __r
   if (threadIdx.x == 0) {
     out[0] = 2.0 * ls;
     const int st = info[emu];
-    out[1] = (double)((st == 0 && bs_status && bs_status[emu] == bs_epoch) ? BACKSOLVE_TIMEOUT : st);
+    int rep = (st == 0 && bs_status && bs_status[emu] == bs_epoch) ? BACKSOLVE_TIMEOUT : st;
+    if (mc_abort && *mc_abort != 0u) rep = MCHOL_ABORTED;       // the one-launch Cholesky gave up: nothing in A is usable
+    out[1] = (double)rep;
   }
 #pragma unroll
   for (int r = 0; r < RMAX; ++r)
@@ -558,8 +560,8 @@ __global__ void extract_kernel(const double* __restrict__ src, int NP, int n, do
 }
 
 // =============================================================================================
-void launch_logdet(const BatchView& v, const int* info, double* res, hipStream_t s, const int* bs_status, int bs_epoch) {
-  hipLaunchKernelGGL(logdet_kernel, dim3(v.nb), dim3(256), 0, s, v, info, res, bs_status, bs_epoch);
+void launch_logdet(const BatchView& v, const int* info, double* res, hipStream_t s, const int* bs_status, int bs_epoch, const unsigned* mc_abort) {
+  hipLaunchKernelGGL(logdet_kernel, dim3(v.nb), dim3(256), 0, s, v, info, res, bs_status, bs_epoch, mc_abort);
 }
 
 void launch_combine_rows(const BatchView& v, const double* M, hipStream_t s) {

@@ -14,8 +14,23 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstdint>
+#include <vector>
 
 namespace mogp {
+
+// Thread index for the device functions shared between the stand-alone kernels and the one-launch Cholesky.  In the
+// latter (MOGP_OPAQUE_TID) the index is laundered through an empty asm statement: otherwise the compiler hoists every
+// per-thread address computation of every task type out of the task loop and spills them (57 VGPRs).
+#ifdef __HIPCC__
+__device__ __forceinline__ int mogp_tid() {
+  int t = threadIdx.x;
+#ifdef MOGP_OPAQUE_TID
+  asm volatile("" : "+v"(t));
+  __builtin_assume(t >= 0 && t < 256);
+#endif
+  return t;
+}
+#endif
 
 constexpr int TILE = 128;       // MFMA macro tile / padding granule
 // The covariance kernels stage two 64-row blocks of X (and, for predict_deriv, a 64 x 65 work tile and a 64 x D
@@ -81,12 +96,25 @@ void launch_update_narrow_pair(const BatchView& v, int c0, int k0, int k1, hipSt
 void launch_update_wide(const BatchView& v, int c0, int k0, int k1, hipStream_t s);
 // trailing lower-triangular update, rows/cols [c0, NP), k in [k0,k1) (c0 multiple of 128)
 void launch_update_trailing(const BatchView& v, int c0, int k0, int k1, hipStream_t s);
+// --- the whole blocked Cholesky as ONE launch (kernels_mchol.hip): persistent workgroups work off a dependency-ordered task
+// queue.  table: mchol_task_table(NP) on the device; ctrl: mchol_ctrl_ints(NP, B) unsigned ints (zeroed by the launcher; ctrl[0]
+// != 0 afterwards = a wait timed out and the factors are unusable: factorise again with a multi-launch schedule); packs:
+// mchol_pack_doubles(NP, B) doubles (one diagonal-block pack per emulator and block column); info as launch_panel128.
+// The matrix of one emulator must be smaller than 4 GB (write-through stores go through a buffer descriptor).
+std::vector<int> mchol_task_table(int NP);
+size_t mchol_ctrl_ints(int NP, int B);
+size_t mchol_pack_doubles(int NP, int B);
+void launch_mchol(const BatchView& v, unsigned* ctrl, size_t ctrl_ints, const int* table, int ntasks, double* packs, int* info, int n_cu,
+                  hipStream_t s);
+constexpr int MCHOL_ABORTED = -3;     // status reported by launch_logdet for every emulator when ctrl[0] != 0
+
 // res (indexed by emulator, RES_STRIDE doubles each): [0] = 2 sum_{i<n} log L_ii, [1] = info[emu] -- or BACKSOLVE_TIMEOUT when the
 // factorisation succeeded but bs_status[emu] == bs_epoch (the one-launch back substitution gave up waiting) --,
 // [2 + r*RMAX + s] = sum_{c<n} L[n+r,c] L[n+s,c]  (Gram matrix of the right-hand-side rows; [2] = y^T y)
 constexpr int RES_STRIDE = 2 + RMAX * RMAX;
 constexpr int BACKSOLVE_TIMEOUT = -2;
-void launch_logdet(const BatchView& v, const int* info, double* res, hipStream_t s, const int* bs_status = nullptr, int bs_epoch = 0);
+void launch_logdet(const BatchView& v, const int* info, double* res, hipStream_t s, const int* bs_status = nullptr, int bs_epoch = 0,
+                   const unsigned* mc_abort = nullptr);
 // alpha[c] = sum_r M[emu][c][r] Z[r], c < RA   (M: indexed by emulator, (RMAX+1) x RMAX row-major)
 void launch_combine_rows(const BatchView& v, const double* M, hipStream_t s);
 // alpha = L^-T y (y = row n of A)

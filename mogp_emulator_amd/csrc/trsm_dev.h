@@ -31,10 +31,15 @@ constexpr int TL_PK = 112 * 16 + 256;                 // row block image: A oper
 constexpr int TL_TS = 16 * 18;                        // one 16 x 16 block of the slab, row stride 18
 constexpr int TRSM128L_LDS = 2 * TL_PK + 4 * 2 * TL_TS;
 
+// SC1_OUT: the solved rows are stored write-through (chol128_dev.h, st16): other workgroups of the same launch read them
+// as GEMM operands after a flag hand-off (kernels_mchol.hip).  The emulator's matrix must then be smaller than 4 GB.
+template <bool SC1_OUT = false>
 __device__ __forceinline__ void trsm128_lds_dev(const BatchView& v, int c0, int r0, const double* __restrict__ pk, int emu, int rowblock,
                                                 double* lds) {
+  Sc1Buf ab;
+  if (SC1_OUT) ab = sc1_buf(v.A + (size_t)emu * v.MS, (unsigned)(v.MS * sizeof(double)));
   const int ld = v.LD;
-  const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int t = mogp_tid(), lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int g = lane >> 4, i = lane & 15;
   double* slab = v.A + (size_t)emu * v.MS + (size_t)(r0 + rowblock * 64 + wave * 16) * ld + c0;   // 16 rows x 128 columns
   double* pkb[2] = {lds, lds + TL_PK};
@@ -102,8 +107,8 @@ __device__ __forceinline__ void trsm128_lds_dev(const BatchView& v, int c0, int 
     {
       const v2d_p o0 = *reinterpret_cast<const v2d_p*>(ts + sr0 * 18 + sp);
       const v2d_p o1 = *reinterpret_cast<const v2d_p*>(ts + (sr0 + 8) * 18 + sp);
-      *reinterpret_cast<v2d_p*>(slab + (size_t)sr0 * ld + 16 * b + sp) = o0;
-      *reinterpret_cast<v2d_p*>(slab + (size_t)(sr0 + 8) * ld + 16 * b + sp) = o1;
+      st16<SC1_OUT>(ab, slab + (size_t)sr0 * ld + 16 * b + sp, o0);
+      st16<SC1_OUT>(ab, slab + (size_t)(sr0 + 8) * ld + 16 * b + sp, o1);
     }
     if (b < 7) {
       pack_deposit(b + 1, pkb[(b + 1) & 1]);
