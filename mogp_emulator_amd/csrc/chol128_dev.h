@@ -175,7 +175,13 @@ __device__ __forceinline__ void c128_column_steps(c128_v4d& Dn, c128_v4d& Xn, c1
 // triangle of the two 64 x 64 diagonal tiles zeroed), pk the pack above, *info_slot = c0 + 1 if it was 0 and the block is not
 // positive definite (the failing column inside the block is not recorded: the engine only tests for non-zero).  All 256 threads must call; lds: C128_LDS_DOUBLES doubles.
 // SC1_PACK: the pack is stored write-through (see st16) because the panel solves that read it belong to the same launch.
-template <bool SC1_PACK = false>
+// PRE (one-launch Cholesky): before it is factored, the block receives the rank-128 update with the panel to its LEFT,
+// A -= X X^T, X = the 128 x 128 tile at A - 128 (rows of this block, previous block column).  X is streamed through two
+// LDS images of 16 columns each and applied to the register-resident sub-blocks with the MFMA pattern of the rank-16
+// updates below, so the last panel's share of the diagonal block costs no read-modify-write pass and no hand-off of its
+// own.  lds must then hold C128_LDS_PRE_DOUBLES.
+constexpr int C128_LDS_PRE_DOUBLES = C128_LDS_DOUBLES + 128 * C128_LD;
+template <bool SC1_PACK = false, bool PRE = false>
 __device__ __forceinline__ void chol128_dev(double* __restrict__ A, int ld, double* __restrict__ pk, int* info_slot, int c0, double* lds) {
   Sc1Buf pkb;
   if (SC1_PACK) pkb = sc1_buf(pk, PACK128_STRIDE * sizeof(double));
@@ -235,6 +241,51 @@ __device__ __forceinline__ void chol128_dev(double* __restrict__ A, int ld, doub
       *reinterpret_cast<c128_v2d*>(p) = z2;
       *reinterpret_cast<c128_v2d*>(p + 2) = z2;
     }
+  }
+  if (PRE) {
+    double* img[2] = {lds, lds + C128_LDS_DOUBLES};
+    const double* Xg = A - 128;                                 // X[row][col] = Xg[row * ld + col]
+    const int xr = t >> 3, xc = 2 * (t & 7);                    // this thread's 16-byte pieces: rows xr + 32 i
+    c128_v2d xv[2][4];
+    auto xload = [&](int u, int j) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) xv[u][i] = *reinterpret_cast<const c128_v2d*>(Xg + (size_t)(xr + 32 * i) * ld + 16 * j + xc);
+    };
+    xload(0, 0);
+    xload(1, 1);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      double* S = img[j & 1];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) *reinterpret_cast<c128_v2d*>(S + (xr + 32 * i) * C128_LD + xc) = xv[j & 1][i];
+      __syncthreads();                                          // (image j & 1 was last read in step j - 2: a barrier ago)
+      if (j + 2 < 8) xload(j & 1, j + 2);
+      double bo1[4], bo2[4], a0[4];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        bo1[s] = S[(16 * r1 + cl) * C128_LD + rg + 4 * s];
+        bo2[s] = S[(16 * r2 + cl) * C128_LD + rg + 4 * s];
+        a0[s] = S[cl * C128_LD + rg + 4 * s];
+      }
+#pragma unroll
+      for (int s = 0; s < 4; ++s) Dn = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[s], a0[s], Dn, 0, 0, 0);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        double ak[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) ak[s] = S[(16 * k + cl) * C128_LD + rg + 4 * s];
+        // (sub-blocks the wave does not own, k > r, are skipped with wave-uniform branches: 40 instead of 52 MFMAs per chunk)
+        if (k < 4 && k <= r1 && r1 > 0) {
+#pragma unroll
+          for (int s = 0; s < 4; ++s) R1[k < 4 ? k : 0] = __builtin_amdgcn_mfma_f64_16x16x4f64(ak[s], bo1[s], R1[k < 4 ? k : 0], 0, 0, 0);
+        }
+        if (k <= r2) {
+#pragma unroll
+          for (int s = 0; s < 4; ++s) R2[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(ak[s], bo2[s], R2[k], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();                                            // the first image is the block steps' column image
   }
   c128_v4d nident;                           // minus the identity, transposed layout (symmetric)
 #pragma unroll

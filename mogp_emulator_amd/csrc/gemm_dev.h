@@ -147,6 +147,100 @@ __device__ __forceinline__ void mainloop_w(const double* __restrict__ Ag, int ld
   for (; kt < nk; ++kt) step(kt, I0(), I0());
 }
 
+// Same k-step as mainloop_w (both operands K-major, LDS double buffer, one barrier per 16-deep step), but the global
+// loads run PD steps ahead of the matrix cores through a ring of PD register sets, and the products are ADDED to acc.
+// Written for the one-launch Cholesky: the last 128 columns of a tile's k range are read straight after another
+// workgroup has published them write-through, i.e. from HBM / the infinity cache, and with the one-step prefetch of
+// mainloop_w every one of its 8 steps exposed a full memory latency (25-35 us for 8 steps, per-task stamps of
+// tools/mchol_trace.py); four steps ahead the latency is paid about twice.  nk must be a multiple of PD.
+// park != nullptr: a word that is non-zero while a latency-bound task (the diagonal block of the one-launch Cholesky) runs
+// on THIS CU in the co-resident workgroup; this workgroup then leaves the CU's matrix pipes to it: every step lane 0
+// publishes the word's value (loaded asynchronously a step earlier) through park_lds[0 / 1], and while it is set all waves
+// sleep at a barrier until lane 0 sees it cleared (bounded by park_spins polls).
+template <int BM, int BN, int WR, int WC, int PD>
+__device__ __forceinline__ void mainloop_pf(const double* __restrict__ Ag, int lda, const double* __restrict__ Bg, int ldb, int nk,
+                                            v4d (&acc)[WCfg<BM, BN, WR, WC>::TI][WCfg<BM, BN, WR, WC>::TJ], double* smem,
+                                            const unsigned* park = nullptr, int* park_lds = nullptr, int park_spins = 0) {
+  using C = WCfg<BM, BN, WR, WC>;
+  const int t = mogp_tid(), lane = t & 63, wave = t >> 6;
+  const int wr = wave / WC, wc = wave % WC;
+  const int fr = lane & 15, fk = lane >> 4;
+  if (nk <= 0) return;
+  v2d ra[PD][C::CHA], rb[PD][C::CHB];
+  auto load = [&](int u, int kt) {
+#pragma unroll
+    for (int q = 0; q < C::CHA; ++q) {
+      const int c = t + C::NT * q;
+      ra[u][q] = *reinterpret_cast<const v2d*>(Ag + (size_t)(c >> 3) * lda + (c & 7) * 2 + (size_t)kt * BK);
+    }
+#pragma unroll
+    for (int q = 0; q < C::CHB; ++q) {
+      const int c = t + C::NT * q;
+      rb[u][q] = *reinterpret_cast<const v2d*>(Bg + (size_t)(c >> 3) * ldb + (c & 7) * 2 + (size_t)kt * BK);
+    }
+  };
+  auto store = [&](int u, double* sA, double* sB) {
+#pragma unroll
+    for (int q = 0; q < C::CHA; ++q) {
+      const int c = t + C::NT * q;
+      *reinterpret_cast<v2d*>(sA + (c >> 3) * LDK + (c & 7) * 2) = ra[u][q];
+    }
+#pragma unroll
+    for (int q = 0; q < C::CHB; ++q) {
+      const int c = t + C::NT * q;
+      *reinterpret_cast<v2d*>(sB + (c >> 3) * LDK + (c & 7) * 2) = rb[u][q];
+    }
+  };
+#pragma unroll
+  for (int u = 0; u < PD; ++u) load(u, u);
+  store(0, smem, smem + C::OPA);
+  __syncthreads();
+  unsigned pword = 0;
+  for (int kt0 = 0; kt0 < nk; kt0 += PD) {
+#pragma unroll
+    for (int u = 0; u < PD; ++u) {
+      const int kt = kt0 + u;
+      if (park) {
+        // slot kt & 1 was written during step kt - 1, before the barrier that ended it: every thread reads the same value
+        // (two slots, so that lane 0's next write cannot overtake a slower wave's read)
+        if (kt > 0 && park_lds[kt & 1] != 0) {
+          if (t == 0) {
+            int spins = 0;
+            while (__hip_atomic_load(park, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u && ++spins < park_spins) __builtin_amdgcn_s_sleep(16);
+            pword = 0;
+          }
+          __syncthreads();
+        }
+        if (t == 0) {
+          park_lds[(kt + 1) & 1] = (int)pword;                  // value loaded a step ago; everybody reads it after this step's barrier
+          pword = __hip_atomic_load(park, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+      const double* sA = smem + (kt & 1) * (C::OPA + C::OPB);
+      const double* sB = sA + C::OPA;
+      if (kt + PD < nk) load(u, kt + PD);                 // register set u held step kt, which is in LDS already
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        double a[C::TI], b[C::TJ];
+        const int k = kk * 4 + fk;
+#pragma unroll
+        for (int i = 0; i < C::TI; ++i) a[i] = sA[((wr * C::TI + i) * 16 + fr) * LDK + k];
+#pragma unroll
+        for (int j = 0; j < C::TJ; ++j) b[j] = sB[(wc * 16 * C::TJ + j * 16 + fr) * LDK + k];
+#pragma unroll
+        for (int i = 0; i < C::TI; ++i)
+#pragma unroll
+          for (int j = 0; j < C::TJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+      }
+      if (kt + 1 < nk) {
+        double* dA = smem + ((kt + 1) & 1) * (C::OPA + C::OPB);
+        store((u + 1) % PD, dA, dA + C::OPA);
+      }
+      __syncthreads();
+    }
+  }
+}
+
 // f(row_in_tile, col_in_tile, value) over the accumulator fragment of mainloop_w
 template <int WC, int TI, int TJ, typename F>
 __device__ __forceinline__ void for_each_acc_w(v4d (&acc)[TI][TJ], F f) {

@@ -8,8 +8,9 @@
 // matrix cores (profiles/r02b_timeline_lookahead_B8.txt).  Here the same three device functions (gemm_dev.h, chol128_dev.h,
 // trsm_dev.h) run as TASKS of one kernel, and a task waits for exactly the tiles it needs:
 //
-//   D(c)      the 128 x 128 diagonal block of block column c (chol128_dev); needs the two diagonal GEMM tasks of column c
-//   G(r, c)   r in {2c, 2c+1}: 64 rows of the diagonal block receive the panels 0 .. c-1 (left-looking, long K)
+//   D(c)      the 128 x 128 diagonal block of block column c (chol128_dev): applies panel c-1 to the register-resident block
+//             (chol128_dev<.., PRE>) and factors it; needs T(2c, c-1), T(2c+1, c-1) and the two diagonal GEMM tasks of column c
+//   G(r, c)   r in {2c, 2c+1}: 64 rows of the diagonal block receive the panels 0 .. c-2 (left-looking, long K; off the chain)
 //   T(r, c)   r >= 2c+2: 64 rows x 128 columns below the diagonal block: the same long-K GEMM, then the panel solve with the
 //             pack of D(c) (trsm128_lds_dev).  The accumulators stay in registers while the task waits for panel c-1, so the
 //             look-ahead of the stream schedules (their U1 / U2 split and its extra read-modify-write pass) is implicit:
@@ -31,6 +32,7 @@
 // of view), so no cache can hold a stale copy and no acquire invalidation is needed; tiles and packs are 128-byte aligned,
 // so no line is shared between tasks.
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <vector>
 #define MOGP_OPAQUE_TID 1
@@ -46,8 +48,10 @@ namespace {
 constexpr int MC_LINE = 32;                       // ints per 128-byte line
 constexpr int MC_ABORT = 0, MC_TIMEOUTS = 1;      // ctrl[0], ctrl[1]
 constexpr int MC_HEADS = MC_LINE;                 // queue head q at ctrl[MC_HEADS + q * MC_LINE]
-constexpr int MC_EMU0 = MC_LINE * 9;              // per-emulator blocks start here
-constexpr int MC_LDS_HDR = 2;                     // doubles in front of the operand buffers: [task / ok words]
+constexpr int MC_CU0 = MC_LINE * 9;               // per-CU "a diagonal block is being factored here" words, index xcc * 256 + HW_ID[15:8]
+constexpr int MC_EMU0 = MC_CU0 + 8 * 256;         // per-emulator blocks start here
+constexpr int MC_PD = 4;                          // k-steps the global loads of a GEMM task run ahead (gemm_dev.h, mainloop_pf)
+constexpr int MC_LDS_HDR = 4;                     // doubles in front of the operand buffers: [task / ok words]
 
 __device__ __forceinline__ unsigned ldu(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void stu(unsigned* p, unsigned x) { __hip_atomic_store(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -56,8 +60,16 @@ __device__ __forceinline__ void drain_stores() { asm volatile("s_waitcnt vmcnt(0
 struct McCtx {
   unsigned* ctrl;
   int spin_limit;
-  int* shi;          // LDS: [0] task number, [1] result of a wait
+  int* shi;          // LDS: [0] task number, [1] result of a wait, [2], [3] park words of the GEMM main loop
 };
+
+// optional per-task time stamps (tools/mchol_trace.py; MOGP_MC_TRACE=<file>): 8 x 64-bit words per task,
+// [0] pulled, [1]/[2] last operand wait begins / ends (D: wait for the diagonal tiles), [3]/[4] wait for the pack begins / ends
+// (T only), [5] published, [6] hardware id, [7] task word | queue position << 32; 100 MHz clock (s_memrealtime)
+template <bool TRACE>
+__device__ __forceinline__ void mc_stamp(unsigned long long* tr, int i) {
+  if (TRACE && tr && threadIdx.x == 0) tr[i] = __builtin_amdgcn_s_memrealtime();
+}
 
 // All 256 threads call.  Lane 0 polls until min(*a, *b, *c) >= want (b, c may equal a); returns that minimum, or -1 after a
 // timeout / when another workgroup has aborted.
@@ -97,8 +109,10 @@ __device__ __forceinline__ int mc_wait_min3(const McCtx& cx, const unsigned* a, 
 }  // namespace
 
 // table[p] = (type << 30) | (c << 15) | r;  type 0: D(c), 1: G(r, c), 2: T(r, c)
+template <bool TRACE>
 __global__ __launch_bounds__(256, 2) void mchol_kernel(BatchView v, unsigned* __restrict__ ctrl, const int* __restrict__ table, int ntasks,
-                                                       int emu_stride, double* __restrict__ packs, int* __restrict__ info, int nq, int spin_limit) {
+                                                       int emu_stride, double* __restrict__ packs, int* __restrict__ info, int nq, int spin_limit,
+                                                       int park_on, unsigned long long* __restrict__ trace) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   int* shi = reinterpret_cast<int*>(smem);
   double* lds = smem + MC_LDS_HDR;
@@ -107,6 +121,10 @@ __global__ __launch_bounds__(256, 2) void mchol_kernel(BatchView v, unsigned* __
   const int ld = v.LD;
   const int K = v.NP / 128, K2 = v.NP / 64;
   const int home = (int)blockIdx.x & (nq - 1);          // observed: block b runs on XCD b % 8 (for speed only)
+  // this workgroup's CU: XCC_ID and HW_ID[15:8] (CU / SH / SE); only used to keep the co-resident workgroup off the matrix
+  // pipes while a diagonal block is factored here -- a wrong or shared index costs speed, never correctness
+  unsigned* cuword = ctrl + MC_CU0 + (__builtin_amdgcn_s_getreg(6164) & 7u) * 256u + (__builtin_amdgcn_s_getreg(((8 - 1) << 11) | (8 << 6) | 4) & 255u);
+  const bool use_park = park_on != 0;
   const int emus_q = v.nb / nq;
   const int total = ntasks * emus_q;
   for (int qi = 0; qi < nq; ++qi) {
@@ -129,32 +147,56 @@ __global__ __launch_bounds__(256, 2) void mchol_kernel(BatchView v, unsigned* __
       unsigned* ddone = diagcnt + K;
       double* pk = packs + ((size_t)emu * K + c) * PACK128_STRIDE;
       const int c0 = 128 * c;
+      unsigned long long* tr = TRACE ? trace + ((size_t)z * ntasks + p) * 8 : nullptr;
+      if (TRACE && t == 0) {
+        tr[6] = __builtin_amdgcn_s_getreg(6164) | ((unsigned long long)__builtin_amdgcn_s_getreg(((8 - 1) << 11) | (8 << 6) | 4) << 8);   // XCC_ID, HW_ID
+        tr[7] = (unsigned)word | ((unsigned long long)tk << 32);
+      }
+      mc_stamp<TRACE>(tr, 0);
       if (type == 0) {
         // ---- D(c): diagonal block ------------------------------------------------------------------------------------
-        if (c > 0 && mc_wait_min3(cx, diagcnt + c, diagcnt + c, diagcnt + c, 2u) < 0) return;
-        chol128_dev<true>(A + (size_t)c0 * ld + c0, ld, pk, info + emu, c0, lds);
+        mc_stamp<TRACE>(tr, 1);
+        // the panels 0 .. c-2 arrive through the two G tasks (c >= 2), panel c-1 is applied here, straight from the two
+        // panel-solve tasks that produced it
+        if (c > 1 && mc_wait_min3(cx, diagcnt + c, diagcnt + c, diagcnt + c, 2u) < 0) return;
+        if (c > 0 && mc_wait_min3(cx, rowdone + 2 * c, rowdone + 2 * c + 1, rowdone + 2 * c + 1, (unsigned)c) < 0) return;
+        mc_stamp<TRACE>(tr, 2);
+        if (use_park && t == 0) __hip_atomic_fetch_add(cuword, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (c > 0) chol128_dev<true, true>(A + (size_t)c0 * ld + c0, ld, pk, info + emu, c0, lds);
+        else chol128_dev<true, false>(A + (size_t)c0 * ld + c0, ld, pk, info + emu, c0, lds);
+        if (use_park && t == 0) __hip_atomic_fetch_sub(cuword, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __builtin_amdgcn_s_setprio(0);
         drain_stores();
         __syncthreads();
         if (t == 0) stu(ddone + c, 1u);
+        mc_stamp<TRACE>(tr, 5);
         continue;
       }
       // ---- G / T: 64 rows x 128 columns receive the panels 0 .. c-1 -----------------------------------------------------
       const int r0 = 64 * r;
-      if (c > 0) {
+      // tasks of the dependent chain (diagonal tiles, the two row blocks of the next diagonal block) issue ahead of the
+      // workgroup they share the CU with
+      const bool urgent = type == 1 || r < 2 * c + 4;
+      if (urgent) __builtin_amdgcn_s_setprio(2);
+      const int kend = type == 1 ? c - 1 : c;        // G: the last panel is applied by D(c) itself
+      if (kend > 0) {
         v4d acc[2][4];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
           for (int j = 0; j < 4; ++j) acc[i][j] = (v4d){0., 0., 0., 0.};
         int kb = 0;
-        while (kb < c) {
+        while (kb < kend) {
+          mc_stamp<TRACE>(tr, 1);
           int m = mc_wait_min3(cx, rowdone + r, rowdone + 2 * c, rowdone + 2 * c + 1, (unsigned)(kb + 1));
           if (m < 0) return;
-          m = m < c ? m : c;
-          mainloop_w<64, 128, 2, 2, false, false>(A + (size_t)r0 * ld + 128 * kb, ld, A + (size_t)c0 * ld + 128 * kb, ld, 8 * (m - kb), acc, lds);
+          mc_stamp<TRACE>(tr, 2);
+          m = m < kend ? m : kend;
+          mainloop_pf<64, 128, 2, 2, MC_PD>(A + (size_t)r0 * ld + 128 * kb, ld, A + (size_t)c0 * ld + 128 * kb, ld, 8 * (m - kb), acc, lds,
+                                            (use_park && !urgent) ? cuword : nullptr, shi + 2, 1 << 14);
           kb = m;
         }
+        if (type == 1) mc_stamp<TRACE>(tr, 3);
         if (type == 1) {
           // read by D(c) on another CU: write-through
           for_each_acc_w<2>(acc, [&](int row, int col, double x) {
@@ -167,19 +209,26 @@ __global__ __launch_bounds__(256, 2) void mchol_kernel(BatchView v, unsigned* __
             *pc -= x;
           });
         }
+        if (type == 1) mc_stamp<TRACE>(tr, 4);
         drain_stores();
         __syncthreads();
       }
       if (type == 1) {
         if (t == 0) __hip_atomic_fetch_add(diagcnt + c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        mc_stamp<TRACE>(tr, 5);
+        __builtin_amdgcn_s_setprio(0);
         continue;
       }
       // ---- T: panel solve with the pack of D(c) ---------------------------------------------------------------------------
+      mc_stamp<TRACE>(tr, 3);
       if (mc_wait_min3(cx, ddone + c, ddone + c, ddone + c, 1u) < 0) return;
+      mc_stamp<TRACE>(tr, 4);
       trsm128_lds_dev<true>(v, c0, r0, pk, emu, 0, lds);
       drain_stores();
       __syncthreads();
       if (t == 0) stu(rowdone + r, (unsigned)(c + 1));
+      mc_stamp<TRACE>(tr, 5);
+      __builtin_amdgcn_s_setprio(0);
     }
   }
 }
@@ -187,10 +236,10 @@ __global__ __launch_bounds__(256, 2) void mchol_kernel(BatchView v, unsigned* __
 // ---------------------------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------------------------
-// Topological task order of ONE emulator.  Column c: D(c); the two row blocks of the NEXT diagonal block first -- T(2c+2, c),
-// T(2c+3, c) -- and right behind them the diagonal GEMM tasks of column c+1 that wait for exactly those two, so that the
-// chain D(c) -> T -> G -> D(c+1) is taken by workgroups that are already polling when their input arrives; then the rest of
-// column c from the top down.
+// Topological task order of ONE emulator.  Column c: D(c); the two row blocks of the NEXT diagonal block -- T(2c+2, c),
+// T(2c+3, c): D(c+1) waits for exactly these two, so the chain D(c) -> T -> D(c+1) is taken by workgroups that are already
+// polling when their input arrives --; then the row blocks of the diagonal block after that and, right behind them, the
+// diagonal GEMM tasks of column c+2 (panels 0 .. c, complete with those two solves); then the rest of column c from the top.
 std::vector<int> mchol_task_table(int NP) {
   const int K = NP / 128, K2 = NP / 64;
   std::vector<int> tb;
@@ -198,11 +247,13 @@ std::vector<int> mchol_task_table(int NP) {
   for (int c = 0; c < K; ++c) {
     tb.push_back(word(0, c, 0));
     for (int r = 2 * c + 2; r < std::min(2 * c + 4, K2); ++r) tb.push_back(word(2, c, r));
-    if (c + 1 < K) {
-      tb.push_back(word(1, c + 1, 2 * c + 2));
-      tb.push_back(word(1, c + 1, 2 * c + 3));
+    for (int r = 2 * c + 4; r < std::min(2 * c + 6, K2); ++r) tb.push_back(word(2, c, r));
+    // the diagonal GEMM tasks of column c+2 need the panels 0 .. c: rows 2c+4, 2c+5 of column c, just above
+    if (c + 2 < K) {
+      tb.push_back(word(1, c + 2, 2 * c + 4));
+      tb.push_back(word(1, c + 2, 2 * c + 5));
     }
-    for (int r = 2 * c + 4; r < K2; ++r) tb.push_back(word(2, c, r));
+    for (int r = 2 * c + 6; r < K2; ++r) tb.push_back(word(2, c, r));
   }
   return tb;
 }
@@ -213,17 +264,50 @@ size_t mchol_pack_doubles(int NP, int B) { return (size_t)B * (NP / 128) * PACK1
 
 void launch_mchol(const BatchView& v, unsigned* ctrl, size_t ctrl_ints, const int* table, int ntasks, double* packs, int* info, int n_cu,
                   hipStream_t s) {
-  // MOGP_MC_SPIN: polls before a wait gives up (default 2^22: seconds); MOGP_MC_WGS: workgroups per CU (default 2)
+  // MOGP_MC_SPIN: polls before a wait gives up (default 2^22: seconds)
   static const int spin_limit = [] { const char* e = getenv("MOGP_MC_SPIN"); return e ? atoi(e) : (1 << 22); }();
-  static const int per_cu = [] { const char* e = getenv("MOGP_MC_WGS"); return e ? std::max(1, atoi(e)) : 2; }();
+  // Workgroups per CU and parking, by regime.  rho = (time the matrix cores need at ~45 TFLOP/s) / (length of the dependent
+  // chain, ~55 us per block column).  Chain-bound batches (rho < 1: 8 x n=2000, 2 x n=5000) run ONE workgroup per CU, so that
+  // a diagonal-block task never shares its CU's matrix pipes (measured 1.15 vs 1.25 ms at 8 x n=2000, 2.91 vs 3.01 at
+  // 2 x n=5000); beyond that two per CU (16 x n=2000: 1.62 vs 1.71 ms; n=16000: 26.3 vs 27.9), and up to rho = 2 the
+  // workgroup that shares a CU with a diagonal-block task parks (mainloop_pf) -- with more work than that the diagonal
+  // blocks have slack and a parked workgroup is only lost capacity.  MOGP_MC_WGS = 1 / 2 and MOGP_MC_PARK = 0 / 1 force either.
+  static const int force_wgs = [] { const char* e = getenv("MOGP_MC_WGS"); return e ? std::max(1, atoi(e)) : 0; }();
+  static const int force_park = [] { const char* e = getenv("MOGP_MC_PARK"); return e ? atoi(e) : -1; }();
+  const double npd = v.NP;
+  const double rho = ((double)v.nb * npd * npd * npd / 3.0 / 45e12) / ((npd / 128.0) * 55e-6);
+  const int per_cu = force_wgs ? force_wgs : (rho < 1.0 ? 1 : 2);
+  const int park_on = force_park >= 0 ? force_park : ((per_cu > 1 && rho < 2.0) ? 1 : 0);
   (void)hipMemsetAsync(ctrl, 0, ctrl_ints * sizeof(unsigned), s);
   const int nq = (v.nb % 8 == 0) ? 8 : 1;
-  const size_t lds_doubles = MC_LDS_HDR + std::max<size_t>({(size_t)WCfg<64, 128, 2, 2>::SMEM_DOUBLES, (size_t)TRSM128L_LDS, (size_t)C128_LDS_DOUBLES});
+  // one workgroup per CU is enforced through the LDS request: more than half of the 160 KB
+  const size_t lds_doubles = (per_cu == 1 ? (size_t)11 * 1024 : 0) + MC_LDS_HDR + std::max<size_t>({(size_t)WCfg<64, 128, 2, 2>::SMEM_DOUBLES, (size_t)TRSM128L_LDS, (size_t)C128_LDS_PRE_DOUBLES});
   const int total = ntasks * v.nb;
   const int grid = std::min(per_cu * n_cu, total);
+  // MOGP_MC_TRACE=<file>: per-task time stamps of EVERY launch are appended to the file (analysis only: synchronises)
+  static const char* trace_file = getenv("MOGP_MC_TRACE");
+  if (trace_file) {
+    const size_t words = (size_t)total * 8;
+    unsigned long long* dtr = nullptr;
+    if (hipMalloc(reinterpret_cast<void**>(&dtr), words * 8) != hipSuccess) return;
+    (void)hipMemsetAsync(dtr, 0, words * 8, s);
+    hipLaunchKernelGGL(mchol_kernel<true>, dim3(grid), dim3(256), lds_doubles * sizeof(double), s, v, ctrl, table, ntasks, mchol_emu_stride(v.NP), packs,
+                       info, nq, spin_limit, park_on, dtr);
+    std::vector<unsigned long long> h(words);
+    (void)hipStreamSynchronize(s);
+    (void)hipMemcpy(h.data(), dtr, words * 8, hipMemcpyDeviceToHost);
+    (void)hipFree(dtr);
+    if (FILE* f = fopen(trace_file, "ab")) {
+      const long long hdr[4] = {v.nb, ntasks, v.NP, grid};
+      fwrite(hdr, sizeof(hdr), 1, f);
+      fwrite(h.data(), 8, words, f);
+      fclose(f);
+    }
+    return;
+  }
   prof_begin("mchol", s);
-  hipLaunchKernelGGL(mchol_kernel, dim3(grid), dim3(256), lds_doubles * sizeof(double), s, v, ctrl, table, ntasks, mchol_emu_stride(v.NP), packs, info,
-                     nq, spin_limit);
+  hipLaunchKernelGGL(mchol_kernel<false>, dim3(grid), dim3(256), lds_doubles * sizeof(double), s, v, ctrl, table, ntasks, mchol_emu_stride(v.NP), packs,
+                     info, nq, spin_limit, park_on, (unsigned long long*)nullptr);
   const double n = v.NP;
   prof_end("mchol", s, (double)v.nb * n * n * n / 3.0, (double)v.nb * 8.0 * n * n);
 }

@@ -535,7 +535,9 @@ print("SWITCH-OK", repr(float(f[0])))
 """
 
 
-@pytest.mark.parametrize("env", [{"MOGP_CHOL": "la"}, {"MOGP_CHOL": "left"}, {"MOGP_CHOL": "left", "MOGP_GROUPS": "1"},
+@pytest.mark.parametrize("env", [{"MOGP_CHOL": "mchol"}, {"MOGP_CHOL": "mchol", "MOGP_MC_WGS": "2", "MOGP_MC_PARK": "1"},
+                                 {"MOGP_CHOL": "mchol", "MOGP_MC_WGS": "2", "MOGP_MC_PARK": "0"}, {"MOGP_MCHOL": "0"},
+                                 {"MOGP_CHOL": "la"}, {"MOGP_CHOL": "left"}, {"MOGP_CHOL": "left", "MOGP_GROUPS": "1"},
                                  {"MOGP_CHOL": "right"}, {"MOGP_CHOL": "right", "MOGP_OUTER": "128"}, {"MOGP_TAIL": "0"},
                                  {"MOGP_BACKSOLVE": "0"}, {"MOGP_PV_WAVES": "4"}, {"MOGP_WAITVAL": "0"}, {"MOGP_CHOL": "la", "MOGP_WAITVAL": "1"}, {"MOGP_TRTRI_WT": "4"}, {"MOGP_KS_BUDGET_GB": "0.05"}],
                          ids=lambda e: ",".join(k + "=" + v for k, v in e.items()))
@@ -574,6 +576,45 @@ c = ctypes.c_longlong()
 assert _capi.load().mogp_profile_counter(b"backsolve_timeouts", ctypes.byref(c)) == 0
 print("BS-TIMEOUTS", c.value)
 """
+
+
+_MC_ABORT_SCRIPT = r"""
+import sys, ctypes, numpy as np
+sys.path.insert(0, %(root)r); sys.path.insert(0, %(tests)r)
+import mogp_emulator_amd as M
+from mogp_emulator_amd import _capi
+from oracle import cpu_ref as R
+from test_gpu_parity import synth, weak, make_gp
+n, d, B = 1500, 6, 5
+X, T, Xs = synth(78, n, d, B, 50)
+theta = np.array([-2. * np.log(0.3 * np.sqrt(d))] * d + [0.])
+mo = M.MultiOutputGP_GPU(X, T, nugget=1e-6, priors=weak(d, 1e-6))
+f, g, ok = mo._mogp_gpu.eval(np.tile(theta, (B, 1)), grad=True)      # deferred status: the abort word comes back with the log-determinants
+assert ok.all()
+mo.fit(np.tile(theta, (B, 1)))
+solo = make_gp(X, T[1], nugget=1e-6); solo.fit(theta)                # fit(): status read right after the factorisation
+for k in (0, B - 1):
+    ref = R.GPRef(X, T[k], nugget=1e-6)
+    np.testing.assert_allclose(f[k], ref.fit(theta), rtol=1e-10)
+    np.testing.assert_allclose(g[k], ref.logpost_deriv(theta), rtol=1e-7, atol=1e-7)
+    np.testing.assert_allclose(mo.emulators[k].Kinv_t, ref.Kinv_t, rtol=1e-6, atol=1e-7 * np.abs(ref.Kinv_t).max())
+np.testing.assert_allclose(solo.current_logpost, mo.emulators[1].current_logpost, rtol=1e-10)
+c = ctypes.c_longlong()
+assert _capi.load().mogp_profile_counter(b"mchol_aborts", ctypes.byref(c)) == 0
+print("MC-ABORTS", c.value)
+"""
+
+
+def test_one_launch_cholesky_abort_falls_back_to_the_multi_launch_schedule():
+    """Every wait inside the one-launch Cholesky (kernels_mchol.hip) is bounded; when one gives up the kernel sets its abort
+    word, every workgroup leaves, and the engine must factorise again with a multi-launch schedule.  MOGP_MC_SPIN=0 makes
+    the first unsatisfied wait a timeout, so the fallback runs in every evaluation: results must still be the oracle's."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = _MC_ABORT_SCRIPT % {"root": root, "tests": os.path.join(root, "tests")}
+    out = subprocess.run([sys.executable, "-c", script], env=dict(os.environ, MOGP_CHOL="mchol", MOGP_MC_SPIN="0"), capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "MC-ABORTS" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
+    assert int(out.stdout.split("MC-ABORTS")[1].split()[0]) > 0, "the forced timeouts never happened: the fallback was not exercised"
 
 
 def test_backsolve_chain_timeout_is_retried_not_reported_as_failure():
