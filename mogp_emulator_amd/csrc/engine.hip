@@ -769,6 +769,7 @@ void Engine::eval(const std::vector<int>& ids, const std::vector<const double*>&
     if (aborted) {
       g_mc_aborts += 1;
       mc_force_legacy = true;
+      for (int i : ids) gp[i].factored = gp[i].linv = gp[i].kinv = false;      // (L^-1 of the unusable factor may have been formed)
       factorize(ids, info, true);
       mc_force_legacy = false;
       after_factor(ids, &info);
