@@ -165,7 +165,12 @@ def time_shard(M, GPPriors, cid, n, d, B, m, kernel, nugget, theta, reps, map_st
     t_fit = med(lambda it: mo.eval(th + 1e-3 * it, grad=False))
     t_fg = med(lambda it: mo.eval(th + 1e-3 * it, grad=True))
     t_pr = med(lambda it: mo.predict_variance_batch(Xs, means, vars_))
-    out = {"n": n, "d": d, "emulators": B, "m": m, "kernel": kernel, "fit_ms": t_fit, "fit_grad_ms": t_fg, "predict_ms_host_buffers": t_pr,
+    # the same fit through the multi-launch Cholesky schedule of this regime (rounds 1-2), for comparison
+    from mogp_emulator_amd import _capi
+    _capi.load().mogp_profile_schedule(5, 0)
+    t_fit_ml = med(lambda it: mo.eval(th + 1e-3 * it, grad=False))
+    _capi.load().mogp_profile_schedule(-1, 0)
+    out = {"fit_ms_multi_launch_schedule": t_fit_ml, "n": n, "d": d, "emulators": B, "m": m, "kernel": kernel, "fit_ms": t_fit, "fit_grad_ms": t_fg, "predict_ms_host_buffers": t_pr,
            "fit_ms_per_emulator": t_fit / B, "fit_TFLOPs": B * float(n) ** 3 / 3. / t_fit * 1e-9, "fit_grad_TFLOPs": B * float(n) ** 3 / t_fg * 1e-9}
     if map_starts:
         out.update(time_fit_map(M, X, T, kernel, nugget, map_starts, map_iters))
@@ -471,7 +476,7 @@ def main():
     # per-kernel device times from HIP events on the launch stream
     def read_kernels():
         kern = {}
-        for tag, bound in (("chol_update", "mfma"), ("chol_diag128", "latency"), ("chol_trsm128", "hbm"), ("syrk_trailing", "mfma"),
+        for tag, bound in (("mchol", "mfma"), ("chol_update", "mfma"), ("chol_diag128", "latency"), ("chol_trsm128", "hbm"), ("syrk_trailing", "mfma"),
                            ("trtri_merge", "mfma"), ("kinv", "mfma"), ("predict_var", "mfma"),
                            ("cov_build", "hbm"), ("cross_cov", "hbm"), ("grad_reduce", "hbm")):
             ms, cnt, fl, by = ctypes.c_double(), ctypes.c_longlong(), ctypes.c_double(), ctypes.c_double()
@@ -500,7 +505,7 @@ def main():
         serial_ms = (time.perf_counter() - t0) / 3 * 1e3
         lib.mogp_profile_enable(0)
         lib.mogp_profile_schedule(-1, 0)
-        kern_serial = {k: v for k, v in read_kernels().items() if k.startswith("chol_") or k in ("cov_build", "syrk_trailing")}
+        kern_serial = {k: v for k, v in read_kernels().items() if k.startswith("chol_") or k in ("cov_build", "syrk_trailing", "mchol")}
         for k, v in kern_serial.items():
             v["ms_per_fit_phase"] = v["ms_total"] / 3
             if k in kern:

@@ -213,13 +213,15 @@ int mogp_kernel_eval(int kernel_type, int what, const double* x1, int n1, const 
 /* when enabled, HIP events are recorded on the launch stream around every launch of the tagged kernels */
 int mogp_profile_enable(int on);
 int mogp_profile_reset(void);
-/* force the Cholesky schedule (0 two emulator groups, 1 right-looking, 3 look-ahead, -1 the library's choice) and / or
+/* force the Cholesky schedule (0 two emulator groups, 1 right-looking, 3 look-ahead, 4 one launch / task queue, 5 the multi-launch
+   schedule the library would pick without the one-launch kernel, -1 the library's choice) and / or
    serialise it onto one stream, so that the HIP-event time of a kernel is its time alone on the device */
 int mogp_profile_schedule(int schedule, int single_stream);
 /* sums over launches since reset: total milliseconds, launch count, algorithmic flops and bytes */
 int mogp_profile_get(const char* kernel_tag, double* total_ms, long long* launches, double* alg_flops, double* alg_bytes);
 /* process-wide diagnostic counters: "backsolve_timeouts" = back substitutions that were repeated with the multi-launch
-   path because a wait of the one-launch chain timed out (0 in normal operation); "objective_evals" / "gradient_evals" =
+   path because a wait of the one-launch chain timed out (0 in normal operation); "mchol_aborts" = factorisations the
+   one-launch Cholesky gave up on and a multi-launch schedule repeated (0 in normal operation); "objective_evals" / "gradient_evals" =
    emulator objective evaluations so far (all / with gradient), e.g. to turn a fit_GP_MAP wall time into evaluations/s */
 int mogp_profile_counter(const char* name, long long* out);
 /* device memory helpers so a host program can hand device-resident buffers to the *_dev calls */

@@ -179,7 +179,7 @@ FitOptions& fit_options();
 // FOR MEASUREMENT ONLY: process-global, read by every engine at the start of a factorisation and not synchronised --
 // set it while no evaluation is in flight (bench.py does), never from a thread that races with one.
 struct ScheduleOverride {
-  int schedule = -1;       // 0 two emulator groups, 1 right-looking, 3 look-ahead, 4 one launch (task queue)
+  int schedule = -1;       // 0 two emulator groups, 1 right-looking, 3 look-ahead, 4 one launch (task queue), 5 the multi-launch schedule of the regime
   bool single_stream = false;
 };
 ScheduleOverride& schedule_override();

@@ -454,13 +454,16 @@ void Engine::factorize_blocked(const std::vector<int>& ids, std::vector<int>& in
   // a large batch fills the machine with the update of ONE emulator group while the other factors its panels.
   const long tiles64 = (long)nb * (NP / 64), tiles128 = (long)nb * (NP / TILE);
   const ScheduleOverride& ovr = schedule_override();
-  // Default: below 1024 128-tiles per block column step (everything but the full 64 x n=2000 batch and the replica engines of
-  // a multi-start fit) the ONE-LAUNCH task-queue kernel (schedule 4): fit, ms, one launch / best multi-launch schedule --
-  // 8 x n=2000 1.15 / 1.60, 16 x 1.62 / 1.98, 32 x 2.67 / 3.05, 2 x n=5000 2.91 / 5.27, 16 x n=5000 14.6 / 17.5, n=16000 26.3 / 34.5,
-  // 3 x n=700 0.42 / 0.54; at 64 x n=2000 the two are level (4.9 - 5.0 / 5.0 - 5.07) and the two-group schedule stays.
+  // Default: the ONE-LAUNCH task-queue kernel (schedule 4) up to 2048 128-tiles per block-column step.  Fit, ms, one launch /
+  // best multi-launch schedule: 8 x n=2000 1.12 / 1.60, 16 x 1.54 / 1.98, 32 x 2.58 / 3.05, 64 x 4.73 - 4.84 / 5.06, 120 x 8.46 /
+  // 8.83, 2 x n=5000 2.86 / 5.27, 16 x n=5000 14.4 / 17.5, n=16000 26.3 / 34.5, 3 x n=700 0.40 / 0.54, 64 x n=1000 1.04 / 1.06.
+  // Beyond that (the replica engines of a multi-start fit: 240 x n=2000 17.3 / 16.8) and for thousands of single-block
+  // matrices (2000 x n=100: 0.62 / 0.57, one task each) the two-group multi-launch schedule stays.
   const int legacy = tiles64 < 256 ? 1 : (tiles128 >= 1024 ? 0 : 3);
   static const bool mc_default = [] { const char* e = getenv("MOGP_MCHOL"); return !e || atoi(e) != 0; }();
-  int schedule = ovr.schedule >= 0 ? ovr.schedule : (forced >= 0 ? forced : ((mc_default && tiles128 < 1024) ? 4 : legacy));
+  const bool mc_regime = tiles128 < 2048 && (NP > TILE || nb <= 512);
+  int schedule = ovr.schedule >= 0 ? ovr.schedule : (forced >= 0 ? forced : ((mc_default && mc_regime) ? 4 : legacy));
+  if (schedule == 5) schedule = legacy;            // (mogp_profile_schedule(5, ..): the multi-launch schedule of this regime)
   // the one-launch kernel addresses an emulator's matrix through a 32-bit buffer offset; after an abort the multi-launch
   // schedule of the same regime takes over
   if (schedule == 4 && (mc_force_legacy || MS * sizeof(double) >= (size_t)1 << 32)) schedule = legacy;

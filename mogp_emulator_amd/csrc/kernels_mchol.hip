@@ -63,9 +63,11 @@ struct McCtx {
   int* shi;          // LDS: [0] task number, [1] result of a wait, [2], [3] park words of the GEMM main loop
 };
 
-// optional per-task time stamps (tools/mchol_trace.py; MOGP_MC_TRACE=<file>): 8 x 64-bit words per task,
-// [0] pulled, [1]/[2] last operand wait begins / ends (D: wait for the diagonal tiles), [3]/[4] wait for the pack begins / ends
-// (T only), [5] published, [6] hardware id, [7] task word | queue position << 32; 100 MHz clock (s_memrealtime)
+// optional per-task time stamps (tools/mchol_trace.py; MOGP_MC_TRACE=<file>): MC_TRW 64-bit words per task,
+// [0] pulled, [1] last operand wait begins, [2] ends (D: its inputs are complete), [3] after the GEMM main loop, [4] after the
+// tile has been written back, [5] published, [6] hardware id, [7] task word | queue position << 32, [8] pack seen (T), [9] sum
+// of all waits of the task; 100 MHz clock (s_memrealtime)
+constexpr int MC_TRW = 10;
 template <bool TRACE>
 __device__ __forceinline__ void mc_stamp(unsigned long long* tr, int i) {
   if (TRACE && tr && threadIdx.x == 0) tr[i] = __builtin_amdgcn_s_memrealtime();
@@ -73,8 +75,10 @@ __device__ __forceinline__ void mc_stamp(unsigned long long* tr, int i) {
 
 // All 256 threads call.  Lane 0 polls until min(*a, *b, *c) >= want (b, c may equal a); returns that minimum, or -1 after a
 // timeout / when another workgroup has aborted.
-__device__ __forceinline__ int mc_wait_min3(const McCtx& cx, const unsigned* a, const unsigned* b, const unsigned* c, unsigned want) {
+__device__ __forceinline__ int mc_wait_min3(const McCtx& cx, const unsigned* a, const unsigned* b, const unsigned* c, unsigned want,
+                                            unsigned long long* waited = nullptr) {
   if (threadIdx.x == 0) {
+    const unsigned long long w0 = waited ? __builtin_amdgcn_s_memrealtime() : 0ull;
     int res, spins = 0;
     for (;;) {
       unsigned m = ldu(a);
@@ -99,6 +103,7 @@ __device__ __forceinline__ int mc_wait_min3(const McCtx& cx, const unsigned* a, 
       __builtin_amdgcn_s_sleep(1);
     }
     cx.shi[1] = res;
+    if (waited) waited[9] += __builtin_amdgcn_s_memrealtime() - w0;
   }
   __syncthreads();
   const int r = cx.shi[1];
@@ -147,7 +152,7 @@ __global__ __launch_bounds__(256, 2) void mchol_kernel(BatchView v, unsigned* __
       unsigned* ddone = diagcnt + K;
       double* pk = packs + ((size_t)emu * K + c) * PACK128_STRIDE;
       const int c0 = 128 * c;
-      unsigned long long* tr = TRACE ? trace + ((size_t)z * ntasks + p) * 8 : nullptr;
+      unsigned long long* tr = TRACE ? trace + ((size_t)z * ntasks + p) * MC_TRW : nullptr;
       if (TRACE && t == 0) {
         tr[6] = __builtin_amdgcn_s_getreg(6164) | ((unsigned long long)__builtin_amdgcn_s_getreg(((8 - 1) << 11) | (8 << 6) | 4) << 8);   // XCC_ID, HW_ID
         tr[7] = (unsigned)word | ((unsigned long long)tk << 32);
@@ -158,8 +163,8 @@ __global__ __launch_bounds__(256, 2) void mchol_kernel(BatchView v, unsigned* __
         mc_stamp<TRACE>(tr, 1);
         // the panels 0 .. c-2 arrive through the two G tasks (c >= 2), panel c-1 is applied here, straight from the two
         // panel-solve tasks that produced it
-        if (c > 1 && mc_wait_min3(cx, diagcnt + c, diagcnt + c, diagcnt + c, 2u) < 0) return;
-        if (c > 0 && mc_wait_min3(cx, rowdone + 2 * c, rowdone + 2 * c + 1, rowdone + 2 * c + 1, (unsigned)c) < 0) return;
+        if (c > 1 && mc_wait_min3(cx, diagcnt + c, diagcnt + c, diagcnt + c, 2u, tr) < 0) return;
+        if (c > 0 && mc_wait_min3(cx, rowdone + 2 * c, rowdone + 2 * c + 1, rowdone + 2 * c + 1, (unsigned)c, tr) < 0) return;
         mc_stamp<TRACE>(tr, 2);
         if (use_park && t == 0) __hip_atomic_fetch_add(cuword, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (c > 0) chol128_dev<true, true>(A + (size_t)c0 * ld + c0, ld, pk, info + emu, c0, lds);
@@ -188,7 +193,7 @@ __global__ __launch_bounds__(256, 2) void mchol_kernel(BatchView v, unsigned* __
         int kb = 0;
         while (kb < kend) {
           mc_stamp<TRACE>(tr, 1);
-          int m = mc_wait_min3(cx, rowdone + r, rowdone + 2 * c, rowdone + 2 * c + 1, (unsigned)(kb + 1));
+          int m = mc_wait_min3(cx, rowdone + r, rowdone + 2 * c, rowdone + 2 * c + 1, (unsigned)(kb + 1), tr);
           if (m < 0) return;
           mc_stamp<TRACE>(tr, 2);
           m = m < kend ? m : kend;
@@ -196,21 +201,35 @@ __global__ __launch_bounds__(256, 2) void mchol_kernel(BatchView v, unsigned* __
                                             (use_park && !urgent) ? cuword : nullptr, shi + 2, 1 << 14);
           kb = m;
         }
-        if (type == 1) mc_stamp<TRACE>(tr, 3);
-        if (type == 1) {
-          // read by D(c) on another CU: write-through
-          for_each_acc_w<2>(acc, [&](int row, int col, double x) {
-            double* pc = A + (size_t)(r0 + row) * ld + (c0 + col);
-            __hip_atomic_store(pc, *pc - x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          });
-        } else {
-          for_each_acc_w<2>(acc, [&](int row, int col, double x) {
-            double* pc = A + (size_t)(r0 + row) * ld + (c0 + col);
-            *pc -= x;
-          });
+        mc_stamp<TRACE>(tr, 3);
+        // C -= acc.  All 32 loads of a thread first, then the stores: written as load / subtract / store per element the
+        // compiler keeps program order between a store and the next load (they might alias), and the write-back of a 64 KB
+        // tile was 32 dependent memory round trips (23 - 31 us per task, tools/mchol_trace.py).
+        {
+          double cv[2][4][4];
+          const int lane = t & 63, wave = t >> 6, wr = wave >> 1, wc = wave & 1;
+          double* pc0 = A + (size_t)(r0 + wr * 32 + (lane >> 4)) * ld + (c0 + wc * 64 + (lane & 15));
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+              for (int q = 0; q < 4; ++q) cv[i][j][q] = pc0[(size_t)(i * 16 + 4 * q) * ld + j * 16];
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                double* pc = pc0 + (size_t)(i * 16 + 4 * q) * ld + j * 16;
+                const double x = cv[i][j][q] - acc[i][j][q];
+                // G: read by D(c) on another CU -> write-through; T: read back by this workgroup's panel solve
+                if (type == 1) __hip_atomic_store(pc, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                else *pc = x;
+              }
         }
-        if (type == 1) mc_stamp<TRACE>(tr, 4);
         drain_stores();
+        mc_stamp<TRACE>(tr, 4);
         __syncthreads();
       }
       if (type == 1) {
@@ -220,10 +239,9 @@ __global__ __launch_bounds__(256, 2) void mchol_kernel(BatchView v, unsigned* __
         continue;
       }
       // ---- T: panel solve with the pack of D(c) ---------------------------------------------------------------------------
-      mc_stamp<TRACE>(tr, 3);
-      if (mc_wait_min3(cx, ddone + c, ddone + c, ddone + c, 1u) < 0) return;
-      mc_stamp<TRACE>(tr, 4);
-      trsm128_lds_dev<true>(v, c0, r0, pk, emu, 0, lds);
+      if (mc_wait_min3(cx, ddone + c, ddone + c, ddone + c, 1u, tr) < 0) return;
+      mc_stamp<TRACE>(tr, 8);
+      trsm128_lds_dev<true, true>(v, c0, r0, pk, emu, 0, lds);
       drain_stores();
       __syncthreads();
       if (t == 0) stu(rowdone + r, (unsigned)(c + 1));
@@ -287,7 +305,7 @@ void launch_mchol(const BatchView& v, unsigned* ctrl, size_t ctrl_ints, const in
   // MOGP_MC_TRACE=<file>: per-task time stamps of EVERY launch are appended to the file (analysis only: synchronises)
   static const char* trace_file = getenv("MOGP_MC_TRACE");
   if (trace_file) {
-    const size_t words = (size_t)total * 8;
+    const size_t words = (size_t)total * MC_TRW;
     unsigned long long* dtr = nullptr;
     if (hipMalloc(reinterpret_cast<void**>(&dtr), words * 8) != hipSuccess) return;
     (void)hipMemsetAsync(dtr, 0, words * 8, s);
@@ -298,7 +316,7 @@ void launch_mchol(const BatchView& v, unsigned* ctrl, size_t ctrl_ints, const in
     (void)hipMemcpy(h.data(), dtr, words * 8, hipMemcpyDeviceToHost);
     (void)hipFree(dtr);
     if (FILE* f = fopen(trace_file, "ab")) {
-      const long long hdr[4] = {v.nb, ntasks, v.NP, grid};
+      const long long hdr[4] = {v.nb, ntasks, v.NP, grid + 1000000LL * MC_TRW};
       fwrite(hdr, sizeof(hdr), 1, f);
       fwrite(h.data(), 8, words, f);
       fclose(f);

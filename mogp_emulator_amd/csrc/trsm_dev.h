@@ -33,7 +33,11 @@ constexpr int TRSM128L_LDS = 2 * TL_PK + 4 * 2 * TL_TS;
 
 // SC1_OUT: the solved rows are stored write-through (chol128_dev.h, st16): other workgroups of the same launch read them
 // as GEMM operands after a flag hand-off (kernels_mchol.hip).  The emulator's matrix must then be smaller than 4 GB.
-template <bool SC1_OUT = false>
+// DEEP (one-launch Cholesky, where a panel solve runs next to GEMM tasks and every load sees a loaded memory system): the
+// whole 16 x 128 slab is requested up front (32 VGPRs) and the row-block images two steps ahead instead of one -- the
+// early steps have MFMA chains of 4 - 12 instructions and were bound by one memory latency each (16 - 21 us per solve
+// under load against 8 us alone, tools/mchol_trace.py).  Arithmetic and results are unchanged.
+template <bool SC1_OUT = false, bool DEEP = false>
 __device__ __forceinline__ void trsm128_lds_dev(const BatchView& v, int c0, int r0, const double* __restrict__ pk, int emu, int rowblock,
                                                 double* lds) {
   Sc1Buf ab;
@@ -47,44 +51,54 @@ __device__ __forceinline__ void trsm128_lds_dev(const BatchView& v, int c0, int 
   const double* LT = pk + PACK128_LT;
   // this lane's two 16-byte pieces of a slab block: rows q >> 3, piece q & 7 for q = lane, lane + 64
   const int sr0 = lane >> 3, sp = (lane & 7) * 2;
-  v2d_p sl[2];
+  v2d_p sl[DEEP ? 8 : 1][2];
   auto slab_request = [&](int b) {
-    sl[0] = *reinterpret_cast<const v2d_p*>(slab + (size_t)sr0 * ld + 16 * b + sp);
-    sl[1] = *reinterpret_cast<const v2d_p*>(slab + (size_t)(sr0 + 8) * ld + 16 * b + sp);
+    sl[DEEP ? b : 0][0] = *reinterpret_cast<const v2d_p*>(slab + (size_t)sr0 * ld + 16 * b + sp);
+    sl[DEEP ? b : 0][1] = *reinterpret_cast<const v2d_p*>(slab + (size_t)(sr0 + 8) * ld + 16 * b + sp);
   };
-  auto slab_deposit = [&](double* ts) {
-    *reinterpret_cast<v2d_p*>(ts + sr0 * 18 + sp) = sl[0];
-    *reinterpret_cast<v2d_p*>(ts + (sr0 + 8) * 18 + sp) = sl[1];
+  auto slab_deposit = [&](int b, double* ts) {
+    *reinterpret_cast<v2d_p*>(ts + sr0 * 18 + sp) = sl[DEEP ? b : 0][0];
+    *reinterpret_cast<v2d_p*>(ts + (sr0 + 8) * 18 + sp) = sl[DEEP ? b : 0][1];
   };
   // the workgroup's share of row block b: 8 b pieces of 16 doubles [column c][rows 16b .. 16b+15], then the 256 doubles of inv(L_bb)
-  v2d_p pr[4], pinv;
+  v2d_p pr[DEEP ? 2 : 1][4], pinv[DEEP ? 2 : 1];
   auto pack_request = [&](int b) {
+    const int u = DEEP ? (b & 1) : 0;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int ch = t + 256 * q;
-      if (ch < 128 * b) pr[q] = *reinterpret_cast<const v2d_p*>(LT + (size_t)(ch >> 3) * 128 + 16 * b + (ch & 7) * 2);
+      if (ch < 128 * b) pr[u][q] = *reinterpret_cast<const v2d_p*>(LT + (size_t)(ch >> 3) * 128 + 16 * b + (ch & 7) * 2);
     }
-    if (t < 128) pinv = *reinterpret_cast<const v2d_p*>(pk + PACK128_INV + b * 256 + 2 * t);
+    if (t < 128) pinv[u] = *reinterpret_cast<const v2d_p*>(pk + PACK128_INV + b * 256 + 2 * t);
   };
   auto pack_deposit = [&](int b, double* img) {
+    const int u = DEEP ? (b & 1) : 0;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int ch = t + 256 * q;
-      if (ch < 128 * b) *reinterpret_cast<v2d_p*>(img + (ch >> 3) * 16 + (ch & 7) * 2) = pr[q];
+      if (ch < 128 * b) *reinterpret_cast<v2d_p*>(img + (ch >> 3) * 16 + (ch & 7) * 2) = pr[u][q];
     }
-    if (t < 128) *reinterpret_cast<v2d_p*>(img + 112 * 16 + 2 * t) = pinv;
+    if (t < 128) *reinterpret_cast<v2d_p*>(img + 112 * 16 + 2 * t) = pinv[u];
   };
   pack_request(0);
-  slab_request(0);
+  if (DEEP) {
+    pack_request(1);
+#pragma unroll
+    for (int b = 0; b < 8; ++b) slab_request(b);
+  } else {
+    slab_request(0);
+  }
   pack_deposit(0, pkb[0]);
-  slab_deposit(tsb[0]);
+  slab_deposit(0, tsb[0]);
   __syncthreads();
   v4d_t X[8];
 #pragma unroll
   for (int b = 0; b < 8; ++b) {
     const double* img = pkb[b & 1];
     double* ts = tsb[b & 1];
-    if (b < 7) {
+    if (DEEP) {
+      if (b + 2 < 8) pack_request(b + 2);        // register set b & 1 held row block b, which is in LDS already
+    } else if (b < 7) {
       pack_request(b + 1);
       slab_request(b + 1);
     }
@@ -112,7 +126,7 @@ __device__ __forceinline__ void trsm128_lds_dev(const BatchView& v, int c0, int 
     }
     if (b < 7) {
       pack_deposit(b + 1, pkb[(b + 1) & 1]);
-      slab_deposit(tsb[(b + 1) & 1]);
+      slab_deposit(b + 1, tsb[(b + 1) & 1]);
     }
     __syncthreads();
   }

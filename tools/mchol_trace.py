@@ -1,62 +1,76 @@
-"""Read the per-task time stamps of the one-launch Cholesky (MOGP_MC_TRACE=<file>, kernels_mchol.hip) and print the dependent
-chain of one emulator: per block column D(c) -> T(2c+2, c), T(2c+3, c) -> G(2c+2, c+1), G(2c+3, c+1) -> D(c+1), with the time
-each task spent working / waiting and the hand-off latencies between them.  usage: mchol_trace.py file [launch=-1] [slot=0]"""
+"""Read the per-task time stamps of the one-launch Cholesky (MOGP_MC_TRACE=<file>, kernels_mchol.hip) and print
+  * the dependent chain of one emulator: per block column D(c) -> T(2c+2, c), T(2c+3, c) -> D(c+1),
+  * where the workgroups' time went (by task type: waiting, GEMM, write-back, panel solve, diagonal block),
+  * the number of busy workgroups over time.
+usage: mchol_trace.py file [launch=-1] [slot=0]"""
 import sys
 import numpy as np
 
 raw = np.fromfile(sys.argv[1], dtype=np.uint64)
 launches, off = [], 0
 while off < raw.size:
-    nb, ntasks, NP, grid = [int(x) for x in raw[off:off + 4].astype(np.int64)]
-    words = nb * ntasks * 8
-    launches.append((nb, ntasks, NP, grid, raw[off + 4:off + 4 + words].reshape(nb, ntasks, 8)))
+    nb, ntasks, NP, g = [int(x) for x in raw[off:off + 4].astype(np.int64)]
+    trw, grid = (g // 1000000, g % 1000000) if g >= 1000000 else (8, g)
+    words = nb * ntasks * trw
+    launches.append((nb, ntasks, NP, grid, raw[off + 4:off + 4 + words].reshape(nb, ntasks, trw).astype(np.int64)))
     off += 4 + words
 which = int(sys.argv[2]) if len(sys.argv) > 2 else -1
 slot = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 nb, ntasks, NP, grid, tr = launches[which]
 t0 = int(tr[:, :, 0][tr[:, :, 0] > 0].min())
+tend = int(tr[:, :, 5].max())
 us = lambda x: (int(x) - t0) / 100.0          # 100 MHz
-print("# %d launches in file; launch %d: nb=%d NP=%d tasks/emulator=%d grid=%d; total %.1f us" % (
-    len(launches), which, nb, NP, ntasks, grid, (int(tr[:, :, 5].max()) - t0) / 100.0))
+total_us = (tend - t0) / 100.0
+print("# %d launches in file; launch %d: nb=%d NP=%d tasks/emulator=%d grid=%d; kernel %.1f us" % (len(launches), which, nb, NP, ntasks, grid, total_us))
+w = tr[0, :, 7] & 0xffffffff
+typ, col, row = (w >> 30) & 3, (w >> 15) & 0x7fff, w & 0x7fff
 tasks = {}
 for p in range(ntasks):
-    w = int(tr[slot, p, 7]) & 0xffffffff
-    typ, c, r = (w >> 30) & 3, (w >> 15) & 0x7fff, w & 0x7fff
-    tasks[(typ, c, r if typ else 0)] = tr[slot, p]
+    tasks[(int(typ[p]), int(col[p]), int(row[p]) if typ[p] else 0)] = tr[slot, p]
 K = NP // 128
-print("col |  D: ready  start->done (dur) | T0: pack seen (+lat) done (dur) | T1 done | G0: op seen (+lat) done (dur) | G1 done | D(c+1) sees tiles (+lat) | column period")
+print("col | D: inputs seen -> done (dur) | T0 / T1: pack seen (+lat after D) -> done (dur) | D(c+1) sees the panel (+lat after the later T) | period")
 prev = None
 for c in range(K):
     D = tasks[(0, c, 0)]
-    line = "%3d | D wait %7.1f..%7.1f run ->%7.1f (%5.1f)" % (c, us(D[1]), us(D[2]), us(D[5]), us(D[5]) - us(D[2]))
-    for r in (2 * c + 2, 2 * c + 3):
-        T = tasks.get((2, c, r))
-        if T is not None:
-            line += " | T%d pack@%7.1f (+%4.1f) ->%7.1f (%5.1f)" % (r - 2 * c - 2, us(T[4]), us(T[4]) - us(D[5]), us(T[5]), us(T[5]) - us(T[4]))
+    line = "%3d | D %7.1f ->%7.1f (%5.1f)" % (c, us(D[2]), us(D[5]), us(D[5]) - us(D[2]))
     Ts = [tasks.get((2, c, r)) for r in (2 * c + 2, 2 * c + 3)]
-    if Ts[0] is not None:
+    for i, T in enumerate(Ts):
+        if T is not None:
+            line += " | T%d %7.1f (+%4.1f) ->%7.1f (%5.1f)" % (i, us(T[8]), us(T[8]) - us(D[5]), us(T[5]), us(T[5]) - us(T[8]))
+    if Ts[0] is not None and (0, c + 1, 0) in tasks:
         tdone = max(us(x[5]) for x in Ts if x is not None)
-        Dn = tasks.get((0, c + 1, 0))
-        if Dn is not None:
-            line += " | D' sees panel +%4.1f" % (us(Dn[2]) - tdone)
-            G = [tasks.get((1, c + 1, r)) for r in (2 * c + 2, 2 * c + 3)]
-            if G[0] is not None:
-                line += " (G done %7.1f, %7.1f)" % (us(G[0][5]), us(G[1][5]))
+        line += " | D' +%4.1f" % (us(tasks[(0, c + 1, 0)][2]) - tdone)
     if prev is not None:
         line += " | period %5.1f" % (us(D[2]) - prev)
     prev = us(D[2])
-    print(line)
-ids = set()
-cnt = {}
-for z in range(nb):
-    for p in range(ntasks):
-        ids.add(int(tr[z, p, 6]) & 0xffff)
+    if K <= 20 or c < 6 or c >= K - 4 or c % 10 == 0:
+        print(line)
+# where the time went
+dur = (tr[:, :, 5] - tr[:, :, 0]) / 100.0
+wait = tr[:, :, 9] / 100.0
+print("# by task type (all emulators): count, sum of durations, of which waiting; mean duration / wait / last GEMM segment / write-back / solve")
+for ty, name in ((0, "D"), (1, "G"), (2, "T")):
+    m = typ == ty
+    if not m.any():
+        continue
+    d, wv = dur[:, m], wait[:, m]
+    x = tr[:, m]
+    seg = np.where(x[:, :, 3] > 0, (x[:, :, 3] - x[:, :, 2]) / 100.0, 0.)
+    wb = np.where(x[:, :, 4] > 0, (x[:, :, 4] - x[:, :, 3]) / 100.0, 0.)
+    sol = np.where(x[:, :, 8] > 0, (x[:, :, 5] - x[:, :, 8]) / 100.0, 0.)
+    print("#   %s: %6d tasks, %10.0f us total, %10.0f us waiting (%.0f %%); mean %.1f / %.1f / %.1f / %.1f / %.1f us" % (
+        name, d.size, d.sum(), wv.sum(), 100 * wv.sum() / d.sum(), d.mean(), wv.mean(), seg.mean(), wb.mean(), sol.mean()))
+busy = (dur - wait).sum()
+print("# busy (not waiting) workgroup time %.0f us = %.1f of %d workgroups over the kernel's %.1f us" % (busy, busy / total_us, grid, total_us))
+# busy workgroups over time (20 bins): a task counts as busy outside its waits -- approximated by its busy fraction
+bins = 20
+edges = np.linspace(t0, tend, bins + 1)
+act = np.zeros(bins)
+s_, e_ = tr[:, :, 0].ravel(), tr[:, :, 5].ravel()
+frac = np.clip(1 - (wait / np.maximum(dur, 1e-9)).ravel(), 0, 1)
+for b in range(bins):
+    ov = np.clip(np.minimum(e_, edges[b + 1]) - np.maximum(s_, edges[b]), 0, None)
+    act[b] = (ov * frac).sum() / (edges[b + 1] - edges[b])
+print("# busy workgroups per 1/20 of the kernel: " + " ".join("%d" % a for a in act))
+ids = set(int(v) & 0xffff for v in tr[:, :, 6].ravel())
 print("# distinct (XCC_ID, HW_ID[15:8]) values seen: %d" % len(ids))
-# how busy were the workers: sum of task durations minus waits
-busy = 0.0
-for z in range(nb):
-    for p in range(ntasks):
-        x = tr[z, p]
-        w = (int(x[2]) - int(x[1]) if x[2] and x[1] else 0) + (int(x[4]) - int(x[3]) if x[4] and x[3] else 0)
-        busy += (int(x[5]) - int(x[0]) - w) / 100.0
-print("# sum over tasks of (duration - last waits): %.1f us = %.1f workgroup-equivalents over the launch" % (busy, busy / ((int(tr[:, :, 5].max()) - t0) / 100.0)))
