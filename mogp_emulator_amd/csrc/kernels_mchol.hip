@@ -135,12 +135,18 @@ __global__ __launch_bounds__(256, 2) void mchol_kernel(BatchView v, unsigned* __
   for (int qi = 0; qi < nq; ++qi) {
     const int q = (home + qi) & (nq - 1);                 // own queue first, then help the others
     unsigned* head = ctrl + MC_HEADS + q * MC_LINE;
+    // The number of the NEXT task is drawn while the current one runs (one atomic round trip per task off the path).  Holding
+    // one number ahead keeps the progress argument: a held number is larger than the holder's current one, so the smallest
+    // current task among all workgroups still depends on finished or running tasks only.
+    int next_tk = 0;
+    if (t == 0) next_tk = (int)__hip_atomic_fetch_add(head, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     for (;;) {
-      if (t == 0) shi[0] = (int)__hip_atomic_fetch_add(head, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (t == 0) shi[0] = next_tk;
       __syncthreads();
       const int tk = shi[0];
       __syncthreads();
       if (tk >= total) break;
+      if (t == 0) next_tk = (int)__hip_atomic_fetch_add(head, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       const int p = tk / emus_q, zl = tk - p * emus_q;
       const int z = zl * nq + q;
       const int emu = __builtin_amdgcn_readfirstlane(v.idx ? v.idx[z] : z);
@@ -241,6 +247,8 @@ __global__ __launch_bounds__(256, 2) void mchol_kernel(BatchView v, unsigned* __
       // ---- T: panel solve with the pack of D(c) ---------------------------------------------------------------------------
       if (mc_wait_min3(cx, ddone + c, ddone + c, ddone + c, 1u, tr) < 0) return;
       mc_stamp<TRACE>(tr, 8);
+      // the substitution is a chain of dependent MFMAs: let it issue ahead of the co-resident workgroup's dense MFMA stream
+      if (!urgent) __builtin_amdgcn_s_setprio(1);
       trsm128_lds_dev<true, true>(v, c0, r0, pk, emu, 0, lds);
       drain_stores();
       __syncthreads();
