@@ -231,6 +231,14 @@ class WeakPrior(object):
     def d2logpdx2(self, x):
         return 0.
 
+    def dlogpdtheta(self, x, transform):
+        """chain rule to the raw parameter (gppriors.hpp WeakPrior::dlogpdtheta; Priors.py:617-634)"""
+        return float(self.dlogpdx(x) * transform.dscaled_draw(x))
+
+    def d2logpdtheta2(self, x, transform):
+        """Priors.py:648-666"""
+        return float(self.d2logpdx2(x) * transform.dscaled_draw(x) ** 2 + self.dlogpdx(x) * transform.d2scaled_draw2(x))
+
     def sample(self, transform=None):
         return float(5. * (np.random.rand() - 0.5))
 
@@ -389,25 +397,164 @@ class GPParameters(object):
 # GPPriors proxy (bindings.cu:547-566): the priors live inside the native emulator
 # --------------------------------------------------------------------------------------
 class GPPriors(object):
-    def __init__(self, owner):
-        self._owner = owner
+    """bindings.cu:528-556 / gppriors.hpp:318-510.  Two forms:
 
-    def get_logp(self, theta):
-        data = theta.get_data() if isinstance(theta, GPParameters) else _f64(theta)
-        out = np.zeros(1)
-        check(_lib.mogp_densegp_priors_logp(self._owner._h, dptr(data), int(data.size), dptr(out)))
-        return float(out[0])
+    * ``GPPriors(n_corr, nugget_type)`` -- the constructible container of the native module: ``set_corr`` / ``get_corr`` /
+      ``set_cov`` / ``get_cov`` / ``set_nugget`` / ``create_corr_priors`` / ``create_cov_prior`` / ``make_prior`` /
+      ``get_logp`` / ``get_dlogpdtheta`` / ``get_d2logpdtheta2`` / ``sample`` on host prior objects (O(D) scalar work;
+      arithmetic of the CPU class, Priors.py:291-418);
+    * ``GPPriors(emulator)`` (what ``DenseGP_GPU.get_gppriors()`` returns) -- a view on the priors that live inside a
+      native emulator; ``get_logp`` / ``get_dlogpdtheta`` / ``sample`` go through the C ABI.
+    ``DenseGP_GPU.set_gppriors(priors)`` accepts either."""
 
-    def get_dlogpdtheta(self, theta):
-        data = theta.get_data() if isinstance(theta, GPParameters) else _f64(theta)
-        out = np.zeros(data.size)
-        check(_lib.mogp_densegp_priors_dlogpdtheta(self._owner._h, dptr(data), int(data.size), dptr(out)))
+    def __init__(self, n_corr_or_owner, nug_type=None):
+        if hasattr(n_corr_or_owner, "_h"):
+            self._owner = n_corr_or_owner
+            return
+        self._owner = None
+        self._n_corr = int(n_corr_or_owner)
+        self._nug_type = nugget_type(nugget_type.fit if nug_type is None else nug_type)
+        self._corr = []
+        self._cov = None
+        self._nug = None
+        self._mean = None
+
+    # -- view on a native emulator ---------------------------------------------------------------------------------
+    def _data(self, theta):
+        return theta.get_data() if isinstance(theta, GPParameters) else _f64(theta)
+
+    # -- container ------------------------------------------------------------------------------------------------------
+    def get_nugget_type(self):
+        return self._nug_type if self._owner is None else self._owner.get_nugget_type()
+
+    def set_corr(self, newcorr=None):
+        """set_corr() appends n_corr weak priors (gppriors.hpp:356-360); set_corr(list) replaces them (:351-354)"""
+        self._own_only()
+        if newcorr is None:
+            self._corr.extend(WeakPrior() for _ in range(self._n_corr))
+        else:
+            self._corr = list(newcorr)
+            self._n_corr = len(self._corr)
+
+    def get_corr(self):
+        self._own_only()
+        return list(self._corr)
+
+    def set_cov(self, newcov=None):
+        self._own_only()
+        self._cov = WeakPrior() if newcov is None else newcov
+
+    def get_cov(self):
+        self._own_only()
+        return self._cov
+
+    def set_nugget(self, new=None):
+        """only kept for a fitted nugget (gppriors.hpp:375-391); a (prior_type, [shape, scale]) pair is instantiated"""
+        self._own_only()
+        if self._nug_type == nugget_type.fit:
+            if new is None:
+                new = WeakPrior()
+            elif isinstance(new, (tuple, list)):
+                new = self.make_prior(*new)
+            self._nug = new
+
+    def get_nugget(self):
+        self._own_only()
+        return self._nug
+
+    def get_mean(self):
+        self._own_only()
+        return self._mean
+
+    def set_mean(self, mean=None):
+        self._own_only()
+        self._mean = MeanPriors() if mean is None else mean
+
+    @staticmethod
+    def make_prior(ptype, priorparams=()):
+        """gppriors.hpp:473-488: anything that is not a two-parameter InvGamma / Gamma / LogNormal becomes a weak prior"""
+        ptype = prior_type(ptype)
+        params = list(priorparams)
+        cls = {prior_type.InvGamma: InvGammaPrior, prior_type.Gamma: GammaPrior, prior_type.LogNormal: LogNormalPrior}.get(ptype)
+        if cls is not None and len(params) == 2:
+            return cls(params[0], params[1])
+        return WeakPrior()
+
+    def create_corr_priors(self, all_params):
+        """appends one prior per (prior_type, [shape, scale]) pair (gppriors.hpp:490-497)"""
+        self._own_only()
+        for ptype, params in all_params:
+            self._corr.append(self.make_prior(ptype, params))
+
+    def create_cov_prior(self, params):
+        self._own_only()
+        self._cov = self.make_prior(*params)
+
+    def _own_only(self):
+        if self._owner is not None:
+            raise RuntimeError("this GPPriors object is a view on an emulator's priors; build a GPPriors(n_corr, nugget_type) to edit")
+
+    def _check_theta(self, theta):
+        if not isinstance(theta, GPParameters):
+            raise TypeError("theta must be a GPParameters object")
+        if not theta.data_has_been_set() or theta.get_n_corr() != len(self._corr) or theta.get_nugget_type() != self._nug_type:
+            raise RuntimeError("theta does not match the priors (n_corr, nugget type) or holds no data")
+        if self._cov is None or (self._nug_type == nugget_type.fit and self._nug is None):
+            raise RuntimeError("covariance / nugget priors have not been set")
+
+    def _terms(self, theta):
+        """(prior, scaled value, transform) of every data parameter in theta order"""
+        self._check_theta(theta)
+        corr = np.atleast_1d(theta.get_corr())
+        out = [(pr, float(corr[i]), CorrTransform()) for i, pr in enumerate(self._corr)]
+        out.append((self._cov, float(theta.get_cov()), CovTransform()))
+        if self._nug_type == nugget_type.fit:
+            out.append((self._nug, float(theta.get_nugget_size()), CovTransform()))
         return out
 
+    def get_logp(self, theta):
+        if self._owner is not None:
+            data = self._data(theta)
+            out = np.zeros(1)
+            check(_lib.mogp_densegp_priors_logp(self._owner._h, dptr(data), int(data.size), dptr(out)))
+            return float(out[0])
+        return float(sum(pr.logp(x) for pr, x, _ in self._terms(theta)))
+
+    def get_dlogpdtheta(self, theta):
+        if self._owner is not None:
+            data = self._data(theta)
+            out = np.zeros(data.size)
+            check(_lib.mogp_densegp_priors_dlogpdtheta(self._owner._h, dptr(data), int(data.size), dptr(out)))
+            return out
+        return np.array([pr.dlogpdtheta(x, tr) for pr, x, tr in self._terms(theta)])
+
+    def get_d2logpdtheta2(self, theta):
+        """diagonal of the Hessian with respect to the raw parameters (gppriors.hpp:439-456; Priors.py:356-391)"""
+        self._own_only()
+        return np.array([pr.d2logpdtheta2(x, tr) for pr, x, tr in self._terms(theta)])
+
     def sample(self):
-        out = np.zeros(self._owner.n_params() + _lib.mogp_densegp_n_mean(self._owner._h))
-        check(_lib.mogp_densegp_priors_sample(self._owner._h, dptr(out)))
-        return list(out)
+        if self._owner is not None:
+            out = np.zeros(self._owner.n_params() + _lib.mogp_densegp_n_mean(self._owner._h))
+            check(_lib.mogp_densegp_priors_sample(self._owner._h, dptr(out)))
+            return list(out)
+        vals = list(self._mean.sample(CorrTransform())) if self._mean is not None else []      # gppriors.hpp:458-471
+        vals += [pr.sample(CorrTransform()) for pr in self._corr]
+        vals.append(self._cov.sample(CovTransform()))
+        if self._nug_type == nugget_type.fit:
+            vals.append(self._nug.sample(CovTransform()))
+        return vals
+
+    def native_params(self):
+        """(n_corr, corr_params, cov_params, nug_params) for DenseGP_GPU.create_gppriors"""
+        self._own_only()
+
+        def spec(pr):
+            for t, cls in ((prior_type.InvGamma, InvGammaPrior), (prior_type.Gamma, GammaPrior), (prior_type.LogNormal, LogNormalPrior)):
+                if isinstance(pr, cls):
+                    return (t, [pr.shape, pr.scale])
+            return (prior_type.Weak, [0., 0.])
+        return len(self._corr), [spec(pr) for pr in self._corr], spec(self._cov), spec(self._nug)
 
 
 def _prior_spec(spec):
@@ -515,7 +662,14 @@ class DenseGP_GPU(object):
         return GPPriors(self)
 
     def set_gppriors(self, priors):
-        raise RuntimeError("set_gppriors: pass the prior parameters through create_gppriors")
+        """bindings.cu:62-65: attach a GPPriors(n_corr, nugget_type) container (its distributions are copied into the
+        native emulator; mean priors go through set_mean_priors)"""
+        if not isinstance(priors, GPPriors) or priors._owner is not None:
+            raise RuntimeError("set_gppriors: expected a GPPriors(n_corr, nugget_type) container")
+        n_corr, corr, cov, nug = priors.native_params()
+        if priors.get_cov() is None:
+            raise RuntimeError("set_gppriors: the covariance prior has not been set")
+        self.create_gppriors(n_corr, corr, cov, nug)
 
     def create_gppriors(self, n_corr, corr_params, cov_params, nug_params):
         ct, cp, cvt, cov, ngt, nug = _pack_priors(int(n_corr), corr_params, cov_params, nug_params)
@@ -905,6 +1059,24 @@ class MeanPriors(object):
         self._cov = np.array(cov, dtype=np.float64).reshape(self._mean.size, self._mean.size) if self._mean.size else np.zeros((0, 0))
         if self._mean.size and not np.all(np.diag(self._cov) > 0.):
             raise RuntimeError("all covariances must be greater than zero in MeanPriors")
+        self.set_prior_dists()
+
+    def set_prior_dists(self, ptypes=None, priorparams=None):
+        """set_prior_dists(): one weak prior per mean parameter; set_prior_dists(types, [[shape, scale], ...]): the given
+        distributions -- as in the reference they are only SAMPLED from (start points of a fit), they do not enter the
+        log-posterior (gppriors.hpp:244-275)."""
+        q = self.get_n_params()
+        if ptypes is None:
+            self._dists = [WeakPrior() for _ in range(q)]
+            return
+        ptypes, priorparams = list(ptypes), list(priorparams if priorparams is not None else [])
+        if len(ptypes) != q or len(priorparams) != q:
+            raise RuntimeError("Number of prior types and parameter sets must equal number of meanfunc parameters.")
+        self._dists = [GPPriors.make_prior(t, pp) for t, pp in zip(ptypes, priorparams)]
+
+    def sample(self, transform=None):
+        """one draw per mean parameter (gppriors.hpp:277-283); weak priors draw the raw value from U(-2.5, 2.5)"""
+        return [d.sample(transform) for d in self._dists]
 
     def get_mean(self):
         return self._mean.copy()

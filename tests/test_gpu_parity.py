@@ -418,6 +418,32 @@ def test_native_prior_objects_are_not_silently_weakened():
         _native_prior(Strange())
 
 
+def test_set_gppriors_with_a_constructed_container():
+    """DenseGP_GPU.set_gppriors(GPPriors(n_corr, nugget_type)) (bindings.cu:62-65, 528-556): the distributions of the host
+    container end up inside the native emulator -- its prior view returns the container's numbers, the log-posterior
+    moves by exactly the log-prior, and the cached posterior is not served stale."""
+    from mogp_emulator_amd import libgpgpu as L
+    rng = np.random.default_rng(8)
+    X = rng.uniform(0, 1, (60, 2)); t = np.sin(X.sum(axis=1))
+    gp = make_gp(X, t, nugget="fit")
+    theta = np.array([0.5, 1.0, 0.3, np.log(1e-3)])
+    lp_weak = gp.logposterior(theta)
+    pri = L.GPPriors(2, L.nugget_type.fit)
+    pri.create_corr_priors([(L.prior_type.InvGamma, [2., 1.]), (L.prior_type.Gamma, [3., .5])])
+    pri.create_cov_prior((L.prior_type.LogNormal, [.7, 1.3]))
+    pri.set_nugget((L.prior_type.InvGamma, [3.3, 4.3e-4]))
+    gp._densegp_gpu.set_gppriors(pri)
+    th = L.GPParameters(0, 2, L.nugget_type.fit); th.set_data(theta)
+    view = gp._densegp_gpu.get_gppriors()
+    assert_allclose(view.get_logp(th), pri.get_logp(th), rtol=1e-13)
+    assert_allclose(view.get_dlogpdtheta(th), pri.get_dlogpdtheta(th), rtol=1e-13)
+    assert_allclose(gp.logposterior(theta), lp_weak - pri.get_logp(th), rtol=1e-12)
+    with pytest.raises(RuntimeError):
+        gp._densegp_gpu.set_gppriors(view)                 # a view is not a container
+    with pytest.raises(RuntimeError):
+        view.set_cov()
+
+
 # ------------------------------------------------------------------------------------------------
 # fit_GP_MAP
 # ------------------------------------------------------------------------------------------------

@@ -219,3 +219,67 @@ def test_fit_gp_map_argument_checks():
         _check_common(3, "Nelder-Mead")
     with pytest.raises(AssertionError):
         _check_common(0, "L-BFGS-B")
+
+
+def test_constructible_native_gppriors_match_the_reference():
+    """GPPriors(n_corr, nugget_type) of the native module (mogp_gpu/src/bindings.cu:528-556): logp / dlogpdtheta /
+    d2logpdtheta2 against the reference's values (tests/golden/make_golden_priors2.py), both ways of filling it."""
+    from mogp_emulator_amd import libgpgpu as L
+    g = load_golden("gppriors_native.npz")
+    for nm, cls in (("invgamma", L.InvGammaPrior), ("gamma", L.GammaPrior), ("lognormal", L.LogNormalPrior)):
+        p = cls(2.5, 0.7)
+        assert_allclose([p.d2logpdx2(x) for x in g["x"]], g[nm + "_d2logpdx2"], rtol=1e-13)
+    for k in range(int(g["n_cases"])):
+        nt = str(g["c%d_nugget_type" % k])
+        corr, cov, nug, th = g["c%d_corr" % k], g["c%d_cov" % k], g["c%d_nug" % k], g["c%d_theta" % k]
+        ntype = getattr(L.nugget_type, nt)
+        for way in ("create", "set"):
+            pri = L.GPPriors(len(corr), ntype)
+            if way == "create":
+                pri.create_corr_priors([(L.prior_type(int(c[0])), [c[1], c[2]]) for c in corr])
+                pri.create_cov_prior((L.prior_type(int(cov[0])), [cov[1], cov[2]]))
+                pri.set_nugget((L.prior_type(int(nug[0])), [nug[1], nug[2]]))
+            else:
+                pri.set_corr([L.GPPriors.make_prior(int(c[0]), [c[1], c[2]]) for c in corr])
+                pri.set_cov(L.GPPriors.make_prior(int(cov[0]), [cov[1], cov[2]]))
+                pri.set_nugget(L.GPPriors.make_prior(int(nug[0]), [nug[1], nug[2]]))
+            assert len(pri.get_corr()) == len(corr) and pri.get_nugget_type() == ntype
+            assert (pri.get_nugget() is not None) == (nt == "fit")
+            theta = L.GPParameters(0, len(corr), ntype, 1e-6 if nt == "fixed" else 0.)
+            theta.set_data(th)
+            assert_allclose(pri.get_logp(theta), float(g["c%d_logp" % k]), rtol=1e-12)
+            assert_allclose(pri.get_dlogpdtheta(theta), g["c%d_dlogp" % k], rtol=1e-12, atol=1e-14)
+            assert_allclose(pri.get_d2logpdtheta2(theta), g["c%d_d2logp" % k], rtol=1e-12, atol=1e-14)
+            smp = pri.sample()
+            assert len(smp) == len(th) and np.all(np.isfinite(smp))
+    # defaults and errors of the container
+    pri = L.GPPriors(3, L.nugget_type.fit)
+    pri.set_corr(); pri.set_cov(); pri.set_nugget()
+    assert all(type(p) is L.WeakPrior for p in pri.get_corr()) and type(pri.get_cov()) is L.WeakPrior and type(pri.get_nugget()) is L.WeakPrior
+    theta = L.GPParameters(0, 3, L.nugget_type.fit)
+    theta.set_data(np.array([0.1, 0.2, 0.3, 0.4, -5.]))
+    assert pri.get_logp(theta) == 0. and np.all(pri.get_d2logpdtheta2(theta) == 0.)
+    with pytest.raises(RuntimeError):
+        pri.get_logp(L.GPParameters(0, 2, L.nugget_type.fit))          # no data / wrong shape
+    assert type(L.GPPriors.make_prior(L.prior_type.InvGamma, [1.0])) is L.WeakPrior      # wrong parameter count -> weak
+    fixed = L.GPPriors(1, L.nugget_type.fixed)
+    fixed.set_nugget((L.prior_type.Gamma, [2., 2.]))
+    assert fixed.get_nugget() is None                                   # only a fitted nugget carries a prior
+
+
+def test_native_meanpriors_prior_dists_and_sample():
+    from mogp_emulator_amd import libgpgpu as L
+    mp = L.MeanPriors([1., 2.], [[2., 0.], [0., 3.]])
+    s = mp.sample(L.CorrTransform())
+    assert len(s) == 2 and all(-2.5 <= v <= 2.5 for v in s)             # weak: raw draw from U(-2.5, 2.5)
+    mp.set_prior_dists([L.prior_type.Gamma, L.prior_type.LogNormal], [[2., 1.], [0.5, 1.]])
+    np.random.seed(3)
+    s = mp.sample(L.CovTransform())
+    assert len(s) == 2 and np.all(np.isfinite(s))
+    with pytest.raises(RuntimeError, match="must equal number of meanfunc parameters"):
+        mp.set_prior_dists([L.prior_type.Gamma], [[2., 1.]])
+    mp.set_prior_dists()
+    assert all(type(d) is L.WeakPrior for d in mp._dists)
+    pri = L.GPPriors(1, L.nugget_type.adaptive)
+    pri.set_corr(); pri.set_cov(); pri.set_mean(mp)
+    assert len(pri.sample()) == 2 + 1 + 1                               # mean parameters first (gppriors.hpp:458-471)
