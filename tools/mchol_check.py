@@ -31,7 +31,7 @@ def run(B, n, d, matern, reps):
     mo = gp._mogp_gpu
     th = np.tile(theta, (B, 1)) + 0.01 * np.sin(np.arange(B))[:, None]
     res = {}
-    for name, sched in (("default", -1), ("mchol", 4)):
+    for name, sched in (("default", int(os.environ.get("BASE_SCHED", "-1"))), ("mchol", 4)):
         lib.mogp_profile_schedule(sched, 0)
         f, _, ok = mo.eval(th, grad=False)
         f, _, ok = mo.eval(th, grad=False)
