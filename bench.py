@@ -545,7 +545,7 @@ def main():
             traffic = None
             try:
                 if (n, d, B, m, args.kernel, world) == (2000, 10, 64, 10000, "SquaredExponential", 1):
-                    with open(os.path.join(ROOT, "profiles", "r02b_traffic.json")) as fh:
+                    with open(os.path.join(ROOT, "profiles", "r03_traffic.json")) as fh:
                         traffic = json.load(fh).get(dom, {}).get("traffic_bytes_per_launch")
             except (OSError, ValueError):
                 traffic = None
