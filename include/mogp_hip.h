@@ -219,6 +219,12 @@ int mogp_profile_reset(void);
 int mogp_profile_schedule(int schedule, int single_stream);
 /* sums over launches since reset: total milliseconds, launch count, algorithmic flops and bytes */
 int mogp_profile_get(const char* kernel_tag, double* total_ms, long long* launches, double* alg_flops, double* alg_bytes);
+/* The per-emulator task order of the one-launch Cholesky (kernels_mchol.hip) for n_plus_rhs = n + number of right-hand-side rows,
+   padded to a multiple of 128: entry = (type << 30) | (block column c << 15) | 64-row block r; type 0 D(c): diagonal block, 1 G(r, c):
+   diagonal tile receives the panels 0 .. c-2, 2 T(r, c): panel tile receives the panels 0 .. c-1 and is solved.  Writes up to
+   `capacity` entries, returns the number of tasks.  Host-only (no device needed): the CPU suite checks that the order is
+   topological, which is what the kernel's forward-progress argument rests on. */
+int mogp_mchol_task_table(int n_plus_rhs, int* out, int capacity);
 /* process-wide diagnostic counters: "backsolve_timeouts" = back substitutions that were repeated with the multi-launch
    path because a wait of the one-launch chain timed out (0 in normal operation); "mchol_aborts" = factorisations the
    one-launch Cholesky gave up on and a multi-launch schedule repeated (0 in normal operation); "objective_evals" / "gradient_evals" =

@@ -577,6 +577,14 @@ int mogp_profile_schedule(int schedule, int single_stream) {
   schedule_override().single_stream = single_stream != 0;
   return 0;
 }
+int mogp_mchol_task_table(int n_plus_rhs, int* out, int capacity) {
+  // host-only: the per-emulator task order of the one-launch Cholesky for a matrix of NP = roundup(n_plus_rhs, 128) rows
+  const int NP = (n_plus_rhs + TILE - 1) / TILE * TILE;
+  const std::vector<int> tb = mchol_task_table(NP);
+  if (out)
+    for (int i = 0; i < (int)tb.size() && i < capacity; ++i) out[i] = tb[i];
+  return (int)tb.size();
+}
 int mogp_profile_counter(const char* name, long long* out) {
   const long long v = prof_counter(name);
   if (v < 0 || !out) {

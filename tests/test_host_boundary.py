@@ -283,3 +283,44 @@ def test_native_meanpriors_prior_dists_and_sample():
     pri = L.GPPriors(1, L.nugget_type.adaptive)
     pri.set_corr(); pri.set_cov(); pri.set_mean(mp)
     assert len(pri.sample()) == 2 + 1 + 1                               # mean parameters first (gppriors.hpp:458-471)
+
+
+@pytest.mark.parametrize("n", [1, 100, 128, 129, 300, 640, 2000, 5000, 16000])
+def test_one_launch_cholesky_task_order_is_topological(n):
+    """The forward-progress argument of the one-launch Cholesky (csrc/kernels_mchol.hip) rests on ONE property of its task table:
+    every task only depends on tasks with a smaller number.  Replay the dependency rules of the kernel against the table the
+    library builds (host-only entry point, no device needed):
+      D(c)    needs G(2c, c), G(2c+1, c) (c >= 2) and T(2c, c-1), T(2c+1, c-1) (c >= 1)
+      G(r, c) needs T(r', k) for r' in {r, 2c, 2c+1} and every k <= c-2
+      T(r, c) needs D(c) and T(r', k) for r' in {r, 2c, 2c+1} and every k <= c-1
+    and check that every tile of the lower block triangle is produced exactly once."""
+    import ctypes
+    lib = _capi.load()
+    cnt = lib.mogp_mchol_task_table(n + 1, None, 0)
+    buf = (ctypes.c_int * cnt)()
+    assert lib.mogp_mchol_task_table(n + 1, buf, cnt) == cnt
+    NP = (n + 1 + 127) // 128 * 128
+    K, K2 = NP // 128, NP // 64
+    pos = {}
+    for p, w in enumerate(buf):
+        key = ((w >> 30) & 3, (w >> 15) & 0x7fff, (w & 0x7fff) if (w >> 30) & 3 else 0)
+        assert key not in pos, "task listed twice: %r" % (key,)
+        pos[key] = p
+    assert sorted(c for (t, c, r) in pos if t == 0) == list(range(K))
+    assert sorted((r, c) for (t, c, r) in pos if t == 2) == sorted((r, c) for c in range(K) for r in range(2 * c + 2, K2))
+    assert sorted((r, c) for (t, c, r) in pos if t == 1) == sorted((r, c) for c in range(2, K) for r in (2 * c, 2 * c + 1))
+    for (t, c, r), p in pos.items():
+        deps = []
+        if t == 0:
+            if c >= 2:
+                deps += [(1, c, 2 * c), (1, c, 2 * c + 1)]
+            if c >= 1:
+                deps += [(2, c - 1, 2 * c), (2, c - 1, 2 * c + 1)]
+        else:
+            kend = c - 1 if t == 1 else c
+            for k in range(kend):
+                deps += [(2, k, rr) for rr in {r, 2 * c, 2 * c + 1}]
+            if t == 2:
+                deps.append((0, c, 0))
+        for d in deps:
+            assert d in pos and pos[d] < p, "task %r (position %d) depends on %r (position %s)" % ((t, c, r), p, d, pos.get(d))
