@@ -438,13 +438,12 @@ void Engine::factorize_blocked(const std::vector<int>& ids, std::vector<int>& in
   upload_idx(ids);
   upload_params(ids);
   BatchView v = view(nb);
-  // schedule: 3 = left-looking with look-ahead (default); for A/B: 0 = left-looking in two emulator groups, 1 = right-looking +
-  // look-ahead, 2 = the round-1 look-ahead split (128-wide tiles, short update on the main stream)
+  // schedule: 4 = one launch / task queue (default, kernels_mchol.hip); the multi-launch schedules (fall-back, > 2048 tiles per step):
+  // 3 = left-looking with look-ahead, 0 = left-looking in two emulator groups, 1 = right-looking + look-ahead
   static const int forced = [] {
     const char* e = getenv("MOGP_CHOL");
     if (!e) return -1;
     if (e[0] == 'r') return 1;
-    if (std::string(e) == "leftla") return 2;
     if (std::string(e) == "mchol") return 4;
     return (std::string(e) == "left") ? 0 : 3;
   }();
@@ -619,40 +618,6 @@ void Engine::factorize_blocked(const std::vector<int>& ids, std::vector<int>& in
   }
   HIPCK(hipMemsetAsync(dInfo, 0, B * sizeof(int), stream));
   launch_cov_build(v, stream);
-  if (schedule == 2) {
-    // LEFT-LOOKING: block column o receives ALL earlier panels in one long-K MFMA pass
-    // (C[i, o:o+128] -= A[i, 0:o] A[o:o+128, 0:o]^T, K = o), then is factored.  Every element of the
-    // trailing matrix is read-modified-written once instead of once per outer step, and the GEMM runs
-    // at the K depth where the MFMA main loop is ~85% busy (PMC: 51% for the K=256 right-looking update).
-    // With look-ahead on two streams: the update of block column j+1 is split into the part that only
-    // needs panels < j (K = [0, o), long, runs on the main stream WHILE panel j is factored on the
-    // panel stream) and the short K = 128 part that needs panel j itself.
-    std::vector<int> cols;
-    for (int o = 0; o < n + R; o += TILE) cols.push_back(o);
-    const int K = (int)cols.size();
-    while ((int)evPanel.size() < K + 1) {
-      hipEvent_t a, b;
-      HIPCK(hipEventCreateWithFlags(&a, hipEventDisableTiming));
-      HIPCK(hipEventCreateWithFlags(&b, hipEventDisableTiming));
-      evPanel.push_back(a);
-      evUpd.push_back(b);
-    }
-    for (int j = 0; j < K; ++j) {
-      const int o = cols[j];
-      if (j > 0) {
-        HIPCK(hipStreamWaitEvent(stream, evPanel[j - 1], 0));
-        launch_update_wide(v, o, o - TILE, o, stream);                   // panel j-1 -> column j   (K = 128)
-      }
-      HIPCK(hipEventRecord(evUpd[j], stream));
-      HIPCK(hipStreamWaitEvent(pstream, evUpd[j], 0));
-      panel(v, o, TILE, pstream);
-      HIPCK(hipEventRecord(evPanel[j], pstream));
-      if (j > 0 && j + 1 < K) launch_update_wide(v, o + TILE, 0, o, stream);   // panels < j -> column j+1 (K = o), under panel j
-    }
-    HIPCK(hipStreamWaitEvent(stream, evPanel[K - 1], 0));
-    read_info(info, defer_info);
-    return;
-  }
   std::vector<int> starts;
   // outer block = K depth of the trailing update (MOGP_OUTER: 256 / 512 / 1024 -> C5 fit 45.7 / 41.7 / 44.3 ms)
   static const int OUTERW = [] { const char* e = getenv("MOGP_OUTER"); const int w = e ? atoi(e) : 512; return (w == 128 || w == 256 || w == 512 || w == 1024) ? w : 512; }();
