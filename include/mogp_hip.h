@@ -220,8 +220,8 @@ int mogp_profile_schedule(int schedule, int single_stream);
 /* sums over launches since reset: total milliseconds, launch count, algorithmic flops and bytes */
 int mogp_profile_get(const char* kernel_tag, double* total_ms, long long* launches, double* alg_flops, double* alg_bytes);
 /* The per-emulator task order of the one-launch Cholesky (kernels_mchol.hip) for n_plus_rhs = n + number of right-hand-side rows,
-   padded to a multiple of 128: entry = (type << 30) | (block column c << 15) | 64-row block r; type 0 D(c): diagonal block, 1 G(r, c):
-   diagonal tile receives the panels 0 .. c-2, 2 T(r, c): panel tile receives the panels 0 .. c-1 and is solved.  Writes up to
+   padded to a multiple of 128: entry = (type << 30) | (block column c << 15) | 64-row block r; type 0 D(c): diagonal block, 1 G(s, c): lower
+   64 x 64 tile s = 0, 1, 2 of the diagonal block (s in the r field) receives the panels 0 .. c-2, 2 T(r, c): panel tile receives the panels 0 .. c-1 and is solved.  Writes up to
    `capacity` entries, returns the number of tasks.  Host-only (no device needed): the CPU suite checks that the order is
    topological, which is what the kernel's forward-progress argument rests on. */
 int mogp_mchol_task_table(int n_plus_rhs, int* out, int capacity);

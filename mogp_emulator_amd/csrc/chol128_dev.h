@@ -180,9 +180,16 @@ __device__ __forceinline__ void c128_column_steps(c128_v4d& Dn, c128_v4d& Xn, c1
 // LDS images of 16 columns each and applied to the register-resident sub-blocks with the MFMA pattern of the rank-16
 // updates below, so the last panel's share of the diagonal block costs no read-modify-write pass and no hand-off of its
 // own.  lds must then hold C128_LDS_PRE_DOUBLES.
+// PROG (one-launch Cholesky): *prog = b is published (relaxed agent-scope store by one lane) once the pack entries of the block
+// steps < b -- inv(L_b'b') and the columns 16b' .. 16b'+15 of L^T -- are visible to other workgroups, so that the panel solves
+// of the dependent chain can run one block step behind the factorisation instead of after it (trsm128_lds_dev<.., PIPE>).  The
+// publication costs nothing on the critical path: it happens after the first barrier of block step b, when the only stores a
+// wave still has in flight are those of block step b-1 (a whole block step old; the inverse block's stores are issued after that
+// barrier for this reason), plus one extra barrier.  The caller publishes 8 after its final drain.
 constexpr int C128_LDS_PRE_DOUBLES = C128_LDS_DOUBLES + 128 * C128_LD;
-template <bool SC1_PACK = false, bool PRE = false>
-__device__ __forceinline__ void chol128_dev(double* __restrict__ A, int ld, double* __restrict__ pk, int* info_slot, int c0, double* lds) {
+template <bool SC1_PACK = false, bool PRE = false, bool PROG = false>
+__device__ __forceinline__ void chol128_dev(double* __restrict__ A, int ld, double* __restrict__ pk, int* info_slot, int c0, double* lds,
+                                            unsigned* prog = nullptr) {
   Sc1Buf pkb;
   if (SC1_PACK) pkb = sc1_buf(pk, PACK128_STRIDE * sizeof(double));
   const int t = mogp_tid(), lane = t & 63;
@@ -340,16 +347,31 @@ __device__ __forceinline__ void chol128_dev(double* __restrict__ A, int ld, doub
 #pragma unroll
         for (int s = 0; s < 4; ++s) stage[cl * 16 + rg + 4 * s] = UI[s];
         __builtin_amdgcn_wave_barrier();
-        double* pi = pk + PACK128_INV + b * 256;
+        if (!PROG) {
+          double* pi = pk + PACK128_INV + b * 256;
 #pragma unroll
-        for (int h = 0; h < 2; ++h)
-          st16<SC1_PACK>(pkb, pi + 128 * h + 2 * lane, *reinterpret_cast<const c128_v2d*>(stage + 128 * h + 2 * lane));
+          for (int h = 0; h < 2; ++h)
+            st16<SC1_PACK>(pkb, pi + 128 * h + 2 * lane, *reinterpret_cast<const c128_v2d*>(stage + 128 * h + 2 * lane));
+        }
       }
     }
     C128_STAMPW(4 * b + 2);
     __syncthreads();
     C128_STAMPW(4 * b + 3);
     C128_STAMP(2 + 2 * b);
+    if (PROG) {
+      if (b > 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (stores of block step b - 1: long landed)
+        __syncthreads();
+        if (t == 0) __hip_atomic_store(prog, (unsigned)b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      if (inv) {                                                  // the inverse block staged above (same wave), now stored
+        double* pi = pk + PACK128_INV + b * 256;
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+          st16<SC1_PACK>(pkb, pi + 128 * h + 2 * lane, *reinterpret_cast<const c128_v2d*>(Ibuf + 128 * h + 2 * lane));
+      }
+    }
     // block column b of L leaves the LDS image as full 128-byte row segments: A (row-major) and the transposed pack.
     // All LDS reads first, then the stores (fire and forget: they drain underneath the MFMAs below).
     {

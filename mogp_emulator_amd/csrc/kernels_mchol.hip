@@ -10,7 +10,8 @@
 //
 //   D(c)      the 128 x 128 diagonal block of block column c (chol128_dev): applies panel c-1 to the register-resident block
 //             (chol128_dev<.., PRE>) and factors it; needs T(2c, c-1), T(2c+1, c-1) and the two diagonal GEMM tasks of column c
-//   G(r, c)   r in {2c, 2c+1}: 64 rows of the diagonal block receive the panels 0 .. c-2 (left-looking, long K; off the chain)
+//   G(s, c)   s = 0, 1, 2: the lower 64 x 64 tile (0,0), (1,0), (1,1) of the diagonal block receives the panels 0 .. c-2 (left-looking,
+//             long K; off the chain)
 //   T(r, c)   r >= 2c+2: 64 rows x 128 columns below the diagonal block: the same long-K GEMM, then the panel solve with the
 //             pack of D(c) (trsm128_lds_dev).  The accumulators stay in registers while the task waits for panel c-1, so the
 //             look-ahead of the stream schedules (their U1 / U2 split and its extra read-modify-write pass) is implicit:
@@ -113,7 +114,7 @@ __device__ __forceinline__ int mc_wait_min3(const McCtx& cx, const unsigned* a, 
 
 }  // namespace
 
-// table[p] = (type << 30) | (c << 15) | r;  type 0: D(c), 1: G(r, c), 2: T(r, c)
+// table[p] = (type << 30) | (c << 15) | r;  type 0: D(c), 1: G(s, c) with s in the r field, 2: T(r, c)
 template <bool TRACE>
 __global__ __launch_bounds__(256, 2) void mchol_kernel(BatchView v, unsigned* __restrict__ ctrl, const int* __restrict__ table, int ntasks,
                                                        int emu_stride, double* __restrict__ packs, int* __restrict__ info, int nq, int spin_limit,
@@ -135,18 +136,23 @@ __global__ __launch_bounds__(256, 2) void mchol_kernel(BatchView v, unsigned* __
   for (int qi = 0; qi < nq; ++qi) {
     const int q = (home + qi) & (nq - 1);                 // own queue first, then help the others
     unsigned* head = ctrl + MC_HEADS + q * MC_LINE;
-    // The number of the NEXT task is drawn while the current one runs (one atomic round trip per task off the path).  Holding
-    // one number ahead keeps the progress argument: a held number is larger than the holder's current one, so the smallest
-    // current task among all workgroups still depends on finished or running tasks only.
-    int next_tk = 0;
-    if (t == 0) next_tk = (int)__hip_atomic_fetch_add(head, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // The number of the NEXT task is drawn while the current one runs (one atomic round trip per task off the path) -- but
+    // late in the current task, behind its long GEMM phase: a number drawn at the start sat unserved for the whole task, and
+    // when it belonged to the dependent chain a block column waited 12 - 45 us for it (per-task stamps).  Holding one number
+    // ahead keeps the progress argument: a held number is larger than the holder's current one, so the smallest current task
+    // among all workgroups still depends on finished or running tasks only.
+    int next_tk = -1;
+    auto draw_next = [&]() {
+      if (t == 0 && next_tk < 0) next_tk = (int)__hip_atomic_fetch_add(head, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
     for (;;) {
+      draw_next();
       if (t == 0) shi[0] = next_tk;
       __syncthreads();
       const int tk = shi[0];
       __syncthreads();
       if (tk >= total) break;
-      if (t == 0) next_tk = (int)__hip_atomic_fetch_add(head, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      next_tk = -1;
       const int p = tk / emus_q, zl = tk - p * emus_q;
       const int z = zl * nq + q;
       const int emu = __builtin_amdgcn_readfirstlane(v.idx ? v.idx[z] : z);
@@ -169,27 +175,80 @@ __global__ __launch_bounds__(256, 2) void mchol_kernel(BatchView v, unsigned* __
         mc_stamp<TRACE>(tr, 1);
         // the panels 0 .. c-2 arrive through the two G tasks (c >= 2), panel c-1 is applied here, straight from the two
         // panel-solve tasks that produced it
-        if (c > 1 && mc_wait_min3(cx, diagcnt + c, diagcnt + c, diagcnt + c, 2u, tr) < 0) return;
+        if (c > 1 && mc_wait_min3(cx, diagcnt + c, diagcnt + c, diagcnt + c, 3u, tr) < 0) return;
         if (c > 0 && mc_wait_min3(cx, rowdone + 2 * c, rowdone + 2 * c + 1, rowdone + 2 * c + 1, (unsigned)c, tr) < 0) return;
         mc_stamp<TRACE>(tr, 2);
         if (use_park && t == 0) __hip_atomic_fetch_add(cuword, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (c > 0) chol128_dev<true, true>(A + (size_t)c0 * ld + c0, ld, pk, info + emu, c0, lds);
-        else chol128_dev<true, false>(A + (size_t)c0 * ld + c0, ld, pk, info + emu, c0, lds);
+        // (ddone[c] counts the block steps whose pack entries are visible: 8 = the whole pack)
+        if (c > 0) chol128_dev<true, true, true>(A + (size_t)c0 * ld + c0, ld, pk, info + emu, c0, lds, ddone + c);
+        else chol128_dev<true, false, true>(A + (size_t)c0 * ld + c0, ld, pk, info + emu, c0, lds, ddone + c);
         if (use_park && t == 0) __hip_atomic_fetch_sub(cuword, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __builtin_amdgcn_s_setprio(0);
         drain_stores();
         __syncthreads();
-        if (t == 0) stu(ddone + c, 1u);
+        if (t == 0) stu(ddone + c, 8u);
         mc_stamp<TRACE>(tr, 5);
         continue;
       }
-      // ---- G / T: 64 rows x 128 columns receive the panels 0 .. c-1 -----------------------------------------------------
+      if (type == 1) {
+        // ---- G(s, c): lower 64 x 64 tile s = (0,0), (1,0), (1,1) of the diagonal block receives the panels 0 .. c-2 -----------
+        // (three 64 x 64 tasks rather than two 64 x 128 ones: no work on the upper-right quarter, and half the length per task -- a
+        // 64 x 128 task of a late block column needed ~7 c us of a whole CU, more than one block-column period, and the diagonal
+        // block waited for it: 65 - 98 us periods in the per-task stamps)
+        const int ti = r > 0 ? 1 : 0, tj = r > 1 ? 1 : 0;
+        const int gi0 = c0 + 64 * ti, gj0 = c0 + 64 * tj;
+        __builtin_amdgcn_s_setprio(2);
+        v4d acc[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = (v4d){0., 0., 0., 0.};
+        const int kend = c - 1;
+        int kb = 0;
+        while (kb < kend) {
+          mc_stamp<TRACE>(tr, 1);
+          int m = mc_wait_min3(cx, rowdone + 2 * c + ti, rowdone + 2 * c + tj, rowdone + 2 * c + tj, (unsigned)(kb + 1), tr);
+          if (m < 0) return;
+          mc_stamp<TRACE>(tr, 2);
+          m = m < kend ? m : kend;
+          mainloop_pf<64, 64, 2, 2, MC_PD>(A + (size_t)gi0 * ld + 128 * kb, ld, A + (size_t)gj0 * ld + 128 * kb, ld, 8 * (m - kb), acc, lds);
+          kb = m;
+        }
+        mc_stamp<TRACE>(tr, 3);
+        draw_next();
+        {
+          double cv[2][2][4];
+          const int lane = t & 63, wave = t >> 6, wr = wave >> 1, wc = wave & 1;
+          double* pc0 = A + (size_t)(gi0 + wr * 32 + (lane >> 4)) * ld + (gj0 + wc * 32 + (lane & 15));
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+              for (int q = 0; q < 4; ++q) cv[i][j][q] = pc0[(size_t)(i * 16 + 4 * q) * ld + j * 16];
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+              for (int q = 0; q < 4; ++q)      // read by D(c) on another CU: write-through
+                __hip_atomic_store(pc0 + (size_t)(i * 16 + 4 * q) * ld + j * 16, cv[i][j][q] - acc[i][j][q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        drain_stores();
+        mc_stamp<TRACE>(tr, 4);
+        __syncthreads();
+        if (t == 0) __hip_atomic_fetch_add(diagcnt + c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        mc_stamp<TRACE>(tr, 5);
+        __builtin_amdgcn_s_setprio(0);
+        continue;
+      }
+      // ---- T: 64 rows x 128 columns receive the panels 0 .. c-1 -----------------------------------------------------
       const int r0 = 64 * r;
       // tasks of the dependent chain (diagonal tiles, the two row blocks of the next diagonal block) issue ahead of the
       // workgroup they share the CU with
-      const bool urgent = type == 1 || r < 2 * c + 4;
+      const bool urgent = r < 2 * c + 4;
       if (urgent) __builtin_amdgcn_s_setprio(2);
-      const int kend = type == 1 ? c - 1 : c;        // G: the last panel is applied by D(c) itself
+      const int kend = c;
       if (kend > 0) {
         v4d acc[2][4];
 #pragma unroll
@@ -208,6 +267,7 @@ __global__ __launch_bounds__(256, 2) void mchol_kernel(BatchView v, unsigned* __
           kb = m;
         }
         mc_stamp<TRACE>(tr, 3);
+        draw_next();
         // C -= acc.  All 32 loads of a thread first, then the stores: written as load / subtract / store per element the
         // compiler keeps program order between a store and the next load (they might alias), and the write-back of a 64 KB
         // tile was 32 dependent memory round trips (23 - 31 us per task, tools/mchol_trace.py).
@@ -229,27 +289,31 @@ __global__ __launch_bounds__(256, 2) void mchol_kernel(BatchView v, unsigned* __
               for (int q = 0; q < 4; ++q) {
                 double* pc = pc0 + (size_t)(i * 16 + 4 * q) * ld + j * 16;
                 const double x = cv[i][j][q] - acc[i][j][q];
-                // G: read by D(c) on another CU -> write-through; T: read back by this workgroup's panel solve
-                if (type == 1) __hip_atomic_store(pc, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                else *pc = x;
+                *pc = x;                     // (read back by this workgroup's panel solve)
               }
         }
         drain_stores();
         mc_stamp<TRACE>(tr, 4);
         __syncthreads();
       }
-      if (type == 1) {
-        if (t == 0) __hip_atomic_fetch_add(diagcnt + c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        mc_stamp<TRACE>(tr, 5);
-        __builtin_amdgcn_s_setprio(0);
-        continue;
-      }
       // ---- T: panel solve with the pack of D(c) ---------------------------------------------------------------------------
-      if (mc_wait_min3(cx, ddone + c, ddone + c, ddone + c, 1u, tr) < 0) return;
-      mc_stamp<TRACE>(tr, 8);
-      // the substitution is a chain of dependent MFMAs: let it issue ahead of the co-resident workgroup's dense MFMA stream
-      if (!urgent) __builtin_amdgcn_s_setprio(1);
-      trsm128_lds_dev<true, true>(v, c0, r0, pk, emu, 0, lds);
+      if (urgent) {
+        // chain task: one block step behind the diagonal block that is still being factored (chol128_dev<.., PROG>)
+        bool first = true;
+        auto wait = [&](int b) {
+          const bool ok = mc_wait_min3(cx, ddone + c, ddone + c, ddone + c, (unsigned)(b + 1), tr) >= 0;
+          if (first) mc_stamp<TRACE>(tr, 8);
+          first = false;
+          return ok;
+        };
+        if (!trsm128_lds_dev<true, false, true>(v, c0, r0, pk, emu, 0, lds, wait)) return;
+      } else {
+        if (mc_wait_min3(cx, ddone + c, ddone + c, ddone + c, 8u, tr) < 0) return;
+        mc_stamp<TRACE>(tr, 8);
+        // the substitution is a chain of dependent MFMAs: let it issue ahead of the co-resident workgroup's dense MFMA stream
+        __builtin_amdgcn_s_setprio(1);
+        trsm128_lds_dev<true, true>(v, c0, r0, pk, emu, 0, lds);
+      }
       drain_stores();
       __syncthreads();
       if (t == 0) stu(rowdone + r, (unsigned)(c + 1));
@@ -275,10 +339,8 @@ std::vector<int> mchol_task_table(int NP) {
     for (int r = 2 * c + 2; r < std::min(2 * c + 4, K2); ++r) tb.push_back(word(2, c, r));
     for (int r = 2 * c + 4; r < std::min(2 * c + 6, K2); ++r) tb.push_back(word(2, c, r));
     // the diagonal GEMM tasks of column c+2 need the panels 0 .. c: rows 2c+4, 2c+5 of column c, just above
-    if (c + 2 < K) {
-      tb.push_back(word(1, c + 2, 2 * c + 4));
-      tb.push_back(word(1, c + 2, 2 * c + 5));
-    }
+    if (c + 2 < K)
+      for (int sub = 0; sub < 3; ++sub) tb.push_back(word(1, c + 2, sub));
     for (int r = 2 * c + 6; r < K2; ++r) tb.push_back(word(2, c, r));
   }
   return tb;

@@ -37,9 +37,16 @@ constexpr int TRSM128L_LDS = 2 * TL_PK + 4 * 2 * TL_TS;
 // whole 16 x 128 slab is requested up front (32 VGPRs) and the row-block images two steps ahead instead of one -- the
 // early steps have MFMA chains of 4 - 12 instructions and were bound by one memory latency each (16 - 21 us per solve
 // under load against 8 us alone, tools/mchol_trace.py).  Arithmetic and results are unchanged.
-template <bool SC1_OUT = false, bool DEEP = false>
-__device__ __forceinline__ void trsm128_lds_dev(const BatchView& v, int c0, int r0, const double* __restrict__ pk, int emu, int rowblock,
-                                                double* lds) {
+// PIPE (implies DEEP's slab preload): the pack is still being written -- the diagonal block publishes its progress per block step
+// (chol128_dev<.., PROG>) and wait(b) returns once row block b of the pack (the L^T columns of the block steps < b and inv(L_bb))
+// is visible, or false when the launch has been aborted.  Step b is computed first, then the wait for step b + 1, its request and
+// deposit: the solve runs one block step behind the factorisation and ends ~4 us after it instead of ~9.  Returns false on abort.
+struct TrsmNoWait {
+  __device__ __forceinline__ bool operator()(int) const { return true; }
+};
+template <bool SC1_OUT = false, bool DEEP = false, bool PIPE = false, class WAIT = TrsmNoWait>
+__device__ __forceinline__ bool trsm128_lds_dev(const BatchView& v, int c0, int r0, const double* __restrict__ pk, int emu, int rowblock,
+                                                double* lds, WAIT wait = WAIT()) {
   Sc1Buf ab;
   if (SC1_OUT) ab = sc1_buf(v.A + (size_t)emu * v.MS, (unsigned)(v.MS * sizeof(double)));
   const int ld = v.LD;
@@ -51,14 +58,15 @@ __device__ __forceinline__ void trsm128_lds_dev(const BatchView& v, int c0, int 
   const double* LT = pk + PACK128_LT;
   // this lane's two 16-byte pieces of a slab block: rows q >> 3, piece q & 7 for q = lane, lane + 64
   const int sr0 = lane >> 3, sp = (lane & 7) * 2;
-  v2d_p sl[DEEP ? 8 : 1][2];
+  constexpr bool PRE_SLAB = DEEP || PIPE;
+  v2d_p sl[PRE_SLAB ? 8 : 1][2];
   auto slab_request = [&](int b) {
-    sl[DEEP ? b : 0][0] = *reinterpret_cast<const v2d_p*>(slab + (size_t)sr0 * ld + 16 * b + sp);
-    sl[DEEP ? b : 0][1] = *reinterpret_cast<const v2d_p*>(slab + (size_t)(sr0 + 8) * ld + 16 * b + sp);
+    sl[PRE_SLAB ? b : 0][0] = *reinterpret_cast<const v2d_p*>(slab + (size_t)sr0 * ld + 16 * b + sp);
+    sl[PRE_SLAB ? b : 0][1] = *reinterpret_cast<const v2d_p*>(slab + (size_t)(sr0 + 8) * ld + 16 * b + sp);
   };
   auto slab_deposit = [&](int b, double* ts) {
-    *reinterpret_cast<v2d_p*>(ts + sr0 * 18 + sp) = sl[DEEP ? b : 0][0];
-    *reinterpret_cast<v2d_p*>(ts + (sr0 + 8) * 18 + sp) = sl[DEEP ? b : 0][1];
+    *reinterpret_cast<v2d_p*>(ts + sr0 * 18 + sp) = sl[PRE_SLAB ? b : 0][0];
+    *reinterpret_cast<v2d_p*>(ts + (sr0 + 8) * 18 + sp) = sl[PRE_SLAB ? b : 0][1];
   };
   // the workgroup's share of row block b: 8 b pieces of 16 doubles [column c][rows 16b .. 16b+15], then the 256 doubles of inv(L_bb)
   v2d_p pr[DEEP ? 2 : 1][4], pinv[DEEP ? 2 : 1];
@@ -80,13 +88,20 @@ __device__ __forceinline__ void trsm128_lds_dev(const BatchView& v, int c0, int 
     }
     if (t < 128) *reinterpret_cast<v2d_p*>(img + 112 * 16 + 2 * t) = pinv[u];
   };
-  pack_request(0);
-  if (DEEP) {
-    pack_request(1);
+  if (PIPE) {
 #pragma unroll
     for (int b = 0; b < 8; ++b) slab_request(b);
+    if (!wait(0)) return false;
+    pack_request(0);
   } else {
-    slab_request(0);
+    pack_request(0);
+    if (DEEP) {
+      pack_request(1);
+#pragma unroll
+      for (int b = 0; b < 8; ++b) slab_request(b);
+    } else {
+      slab_request(0);
+    }
   }
   pack_deposit(0, pkb[0]);
   slab_deposit(0, tsb[0]);
@@ -96,7 +111,9 @@ __device__ __forceinline__ void trsm128_lds_dev(const BatchView& v, int c0, int 
   for (int b = 0; b < 8; ++b) {
     const double* img = pkb[b & 1];
     double* ts = tsb[b & 1];
-    if (DEEP) {
+    if (PIPE) {
+      // (request and deposit of step b + 1 follow the compute of step b, behind the wait)
+    } else if (DEEP) {
       if (b + 2 < 8) pack_request(b + 2);        // register set b & 1 held row block b, which is in LDS already
     } else if (b < 7) {
       pack_request(b + 1);
@@ -125,11 +142,16 @@ __device__ __forceinline__ void trsm128_lds_dev(const BatchView& v, int c0, int 
       st16<SC1_OUT>(ab, slab + (size_t)(sr0 + 8) * ld + 16 * b + sp, o1);
     }
     if (b < 7) {
+      if (PIPE) {
+        if (!wait(b + 1)) return false;
+        pack_request(b + 1);
+      }
       pack_deposit(b + 1, pkb[(b + 1) & 1]);
       slab_deposit(b + 1, tsb[(b + 1) & 1]);
     }
     __syncthreads();
   }
+  return true;
 }
 
 }  // namespace mogp

@@ -290,8 +290,8 @@ def test_one_launch_cholesky_task_order_is_topological(n):
     """The forward-progress argument of the one-launch Cholesky (csrc/kernels_mchol.hip) rests on ONE property of its task table:
     every task only depends on tasks with a smaller number.  Replay the dependency rules of the kernel against the table the
     library builds (host-only entry point, no device needed):
-      D(c)    needs G(2c, c), G(2c+1, c) (c >= 2) and T(2c, c-1), T(2c+1, c-1) (c >= 1)
-      G(r, c) needs T(r', k) for r' in {r, 2c, 2c+1} and every k <= c-2
+      D(c)    needs G(0, c), G(1, c), G(2, c) (c >= 2) and T(2c, c-1), T(2c+1, c-1) (c >= 1)
+      G(s, c) (lower 64 x 64 tile (ti, tj) = (0,0), (1,0), (1,1) of the diagonal block) needs T(2c+ti, k), T(2c+tj, k) for every k <= c-2
       T(r, c) needs D(c) and T(r', k) for r' in {r, 2c, 2c+1} and every k <= c-1
     and check that every tile of the lower block triangle is produced exactly once."""
     import ctypes
@@ -308,19 +308,21 @@ def test_one_launch_cholesky_task_order_is_topological(n):
         pos[key] = p
     assert sorted(c for (t, c, r) in pos if t == 0) == list(range(K))
     assert sorted((r, c) for (t, c, r) in pos if t == 2) == sorted((r, c) for c in range(K) for r in range(2 * c + 2, K2))
-    assert sorted((r, c) for (t, c, r) in pos if t == 1) == sorted((r, c) for c in range(2, K) for r in (2 * c, 2 * c + 1))
+    assert sorted((r, c) for (t, c, r) in pos if t == 1) == sorted((sub, c) for c in range(2, K) for sub in range(3))
     for (t, c, r), p in pos.items():
         deps = []
         if t == 0:
             if c >= 2:
-                deps += [(1, c, 2 * c), (1, c, 2 * c + 1)]
+                deps += [(1, c, 0), (1, c, 1), (1, c, 2)]
             if c >= 1:
                 deps += [(2, c - 1, 2 * c), (2, c - 1, 2 * c + 1)]
+        elif t == 1:
+            ti, tj = (1 if r > 0 else 0), (1 if r > 1 else 0)
+            for k in range(c - 1):
+                deps += [(2, k, rr) for rr in {2 * c + ti, 2 * c + tj}]
         else:
-            kend = c - 1 if t == 1 else c
-            for k in range(kend):
+            for k in range(c):
                 deps += [(2, k, rr) for rr in {r, 2 * c, 2 * c + 1}]
-            if t == 2:
-                deps.append((0, c, 0))
+            deps.append((0, c, 0))
         for d in deps:
             assert d in pos and pos[d] < p, "task %r (position %d) depends on %r (position %s)" % ((t, c, r), p, d, pos.get(d))
