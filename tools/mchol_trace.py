@@ -36,7 +36,8 @@ for c in range(K):
     Ts = [tasks.get((2, c, r)) for r in (2 * c + 2, 2 * c + 3)]
     for i, T in enumerate(Ts):
         if T is not None:
-            line += " | T%d %7.1f (+%4.1f) ->%7.1f (%5.1f)" % (i, us(T[8]), us(T[8]) - us(D[5]), us(T[5]), us(T[5]) - us(T[8]))
+            line += " | T%d %7.1f (+%4.1f) ->%7.1f (%5.1f) [drawn %7.1f ops %7.1f written %7.1f]" % (
+                i, us(T[8]), us(T[8]) - us(D[5]), us(T[5]), us(T[5]) - us(T[8]), us(T[0]), us(T[2]) if T[2] else -1, us(T[4]) if T[4] else -1)
     if Ts[0] is not None and (0, c + 1, 0) in tasks:
         tdone = max(us(x[5]) for x in Ts if x is not None)
         line += " | D' +%4.1f" % (us(tasks[(0, c + 1, 0)][2]) - tdone)
