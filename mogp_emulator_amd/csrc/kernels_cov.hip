@@ -294,19 +294,43 @@ __global__ __launch_bounds__(256) void predict_deriv_kernel(BatchView v, const d
         G[(4 * ty + a) * 65 + 4 * tx + b] = (j < n) ? 2.0 * sig2 * f * alpha[j] : 0.0;
       }
     __syncthreads();
-    for (int d = 0; d < D; ++d) {
-      const double xm = si[d * 64 + row];
-      double s = 0.;
-#pragma unroll 4
+    if (KT < 2) {
+      // sum_j G_mj (x*_md - x_jd) = x*_md sum_j G_mj - sum_j G_mj x_jd: the thread's 16 values of G stay in registers for all D
+      // dimensions and every pair costs ONE fused multiply-add per dimension (before: G re-read from LDS for every dimension,
+      // two LDS reads and two operations per pair and dimension -- the kernel was LDS-bound, 10 ms for 64 x 10^4 points x n=2000).
+      // The coordinates are taken relative to the workgroup's first test point, so that the two sums stay of the size of the
+      // differences.
+      double g[16], gsum = 0.;
+#pragma unroll
       for (int q = 0; q < 16; ++q) {
-        const int j = part * 16 + q;
-        const double df = xm - sj[d * 64 + j];
-        if (KT < 2) s = __builtin_fma(G[row * 65 + j], df, s);
-        else s = __builtin_fma(G[row * 65 + j] * mat52_dlog(P[d] * df * df), df, s);
+        g[q] = G[row * 65 + part * 16 + q];
+        gsum += g[q];
       }
-      s += __shfl_xor(s, 1);
-      s += __shfl_xor(s, 2);
-      if (part == 0) dacc[row * D + d] += P[d] * s;
+      for (int d = 0; d < D; ++d) {
+        const double x0 = si[d * 64];
+        const double* xj = sj + d * 64 + part * 16;
+        double u = 0.;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) u = __builtin_fma(g[q], xj[q] - x0, u);
+        double s = __builtin_fma(si[d * 64 + row] - x0, gsum, -u);
+        s += __shfl_xor(s, 1);
+        s += __shfl_xor(s, 2);
+        if (part == 0) dacc[row * D + d] += P[d] * s;
+      }
+    } else {
+      for (int d = 0; d < D; ++d) {
+        const double xm = si[d * 64 + row];
+        double s = 0.;
+#pragma unroll 4
+        for (int q = 0; q < 16; ++q) {
+          const int j = part * 16 + q;
+          const double df = xm - sj[d * 64 + j];
+          s = __builtin_fma(G[row * 65 + j] * mat52_dlog(P[d] * df * df), df, s);
+        }
+        s += __shfl_xor(s, 1);
+        s += __shfl_xor(s, 2);
+        if (part == 0) dacc[row * D + d] += P[d] * s;
+      }
     }
   }
   __syncthreads();
