@@ -140,13 +140,9 @@ Engine::Engine(const double* X, int n_, int D_, const double* targets, int B_, u
   for (int d : mean.dims)
     if (d >= D) throw std::runtime_error("Dimension index must be less than " + std::to_string(D));
   NP = roundup(n + R, TILE);
-  // Row stride.  A non-power-of-two stride (NP + 16) was tried against L2 set aliasing of the
-  // 16 KiB-strided tile rows and measured SLOWER on MI355X (fit 7.5 -> 8.2 ms, fit+grad 15.3 -> 16.2 ms),
-  // so the default pad is 0; MOGP_LDPAD (even) re-enables it for experiments.
-  {
-    const char* e = getenv("MOGP_LDPAD");
-    LD = NP + (e ? (atoi(e) & ~1) : 0);
-  }
+  // Row stride = NP.  A non-power-of-two stride (NP + 16) was tried against L2 set aliasing of the 16 KiB-strided tile rows
+  // and measured SLOWER on MI355X (fit 7.5 -> 8.2 ms, fit+grad 15.3 -> 16.2 ms; predictive variance unchanged).
+  LD = NP;
   MS = (size_t)NP * LD;
   NC = uniform() ? 1 : D;
   PS = D + 2;
@@ -685,7 +681,7 @@ void Engine::eval(const std::vector<int>& ids, const std::vector<const double*>&
         v = view((int)todo.size());
         launch_alpha_from_linv(v, stream);
       } else {
-        // single right-hand side: the one-launch chain (MOGP_BACKSOLVE=1 / 0: per-block launches / one workgroup per emulator)
+        // single right-hand side: the one-launch chain (MOGP_BACKSOLVE=1: per-block launches, the path a timed-out chain falls back to)
         static const bool chain = [] { const char* e = getenv("MOGP_BACKSOLVE"); return !e; }();
         if (chain && R == 1 && pass == 0) {
           const size_t nfl = (size_t)B * ((n + 127) / 128);

@@ -73,69 +73,10 @@ __global__ __launch_bounds__(256) void logdet_kernel(BatchView v, const int* __r
     }
 }
 
-// ---------------------------------------------------------------------------------------------
-// alpha = L^-T y, blocked right-looking back substitution, one 512-thread workgroup per emulator.
-//   for kb = last .. 0:  alpha_kb = L_kk^-T w_kb ;  w[0:k0] -= L[kb rows, 0:k0]^T alpha_kb
-// The 64x64 transposed solve runs in wave 0 with lane i holding column i of L_kk in registers
-// (= row i of U = L_kk^T): per step one multiply by the reciprocal diagonal, one v_readlane
-// broadcast and one FMA per lane, no LDS and no division on the dependent chain.
-// ---------------------------------------------------------------------------------------------
-constexpr int BS_THREADS = 512;   // 1024 threads measured 2x slower: the kernel is bound by one CU's ~25 GB/s streaming rate
-
-__global__ __launch_bounds__(BS_THREADS) void backsolve_kernel(BatchView v) {
-  __shared__ double ab[64];
-  const int emu = slot_emu(v.idx, blockIdx.x);
-  const int ld = v.LD, n = v.n;
-  const double* A = v.A + (size_t)emu * v.MS;
-  double* w = v.Z + (size_t)emu * v.R * ld;          // R == 1 only (the launcher falls back to the multi-launch path otherwise)
-  const int t = threadIdx.x;
-  for (int i = t; i < ld; i += BS_THREADS) w[i] = (i < n) ? A[(size_t)n * ld + i] : 0.0;
-  __syncthreads();
-  const int nblk = (n + 63) / 64;
-  for (int kb = nblk - 1; kb >= 0; --kb) {
-    const int k0 = kb * 64;
-    if (t < 64) {
-      double u[64];
-#pragma unroll
-      for (int j = 0; j < 64; ++j) u[j] = A[(size_t)(k0 + j) * ld + k0 + t];     // u[j] = L[k0+j][k0+t], coalesced in t
-      const double rdg = 1.0 / A[(size_t)(k0 + t) * ld + k0 + t];
-      double b = w[k0 + t];
-      double xout = 0.0;
-#pragma unroll
-      for (int j = 63; j >= 0; --j) {
-        double xj = readlane_f64(b * rdg, j);
-        if (k0 + j >= n) xj = 0.0;            // identity padding and the y row take no part
-        if (t == j) xout = xj;
-        b = __builtin_fma(-u[j], xj, b);      // only lanes < j use it afterwards
-      }
-      ab[t] = xout;
-      w[k0 + t] = xout;
-    }
-    __syncthreads();
-    // w[c] -= sum_r L[k0+r][c] alpha[k0+r], c < k0: threads own column pairs, rows are contiguous
-    for (int c = 2 * t; c < k0; c += 2 * BS_THREADS) {
-      v2d s = {0., 0.};
-      const double* p = A + (size_t)k0 * ld + c;
-#pragma unroll 16
-      for (int r = 0; r < 64; ++r) {
-        const v2d x = *reinterpret_cast<const v2d*>(p + (size_t)r * ld);
-        const double ar = ab[r];
-        s[0] = __builtin_fma(x[0], ar, s[0]);
-        s[1] = __builtin_fma(x[1], ar, s[1]);
-      }
-      v2d cur = *reinterpret_cast<v2d*>(w + c);
-      cur[0] -= s[0];
-      cur[1] -= s[1];
-      *reinterpret_cast<v2d*>(w + c) = cur;
-    }
-    __syncthreads();
-  }
-}
-
-// Multi-launch variant of the back substitution: per 64-row block one tiny diagonal-solve launch
-// (one wave per emulator) and one gemv launch spread over as many workgroups as there are column
-// chunks.  The single-workgroup kernel above is bound by ONE CU's streaming rate (~25 GB/s: 0.7 ms at
-// n=2000, 40 ms at n=16000); here all CUs stream L.
+// Multi-launch back substitution alpha = L^-T y (several right-hand sides, and the fall-back of the one-launch chain below):
+// per 64-row block one tiny diagonal-solve launch (one wave per emulator) and one gemv launch spread over as many
+// workgroups as there are column chunks, so that all CUs stream L (one workgroup per emulator is bound by ONE CU's
+// streaming rate, ~25 GB/s: 0.7 ms at n=2000, 40 ms at n=16000; that variant was removed in round 3).
 __global__ __launch_bounds__(256) void backsolve_init_kernel(BatchView v) {
   const int emu = slot_emu(v.idx, blockIdx.y);
   const int ld = v.LD, n = v.n, R = v.R;
@@ -577,24 +518,16 @@ void launch_backsolve_chain(const BatchView& v, int* flags, int epoch, int* stat
 }
 
 void launch_backsolve(const BatchView& v, hipStream_t s) {
-  static const int mode = [] { const char* e = getenv("MOGP_BACKSOLVE"); return e ? atoi(e) : 1; }();   // 0: one workgroup per emulator
-  if (mode == 0 && v.R == 1) {
-    hipLaunchKernelGGL(backsolve_kernel, dim3(v.nb), dim3(BS_THREADS), 0, s, v);
-    return;
-  }
   hipLaunchKernelGGL(backsolve_init_kernel, dim3((v.NP + 255) / 256, v.nb), dim3(256), 0, s, v);
   const int nblk = (v.n + 63) / 64;
-  // MOGP_BSGEMV: 1 one-wave gemv, 4 four-wave gemv, default (5) four-wave gemv that also solves the next diagonal block
-  static const int bsg = [] { const char* e = getenv("MOGP_BSGEMV"); return e ? atoi(e) : 5; }();
   for (int kb = nblk - 1; kb >= 0; --kb) {
     const int k0 = kb * 64;
-    const bool fused = v.R == 1 && bsg == 5;
+    // one right-hand side: the four-wave gemv also solves the NEXT diagonal block (one launch per block instead of two)
+    const bool fused = v.R == 1;
     if (!fused || kb == nblk - 1) hipLaunchKernelGGL(backsolve_diag_kernel, dim3(v.nb), dim3(64), 0, s, v, k0);
     if (k0 > 0) {
       const dim3 grid((k0 / 2 + BSG_THREADS - 1) / BSG_THREADS, v.nb);
       if (fused) hipLaunchKernelGGL(backsolve_gemv4_kernel<true>, grid, dim3(256), 0, s, v, k0);
-      else if (v.R == 1 && bsg == 4) hipLaunchKernelGGL(backsolve_gemv4_kernel<false>, grid, dim3(256), 0, s, v, k0);
-      else if (v.R == 1) hipLaunchKernelGGL(backsolve_gemv_kernel<1>, grid, dim3(BSG_THREADS), 0, s, v, k0);
       else hipLaunchKernelGGL(backsolve_gemv_kernel<RMAX>, grid, dim3(BSG_THREADS), 0, s, v, k0);
     }
   }

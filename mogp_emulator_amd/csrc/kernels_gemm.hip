@@ -286,21 +286,14 @@ __global__ __launch_bounds__(256, 2) void kinv_kernel(BatchView v, int ntiles, i
 }
 
 // ---------------------------------------------------------------------------------------------
-// predictive variance partials: V = Linv * Ks^T (never stored);  partial[z][ti][m] = sum_{i in tile ti} V[i,m]^2
+// V = Linv * Ks^T written out (NP x MP per slot): first half of the full predictive covariance (fullcov_kernel below).  The
+// predictive VARIANCE never stores V (predict_var_w_kernel).  A workgroup takes the pair of row tiles (nti-1-p, p) for its
+// column tile, so that every workgroup of the launch is equally long (K = 128 (nti + 1)); 2 x 2 waves, 128 x 128 tiles.
 // ---------------------------------------------------------------------------------------------
-template <bool STORE>   // STORE: V itself is written (NP x MP per slot) for the full predictive covariance instead of its column norms
-__global__ __launch_bounds__(256, 2) void predict_var_kernel(BatchView v, const double* __restrict__ Ks, int MP, int nti, int ntj,
-                                                           double* __restrict__ partial) {
+__global__ __launch_bounds__(256, 2) void predict_v_store_kernel(BatchView v, const double* __restrict__ Ks, int MP, int nti, int ntj,
+                                                               double* __restrict__ Vout) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   using C = Cfg<4>;
-  // Work decomposition for L2 reuse.  L^-1 is lower triangular, so row tile ti needs K = 128 (ti + 1): a workgroup
-  // takes the PAIR of row tiles (nti-1-p, p) for its column tile, which makes every workgroup of the launch equally
-  // long (K = 128 (nti + 1)).  Tiles are walked in super-tiles of 4 pairs x 16 column tiles (64 workgroups = one
-  // XCD's resident set; the 8-wave kernel below uses 8 x 8): the workgroups that share an L^-1 row panel have identical K and those that
-  // share a K* panel differ by a few x 128, and because all workgroups finish together the next super-tile also starts
-  // together -- panels are fetched from HBM once per super-tile and re-used out of the 4 MiB L2 while the 64
-  // workgroups sweep k in step.  (Unpaired 8 x 8 super-tiles drifted apart: short row tiles finished early, their
-  // successors started staggered, and the L2 hit rate fell to ~50 %: 49.5 GB of HBM traffic per launch by PMC.)
   const int npairs = (nti + 1) / 2;
   const int nsr = (npairs + 3) / 4, nsc = (ntj + 15) / 16;
   int z, tile;
@@ -314,37 +307,15 @@ __global__ __launch_bounds__(256, 2) void predict_var_kernel(BatchView v, const 
   const double* Li = v.Linv + (size_t)emu * v.MS;
   const double* K = Ks + (size_t)z * MP * ld;
   const int j0 = tj * C::BM;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int wr = wave >> 1, wc = wave & 1;
   const int ti_long = nti - 1 - pr, ti_short = pr;
+  double* V = Vout + (size_t)z * v.NP * MP;
   for (int pass = 0; pass < 2; ++pass) {
     if (pass == 1 && ti_short == ti_long) break;
     const int ti = pass == 0 ? ti_long : ti_short;
     const int i0 = ti * C::BM;
     v4d acc[4][4];
     gemm_mainloop<4, true, true>(Li + (size_t)i0 * ld, ld, K + (size_t)j0 * ld, ld, (i0 + C::BM) / BK, acc, smem);
-    if (STORE) {
-      double* V = partial + (size_t)z * v.NP * MP;
-      for_each_acc<4>(acc, [&](int r, int c, double x) { V[(size_t)(i0 + r) * MP + j0 + c] = x; });
-      continue;
-    }
-    // column sums of squares over the tile's 128 rows
-    __syncthreads();
-    double* red = smem;  // [2 (wr)][128]
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      double s = 0.;
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) s += acc[i][j][r] * acc[i][j][r];
-      s += __shfl_xor(s, 16);
-      s += __shfl_xor(s, 32);
-      if (lane < 16) red[wr * 128 + wc * 64 + j * 16 + lane] = s;
-    }
-    __syncthreads();
-    if (threadIdx.x < 128) partial[((size_t)z * nti + ti) * MP + j0 + threadIdx.x] = red[threadIdx.x] + red[128 + threadIdx.x];
-    __syncthreads();                 // red aliases the operand buffers of the next pass
+    for_each_acc<4>(acc, [&](int r, int c, double x) { V[(size_t)(i0 + r) * MP + j0 + c] = x; });
   }
 }
 
@@ -524,23 +495,15 @@ void launch_update_trailing(const BatchView& v, int c0, int k0, int k1, hipStrea
 }
 
 void launch_trtri_merges(const BatchView& v, hipStream_t s) {
-  static const int wt = [] { const char* e = getenv("MOGP_TRTRI_WT"); return e ? atoi(e) : 2; }();
+  // 64 x 64 tiles at every level (128 x 128 tiles for the upper levels measured slower: trtri 4.9 vs 4.1 ms at 64 x n=2000)
   for (int h = 64; h < v.NP; h *= 2) {
     const int nodes = (v.NP + 2 * h - 1) / (2 * h);
-    if (h == 64 || wt == 2) {
-      const int tpd = h / 64;
-      // algorithmic flops per node: two triangular-times-dense products of size h, h^3 flops each (h^3 / 2 multiply-adds)
-      if (h > 64) prof_begin("trtri_merge", s);
-      hipLaunchKernelGGL((trtri_merge_kernel<2, 0>), dim3(padded_grid(v.nb, tpd * tpd * nodes)), dim3(256), smem_bytes<2>(), s, v, h, tpd, nodes);
-      hipLaunchKernelGGL((trtri_merge_kernel<2, 1>), dim3(padded_grid(v.nb, tpd * tpd * nodes)), dim3(256), smem_bytes<2>(), s, v, h, tpd, nodes);
-      if (h > 64) prof_end("trtri_merge", s, (double)v.nb * nodes * 2.0 * h * h * h, 0.);
-    } else {
-      const int tpd = h / 128;
-      prof_begin("trtri_merge", s);
-      hipLaunchKernelGGL((trtri_merge_kernel<4, 0>), dim3(padded_grid(v.nb, tpd * tpd * nodes)), dim3(256), smem_bytes<4>(), s, v, h, tpd, nodes);
-      hipLaunchKernelGGL((trtri_merge_kernel<4, 1>), dim3(padded_grid(v.nb, tpd * tpd * nodes)), dim3(256), smem_bytes<4>(), s, v, h, tpd, nodes);
-      prof_end("trtri_merge", s, (double)v.nb * nodes * 2.0 * h * h * h, 0.);
-    }
+    const int tpd = h / 64;
+    // algorithmic flops per node: two triangular-times-dense products of size h, h^3 flops each (h^3 / 2 multiply-adds)
+    if (h > 64) prof_begin("trtri_merge", s);
+    hipLaunchKernelGGL((trtri_merge_kernel<2, 0>), dim3(padded_grid(v.nb, tpd * tpd * nodes)), dim3(256), smem_bytes<2>(), s, v, h, tpd, nodes);
+    hipLaunchKernelGGL((trtri_merge_kernel<2, 1>), dim3(padded_grid(v.nb, tpd * tpd * nodes)), dim3(256), smem_bytes<2>(), s, v, h, tpd, nodes);
+    if (h > 64) prof_end("trtri_merge", s, (double)v.nb * nodes * 2.0 * h * h * h, 0.);
   }
 }
 
@@ -556,19 +519,15 @@ void launch_kinv(const BatchView& v, hipStream_t s) {
 void launch_predict_var(const BatchView& v, const double* Ks, int m, int MP, double* partial, double* var, int var_ld, hipStream_t s) {
   const int nti = (v.n + 127) / 128, ntj = MP / 128;
   prof_begin("predict_var", s);
-  // measured (TFLOP/s): 2 x 2 waves 59.2, 2 x 4 waves 61.1, 4 x 2 waves 60.7, 4 x 4 waves 57.3; MOGP_PV_WAVES=4 selects the 2 x 2 kernel
-  static const int waves = [] { const char* e = getenv("MOGP_PV_WAVES"); return e ? atoi(e) : 8; }();
+  // 2 x 4 waves per 128 x 128 tile (measured, TFLOP/s, dense form: 2 x 2 waves 59.2, 2 x 4 waves 61.1, 4 x 2 waves 60.7, 4 x 4 waves 57.3).
   // super-tile = 2^lgc column tiles x 64/2^lgc row-tile pairs.  Measured at nti = 16 (8 pairs), m = 5632, L2-miss bytes per launch /
   // TFLOP/s: 8x8 37 GB / 62.3, 4 pairs x 16 44 GB / 61.9, 2 x 32 53 GB / 60.4, 1 x 64 54 GB / 60.4; without the XCD-aware
   // block decode (workgroups of a super-tile spread over all eight L2s) 47 GB but only 52.1 TFLOP/s
   static const int lgc = [] { const char* e = getenv("MOGP_PV_LGC"); return e ? atoi(e) : 3; }();
-  if (waves == 8) {
+  {
     const int SC = 1 << lgc, SR = 64 >> lgc;
     const int nsup = (((nti + 1) / 2 + SR - 1) / SR) * ((ntj + SC - 1) / SC) * 64;
     hipLaunchKernelGGL((predict_var_w_kernel<2, 4, true>), dim3(padded_grid(v.nb, nsup)), dim3(512), smem_bytes<4>(), s, v, Ks, MP, nti, ntj, partial, lgc);
-  } else {
-    const int nsup = (((nti + 1) / 2 + 3) / 4) * ((ntj + 15) / 16) * 64;
-    hipLaunchKernelGGL(predict_var_kernel<false>, dim3(padded_grid(v.nb, nsup)), dim3(256), smem_bytes<4>(), s, v, Ks, MP, nti, ntj, partial);
   }
   prof_end("predict_var", s, (double)v.nb * (double)m * v.n * v.n, 0.);
   hipLaunchKernelGGL(predict_var_finish_kernel, dim3((m + 255) / 256, v.nb), dim3(256), 0, s, v, partial, m, MP, nti, var, var_ld);
@@ -588,7 +547,7 @@ void launch_predict_fullcov(const BatchView& v, const double* Ks, int m, int MP,
   const int nti = (v.n + 127) / 128, ntj = MP / 128;
   const int nsup = (((nti + 1) / 2 + 3) / 4) * ((ntj + 15) / 16) * 64;
   prof_begin("predict_var", s);
-  hipLaunchKernelGGL(predict_var_kernel<true>, dim3(padded_grid(v.nb, nsup)), dim3(256), smem_bytes<4>(), s, v, Ks, MP, nti, ntj, V);
+  hipLaunchKernelGGL(predict_v_store_kernel, dim3(padded_grid(v.nb, nsup)), dim3(256), smem_bytes<4>(), s, v, Ks, MP, nti, ntj, V);
   prof_end("predict_var", s, (double)v.nb * (double)m * v.n * v.n, 0.);
   const int ntiles = ntj * (ntj + 1) / 2;
   const int kend = ((v.n + 15) / 16) * 16;

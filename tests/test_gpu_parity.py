@@ -565,7 +565,7 @@ print("SWITCH-OK", repr(float(f[0])))
                                  {"MOGP_CHOL": "mchol", "MOGP_MC_WGS": "2", "MOGP_MC_PARK": "0"}, {"MOGP_MCHOL": "0"},
                                  {"MOGP_CHOL": "la"}, {"MOGP_CHOL": "left"}, {"MOGP_CHOL": "left", "MOGP_GROUPS": "1"},
                                  {"MOGP_CHOL": "right"}, {"MOGP_CHOL": "right", "MOGP_OUTER": "128"}, {"MOGP_TAIL": "0"},
-                                 {"MOGP_BACKSOLVE": "0"}, {"MOGP_PV_WAVES": "4"}, {"MOGP_WAITVAL": "0"}, {"MOGP_CHOL": "la", "MOGP_WAITVAL": "1"}, {"MOGP_TRTRI_WT": "4"}, {"MOGP_KS_BUDGET_GB": "0.05"}],
+                                 {"MOGP_BACKSOLVE": "1"}, {"MOGP_WAITVAL": "0"}, {"MOGP_CHOL": "la", "MOGP_WAITVAL": "1"}, {"MOGP_KS_BUDGET_GB": "0.05"}],
                          ids=lambda e: ",".join(k + "=" + v for k, v in e.items()))
 def test_cholesky_schedules_and_switches(env):
     """Every A/B switch libmogp_hip.so still reads goes through the C2 full-size parity check in its own
