@@ -1641,6 +1641,17 @@ void Engine::fit_map(const std::vector<int>& ids_in, int n_tries, const double* 
       const double fit = 0.5 * (double)free_b / (per_emu * ne);
       chunk = (int)std::max(1.0, std::min((double)n_tries, std::floor(fit)));
     }
+    // Replicas beyond what fills the device buy nothing, and their buffers are fresh allocations: tens of GB of them cost
+    // seconds (constructing a 512-emulator engine of n = 2000 and its first evaluation: 1.2 s + 1.0 s against 93 ms for
+    // every later evaluation).  64 emulators x 15 starts of n = 2000 as ONE batch of 960 replicas took 3.7 - 5.8 s; capped
+    // at 256 replicas 2.44 s, 128: 2.52 s, one start at a time (no replicas) 2.48 s.  Cap: twice the batch up to which
+    // the one-launch Cholesky is used (nb * NP / 128 < 2048, factorize_blocked); the starts are dealt to equal passes
+    // (15 starts, at most 4 at a time -> 4 passes of 4, 4, 4, 3).  MOGP_START_REPLICAS overrides the cap.
+    static const long replica_cap = [] { const char* e = getenv("MOGP_START_REPLICAS"); return e ? atol(e) : 0L; }();
+    const long cap = replica_cap > 0 ? replica_cap : std::max<long>(ne, 4095 / std::max(1, NP / TILE));
+    chunk = (int)std::max<long>(1, std::min<long>(chunk, cap / ne));
+    const int passes = (n_tries + chunk - 1) / chunk;
+    chunk = (n_tries + passes - 1) / passes;
   }
   if (chunk <= 1) {
     std::vector<double> f;

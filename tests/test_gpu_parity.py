@@ -656,6 +656,36 @@ def test_backsolve_chain_timeout_is_retried_not_reported_as_failure():
     assert int(out.stdout.split("BS-TIMEOUTS")[1].split()[0]) > 0, "the forced timeouts never happened: the test did not exercise the fallback"
 
 
+_STARTS_SCRIPT = r"""
+import sys, numpy as np
+sys.path.insert(0, %(root)r); sys.path.insert(0, %(tests)r)
+import mogp_emulator_amd as M
+from mogp_emulator_amd import libgpgpu
+from test_gpu_parity import synth
+X, T, _ = synth(4242, 300, 4, 6, 8)
+libgpgpu.set_fit_options(max_iter=40, ftol=1e-9, gtol=1e-6, seed=11)
+mo = M.fit_GP_MAP(M.MultiOutputGP_GPU(X, T, nugget="fit"), n_tries=5)
+assert mo.get_indices_not_fit() == []
+print("STARTS-OK", " ".join(repr(float(em.current_logpost)) for em in mo.emulators))
+"""
+
+
+def test_fit_GP_MAP_is_independent_of_how_the_starts_are_scheduled():
+    """The starts of fit_GP_MAP run on replica engines, as many at a time as the replica cap allows (Engine::fit_map).  The
+    starting points are drawn before the scheduling and a run never sees its batch neighbours, so all starts at once,
+    capped passes (2 + 2 + 1 starts) and one start after the other must end at the same optima."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = _STARTS_SCRIPT % {"root": root, "tests": os.path.join(root, "tests")}
+    res = []
+    for env in ({}, {"MOGP_START_REPLICAS": "12"}, {"MOGP_PARALLEL_STARTS": "0"}):
+        out = subprocess.run([sys.executable, "-c", script], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0 and "STARTS-OK" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
+        res.append(np.array([float(x) for x in out.stdout.split("STARTS-OK")[1].split()]))
+    assert_allclose(res[1], res[0], rtol=1e-9)
+    assert_allclose(res[2], res[0], rtol=1e-9)
+
+
 def test_c5_shaped_single_large_identities():
     # n = 4000, d = 8 (C5 family at a quarter size): no oracle, identities only
     n, d = 4000, 8

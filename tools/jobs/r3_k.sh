@@ -1,9 +1,13 @@
 #!/bin/bash
-export TMPDIR=/tmp
-cd /root/repo
-for l in pd2 pd4 pd6; do
-  for cfg in "B=64 N=2000 D=10 M=256" "B=16 N=5000 D=20 M=256" "B=1 N=16000 D=8 M=256" "B=8 N=2000 D=10 M=256"; do
-    env $cfg REPS=5 MOGP_LIB_PATH=$PWD/build_ab/lib_$l.so python tools/kern_times.py 2>&1 | grep -E "fit |mchol" | tr '\n' ' '; echo " [$l $cfg]"
-  done
-done
-MOGP_BENCH_BACKEND=gloo timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 2 --warmup 1 2>/dev/null | tail -1 | cut -c1-600
+cd /root/repo; mkdir -p gpurun_out/k; export TMPDIR=/tmp
+timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "starts or fit_GP_MAP or map" > gpurun_out/k/tests.txt 2>&1
+tail -n 5 gpurun_out/k/tests.txt
+timeout 900 python bench.py --no-cpu-baseline > gpurun_out/k/bench.json 2> gpurun_out/k/bench.err
+python - <<'PY'
+import json
+d=json.loads(open("gpurun_out/k/bench.json").read().strip().splitlines()[-1])
+print(d["value"], d["fit_grad_per_s"], d["predict_pts_per_s"])
+print(json.dumps(d["fit_GP_MAP_15_starts_64_emulators"]))
+for e in d["shard_sweep"]: print(e["emulators"], e["n"], e.get("fit_GP_MAP_s"), e.get("fit_GP_MAP_emulator_fits_per_s"), e.get("fit_GP_MAP_TFLOPs"))
+print(d.get("tsunami_benchmark"))
+PY
