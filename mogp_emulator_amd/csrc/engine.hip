@@ -1,6 +1,7 @@
 #include "engine.h"
 
 #include <algorithm>
+#include <memory>
 #include <atomic>
 #include <cmath>
 #include <cstdlib>
@@ -1689,39 +1690,45 @@ void Engine::fit_map(const std::vector<int>& ids_in, int n_tries, const double* 
       for (int e = 0; e < ne; ++e) keep_best(e, f[e], x[e]);
     }
   } else {
+    // ONE replica engine for all passes: `chunk` copies of every listed emulator (replica e * chunk + s = emulator e); a
+    // shorter last pass uses the first copies only.  (A fresh engine per pass paid for tens of GB of new allocations each time.)
+    std::unique_ptr<Engine> rep;
     for (int s0 = 0; s0 < n_tries; s0 += chunk) {
       const int c = std::min(chunk, n_tries - s0);
-      if (c == 1) {
+      if (c == 1 && !rep) {
         std::vector<double> f;
         std::vector<std::vector<double>> x;
         run_starts(ids, x0[s0], f, x);
         for (int e = 0; e < ne; ++e) keep_best(e, f[e], x[e]);
         continue;
       }
-      // replica engine: c copies of every listed emulator
-      std::vector<double> targets((size_t)ne * c * n);
-      for (int e = 0; e < ne; ++e)
-        for (int s = 0; s < c; ++s)
-          std::copy(hT.begin() + (size_t)ids[e] * n, hT.begin() + (size_t)(ids[e] + 1) * n, targets.begin() + ((size_t)e * c + s) * n);
-      Engine rep(hX.data(), n, D, targets.data(), ne * c, testing_size, mean, kernel_type, gp[ids[0]].nug_type, gp[ids[0]].nug_size, analytic);
-      std::vector<int> rids(ne * c);
-      std::vector<std::vector<double>> rx0(ne * c);
+      if (!rep) {
+        std::vector<double> targets((size_t)ne * chunk * n);
+        for (int e = 0; e < ne; ++e)
+          for (int s = 0; s < chunk; ++s)
+            std::copy(hT.begin() + (size_t)ids[e] * n, hT.begin() + (size_t)(ids[e] + 1) * n, targets.begin() + ((size_t)e * chunk + s) * n);
+        rep.reset(new Engine(hX.data(), n, D, targets.data(), ne * chunk, testing_size, mean, kernel_type, gp[ids[0]].nug_type, gp[ids[0]].nug_size, analytic));
+        for (int e = 0; e < ne; ++e)
+          for (int s = 0; s < chunk; ++s) {
+            const GPState& src = gp[ids[e]];
+            GPState& dst = rep->gp[e * chunk + s];
+            dst.nug_type = src.nug_type;
+            dst.nug_size = src.nug_size;
+            dst.pri = src.pri;
+            dst.mp_b = src.mp_b; dst.mp_Binv = src.mp_Binv; dst.mp_Binvb = src.mp_Binvb; dst.mp_logdetB = src.mp_logdetB;
+            dst.data.assign(src.data.size(), 0.);
+          }
+      }
+      std::vector<int> rids;
+      std::vector<std::vector<double>> rx0;
       for (int e = 0; e < ne; ++e)
         for (int s = 0; s < c; ++s) {
-          const int r = e * c + s;
-          const GPState& src = gp[ids[e]];
-          GPState& dst = rep.gp[r];
-          dst.nug_type = src.nug_type;
-          dst.nug_size = src.nug_size;
-          dst.pri = src.pri;
-          dst.mp_b = src.mp_b; dst.mp_Binv = src.mp_Binv; dst.mp_Binvb = src.mp_Binvb; dst.mp_logdetB = src.mp_logdetB;
-          dst.data.assign(src.data.size(), 0.);
-          rids[r] = r;
-          rx0[r] = x0[s0 + s][e];
+          rids.push_back(e * chunk + s);
+          rx0.push_back(x0[s0 + s][e]);
         }
       std::vector<double> f;
       std::vector<std::vector<double>> x;
-      rep.run_starts(rids, rx0, f, x);
+      rep->run_starts(rids, rx0, f, x);
       for (int e = 0; e < ne; ++e)
         for (int s = 0; s < c; ++s) keep_best(e, f[e * c + s], x[e * c + s]);
     }
