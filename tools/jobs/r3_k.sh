@@ -1,8 +1,7 @@
 #!/bin/bash
-cd /root/repo; mkdir -p gpurun_out/k; export TMPDIR=/tmp; rm -f gpurun_out/k/rep.txt
-for cfg in "64 2000 10" "32 2000 10" "16 5000 20" "4 5000 20"; do set -- $cfg
-  echo "== B=$1 N=$2 D=$3" >> gpurun_out/k/rep.txt
-  B=$1 N=$2 D=$3 timeout 900 python tools/fitmap_timing.py 2>&1 | tail -n 2 >> gpurun_out/k/rep.txt
+cd /root/repo; mkdir -p gpurun_out/k; export TMPDIR=/tmp; rm -f gpurun_out/k/rev.txt
+for cfg in "64 2000" "8 2000" "16 5000" "2 5000"; do set -- $cfg
+  echo "== B=$1 N=$2" >> gpurun_out/k/rev.txt
+  B=$1 N=$2 WHAT=grad REPS=8 M=256 timeout 600 python tools/ab.py "MOGP_KINV_REV=0 MOGP_TRTRI_REV=0" "MOGP_KINV_REV=1 MOGP_TRTRI_REV=0" "MOGP_KINV_REV=0 MOGP_TRTRI_REV=1" "" >> gpurun_out/k/rev.txt 2>&1
 done
-cat gpurun_out/k/rep.txt
-timeout 600 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "fit_GP_MAP or starts" 2>&1 | tail -n 2
+cat gpurun_out/k/rev.txt
