@@ -1,7 +1,7 @@
 #!/bin/bash
-cd /root/repo; mkdir -p gpurun_out/k; export TMPDIR=/tmp; rm -f gpurun_out/k/rev.txt
-for cfg in "64 2000" "8 2000" "16 5000" "2 5000"; do set -- $cfg
-  echo "== B=$1 N=$2" >> gpurun_out/k/rev.txt
-  B=$1 N=$2 WHAT=grad REPS=8 M=256 timeout 600 python tools/ab.py "MOGP_KINV_REV=0 MOGP_TRTRI_REV=0" "MOGP_KINV_REV=1 MOGP_TRTRI_REV=0" "MOGP_KINV_REV=0 MOGP_TRTRI_REV=1" "" >> gpurun_out/k/rev.txt 2>&1
+cd /root/repo; mkdir -p gpurun_out/k; export TMPDIR=/tmp; rm -f gpurun_out/k/misc.txt
+for cfg in "1 2000 10000" "1 500 10000" "4 2000 10000" "64 2000 100000" "512 500 1000" "2000 100 1000"; do set -- $cfg
+  echo "== B=$1 N=$2 M=$3" >> gpurun_out/k/misc.txt
+  B=$1 N=$2 M=$3 REPS=5 timeout 600 python tools/ab.py "" 2>&1 | tail -n 1 >> gpurun_out/k/misc.txt
 done
-cat gpurun_out/k/rev.txt
+cat gpurun_out/k/misc.txt
