@@ -66,12 +66,19 @@ void prof_end(const char* tag, hipStream_t s, double flops, double bytes) {
 }
 void prof_enable(bool on) { g_prof_on = on; }
 static std::atomic<long long> g_bs_timeouts{0}, g_obj_evals{0}, g_grad_evals{0}, g_mc_aborts{0};
+static std::atomic<long long> g_lb_iters{0}, g_ls_short{0}, g_ls_long{0}, g_lb_runs{0};
 long long prof_counter(const char* name) {
   const std::string s(name ? name : "");
   if (s == "backsolve_timeouts") return g_bs_timeouts.load();
   if (s == "mchol_aborts") return g_mc_aborts.load();          // one-launch factorisations repeated with a multi-launch schedule
   if (s == "objective_evals") return g_obj_evals.load();      // emulator objective evaluations (with or without gradient)
   if (s == "gradient_evals") return g_grad_evals.load();      // of which with gradient
+  // optimiser statistics of fit_GP_MAP: runs started, accepted L-BFGS steps, line-search trial points that were shortened
+  // (sufficient decrease failed) / lengthened (curvature condition failed)
+  if (s == "lbfgs_runs") return g_lb_runs.load();
+  if (s == "lbfgs_iterations") return g_lb_iters.load();
+  if (s == "linesearch_shortened") return g_ls_short.load();
+  if (s == "linesearch_lengthened") return g_ls_long.load();
   return -1;
 }
 bool prof_is_on() { return g_prof_on; }
@@ -1502,6 +1509,7 @@ void Engine::run_starts(const std::vector<int>& ids, const std::vector<std::vect
       s.x = x0[e];
       s.xt = s.x;
     }
+    g_lb_runs += ne;
     for (int round = 0; round < opt.max_iter * 25; ++round) {
       std::vector<int> act, actid;
       std::vector<const double*> th;
@@ -1572,12 +1580,14 @@ void Engine::run_starts(const std::vector<int>& ids, const std::vector<std::vect
         if (!gfinite || !(fv[q] <= s.f + c1 * s.step * s.slope)) {
           s.step_hi = s.step;
           s.step = 0.5 * (s.step_lo + s.step_hi);
+          g_ls_short += 1;
         } else {
           double st_slope = 0.;
           for (int k = 0; k < s.np; ++k) st_slope += gq[k] * s.d[k];
           if (st_slope < c2 * s.slope && s.ls_iter < 10) {
             s.step_lo = s.step;
             s.step = (s.step_hi > 0.) ? 0.5 * (s.step_lo + s.step_hi) : 2.0 * s.step;
+            g_ls_long += 1;
           } else {
             accept = true;
           }
@@ -1610,6 +1620,7 @@ void Engine::run_starts(const std::vector<int>& ids, const std::vector<std::vect
           if (s.S.size() > 10) { s.S.erase(s.S.begin()); s.Y.erase(s.Y.begin()); s.rho.erase(s.rho.begin()); }
         }
         s.iter++;
+        g_lb_iters += 1;
         double gmax = 0.;
         for (int k = 0; k < s.np; ++k) gmax = std::max(gmax, std::fabs(s.g[k]));
         if (std::fabs(fold - s.f) <= opt.ftol * std::max(1.0, std::fabs(s.f)) || gmax <= opt.gtol || s.iter >= opt.max_iter) {

@@ -21,4 +21,5 @@ for rep in range(2):
     dt = time.perf_counter() - t0
     lib.mogp_profile_enable(0)
     ev, gv = counter("objective_evals") - e0, counter("gradient_evals") - g0
+    print("  runs %d, accepted steps %d, trial points shortened %d / lengthened %d" % tuple(counter(k) for k in ("lbfgs_runs", "lbfgs_iterations", "linesearch_shortened", "linesearch_lengthened")))
     print("B=%d n=%d tries=%d max_iter=%d: %.3f s, %d obj / %d grad evals, %.1f TF, %.3f ms per eval" % (B, n, tries, mi, dt, ev, gv, (gv * 2.0 / 3.0 + ev / 3.0) * float(n) ** 3 / dt * 1e-12, dt / max(ev, 1) * 1e3), flush=True)
