@@ -228,7 +228,9 @@ int mogp_mchol_task_table(int n_plus_rhs, int* out, int capacity);
 /* process-wide diagnostic counters: "backsolve_timeouts" = back substitutions that were repeated with the multi-launch
    path because a wait of the one-launch chain timed out (0 in normal operation); "mchol_aborts" = factorisations the
    one-launch Cholesky gave up on and a multi-launch schedule repeated (0 in normal operation); "objective_evals" / "gradient_evals" =
-   emulator objective evaluations so far (all / with gradient), e.g. to turn a fit_GP_MAP wall time into evaluations/s */
+   emulator objective evaluations so far (all / with gradient), e.g. to turn a fit_GP_MAP wall time into evaluations/s;
+   "lbfgs_runs" / "lbfgs_iterations" / "linesearch_shortened" / "linesearch_lengthened" = optimiser runs started by fit_GP_MAP,
+   their accepted steps, and the line-search trial points that failed the sufficient-decrease / the curvature test */
 int mogp_profile_counter(const char* name, long long* out);
 /* device memory helpers so a host program can hand device-resident buffers to the *_dev calls */
 void* mogp_dev_malloc(unsigned long long bytes);
