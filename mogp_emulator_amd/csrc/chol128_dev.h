@@ -186,10 +186,23 @@ __device__ __forceinline__ void c128_column_steps(c128_v4d& Dn, c128_v4d& Xn, c1
 // publication costs nothing on the critical path: it happens after the first barrier of block step b, when the only stores a
 // wave still has in flight are those of block step b-1 (a whole block step old; the inverse block's stores are issued after that
 // barrier for this reason), plus one extra barrier.  The caller publishes 8 after its final drain.
+// PRE with a WAIT: the panel to the left is still being solved -- wait(j) returns once its columns 16j .. 16j+15 (all 128 rows)
+// are visible (false: the launch has been aborted, and chol128_dev returns false), wait.known(j) says whether that is known
+// already without asking.  The update then runs in step with the panel solve that produces X (trsm128_lds_dev<.., PUB>) and is
+// complete ~2 us after the solve instead of 14 us after it.  Pieces that are known to be there are requested two steps ahead as
+// before; a piece that has to be waited for is requested after the arithmetic of the current one.  after_pre() is called by all
+// threads when the update is done (the one-launch Cholesky parks the workgroup it shares the CU with from there on).
+struct C128NoWait {
+  __device__ __forceinline__ bool known(int) const { return true; }
+  __device__ __forceinline__ bool operator()(int) { return true; }
+};
+struct C128Nop {
+  __device__ __forceinline__ void operator()() const {}
+};
 constexpr int C128_LDS_PRE_DOUBLES = C128_LDS_DOUBLES + 128 * C128_LD;
-template <bool SC1_PACK = false, bool PRE = false, bool PROG = false>
-__device__ __forceinline__ void chol128_dev(double* __restrict__ A, int ld, double* __restrict__ pk, int* info_slot, int c0, double* lds,
-                                            unsigned* prog = nullptr) {
+template <bool SC1_PACK = false, bool PRE = false, bool PROG = false, class WAIT = C128NoWait, class AFTER = C128Nop>
+__device__ __forceinline__ bool chol128_dev(double* __restrict__ A, int ld, double* __restrict__ pk, int* info_slot, int c0, double* lds,
+                                            unsigned* prog = nullptr, WAIT wait = WAIT(), AFTER after_pre = AFTER()) {
   Sc1Buf pkb;
   if (SC1_PACK) pkb = sc1_buf(pk, PACK128_STRIDE * sizeof(double));
   const int t = mogp_tid(), lane = t & 63;
@@ -258,7 +271,9 @@ __device__ __forceinline__ void chol128_dev(double* __restrict__ A, int ld, doub
 #pragma unroll
       for (int i = 0; i < 4; ++i) xv[u][i] = *reinterpret_cast<const c128_v2d*>(Xg + (size_t)(xr + 32 * i) * ld + 16 * j + xc);
     };
+    if (!wait(0)) return false;
     xload(0, 0);
+    if (!wait(1)) return false;
     xload(1, 1);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -266,7 +281,8 @@ __device__ __forceinline__ void chol128_dev(double* __restrict__ A, int ld, doub
 #pragma unroll
       for (int i = 0; i < 4; ++i) *reinterpret_cast<c128_v2d*>(S + (xr + 32 * i) * C128_LD + xc) = xv[j & 1][i];
       __syncthreads();                                          // (image j & 1 was last read in step j - 2: a barrier ago)
-      if (j + 2 < 8) xload(j & 1, j + 2);
+      const bool ahead = j + 2 < 8 && wait.known(j + 2);
+      if (ahead) xload(j & 1, j + 2);
       double bo1[4], bo2[4], a0[4];
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
@@ -291,8 +307,13 @@ __device__ __forceinline__ void chol128_dev(double* __restrict__ A, int ld, doub
           for (int s = 0; s < 4; ++s) R2[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(ak[s], bo2[s], R2[k], 0, 0, 0);
         }
       }
+      if (j + 2 < 8 && !ahead) {
+        if (!wait(j + 2)) return false;
+        xload(j & 1, j + 2);
+      }
     }
     __syncthreads();                                            // the first image is the block steps' column image
+    after_pre();
   }
   c128_v4d nident;                           // minus the identity, transposed layout (symmetric)
 #pragma unroll
@@ -439,6 +460,7 @@ __device__ __forceinline__ void chol128_dev(double* __restrict__ A, int ld, doub
   // wave 0 took part in every block step: its last reciprocal square root is NaN iff some pivot was not a positive finite number
   if (w == 0 && lane == 0 && !(rs_last > 0.0) && *info_slot == 0) *info_slot = c0 + 1;
   C128_STAMP(18);
+  return true;
 }
 
 }  // namespace mogp

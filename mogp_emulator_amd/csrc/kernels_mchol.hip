@@ -112,6 +112,24 @@ __device__ __forceinline__ int mc_wait_min3(const McCtx& cx, const unsigned* a, 
   return r;
 }
 
+// chol128_dev<.., PRE>'s view of the panel to its left: piece j (columns 16j .. 16j+15 of both 64-row tiles) is there once both
+// progress words have reached base + j + 1.  One poll returns how far the solves are, so a finished panel costs one wait.
+struct PieceWait {
+  const McCtx& cx;
+  const unsigned *a, *b;
+  unsigned base;
+  int avail;
+  unsigned long long* tr;
+  __device__ __forceinline__ bool known(int j) const { return avail > j; }
+  __device__ __forceinline__ bool operator()(int j) {
+    if (avail > j) return true;
+    const int m = mc_wait_min3(cx, a, b, b, base + (unsigned)j + 1u, tr);
+    if (m < 0) return false;
+    avail = m - (int)base;
+    return true;
+  }
+};
+
 }  // namespace
 
 // table[p] = (type << 30) | (c << 15) | r;  type 0: D(c), 1: G(s, c) with s in the r field, 2: T(r, c)
@@ -162,6 +180,7 @@ __global__ __launch_bounds__(256, 2) void mchol_kernel(BatchView v, unsigned* __
       unsigned* rowdone = ctrl + MC_EMU0 + (size_t)emu * emu_stride;
       unsigned* diagcnt = rowdone + K2;
       unsigned* ddone = diagcnt + K;
+      unsigned* rowprog = ddone + K;          // row tile r: 8 c + b = the first b 16-column pieces of its block column c are visible
       double* pk = packs + ((size_t)emu * K + c) * PACK128_STRIDE;
       const int c0 = 128 * c;
       unsigned long long* tr = TRACE ? trace + ((size_t)z * ntasks + p) * MC_TRW : nullptr;
@@ -176,12 +195,19 @@ __global__ __launch_bounds__(256, 2) void mchol_kernel(BatchView v, unsigned* __
         // the panels 0 .. c-2 arrive through the two G tasks (c >= 2), panel c-1 is applied here, straight from the two
         // panel-solve tasks that produced it
         if (c > 1 && mc_wait_min3(cx, diagcnt + c, diagcnt + c, diagcnt + c, 3u, tr) < 0) return;
-        if (c > 0 && mc_wait_min3(cx, rowdone + 2 * c, rowdone + 2 * c + 1, rowdone + 2 * c + 1, (unsigned)c, tr) < 0) return;
-        mc_stamp<TRACE>(tr, 2);
-        if (use_park && t == 0) __hip_atomic_fetch_add(cuword, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        auto park = [&]() {
+          mc_stamp<TRACE>(tr, 2);
+          if (use_park && t == 0) __hip_atomic_fetch_add(cuword, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        };
         // (ddone[c] counts the block steps whose pack entries are visible: 8 = the whole pack)
-        if (c > 0) chol128_dev<true, true, true>(A + (size_t)c0 * ld + c0, ld, pk, info + emu, c0, lds, ddone + c);
-        else chol128_dev<true, false, true>(A + (size_t)c0 * ld + c0, ld, pk, info + emu, c0, lds, ddone + c);
+        if (c > 0) {
+          // panel c-1 is consumed in 16-column pieces while the two panel-solve tasks still produce it (rowprog)
+          PieceWait pw{cx, rowprog + 2 * c, rowprog + 2 * c + 1, 8u * (unsigned)(c - 1), 0, tr};
+          if (!chol128_dev<true, true, true>(A + (size_t)c0 * ld + c0, ld, pk, info + emu, c0, lds, ddone + c, pw, park)) return;
+        } else {
+          park();
+          chol128_dev<true, false, true>(A + (size_t)c0 * ld + c0, ld, pk, info + emu, c0, lds, ddone + c);
+        }
         if (use_park && t == 0) __hip_atomic_fetch_sub(cuword, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __builtin_amdgcn_s_setprio(0);
         drain_stores();
@@ -306,7 +332,11 @@ __global__ __launch_bounds__(256, 2) void mchol_kernel(BatchView v, unsigned* __
           first = false;
           return ok;
         };
-        if (!trsm128_lds_dev<true, false, true>(v, c0, r0, pk, emu, 0, lds, wait)) return;
+        // (its solved rows are published piece by piece: the next diagonal block applies them as they come)
+        auto pub = [&](int b) {
+          if (t == 0) stu(rowprog + r, 8u * (unsigned)c + (unsigned)b + 1u);
+        };
+        if (!trsm128_lds_dev<true, false, true>(v, c0, r0, pk, emu, 0, lds, wait, pub)) return;
       } else {
         if (mc_wait_min3(cx, ddone + c, ddone + c, ddone + c, 8u, tr) < 0) return;
         mc_stamp<TRACE>(tr, 8);
@@ -316,7 +346,10 @@ __global__ __launch_bounds__(256, 2) void mchol_kernel(BatchView v, unsigned* __
       }
       drain_stores();
       __syncthreads();
-      if (t == 0) stu(rowdone + r, (unsigned)(c + 1));
+      if (t == 0) {
+        stu(rowprog + r, 8u * (unsigned)(c + 1));
+        stu(rowdone + r, (unsigned)(c + 1));
+      }
       mc_stamp<TRACE>(tr, 5);
       __builtin_amdgcn_s_setprio(0);
     }
@@ -356,7 +389,7 @@ std::vector<int> mchol_task_table(int NP) {
   return tb;
 }
 
-int mchol_emu_stride(int NP) { return (NP / 64 + 2 * (NP / 128) + MC_LINE - 1) / MC_LINE * MC_LINE; }
+int mchol_emu_stride(int NP) { return (2 * (NP / 64) + 2 * (NP / 128) + MC_LINE - 1) / MC_LINE * MC_LINE; }   // rowdone | diagcnt | ddone | rowprog
 size_t mchol_ctrl_ints(int NP, int B) { return MC_EMU0 + (size_t)B * mchol_emu_stride(NP); }
 size_t mchol_pack_doubles(int NP, int B) { return (size_t)B * (NP / 128) * PACK128_STRIDE; }
 

@@ -1,5 +1,6 @@
 // 128-wide panel solve below a factored 128 x 128 diagonal block, on the matrix cores.
 #pragma once
+#include <type_traits>
 #include "launch.h"
 #include "chol128_dev.h"
 
@@ -41,12 +42,21 @@ constexpr int TRSM128L_LDS = 2 * TL_PK + 4 * 2 * TL_TS;
 // (chol128_dev<.., PROG>) and wait(b) returns once row block b of the pack (the L^T columns of the block steps < b and inv(L_bb))
 // is visible, or false when the launch has been aborted.  Step b is computed first, then the wait for step b + 1, its request and
 // deposit: the solve runs one block step behind the factorisation and ends ~4 us after it instead of ~9.  Returns false on abort.
+// PUB (with PIPE): pub(b) is called by all threads once the 16 columns 16b .. 16b+15 of the workgroup's 64 solved rows are
+// visible to other workgroups (every wave has drained its write-through stores, then a barrier), b = 0 .. 6; the caller
+// publishes the last block with its own final drain.  The diagonal block of the NEXT block column consumes the rows in
+// these pieces (chol128_dev<.., PRE> with a wait), two block steps behind the factorisation that feeds this solve.  The
+// drain sits in the slack of the solve: it is one block step behind a factorisation that takes ~4 us per step.
 struct TrsmNoWait {
   __device__ __forceinline__ bool operator()(int) const { return true; }
 };
-template <bool SC1_OUT = false, bool DEEP = false, bool PIPE = false, class WAIT = TrsmNoWait>
+struct TrsmNoPub {
+  __device__ __forceinline__ void operator()(int) const {}
+};
+template <bool SC1_OUT = false, bool DEEP = false, bool PIPE = false, class WAIT = TrsmNoWait, class PUB = TrsmNoPub>
 __device__ __forceinline__ bool trsm128_lds_dev(const BatchView& v, int c0, int r0, const double* __restrict__ pk, int emu, int rowblock,
-                                                double* lds, WAIT wait = WAIT()) {
+                                                double* lds, WAIT wait = WAIT(), PUB pub = PUB()) {
+  constexpr bool PUBLISH = PIPE && !std::is_same<PUB, TrsmNoPub>::value;
   Sc1Buf ab;
   if (SC1_OUT) ab = sc1_buf(v.A + (size_t)emu * v.MS, (unsigned)(v.MS * sizeof(double)));
   const int ld = v.LD;
@@ -140,6 +150,11 @@ __device__ __forceinline__ bool trsm128_lds_dev(const BatchView& v, int c0, int 
       const v2d_p o1 = *reinterpret_cast<const v2d_p*>(ts + (sr0 + 8) * 18 + sp);
       st16<SC1_OUT>(ab, slab + (size_t)sr0 * ld + 16 * b + sp, o0);
       st16<SC1_OUT>(ab, slab + (size_t)(sr0 + 8) * ld + 16 * b + sp, o1);
+    }
+    if (PUBLISH && b < 7) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      pub(b);
     }
     if (b < 7) {
       if (PIPE) {
