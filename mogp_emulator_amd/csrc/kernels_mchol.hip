@@ -362,29 +362,38 @@ __global__ __launch_bounds__(256, 2) void mchol_kernel(BatchView v, unsigned* __
 // Topological task order of ONE emulator.  The dependent chain D(c) -> T(2c+2, c), T(2c+3, c) -> D(c+1) is listed ONE BLOCK COLUMN
 // AHEAD of the bulk of its column: the queue hands out numbers only as fast as workgroups come free (with 8 x n=2000 on 256
 // workgroups it runs barely ahead of the chain), and a chain task drawn 35 us before its diagonal block still had 50 - 70 us of
-// long-K GEMM of its own to do (per-task stamps: the block column then took 65 - 100 us instead of 48).  Order:
-//   D(0); T(2, 0), T(3, 0);
-//   for c = 0, 1, ...:  D(c+1);  T(2c+4, c), T(2c+5, c);  T(2c+4, c+1), T(2c+5, c+1);  G(0..2, c+2);  T(r, c) for r >= 2c+6
+// long-K GEMM of its own to do (per-task stamps: the block column then took 65 - 100 us instead of 48).  The pair below the
+// chain rows, T(2c+4, c), T(2c+5, c), is part of the chain too -- the chain tasks of column c+1 cannot apply panel c to their
+// own rows before it is solved -- and sits in front of the bulk of column c-1 (listed behind D(c+1) its 8c k-steps of GEMM
+// started when the chain already needed it: in the late block columns of n = 2000 the panel solves saw their pack 15 - 20 us
+// after the diagonal block had finished).  Order:
+//   D(0); T(2, 0), T(3, 0); T(4, 0), T(5, 0);
+//   for c = 0, 1, ...:  D(c+1);  T(2c+4, c+1), T(2c+5, c+1);  G(0..2, c+2);  T(2c+6, c), T(2c+7, c);  T(2c+6, c+1), T(2c+7, c+1);
+//                       T(r, c) for r >= 2c+8
 // (a workgroup that draws a chain task early does its GEMM and then waits: at most a handful of waiting workgroups per emulator).
 std::vector<int> mchol_task_table(int NP) {
   const int K = NP / 128, K2 = NP / 64;
-  std::vector<int> tb;
   auto word = [](int type, int c, int r) { return (type << 30) | (c << 15) | r; };
+  std::vector<int> tb;
   auto T = [&](int r, int c) {
     if (c < K && r < K2 && r >= 2 * c + 2) tb.push_back(word(2, c, r));
   };
   tb.push_back(word(0, 0, 0));
   T(2, 0);
   T(3, 0);
+  T(4, 0);
+  T(5, 0);
   for (int c = 0; c < K; ++c) {
     if (c + 1 < K) tb.push_back(word(0, c + 1, 0));
-    T(2 * c + 4, c);
-    T(2 * c + 5, c);
     T(2 * c + 4, c + 1);
     T(2 * c + 5, c + 1);
     if (c + 2 < K)
       for (int sub = 0; sub < 3; ++sub) tb.push_back(word(1, c + 2, sub));
-    for (int r = 2 * c + 6; r < K2; ++r) T(r, c);
+    T(2 * c + 6, c);
+    T(2 * c + 7, c);
+    T(2 * c + 6, c + 1);
+    T(2 * c + 7, c + 1);
+    for (int r = 2 * c + 8; r < K2; ++r) T(r, c);
   }
   return tb;
 }
