@@ -1069,7 +1069,9 @@ void Engine::grad_current(const std::vector<int>& ids, double* grad, int grad_ld
 
 void Engine::ensure_predict_scratch(int nb, int MC) {
   grow(dKs, capKs, (size_t)nb * MC * LD);
-  grow(dVarPartial, capVarPartial, (size_t)nb * ((n + 127) / 128) * MC);
+  // partial sums per row tile, then the super-tile counters of predict_var_w_kernel (launch_predict_var; unsigned words, counted generously)
+  const size_t nti = (n + 127) / 128;
+  grow(dVarPartial, capVarPartial, (size_t)nb * nti * MC + (size_t)nb * (nti + 1) * (MC / 128 + 8));
 }
 
 void Engine::predict(const std::vector<int>& ids, const double* Xs, int m, bool xs_on_device, double* means, double* vars, long out_ld,

@@ -41,10 +41,19 @@ struct WCfg {
 // around MFMA groups inside one loop costs more in register copies and exposed LDS latency than the skipped MFMAs save.)
 // Callers must not depend on the row -> accumulator map.
 // ZERO = false: the products are ADDED to what acc holds on entry (a k range continued after a wait).
-template <int BM, int BN, int WR, int WC, bool TRIA = false, bool ZERO = true>
+// DESC (with TRIA): the k range is walked from its END to its start -- the diagonal block first, with the set of active sub-tiles
+// growing instead of shrinking.  The predictive-variance kernel walks the short row tile of a pair this way, so that at any time all
+// workgroups of a super-tile that are in their short pass read the SAME k slice of the cross-covariance panel (see there).
+// SY: called by every thread at the start (after the step's global loads have been requested) and at the end (in front of the
+// barrier) of every k-step: the hook through which the predictive-variance kernel keeps the workgroups of a super-tile in step.
+struct StepNoSync {
+  __device__ __forceinline__ void begin_step(int) {}
+  __device__ __forceinline__ void end_step(int) {}
+};
+template <int BM, int BN, int WR, int WC, bool TRIA = false, bool ZERO = true, bool DESC = false, class SY = StepNoSync>
 __device__ __forceinline__ void mainloop_w(const double* __restrict__ Ag, int lda, const double* __restrict__ Bg, int ldb, int nk,
                                            v4d (&acc)[WCfg<BM, BN, WR, WC>::TI][WCfg<BM, BN, WR, WC>::TJ], double* smem,
-                                           int nk_full = 0, int a_rows = BM) {
+                                           int nk_full = 0, int a_rows = BM, SY* sy = nullptr) {
   using C = WCfg<BM, BN, WR, WC>;
   const int t = mogp_tid(), lane = t & 63;
   const int wave = TRIA ? __builtin_amdgcn_readfirstlane(t >> 6) : (t >> 6);
@@ -57,20 +66,25 @@ __device__ __forceinline__ void mainloop_w(const double* __restrict__ Ag, int ld
       for (int j = 0; j < C::TJ; ++j) acc[i][j] = (v4d){0., 0., 0., 0.};
   }
   if (nk <= 0) return;
+  static_assert(!DESC || TRIA, "the descending walk is only written for the triangular operand");
+  if (DESC) {
+    Ag += (size_t)(nk - 1) * BK;
+    Bg += (size_t)(nk - 1) * BK;
+  }
   v2d ra[C::CHA], rb[C::CHB];
+  // chunk q of a thread = rows (t >> 3) + q NT/8: ONE 32-bit byte offset per operand and thread against wave-uniform bases (scalar
+  // base + vector offset addressing: no 64-bit address arithmetic per load, three address registers fewer than per-thread pointers)
+  const unsigned offA = (unsigned)(((t >> 3) * lda + (t & 7) * 2) * (int)sizeof(double));
+  const unsigned offB = (unsigned)(((t >> 3) * ldb + (t & 7) * 2) * (int)sizeof(double));
   auto loadA = [&]() {
 #pragma unroll
-    for (int q = 0; q < C::CHA; ++q) {
-      const int c = t + C::NT * q;
-      ra[q] = *reinterpret_cast<const v2d*>(Ag + (size_t)(c >> 3) * lda + (c & 7) * 2);
-    }
+    for (int q = 0; q < C::CHA; ++q)
+      ra[q] = *reinterpret_cast<const v2d*>(reinterpret_cast<const char*>(Ag + (size_t)q * (C::NT / 8) * lda) + offA);
   };
   auto loadB = [&]() {
 #pragma unroll
-    for (int q = 0; q < C::CHB; ++q) {
-      const int c = t + C::NT * q;
-      rb[q] = *reinterpret_cast<const v2d*>(Bg + (size_t)(c >> 3) * ldb + (c & 7) * 2);
-    }
+    for (int q = 0; q < C::CHB; ++q)
+      rb[q] = *reinterpret_cast<const v2d*>(reinterpret_cast<const char*>(Bg + (size_t)q * (C::NT / 8) * ldb) + offB);
   };
   auto store = [&](double* sA, double* sB) {
 #pragma unroll
@@ -91,15 +105,17 @@ __device__ __forceinline__ void mainloop_w(const double* __restrict__ Ag, int ld
   // one k-step with the sub-tiles [S, E) of this wave
   auto step = [&](int kt, auto S_, auto E_) {
     constexpr int S = decltype(S_)::value, E = decltype(E_)::value;
-    const double* sA = smem + (kt & 1) * (C::OPA + C::OPB);
+    const int par = DESC ? ((nk - 1 - kt) & 1) : (kt & 1);
+    const double* sA = smem + par * (C::OPA + C::OPB);
     const double* sB = sA + C::OPA;
-    const bool more = (kt + 1 < nk);
+    const bool more = DESC ? (kt > 0) : (kt + 1 < nk);
     if (more) {
-      Ag += BK;
-      Bg += BK;
+      Ag += DESC ? -BK : BK;
+      Bg += DESC ? -BK : BK;
       loadA();
       loadB();
     }
+    if (!std::is_same<SY, StepNoSync>::value) sy->begin_step(t);
     if (S < E) {
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) {
@@ -116,9 +132,10 @@ __device__ __forceinline__ void mainloop_w(const double* __restrict__ Ag, int ld
       }
     }
     if (more) {
-      double* dA = smem + ((kt + 1) & 1) * (C::OPA + C::OPB);
+      double* dA = smem + (par ^ 1) * (C::OPA + C::OPB);
       store(dA, dA + C::OPA);
     }
+    if (!std::is_same<SY, StepNoSync>::value) sy->end_step(t);
     __syncthreads();
   };
   using I0 = std::integral_constant<int, 0>;
@@ -140,6 +157,25 @@ __device__ __forceinline__ void mainloop_w(const double* __restrict__ Ag, int ld
   int n_act = 0;     // sub-tiles of this wave that contain real rows
 #pragma unroll
   for (int i = 0; i < C::TI; ++i) n_act += ((i * WR + wr) * 16 < a_rows) ? 1 : 0;
+  if (DESC) {
+    // sub-tile i is idle while kt >= nk_full + i WR + wr + 1: phase S (sub-tiles [S, E) active) lasts down to the first step of
+    // sub-tile S - 1; phase S = E only moves operands
+    kt = nk - 1;
+    auto phases_d = [&](auto E_) {
+      constexpr int E = decltype(E_)::value;
+      if (E >= 4) for (const int lo = nk_full + 3 * WR + wr + 1; kt >= lo; --kt) step(kt, std::integral_constant<int, 4>(), E_);
+      if (E >= 3) for (const int lo = nk_full + 2 * WR + wr + 1; kt >= lo; --kt) step(kt, std::integral_constant<int, 3>(), E_);
+      if (E >= 2) for (const int lo = nk_full + 1 * WR + wr + 1; kt >= lo; --kt) step(kt, std::integral_constant<int, 2>(), E_);
+      if (E >= 1) for (const int lo = nk_full + 0 * WR + wr + 1; kt >= lo; --kt) step(kt, std::integral_constant<int, 1>(), E_);
+      for (; kt >= 0; --kt) step(kt, I0(), E_);
+    };
+    if (n_act == 4) phases_d(std::integral_constant<int, 4>());
+    else if (n_act == 3) phases_d(std::integral_constant<int, 3>());
+    else if (n_act == 2) phases_d(std::integral_constant<int, 2>());
+    else if (n_act == 1) phases_d(std::integral_constant<int, 1>());
+    else phases_d(I0());
+    return;
+  }
   if (n_act == 4) phases(std::integral_constant<int, 4>());
   else if (n_act == 3) phases(std::integral_constant<int, 3>());
   else if (n_act == 2) phases(std::integral_constant<int, 2>());

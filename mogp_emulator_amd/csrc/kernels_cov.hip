@@ -15,10 +15,13 @@
 // pieces of full 512-byte row segments.  exp(theta_d) is precomputed once per emulator on the
 // host (parameter block P), not per pair as in the reference.
 #include <algorithm>
+#include <type_traits>
 #include "launch.h"
 #include "cov_dev.h"
 
 namespace mogp {
+
+typedef double v2d __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ int slot_emu2(const int* idx, int z) { return idx ? idx[z] : z; }
 
@@ -368,26 +371,35 @@ __global__ __launch_bounds__(256) void grad_kernel(BatchView v, int ntiles, doub
   const double* alpha = v.alpha + ((size_t)emu * v.RA + (v.R > 1 ? 1 : 0)) * ld;
   double* si = sm;
   double* sj = sm + 64 * D;
-  double* wsum = sm + 128 * D;        // [4 waves][D+3]
+  double* red = sm + 128 * D;         // [8 quantities][256 threads]
+  // the thread's 4 x 4 entries of K^-1, requested before anything else as 16-byte pieces: the buffer holds NP x LD entries, so
+  // every address of a tile is valid whatever n is (entries that do not count are masked below)
+  v2d kin2[4][2];
+  {
+    const double* kp = Ki + (size_t)(i0 + 4 * (threadIdx.x >> 4)) * ld + j0 + 4 * (threadIdx.x & 15);
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      kin2[a][0] = *reinterpret_cast<const v2d*>(kp + (size_t)a * ld);
+      kin2[a][1] = *reinterpret_cast<const v2d*>(kp + (size_t)a * ld + 2);
+    }
+  }
   stage_rows(v.X + (size_t)emu * v.XS, n, D, i0, si);
   stage_rows(v.X + (size_t)emu * v.XS, n, D, j0, sj);
   __syncthreads();
   const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   // KT < 2: r2 holds squared distances; product kernel: r2 holds the kernel values themselves
   double r2[4][4];
   if (KT < 2) micro_r2(si, sj, P, D, ty, tx, r2);
   else micro_k<KT>(si, sj, P, D, ty, tx, r2);
   const double sig2 = P[D];
-  double G[4][4];                     // w * W * sigma^2 * dk/dr2   (product kernel: w * W * sigma^2 * k)
   double scov = 0., strace = 0., saa = 0.;
-  // rank-R correction sum_c g_c[i] g_c[j] for the micro tile (R = 1: alpha_i alpha_j)
-  double corr[4][4], gsq[4];
+  // W = K^-1 - (rank-R correction sum_c g_c[i] g_c[j]; R = 1: alpha_i alpha_j) for the micro tile
+  double W[4][4], gsq[4];
 #pragma unroll
   for (int a = 0; a < 4; ++a) {
     gsq[a] = 0.;
 #pragma unroll
-    for (int b = 0; b < 4; ++b) corr[a][b] = 0.;
+    for (int b = 0; b < 4; ++b) W[a][b] = 0.;
   }
   for (int c = 0; c < R; ++c) {
     const double* g = alpha + (size_t)c * ld;
@@ -400,33 +412,56 @@ __global__ __launch_bounds__(256) void grad_kernel(BatchView v, int ntiles, doub
     for (int a = 0; a < 4; ++a) {
       gsq[a] = __builtin_fma(gi[a], gi[a], gsq[a]);
 #pragma unroll
-      for (int b = 0; b < 4; ++b) corr[a][b] = __builtin_fma(gi[a], gj[b], corr[a][b]);
+      for (int b = 0; b < 4; ++b) W[a][b] = __builtin_fma(-gi[a], gj[b], W[a][b]);
     }
   }
+  // Branch-free over the 16 pairs: with `if (weight != 0)` around each pair every K^-1 entry was one 8-byte load inside its own
+  // basic block -- 16 dependent load -> exp -> next-branch round trips per thread, and the constants of the exponential were
+  // materialised 16 times (78 instructions per pair; 0.63 ms for 64 x n=2000, 1.8 x the kernel's vector-ALU floor).
+  double G[4][4];                     // w * W * sigma^2 * dk/dr2   (product kernel: w * W * sigma^2 * k)
+  // INTERIOR: a tile strictly below the diagonal whose rows are all real -- every pair counts twice, nothing to mask (15 of 16
+  // tiles at n = 2000)
+  auto pairs = [&](auto interior_) {
+    constexpr bool INTERIOR = decltype(interior_)::value;
 #pragma unroll
-  for (int a = 0; a < 4; ++a) {
-    const int i = i0 + 4 * ty + a;
+    for (int a = 0; a < 4; ++a) {
+      const int i = i0 + 4 * ty + a;
 #pragma unroll
-    for (int b = 0; b < 4; ++b) {
-      const int j = j0 + 4 * tx + b;
-      double w = 0.0;
-      if (i < n && j < n) w = (j < i) ? 2.0 : ((j == i) ? 1.0 : 0.0);
-      double g = 0.0;
-      if (w != 0.0) {
-        const double kin = Ki[(size_t)i * ld + j];
-        const double W = kin - corr[a][b];
+      for (int b = 0; b < 4; ++b) {
+        const int j = j0 + 4 * tx + b;
+        const double kin = (b < 2) ? kin2[a][0][b] : kin2[a][1][b - 2];
+        // weight of the pair in the symmetric sums: 2 strictly below the diagonal, 1 on it, 0 above it and in the padding
+        const bool live = INTERIOR || ((i < n) && (j <= i));
+        const double w = INTERIOR ? 2.0 : (live ? ((j < i) ? 2.0 : 1.0) : 0.0);
+        const double Wv = live ? kin + W[a][b] : 0.0;
         const double kval = (KT < 2) ? kern_val<KT>(r2[a][b]) : r2[a][b];
-        scov += w * W * sig2 * kval;
-        g = (KT < 2) ? w * W * sig2 * kern_dr2<KT>(r2[a][b]) : w * W * sig2 * kval;
-        if (i == j) {
+        const double wk = w * Wv * sig2;
+        scov = __builtin_fma(wk, kval, scov);
+        G[a][b] = (KT < 2) ? wk * kern_dr2<KT>(r2[a][b]) : wk * kval;
+        if (!INTERIOR && live && i == j) {
           strace += kin;
           saa += gsq[a];
         }
       }
-      G[a][b] = g;
     }
-  }
+  };
+  if (ti > tj && i0 + 64 <= n) pairs(std::true_type());
+  else pairs(std::false_type());
+  // Workgroup sums of the D + 3 quantities, eight at a time through LDS: thread t parks its partial of quantity q in
+  // red[q & 7][t]; then thread (q', part) = (t >> 5, t & 31) adds eight neighbours and the 32 parts meet in five shuffles -- one
+  // dependent chain per eight quantities (a wave reduction per quantity was a chain of six LDS-crossbar round trips each).
   const int NQ = D + 3;
+  const int t = threadIdx.x;
+  auto flush = [&](int q0) {
+    __syncthreads();
+    const int q = t >> 5, part = t & 31;
+    const v2d* rp = reinterpret_cast<const v2d*>(red + q * 256 + part * 8);
+    const v2d u0 = rp[0], u1 = rp[1], u2 = rp[2], u3 = rp[3];
+    double s = ((u0[0] + u0[1]) + (u1[0] + u1[1])) + ((u2[0] + u2[1]) + (u3[0] + u3[1]));
+    for (int off = 16; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    if (part == 0 && q0 + q < NQ) partial[((size_t)z * ntiles + tile) * NQ + q0 + q] = s;
+    __syncthreads();
+  };
   for (int p = 0; p < NQ; ++p) {
     double s;
     if (p < D) {
@@ -449,13 +484,8 @@ __global__ __launch_bounds__(256) void grad_kernel(BatchView v, int ntiles, doub
     } else if (p == D) s = scov;
     else if (p == D + 1) s = strace;
     else s = saa;
-    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
-    if (lane == 0) wsum[wave * NQ + p] = s;
-  }
-  __syncthreads();
-  if (threadIdx.x < NQ) {
-    const int p = threadIdx.x;
-    partial[((size_t)z * ntiles + tile) * NQ + p] = wsum[p] + wsum[NQ + p] + wsum[2 * NQ + p] + wsum[3 * NQ + p];
+    red[(p & 7) * 256 + t] = s;
+    if ((p & 7) == 7 || p == NQ - 1) flush(p & ~7);
   }
 }
 
@@ -702,7 +732,7 @@ void launch_grad_lowrank(const BatchView& v, int emu, const double* W2, int m, d
 
 void launch_grad(const BatchView& v, double* partial, double* out, hipStream_t s) {
   const int ntiles = grad_num_tiles(v.n);
-  const size_t sm = (size_t)(128 * v.D + 4 * (v.D + 3)) * sizeof(double);
+  const size_t sm = (size_t)(128 * v.D + 8 * 256) * sizeof(double);
   prof_begin("grad_reduce", s);
 #define CALL(K) hipLaunchKernelGGL((grad_kernel<K>), dim3(ntiles, v.nb), dim3(256), sm, s, v, ntiles, partial)
   KT_DISPATCH(v.kernel_type, CALL);

@@ -565,7 +565,8 @@ print("SWITCH-OK", repr(float(f[0])))
                                  {"MOGP_CHOL": "mchol", "MOGP_MC_WGS": "2", "MOGP_MC_PARK": "0"}, {"MOGP_MCHOL": "0"},
                                  {"MOGP_CHOL": "la"}, {"MOGP_CHOL": "left"}, {"MOGP_CHOL": "left", "MOGP_GROUPS": "1"},
                                  {"MOGP_CHOL": "right"}, {"MOGP_CHOL": "right", "MOGP_OUTER": "128"}, {"MOGP_TAIL": "0"},
-                                 {"MOGP_BACKSOLVE": "1"}, {"MOGP_WAITVAL": "0"}, {"MOGP_CHOL": "la", "MOGP_WAITVAL": "1"}, {"MOGP_KS_BUDGET_GB": "0.05"}],
+                                 {"MOGP_BACKSOLVE": "1"}, {"MOGP_WAITVAL": "0"}, {"MOGP_CHOL": "la", "MOGP_WAITVAL": "1"}, {"MOGP_KS_BUDGET_GB": "0.05"},
+                                 {"MOGP_PV_SYNC": "1000"}, {"MOGP_PV_SYNC": "1"}, {"MOGP_PV_SYNC": "1000", "MOGP_PV_DESC": "0"}, {"MOGP_PV_DESC": "1"}],
                          ids=lambda e: ",".join(k + "=" + v for k, v in e.items()))
 def test_cholesky_schedules_and_switches(env):
     """Every A/B switch libmogp_hip.so still reads goes through the C2 full-size parity check in its own
@@ -575,6 +576,39 @@ def test_cholesky_schedules_and_switches(env):
     script = _SWITCH_SCRIPT % {"root": root, "tests": os.path.join(root, "tests"), "bitwise": "MOGP_CHOL" in env}
     out = subprocess.run([sys.executable, "-c", script], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "SWITCH-OK" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
+
+
+_PV_SYNC_SCRIPT = r"""
+import sys, numpy as np
+sys.path.insert(0, %(root)r); sys.path.insert(0, %(tests)r)
+import mogp_emulator_amd as M
+from oracle import cpu_ref as R
+from test_gpu_parity import synth, weak
+for n, d, B, m in ((600, 3, 3, 700), (129, 2, 1, 130), (900, 5, 16, 1100), (1300, 4, 5, 260)):
+    X, T, Xs = synth(900 + n, n, d, B, m)
+    theta = np.array([-2. * np.log(0.3 * np.sqrt(d))] * d + [0.])
+    mo = M.MultiOutputGP_GPU(X, T, nugget=1e-6, priors=weak(d, 1e-6))
+    mo.fit(np.tile(theta, (B, 1)))
+    mean, unc, _ = mo.predict(Xs, deriv=False)
+    for k in (0, B - 1):
+        ref = R.GPRef(X, T[k], nugget=1e-6); ref.fit(theta)
+        mu, var, _ = ref.predict(Xs)
+        np.testing.assert_allclose(mean[k], mu, rtol=1e-7, atol=1e-8)
+        np.testing.assert_allclose(unc[k], var, atol=1e-7)
+print("PV-SYNC-OK")
+"""
+
+
+@pytest.mark.parametrize("spins", ["1000", "1"])
+def test_predictive_variance_lockstep_form_on_ragged_shapes(spins):
+    """MOGP_PV_SYNC > 0 runs the predictive variance as persistent workgroups that wait (bounded) for the others of their
+    super-tile: odd numbers of row tiles (a pair with one tile), partial super-tiles, batches that are not a multiple of 8 and
+    a wait budget of one poll (every unsatisfied wait gives up) must all give the oracle's variances."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = _PV_SYNC_SCRIPT % {"root": root, "tests": os.path.join(root, "tests")}
+    out = subprocess.run([sys.executable, "-c", script], env=dict(os.environ, MOGP_PV_SYNC=spins), capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "PV-SYNC-OK" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
 
 
 _BS_TIMEOUT_SCRIPT = r"""
