@@ -203,17 +203,16 @@ __device__ __forceinline__ void mainloop_pf(const double* __restrict__ Ag, int l
   const int fr = lane & 15, fk = lane >> 4;
   if (nk <= 0) return;
   v2d ra[PD][C::CHA], rb[PD][C::CHB];
+  // one 32-bit byte offset per operand and thread against wave-uniform bases (as in mainloop_w)
+  const unsigned offA = (unsigned)(((t >> 3) * lda + (t & 7) * 2) * (int)sizeof(double));
+  const unsigned offB = (unsigned)(((t >> 3) * ldb + (t & 7) * 2) * (int)sizeof(double));
   auto load = [&](int u, int kt) {
 #pragma unroll
-    for (int q = 0; q < C::CHA; ++q) {
-      const int c = t + C::NT * q;
-      ra[u][q] = *reinterpret_cast<const v2d*>(Ag + (size_t)(c >> 3) * lda + (c & 7) * 2 + (size_t)kt * BK);
-    }
+    for (int q = 0; q < C::CHA; ++q)
+      ra[u][q] = *reinterpret_cast<const v2d*>(reinterpret_cast<const char*>(Ag + (size_t)q * (C::NT / 8) * lda + (size_t)kt * BK) + offA);
 #pragma unroll
-    for (int q = 0; q < C::CHB; ++q) {
-      const int c = t + C::NT * q;
-      rb[u][q] = *reinterpret_cast<const v2d*>(Bg + (size_t)(c >> 3) * ldb + (c & 7) * 2 + (size_t)kt * BK);
-    }
+    for (int q = 0; q < C::CHB; ++q)
+      rb[u][q] = *reinterpret_cast<const v2d*>(reinterpret_cast<const char*>(Bg + (size_t)q * (C::NT / 8) * ldb + (size_t)kt * BK) + offB);
   };
   auto store = [&](int u, double* sA, double* sB) {
 #pragma unroll

