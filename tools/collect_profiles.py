@@ -43,8 +43,17 @@ with open(os.path.join(dst, "r03_traffic.json"), "w") as fh:
     json.dump({"predict_var": {"traffic_bytes_per_launch": per_launch,
                                "source": "profiles/r03_%s_pmc_fetch_write_kb.txt: (2 x FETCH_SIZE + WRITE_SIZE) KB x 1024 / launches, separate --pmc passes "
                                          "(bash tools/pmc_fetch.sh), gfx950 FETCH_SIZE x2 correction; WRITE_SIZE of this kernel is scratch traffic of the phase "
-                                         "changes (88 B per thread)" % tag,
+                                         "changes (84 B per thread)" % tag,
                                "config": "64 outputs n=2000 d=10 m=10000, one launch of 10112 padded points per predict (MOGP_KS_BUDGET_GB=12)"}}, fh)
+if os.path.exists(os.path.join(src, "pmc_fetch_write_kb_pv_sync.txt")):
+    t2 = rd("pmc_fetch_write_kb_pv_sync.txt")
+    r2 = [l for l in t2.splitlines() if "predict_var_w_kernel" in l][0].split()
+    f2, w2, c2 = float(r2[-4]), float(r2[-3]), int(r2[-1])
+    wr("pmc_fetch_write_kb_pv_sync.txt",
+       "# commit %s: the same two passes with MOGP_PV_SYNC=1000 (predictive variance as persistent workgroups in soft lock-step, short pass\n"
+       "#   downward): (2 x %.4g + %.4g) KB x 1024 / %d launches = %.1f GB per launch (default above: %.1f GB).  Time of the predict phase,\n"
+       "#   default / lock-step alternating in one job (tools/ab.py):\n%s" % (tag, f2, w2, c2, (2 * f2 + w2) * 1024 / c2 / 1e9, per_launch / 1e9,
+                                                                    "".join("#   " + l + "\n" for l in rd("pv_sync_ab.txt").strip().splitlines())) + t2)
 # SQ
 txt = rd("pmc_sq.txt")
 busy = {}

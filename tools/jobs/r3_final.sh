@@ -30,6 +30,10 @@ done
 # 5. L2-miss traffic (FETCH_SIZE / WRITE_SIZE, separate passes) and SQ counters (own pass), default workload
 cd $R
 bash tools/pmc_fetch.sh $O/pmc_fetch_write_kb.txt
+# 5b. the lock-step form of the predictive variance (MOGP_PV_SYNC): same two passes, and its time against the default in the same job
+bash tools/pmc_fetch.sh $O/pmc_fetch_write_kb_pv_sync.txt MOGP_PV_SYNC=1000
+WHAT=predict REPS=8 timeout 600 python tools/ab.py "" "MOGP_PV_SYNC=1000" "" "MOGP_PV_SYNC=1000" 2>&1 | tail -4 > $O/pv_sync_ab.txt
+cat $O/pv_sync_ab.txt
 cd /tmp
 PMC_M=10000 timeout 300 rocprofv3 --pmc SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE -d $O/sq -- python $R/tools/pmc_step.py > /dev/null 2>&1
 cd $R
