@@ -13,13 +13,14 @@
 // (launch_update_narrow / launch_update_trailing), which also keeps the diagonal that the next block's pivot search
 // reads up to date.  The host drops an emulator from the batch when its factorisation stops early.
 //
-// Rank-deficient case, with the semantics of the unblocked dpstf2 (what LAPACK runs for n up to its block size; beyond
-// that the content of the skipped block depends on the LAPACK build's internal blocking and is not a defined result):
-// the rows that were never chosen hold the interchanged INPUT entries below the diagonal and the diagonal
-// l_{r-1,r-1} / ((r+1)(r+2)...(i+1)); the forward substitution of the right-hand-side rows is continued through that
-// block so that rows n.. of A hold L^-1 [t, H] for the complete factor.
+// Rank-deficient case, with the semantics of LAPACK's blocked dpstrf at its 64-column block size (= this blocking): the rows
+// that were never chosen hold, below the diagonal, what the factorisation left there -- the interchanged input entries
+// minus the rank-64 updates of the COMPLETED block columns (for n <= 64: the input entries, as the unblocked dpstf2) -- and the
+// diagonal l_{r-1,r-1} / ((r+1)(r+2)...(i+1)); the forward substitution of the right-hand-side rows is continued through
+// that block so that rows n.. of A hold L^-1 [t, H] for the complete factor (pstrf_tail_kernel).
 #include <cfloat>
 #include <cmath>
+#include <cstdlib>
 #include "launch.h"
 #include "cov_dev.h"
 
@@ -269,11 +270,11 @@ __device__ __forceinline__ double cov_pair_global(const BatchView& v, const doub
   return P[D] * (k * exp(-ssum));
 }
 
-// Emulators whose factorisation stopped at rank r < n: put the input entries back into the block that was skipped (the
-// trailing updates of the completed block columns have touched it), set its replacement diagonal, and take the
-// right-hand-side rows through it.  A0 != null: the input matrix (n x n, row-major) instead of the kernel function.
+// Emulators whose factorisation stopped at rank r < n: set the replacement diagonal of the block that was skipped and take the
+// right-hand-side rows through it (regen: first put the INPUT entries back into that block -- A0 != null: from the input matrix
+// (n x n, row-major) instead of the kernel function).
 __global__ __launch_bounds__(PSTRF_THREADS) void pstrf_tail_kernel(BatchView v, const int* __restrict__ perm, const int* __restrict__ rank,
-                                                                    const double* __restrict__ X0, const double* __restrict__ A0) {
+                                                                    const double* __restrict__ X0, const double* __restrict__ A0, int regen) {
   const int emu = v.idx ? v.idx[blockIdx.x] : blockIdx.x;
   const int n = v.n, ld = v.LD, r = rank[emu];
   if (r <= 0 || r >= n) return;
@@ -282,10 +283,19 @@ __global__ __launch_bounds__(PSTRF_THREADS) void pstrf_tail_kernel(BatchView v, 
   const double* prm = v.P ? v.P + (size_t)emu * v.PS : nullptr;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int m = n - r;
-  for (long e = tid; e < (long)m * m; e += PSTRF_THREADS) {
-    const int i = r + (int)(e / m), j = r + (int)(e % m);
-    if (j >= i) continue;
-    A[(size_t)i * ld + j] = A0 ? A0[(size_t)P[i] * n + P[j]] : cov_pair_global(v, X0, prm, P[i], P[j]);
+  // The block that was skipped keeps what the factorisation left in it, as with LAPACK's blocked dpstrf (64-column blocks, as here):
+  // the interchanged input entries MINUS the rank-64 updates of the completed block columns -- for n <= 64 the input entries
+  // themselves (the golden vectors at n = 43), beyond that the Schur complement with respect to the completed blocks, which for
+  // rows skipped as repeats of earlier pivots is rounding residue.  (Rounds 1-3 put the input entries back for every n, the
+  // semantics of the unblocked dpstf2: with two skipped rows the forward substitution then multiplies the first one's amplified
+  // rounding residue by an O(1) entry and divides by a replacement diagonal ~1e-8 -- log-posteriors off by up to 0.11 relative
+  // against scipy's dpstrf in the randomised test, n = 400, two repeated points.)  MOGP_PIVOT_TAIL=input restores that.
+  if (regen) {
+    for (long e = tid; e < (long)m * m; e += PSTRF_THREADS) {
+      const int i = r + (int)(e / m), j = r + (int)(e % m);
+      if (j >= i) continue;
+      A[(size_t)i * ld + j] = A0 ? A0[(size_t)P[i] * n + P[j]] : cov_pair_global(v, X0, prm, P[i], P[j]);
+    }
   }
   for (int e = tid; e < v.R * m; e += PSTRF_THREADS) {
     const int c = e / m, j = r + e % m;
@@ -345,7 +355,8 @@ void launch_pstrf_panel(const BatchView& v, int k0, int jb, int* perm, int* rank
 }
 
 void launch_pstrf_tail(const BatchView& v, const int* perm, const int* rank, const double* X0, const double* A0, hipStream_t s) {
-  hipLaunchKernelGGL(pstrf_tail_kernel, dim3(v.nb), dim3(PSTRF_THREADS), 0, s, v, perm, rank, X0, A0);
+  static const int regen = [] { const char* e = getenv("MOGP_PIVOT_TAIL"); return (e && e[0] == 'i') ? 1 : 0; }();
+  hipLaunchKernelGGL(pstrf_tail_kernel, dim3(v.nb), dim3(PSTRF_THREADS), 0, s, v, perm, rank, X0, A0, regen);
 }
 
 void launch_pstrf_end(const BatchView& v, hipStream_t s) {

@@ -207,6 +207,29 @@ def test_multioutput_pivot_with_repeated_points_vs_oracle():
         assert sorted(canon(P[rank:])) == sorted(canon(ref.L.P[rank:]))
 
 
+def test_two_repeated_points_beyond_one_block_keep_lapacks_blocked_tail():
+    """n > 64 with TWO repeated design points: the block the factorisation skipped keeps the entries LAPACK's blocked dpstrf leaves
+    there (input entries minus the updates of the completed 64-column blocks -- rounding residue for repeats of earlier pivots),
+    cholesky.py:315-325.  With the INPUT entries in that block (dpstf2 semantics, rounds 1-3) the forward substitution multiplies
+    the first skipped row's amplified rounding residue by an O(1) entry and divides by a replacement diagonal ~1e-8: the
+    log-posteriors of this configuration (a case of the randomised test) were off by up to 0.11 relative for four of nine outputs."""
+    rng = np.random.default_rng(308)
+    n, D, B = 400, 2, 9
+    X = rng.random((n, D))
+    X[n - 2:] = X[:2]
+    T = np.stack([np.sin(3 * X[:, 0] + k) + 0.3 * X[:, -1] ** 2 + 0.05 * rng.normal(size=n) + k for k in range(B)])
+    T[:, n - 2:] = T[:, :2]
+    thetas = np.tile(np.r_[rng.uniform(3.0, 5.0, size=D), rng.uniform(-0.5, 0.5)], (B, 1)) + 0.05 * rng.normal(size=(B, D + 1)) * (np.arange(D + 1) < D)
+    for kern in ("Matern52",):
+        mo = M.MultiOutputGP_GPU(X, T, kernel=kern, nugget="pivot", priors=weak(D), mean=LibGPGPU.PolyMeanFunc([(0, 1)]), analytic_mean=True)
+        f, _, ok = mo._mogp_gpu.eval(thetas, grad=False)
+        assert ok.all()
+        for k in range(B):
+            ref = R.GPRefMean(X, T[k], [(0, 1)], True, kernel=kern, nugget="pivot")
+            assert_allclose(f[k], ref.fit(thetas[k]), rtol=1e-6)
+            assert ref.L.P.shape == (n,)
+
+
 def test_fit_GP_MAP_with_pivoting_reaches_the_reference_optimum():
     g = load_golden("pivot.npz")
     gp = M.GaussianProcessGPU(g["X"], g["t"], nugget="pivot")            # default priors, as the fixture
@@ -216,8 +239,8 @@ def test_fit_GP_MAP_with_pivoting_reaches_the_reference_optimum():
 
 @pytest.mark.parametrize("kern", ["SquaredExponential", "Matern52", "ProductMat52"])
 def test_gradient_with_repeated_points_vs_oracle(kern):
-    # n <= 64 so that the oracle's LAPACK runs its unblocked dpstf2: beyond its block size the content of the skipped
-    # block -- and with it the trace term of the gradient, which goes through (L L^T)^-1 -- depends on the LAPACK build.
+    # n <= 64: one block, the skipped block holds the input entries on both sides whatever the LAPACK build (beyond that the
+    # device follows reference LAPACK's 64-column blocking, test_two_repeated_points_beyond_one_block_keep_lapacks_blocked_tail).
     rng = np.random.default_rng(33)
     n0, d = 57, 3
     X0 = rng.random((n0, d))

@@ -15,6 +15,7 @@ LARGE = len(sys.argv) > 3 and sys.argv[3] == "large"       # several block colum
 KERNELS = ["SquaredExponential", "Matern52", "ProductMat52", "UniformSqExp", "UniformMat52"]
 bad = 0
 with_repeats = 0
+ONLY = set(int(x) for x in os.environ["FUZZ_ONLY"].split(",")) if os.environ.get("FUZZ_ONLY") else None
 
 
 def close(tag, a, b, rtol, atol, ctx):
@@ -92,9 +93,18 @@ for case in range(cases):
         with_repeats += 1
     ctx = "case %d: n=%d D=%d B=%d m=%d %s nugget=%s mean=%s priors=%s meanprior=%s repeats=%d" % (
         case, n, D, B, m, kern, nug_kind, mean_kind, "proper" if proper else "weak", mean_prior is not None, n_rep)
+    # FUZZ_ONLY=<case>[,<case>...]: evaluate only these cases (every random draw of the others is still made, so the cases are the same)
+    thetas = np.tile(theta, (B, 1)) + 0.05 * rng.normal(size=(B, theta.size)) * (np.arange(theta.size) < nc)
+    if ONLY is not None and case not in ONLY:
+        continue
+    if os.environ.get("FUZZ_NUGGET") and nug_kind != os.environ["FUZZ_NUGGET"]:      # only one nugget type (e.g. pivot), same cases
+        continue
+    if os.environ.get("FUZZ_DUMP"):      # inputs of the selected cases for a host-side look (no device needed)
+        np.savez(os.environ["FUZZ_DUMP"] + "_%d.npz" % case, X=X, T=T, Xs=Xs, theta=theta, thetas=thetas, kern=kern, nug_kind=nug_kind, mean_kind=mean_kind,
+                 beta_theta=np.zeros(0) if beta_theta is None else beta_theta)
+        continue
     try:
         mo = M.MultiOutputGP_GPU(X, T, kernel=kern, nugget=nug_arg, priors=gpri, **kw)
-        thetas = np.tile(theta, (B, 1)) + 0.05 * rng.normal(size=(B, theta.size)) * (np.arange(theta.size) < nc)
         full = thetas if beta_theta is None else np.hstack([beta_theta, thetas])
         f, g, ok = mo._mogp_gpu.eval(full, grad=True)
         mo.fit(full)
