@@ -1,5 +1,6 @@
 #!/bin/bash
 # one-launch Cholesky: task orders MOGP_MC_LA = 1 (default) / 2 / 3
+# (MOGP_MC_LA was an experiment of this job only: the alternative task orders are not in the tree, DESIGN.md section 5 list)
 export TMPDIR=/tmp
 cd /root/repo
 O=gpurun_out/r3la; rm -rf $O; mkdir -p $O
