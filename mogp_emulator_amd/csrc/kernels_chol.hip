@@ -260,9 +260,12 @@ __global__ __launch_bounds__(256) void backsolve_chain_kernel(BatchView v, int* 
     Ld[blk][r * 65 + cc] = x[0];
     Ld[blk][r * 65 + cc + 1] = x[1];
   }
-  // tile of 64 rows [k0, k0+64) x columns [j0, j0+128): lane -> two columns, wave -> 16 of the rows
-  v2d tv[16];
-  auto load_tile = [&](int k0) {
+  // tile of 64 rows [k0, k0+64) x columns [j0, j0+128): lane -> two columns, wave -> 16 of the rows.  TWO register sets: both tiles of
+  // the chunk that is folded next (and, last, the chunk's own off-diagonal tile) are requested a whole step before they are used --
+  // the loads do not depend on alpha, so their latency sits under the wait for the flag instead of on the chain (with one set the
+  // second tile of every chunk and the own tile were requested when they were needed: ~1.5 us each per chain step)
+  v2d tA[16], tB[16];
+  auto load_tile = [&](v2d (&tv)[16], int k0) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int row = k0 + 16 * rg + i;
@@ -270,7 +273,7 @@ __global__ __launch_bounds__(256) void backsolve_chain_kernel(BatchView v, int* 
     }
   };
   // w[cols] -= tile^T x, x = xs[xoff .. xoff+64); ncols = 128 (a block below the chunk) or 64 (inside the chunk)
-  auto apply_tile = [&](int xoff, int ncols) {
+  auto apply_tile = [&](const v2d (&tv)[16], int xoff, int ncols) {
     v2d s = {0., 0.};
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
@@ -311,12 +314,13 @@ __global__ __launch_bounds__(256) void backsolve_chain_kernel(BatchView v, int* 
   };
   __syncthreads();
   // blocks below the chunk, from the bottom up: chunk cc' = nch-1 .. c+1, each with two 64-row blocks
-  int first = 1;
+  if (nch - 1 > c) {
+    load_tile(tA, 128 * (nch - 1) + 64);
+    load_tile(tB, 128 * (nch - 1));
+  } else {
+    load_tile(tA, j0 + 64);                    // rightmost chunk: only its own off-diagonal tile
+  }
   for (int cc = nch - 1; cc > c; --cc) {
-    if (first) {
-      load_tile(128 * cc + 64);
-      first = 0;
-    }
     if (t == 0) {
       int spins = 0;
       bool seen = false;
@@ -326,15 +330,15 @@ __global__ __launch_bounds__(256) void backsolve_chain_kernel(BatchView v, int* 
     __syncthreads();
     if (t < 128) xs[t] = ld_agent(alpha + 128 * cc + t);
     __syncthreads();
-    apply_tile(64, 128);                       // rows 128cc+64 ..
-    load_tile(128 * cc);
-    apply_tile(0, 128);                        // rows 128cc ..
-    if (cc - 1 > c) load_tile(128 * (cc - 1) + 64);
+    apply_tile(tA, 64, 128);                   // rows 128cc+64 ..
+    if (cc - 1 > c) load_tile(tA, 128 * (cc - 1) + 64);
+    else load_tile(tA, j0 + 64);               // own rows j0+64 .. x columns j0 .. (only the first 64 columns are used)
+    apply_tile(tB, 0, 128);                    // rows 128cc ..
+    if (cc - 1 > c) load_tile(tB, 128 * (cc - 1));
   }
   // own rows: upper diagonal block, the 64 x 64 block between the two, lower diagonal block
-  load_tile(j0 + 64);                          // rows j0+64 .. x columns j0 .. (only the first 64 columns are used)
   solve_diag(1);
-  apply_tile(64, 64);
+  apply_tile(tA, 64, 64);
   solve_diag(0);
   // publish: payload drained, then the flag
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
