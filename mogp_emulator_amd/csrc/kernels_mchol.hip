@@ -136,7 +136,7 @@ struct PieceWait {
 template <bool TRACE>
 __global__ __launch_bounds__(256, 2) void mchol_kernel(BatchView v, unsigned* __restrict__ ctrl, const int* __restrict__ table, int ntasks,
                                                        int emu_stride, double* __restrict__ packs, int* __restrict__ info, int nq, int spin_limit,
-                                                       int park_on, unsigned long long* __restrict__ trace) {
+                                                       int park_on, unsigned long long* __restrict__ trace, int tile_solve) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   int* shi = reinterpret_cast<int*>(smem);
   double* lds = smem + MC_LDS_HDR;
@@ -294,6 +294,38 @@ __global__ __launch_bounds__(256, 2) void mchol_kernel(BatchView v, unsigned* __
         }
         mc_stamp<TRACE>(tr, 3);
         draw_next();
+        if (!urgent && tile_solve) {
+          // bulk task: the tile C - acc goes to the panel solve through LDS, not through global memory (trsm128_tile_dev)
+          const int lane = t & 63, wave = t >> 6, wr = wave >> 1, wc = wave & 1;
+          const double* pc0 = A + (size_t)(r0 + wr * 32 + (lane >> 4)) * ld + (c0 + wc * 64 + (lane & 15));
+          double cv[2][4][4];
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+              for (int q = 0; q < 4; ++q) cv[i][j][q] = pc0[(size_t)(i * 16 + 4 * q) * ld + j * 16];
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+              for (int q = 0; q < 4; ++q) acc[i][j][q] = cv[i][j][q] - acc[i][j][q];
+          mc_stamp<TRACE>(tr, 4);
+          if (mc_wait_min3(cx, ddone + c, ddone + c, ddone + c, 8u, tr) < 0) return;
+          mc_stamp<TRACE>(tr, 8);
+          __builtin_amdgcn_s_setprio(1);
+          trsm128_tile_dev<true>(v, c0, r0, pk, emu, lds, acc);
+          drain_stores();
+          __syncthreads();
+          if (t == 0) {
+            stu(rowprog + r, 8u * (unsigned)(c + 1));
+            stu(rowdone + r, (unsigned)(c + 1));
+          }
+          mc_stamp<TRACE>(tr, 5);
+          __builtin_amdgcn_s_setprio(0);
+          continue;
+        }
         // C -= acc.  All 32 loads of a thread first, then the stores: written as load / subtract / store per element the
         // compiler keeps program order between a store and the next load (they might alias), and the write-back of a 64 KB
         // tile was 32 dependent memory round trips (23 - 31 us per task, tools/mchol_trace.py).
@@ -418,10 +450,13 @@ void launch_mchol(const BatchView& v, unsigned* ctrl, size_t ctrl_ints, const in
   const double rho = ((double)v.nb * npd * npd * npd / 3.0 / 45e12) / ((npd / 128.0) * 55e-6);
   const int per_cu = force_wgs ? force_wgs : (rho < 1.0 ? 1 : 2);
   const int park_on = force_park >= 0 ? force_park : ((per_cu > 1 && rho < 2.0) ? 1 : 0);
+  // MOGP_MC_TILE=0: bulk tasks write C - acc back and solve from global memory (rounds 3a-3c) instead of handing the tile over in LDS
+  static const int tile_solve = [] { const char* e = getenv("MOGP_MC_TILE"); return e ? atoi(e) : 1; }();
   (void)hipMemsetAsync(ctrl, 0, ctrl_ints * sizeof(unsigned), s);
   const int nq = (v.nb % 8 == 0) ? 8 : 1;
   // one workgroup per CU is enforced through the LDS request: more than half of the 160 KB
-  const size_t lds_doubles = (per_cu == 1 ? (size_t)11 * 1024 : 0) + MC_LDS_HDR + std::max<size_t>({(size_t)WCfg<64, 128, 2, 2>::SMEM_DOUBLES, (size_t)TRSM128L_LDS, (size_t)C128_LDS_PRE_DOUBLES});
+  const size_t lds_doubles = (per_cu == 1 ? (size_t)11 * 1024 : 0) + MC_LDS_HDR + std::max<size_t>({(size_t)WCfg<64, 128, 2, 2>::SMEM_DOUBLES, (size_t)TRSM128L_LDS, (size_t)C128_LDS_PRE_DOUBLES,
+                                                                                                                   tile_solve ? (size_t)TRSM128T_LDS : (size_t)0});
   const int total = ntasks * v.nb;
   const int grid = std::min(per_cu * n_cu, total);
   // MOGP_MC_TRACE=<file>: per-task time stamps of EVERY launch are appended to the file (analysis only: synchronises)
@@ -432,7 +467,7 @@ void launch_mchol(const BatchView& v, unsigned* ctrl, size_t ctrl_ints, const in
     if (hipMalloc(reinterpret_cast<void**>(&dtr), words * 8) != hipSuccess) return;
     (void)hipMemsetAsync(dtr, 0, words * 8, s);
     hipLaunchKernelGGL(mchol_kernel<true>, dim3(grid), dim3(256), lds_doubles * sizeof(double), s, v, ctrl, table, ntasks, mchol_emu_stride(v.NP), packs,
-                       info, nq, spin_limit, park_on, dtr);
+                       info, nq, spin_limit, park_on, dtr, tile_solve);
     std::vector<unsigned long long> h(words);
     (void)hipStreamSynchronize(s);
     (void)hipMemcpy(h.data(), dtr, words * 8, hipMemcpyDeviceToHost);
@@ -447,7 +482,7 @@ void launch_mchol(const BatchView& v, unsigned* ctrl, size_t ctrl_ints, const in
   }
   prof_begin("mchol", s);
   hipLaunchKernelGGL(mchol_kernel<false>, dim3(grid), dim3(256), lds_doubles * sizeof(double), s, v, ctrl, table, ntasks, mchol_emu_stride(v.NP), packs,
-                     info, nq, spin_limit, park_on, (unsigned long long*)nullptr);
+                     info, nq, spin_limit, park_on, (unsigned long long*)nullptr, tile_solve);
   const double n = v.NP;
   prof_end("mchol", s, (double)v.nb * n * n * n / 3.0, (double)v.nb * 8.0 * n * n);
 }

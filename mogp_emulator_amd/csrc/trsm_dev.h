@@ -169,4 +169,97 @@ __device__ __forceinline__ bool trsm128_lds_dev(const BatchView& v, int c0, int 
   return true;
 }
 
+// The same solve for a 64 x 128 tile that a GEMM task of the one-launch Cholesky still holds in REGISTERS (x = C - acc in the fp64 MFMA
+// accumulator layout of a 2 x 2-wave 64 x 128 tile: wave (wr, wc) rows 32 wr + 16 i + (lane >> 4) + 4 q, columns 64 wc + 16 j + (lane & 15)):
+// the tile goes to the solving waves through LDS instead of through global memory (store, drain, barrier, 16-byte re-reads: ~5 us of
+// write-back plus the slab latency in front of the first block step, per-task stamps of tools/mchol_trace.py).  Wave w solves the slab
+// of rows 16 w .. 16 w + 15 as above; the stage holds HALF a tile -- [4 slabs][4 blocks][16 x 18] -- so the column half 0 .. 63 (held by
+// the waves wc = 0) is deposited first, block steps 0 - 3 run, then the waves wc = 1 deposit the other half into the same slots.  Same
+// arithmetic in the same order as trsm128_lds_dev: bit-identical results.  lds: TRSM128T_LDS doubles.
+constexpr int TRSM128T_LDS = 2 * TL_PK + 16 * TL_TS;
+template <bool SC1_OUT>
+__device__ __forceinline__ void trsm128_tile_dev(const BatchView& v, int c0, int r0, const double* __restrict__ pk, int emu, double* lds,
+                                                 const v4d_t (&x)[2][4]) {
+  Sc1Buf ab;
+  if (SC1_OUT) ab = sc1_buf(v.A + (size_t)emu * v.MS, (unsigned)(v.MS * sizeof(double)));
+  const int ld = v.LD;
+  const int t = mogp_tid(), lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int g = lane >> 4, i = lane & 15;
+  const int wr = wave >> 1, wc = wave & 1;
+  double* slab = v.A + (size_t)emu * v.MS + (size_t)(r0 + wave * 16) * ld + c0;   // 16 rows x 128 columns
+  double* pkb[2] = {lds, lds + TL_PK};
+  double* stage = lds + 2 * TL_PK;                       // [slab w][block b & 3][16 x 18]
+  const double* LT = pk + PACK128_LT;
+  const int sr0 = lane >> 3, sp = (lane & 7) * 2;
+  v2d_p pr[2][4], pinv[2];
+  auto pack_request = [&](int b) {
+    const int u = b & 1;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int ch = t + 256 * q;
+      if (ch < 128 * b) pr[u][q] = *reinterpret_cast<const v2d_p*>(LT + (size_t)(ch >> 3) * 128 + 16 * b + (ch & 7) * 2);
+    }
+    if (t < 128) pinv[u] = *reinterpret_cast<const v2d_p*>(pk + PACK128_INV + b * 256 + 2 * t);
+  };
+  auto pack_deposit = [&](int b, double* img) {
+    const int u = b & 1;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int ch = t + 256 * q;
+      if (ch < 128 * b) *reinterpret_cast<v2d_p*>(img + (ch >> 3) * 16 + (ch & 7) * 2) = pr[u][q];
+    }
+    if (t < 128) *reinterpret_cast<v2d_p*>(img + 112 * 16 + 2 * t) = pinv[u];
+  };
+  // the waves of column half h put their 32 x 64 piece where the slabs' block steps read it
+  auto tile_deposit = [&](int h) {
+    if (wc == h) {
+#pragma unroll
+      for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) stage[((2 * wr + ii) * 4 + j) * TL_TS + (g + 4 * q) * 18 + i] = x[ii][j][q];
+    }
+  };
+  pack_request(0);
+  pack_request(1);
+  tile_deposit(0);
+  pack_deposit(0, pkb[0]);
+  __syncthreads();
+  v4d_t X[8];
+#pragma unroll
+  for (int b = 0; b < 8; ++b) {
+    const double* img = pkb[b & 1];
+    double* ts = stage + (wave * 4 + (b & 3)) * TL_TS;
+    if (b + 2 < 8) pack_request(b + 2);
+    v4d_t T;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) T[r] = ts[i * 18 + g + 4 * r];
+#pragma unroll
+    for (int a = 0; a < b; ++a)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) T = __builtin_amdgcn_mfma_f64_16x16x4f64(-img[(16 * a + g + 4 * r) * 16 + i], X[a][r], T, 0, 0, 0);
+    const double* inv = img + 112 * 16;
+    X[b] = (v4d_t){0., 0., 0., 0.};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) X[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(inv[(g + 4 * r) * 16 + i], T[r], X[b], 0, 0, 0);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) ts[i * 18 + g + 4 * r] = X[b][r];
+    __builtin_amdgcn_wave_barrier();
+    {
+      const v2d_p o0 = *reinterpret_cast<const v2d_p*>(ts + sr0 * 18 + sp);
+      const v2d_p o1 = *reinterpret_cast<const v2d_p*>(ts + (sr0 + 8) * 18 + sp);
+      st16<SC1_OUT>(ab, slab + (size_t)sr0 * ld + 16 * b + sp, o0);
+      st16<SC1_OUT>(ab, slab + (size_t)(sr0 + 8) * ld + 16 * b + sp, o1);
+    }
+    if (b == 3) {
+      __syncthreads();                // every slab has read block 3 and taken X_3 out of its slot
+      tile_deposit(1);
+    }
+    if (b < 7) pack_deposit(b + 1, pkb[(b + 1) & 1]);
+    __syncthreads();
+  }
+}
+
 }  // namespace mogp
