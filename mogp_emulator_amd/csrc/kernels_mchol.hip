@@ -133,8 +133,10 @@ struct PieceWait {
 }  // namespace
 
 // table[p] = (type << 30) | (c << 15) | r;  type 0: D(c), 1: G(s, c) with s in the r field, 2: T(r, c)
-template <bool TRACE>
-__global__ __launch_bounds__(256, 2) void mchol_kernel(BatchView v, unsigned* __restrict__ ctrl, const int* __restrict__ table, int ntasks,
+// SOLO: the launch runs ONE workgroup per CU (chain-bound batches): the kernel may then use the whole register file of a SIMD for its one
+// wave -- the diagonal block's spills go to AGPRs instead of scratch memory
+template <bool TRACE, bool SOLO = false>
+__global__ __launch_bounds__(256, SOLO ? 1 : 2) void mchol_kernel(BatchView v, unsigned* __restrict__ ctrl, const int* __restrict__ table, int ntasks,
                                                        int emu_stride, double* __restrict__ packs, int* __restrict__ info, int nq, int spin_limit,
                                                        int park_on, unsigned long long* __restrict__ trace, int tile_solve) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -481,7 +483,12 @@ void launch_mchol(const BatchView& v, unsigned* ctrl, size_t ctrl_ints, const in
     return;
   }
   prof_begin("mchol", s);
-  hipLaunchKernelGGL(mchol_kernel<false>, dim3(grid), dim3(256), lds_doubles * sizeof(double), s, v, ctrl, table, ntasks, mchol_emu_stride(v.NP), packs,
+  static const int solo_ok = [] { const char* e = getenv("MOGP_MC_SOLO"); return e ? atoi(e) : 1; }();
+  if (per_cu == 1 && solo_ok)
+    hipLaunchKernelGGL((mchol_kernel<false, true>), dim3(grid), dim3(256), lds_doubles * sizeof(double), s, v, ctrl, table, ntasks, mchol_emu_stride(v.NP), packs,
+                     info, nq, spin_limit, park_on, (unsigned long long*)nullptr, tile_solve);
+  else
+    hipLaunchKernelGGL(mchol_kernel<false>, dim3(grid), dim3(256), lds_doubles * sizeof(double), s, v, ctrl, table, ntasks, mchol_emu_stride(v.NP), packs,
                      info, nq, spin_limit, park_on, (unsigned long long*)nullptr, tile_solve);
   const double n = v.NP;
   prof_end("mchol", s, (double)v.nb * n * n * n / 3.0, (double)v.nb * 8.0 * n * n);
