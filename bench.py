@@ -15,8 +15,8 @@ A "step" is one pass of the hot path over the rank's shard:
 `value` = fits/s over the whole job = emulators x steps / time spent in the fit phase (max over ranks);
 fit+grad/s and predict pts/s are reported next to it from the same timed steps.
 
-other_configs (N = 1): BASELINE's C4 (16 x n=5000, Matern-5/2, fitted nugget) and C5 (n=16000) timed on this GPU with their
-tagged kernels; nccl_world1 (N = 1): the two exchange payloads through RCCL in a one-rank process group; shard_sweep also
+other_configs (N = 1): BASELINE's C2 (one n=2000 emulator, predict m=10^4), C4 (16 x n=5000, Matern-5/2, fitted nugget) and
+C5 (n=16000) timed on this GPU with their tagged kernels; nccl_world1 (N = 1): the two exchange payloads through RCCL in a one-rank process group; shard_sweep also
 times fit_GP_MAP with 15 concurrent starts per emulator (the workload users run at shard size).
 roofline: for the kernel with the largest share of device time; `achieved` = algorithmic flops (n^3/3 per
 Cholesky, m n^2 per predictive variance, ...) of all its launches in the timed steps / their total duration measured with
@@ -234,11 +234,19 @@ def time_other_config(M, GPPriors, lib, read_kernels, tag, cid, n, d, B, m, kern
     for v in kern.values():
         v["ms_per_fit"] = v["ms_total"] / 2
     t_fg = med(lambda it: mo.eval(th + 1e-3 * it, grad=True), max(1, reps - 1))
-    t_pr = med(lambda it: mo.predict_variance_batch(Xs, means, vars_), max(1, reps - 1))
+    t_pr_host = med(lambda it: mo.predict_variance_batch(Xs, means, vars_), max(1, reps - 1))
+    # X* and the outputs resident in HBM, as in the headline's predict phase (the host-buffer call adds PCIe both ways)
+    import torch
+    dev = torch.device("cuda", torch.cuda.current_device())
+    d_Xs = torch.from_numpy(Xs).to(dev)
+    d_mean = torch.empty((B, m), dtype=torch.float64, device=dev)
+    d_var = torch.empty((B, m), dtype=torch.float64, device=dev)
+    t_pr = med(lambda it: mo.predict_variance_batch_dev(d_Xs.data_ptr(), m, d_mean.data_ptr(), d_var.data_ptr()), max(1, reps - 1))
     assert ok.all() and np.all(np.isfinite(means)) and np.all(np.isfinite(vars_))
+    assert np.allclose(d_mean.cpu().numpy(), means, rtol=1e-12, atol=1e-12)
     fit_tf, fg_tf, pv_tf = B * float(n) ** 3 / 3. / t_fit * 1e-9, B * float(n) ** 3 / t_fg * 1e-9, B * float(m) * float(n) ** 2 / t_pr * 1e-9
     return {"config": tag, "workload": "%d outputs x n=%d x d=%d, %s, nugget %s, predict m=%d" % (B, n, d, kernel, nugget, m),
-            "fit_ms": t_fit, "fit_grad_ms": t_fg, "predict_ms_host_buffers": t_pr,
+            "fit_ms": t_fit, "fit_grad_ms": t_fg, "predict_ms": t_pr, "predict_ms_host_buffers": t_pr_host,
             "fits_per_s": B / t_fit * 1e3, "fit_grad_per_s": B / t_fg * 1e3, "predict_pts_per_s": B * m / t_pr * 1e3,
             "fit_TFLOPs": fit_tf, "fit_frac_of_fp64_mfma_peak": fit_tf / FP64_MFMA_PEAK_TF,
             "fit_grad_TFLOPs": fg_tf, "fit_grad_frac": fg_tf / FP64_MFMA_PEAK_TF,
@@ -301,6 +309,21 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the C4 / C5 block (other_configs)")
     args = ap.parse_args()
+
+    # `python bench.py --gpus N` outside a launcher: start the N ranks ourselves (one process per GPU, the launch line the
+    # driver documents), rank 0 of the children prints the JSON line.  Under torch.distributed.run WORLD_SIZE is set and
+    # has to agree with --gpus.
+    if "WORLD_SIZE" not in os.environ:
+        if args.gpus > 1:
+            import socket
+            s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+            cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+                   "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+            sys.stdout.flush()
+            os.execv(sys.executable, cmd)
+    elif int(os.environ["WORLD_SIZE"]) != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%s (launch with --nproc-per-node equal to --gpus)" % (
+            args.gpus, os.environ["WORLD_SIZE"]))
 
     # The contract is ONE JSON line on stdout.  RCCL (and other native libraries) print banners to the C-level stdout, which
     # is flushed at exit, i.e. AFTER Python's: keep the real stdout aside for the JSON line and send everything else to stderr.
@@ -413,7 +436,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_shard_sweep and (n, d, B) == (2000, 10, 64):
         # the per-GPU shards of the 2 / 4 / 8-GPU runs of THIS workload, and of C4 (16 x n=5000 over 8 GPUs), on one GPU
         # (+ what users run at shard size: fit_GP_MAP with 15 concurrent starts and a fixed cap of 10 iterations)
-        sweep = [time_shard(M, GPPriors, 2, n, d, b, m, args.kernel, nugget, theta, 7, map_starts=15) for b in (8, 16, 32)]
+        sweep = [time_shard(M, GPPriors, 2, n, d, b, m, args.kernel, nugget, theta, 7, map_starts=15) for b in (1, 8, 16, 32)]
         sweep.append(time_shard(M, GPPriors, 4, 5000, 20, 2, m, "Matern52", "fit",
                                 np.array([-2. * np.log(0.3 * np.sqrt(20))] * 20 + [0., np.log(1e-4)]), 3))
         extras["shard_sweep"] = sweep
@@ -519,6 +542,10 @@ def main():
         # n=5000, d=20; C5 = one output, n=16000, d=8.  ~0.5 s of GPU time each.
         if not args.no_other_configs and (n, d, B) == (2000, 10, 64):
             extras["other_configs"] = [
+                # C2: the single-output fit + 10^4-point predict every GaussianProcessGPU.fit / .predict of the reference
+                # wrapper runs (GaussianProcessGPU.py:431-438, densegp_gpu.hpp:451-474): one matrix, chain-bound
+                time_other_config(M, GPPriors, lib, read_kernels, "C2", 2, 2000, 10, 1, m, "SquaredExponential", 1e-6,
+                                  np.array([-2. * np.log(0.3 * np.sqrt(10))] * 10 + [0.]), 9),
                 time_other_config(M, GPPriors, lib, read_kernels, "C4", 4, 5000, 20, 16, m, "Matern52", "fit",
                                   np.array([-2. * np.log(0.3 * np.sqrt(20))] * 20 + [0., np.log(1e-4)]), 3),
                 time_other_config(M, GPPriors, lib, read_kernels, "C5", 5, 16000, 8, 1, m, "SquaredExponential", 1e-6,
@@ -564,6 +591,8 @@ def main():
             "config": {"workload": "MultiOutputGP %d outputs in total (%d on this GPU) x n=%d x d=%d, %s kernel, fixed nugget 1e-6, predict m=%d (unc=True)" % (
                 total_emus, B, n, d, args.kernel, m), "outputs_total": total_emus, "outputs_per_gpu": per_rank, "n": n, "d": d, "m_predict": m,
                 "parallelism": "emulator-shard x%d, one all_gather of (mean, var) per step" % world},
+            "rccl_ranks": dist.get_world_size() if dist.is_initialized() else 1,
+            "collective_backend": dist.get_backend() if dist.is_initialized() else None,
             # one step = fit phase + fit+gradient phase + predict phase (+ gather); the headline metric has two parts
             # (fits/s and predict pts/s), each taken from its own phase of the SAME timed K steps, max over ranks:
             "value_definition": "value = outputs * steps / (time of the fit phases inside the timed steps); "

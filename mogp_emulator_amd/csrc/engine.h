@@ -140,6 +140,7 @@ class Engine {
   int mc_ntasks = 0;
   unsigned* dMcCtrl = nullptr;
   size_t mc_ctrl_ints = 0;
+  int mc_slots = 0;              // batch slots dMcCtrl / dMcPacks are sized for (grown to the largest one-launch batch seen)
   double* dMcPacks = nullptr;
   bool mc_used = false;          // the last factorisation of this engine went through the one-launch kernel (its abort word is live)
   bool mc_force_legacy = false;  // transient: repeat a factorisation with a multi-launch schedule after an abort

@@ -65,6 +65,12 @@ void prof_end(const char* tag, hipStream_t s, double flops, double bytes) {
   r.launches += 1;
 }
 void prof_enable(bool on) { g_prof_on = on; }
+// sets a flag for the lifetime of a scope (cleared again when the scope is left through an exception)
+struct FlagGuard {
+  bool& b;
+  explicit FlagGuard(bool& f) : b(f) { b = true; }
+  ~FlagGuard() { b = false; }
+};
 static std::atomic<long long> g_bs_timeouts{0}, g_obj_evals{0}, g_grad_evals{0}, g_mc_aborts{0};
 static std::atomic<long long> g_lb_iters{0}, g_ls_short{0}, g_ls_long{0}, g_lb_runs{0};
 long long prof_counter(const char* name) {
@@ -478,22 +484,32 @@ void Engine::factorize_blocked(const std::vector<int>& ids, std::vector<int>& in
       mc_ntasks = (int)tb.size();
       dMcTable = dalloc<int>(tb.size());
       HIPCK(hipMemcpy(dMcTable, tb.data(), tb.size() * sizeof(int), hipMemcpyHostToDevice));
-      mc_ctrl_ints = mchol_ctrl_ints(NP, B);
+    }
+    if (nb > mc_slots) {
+      // control rows and packs are per batch SLOT of a launch, sized for the largest launch seen so far -- not for the engine's B: a
+      // few-emulator retry on an engine whose full batch stays on the multi-launch schedules (B * NP / 128 >= 2048) would otherwise
+      // allocate B packs per block column (4.7 GB at B = 2000, n = 2000)
+      HIPCK(hipStreamSynchronize(stream));
+      if (dMcCtrl) HIPCK(hipFree(dMcCtrl));
+      if (dMcPacks) HIPCK(hipFree(dMcPacks));
+      dMcCtrl = nullptr;
+      dMcPacks = nullptr;
+      mc_slots = nb;
+      mc_ctrl_ints = mchol_ctrl_ints(NP, mc_slots);
       dMcCtrl = dalloc<unsigned>(mc_ctrl_ints);
-      dMcPacks = dalloc<double>(mchol_pack_doubles(NP, B));
+      dMcPacks = dalloc<double>(mchol_pack_doubles(NP, mc_slots));
     }
     HIPCK(hipMemsetAsync(dInfo, 0, B * sizeof(int), stream));
     launch_cov_build(v, stream);
-    launch_mchol(v, dMcCtrl, mc_ctrl_ints, dMcTable, mc_ntasks, dMcPacks, dInfo, n_cu, stream);
+    launch_mchol(v, dMcCtrl, mchol_ctrl_ints(NP, nb), dMcTable, mc_ntasks, dMcPacks, dInfo, n_cu, stream);
     if (!defer_info) {
       read_info(info, false);
       unsigned aborted = 0;
       HIPCK(hipMemcpy(&aborted, dMcCtrl, sizeof(unsigned), hipMemcpyDeviceToHost));
       if (aborted) {
         g_mc_aborts += 1;
-        mc_force_legacy = true;
+        FlagGuard legacy_only(mc_force_legacy);          // reset also when the repeat throws
         factorize_blocked(ids, info, false);
-        mc_force_legacy = false;
       }
     }
     return;
@@ -740,10 +756,11 @@ void Engine::eval(const std::vector<int>& ids, const std::vector<const double*>&
     for (int i : ids) aborted = aborted || info[i] == MCHOL_ABORTED;
     if (aborted) {
       g_mc_aborts += 1;
-      mc_force_legacy = true;
       for (int i : ids) gp[i].factored = gp[i].linv = gp[i].kinv = false;      // (L^-1 of the unusable factor may have been formed)
-      factorize(ids, info, true);
-      mc_force_legacy = false;
+      {
+        FlagGuard legacy_only(mc_force_legacy);        // reset also when the repeat throws
+        factorize(ids, info, true);
+      }
       after_factor(ids, &info);
     }
   }

@@ -579,7 +579,7 @@ void launch_cov_build(const BatchView& v, hipStream_t s) {
   KT_DISPATCH(v.kernel_type, CALL);
 #undef CALL
   // algorithmic bytes: lower triangle written once (4 n^2) + X read once per emulator
-  prof_end("cov_build", s, 0., (double)v.nb * (4.0 * (double)v.NP * (double)v.NP + 8.0 * v.n * v.D));
+  prof_end("cov_build", s, 0., (double)v.nb * (4.0 * (double)v.n * (double)v.n + 8.0 * v.n * v.D));      // algorithmic: the lower triangle of the n x n matrix, not the padded tiles
 }
 
 void launch_kernel_object(int kt, const double* x1, int n1, const double* x2, int n2, int D, const double* P, int mode, double* out, hipStream_t s) {
@@ -616,7 +616,7 @@ void launch_cross_cov_mean(const BatchView& v, const double* Xs, int m, int MP, 
   } while (0)
   KT_DISPATCH(v.kernel_type, CALL);
 #undef CALL
-  prof_end("cross_cov", s, 0., (double)v.nb * (8.0 * MP * (double)v.NP + 8.0 * ((double)m + v.n) * v.D));
+  prof_end("cross_cov", s, 0., (double)v.nb * (8.0 * (double)m * (double)v.n + 8.0 * ((double)m + v.n) * v.D));      // algorithmic m x n entries, not the padded MP x NP
 }
 
 void launch_predict_deriv(const BatchView& v, const double* Xs, int m, double* deriv, long deriv_stride, hipStream_t s) {

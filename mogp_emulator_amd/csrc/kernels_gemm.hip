@@ -558,7 +558,9 @@ void launch_trtri_merges(const BatchView& v, hipStream_t s) {
     if (h > 64) prof_begin("trtri_merge", s);
     hipLaunchKernelGGL((trtri_merge_kernel<2, 0>), dim3(padded_grid(v.nb, tpd * tpd * nodes)), dim3(256), smem_bytes<2>(), s, v, h, tpd, nodes);
     hipLaunchKernelGGL((trtri_merge_kernel<2, 1>), dim3(padded_grid(v.nb, tpd * tpd * nodes)), dim3(256), smem_bytes<2>(), s, v, h, tpd, nodes);
-    if (h > 64) prof_end("trtri_merge", s, (double)v.nb * nodes * 2.0 * h * h * h, 0.);
+    // tagged with the ALGORITHMIC share: the levels sum to NP^3 / 3 on the padded matrix, the inverse of the n x n factor is n^3 / 3
+    const double alg = ((double)v.n / v.NP) * ((double)v.n / v.NP) * ((double)v.n / v.NP);
+    if (h > 64) prof_end("trtri_merge", s, (double)v.nb * nodes * 2.0 * h * h * h * alg, 0.);
   }
 }
 

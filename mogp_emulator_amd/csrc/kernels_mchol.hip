@@ -179,11 +179,11 @@ __global__ __launch_bounds__(256, SOLO ? 1 : 2) void mchol_kernel(BatchView v, u
       const int word = table[p];
       const int type = (word >> 30) & 3, c = (word >> 15) & 0x7fff, r = word & 0x7fff;
       double* A = v.A + (size_t)emu * v.MS;
-      unsigned* rowdone = ctrl + MC_EMU0 + (size_t)emu * emu_stride;
+      unsigned* rowdone = ctrl + MC_EMU0 + (size_t)z * emu_stride;      // control rows and packs belong to the batch SLOT z of this launch
       unsigned* diagcnt = rowdone + K2;
       unsigned* ddone = diagcnt + K;
       unsigned* rowprog = ddone + K;          // row tile r: 8 c + b = the first b 16-column pieces of its block column c are visible
-      double* pk = packs + ((size_t)emu * K + c) * PACK128_STRIDE;
+      double* pk = packs + ((size_t)z * K + c) * PACK128_STRIDE;
       const int c0 = 128 * c;
       unsigned long long* tr = TRACE ? trace + ((size_t)z * ntasks + p) * MC_TRW : nullptr;
       if (TRACE && t == 0) {
@@ -463,10 +463,12 @@ void launch_mchol(const BatchView& v, unsigned* ctrl, size_t ctrl_ints, const in
   const int grid = std::min(per_cu * n_cu, total);
   // MOGP_MC_TRACE=<file>: per-task time stamps of EVERY launch are appended to the file (analysis only: synchronises)
   static const char* trace_file = getenv("MOGP_MC_TRACE");
+  const size_t words = (size_t)total * MC_TRW;
+  unsigned long long* dtr = nullptr;
   if (trace_file) {
-    const size_t words = (size_t)total * MC_TRW;
-    unsigned long long* dtr = nullptr;
-    if (hipMalloc(reinterpret_cast<void**>(&dtr), words * 8) != hipSuccess) return;
+    if (hipMalloc(reinterpret_cast<void**>(&dtr), words * 8) != hipSuccess) dtr = nullptr;   // no room for the stamps: factorise untraced
+  }
+  if (trace_file && dtr) {
     (void)hipMemsetAsync(dtr, 0, words * 8, s);
     hipLaunchKernelGGL(mchol_kernel<true>, dim3(grid), dim3(256), lds_doubles * sizeof(double), s, v, ctrl, table, ntasks, mchol_emu_stride(v.NP), packs,
                        info, nq, spin_limit, park_on, dtr, tile_solve);
@@ -490,7 +492,7 @@ void launch_mchol(const BatchView& v, unsigned* ctrl, size_t ctrl_ints, const in
   else
     hipLaunchKernelGGL(mchol_kernel<false>, dim3(grid), dim3(256), lds_doubles * sizeof(double), s, v, ctrl, table, ntasks, mchol_emu_stride(v.NP), packs,
                      info, nq, spin_limit, park_on, (unsigned long long*)nullptr, tile_solve);
-  const double n = v.NP;
+  const double n = v.n;                 // ALGORITHMIC work (n^3 / 3 per emulator), not the padded NP the tiles cover
   prof_end("mchol", s, (double)v.nb * n * n * n / 3.0, (double)v.nb * 8.0 * n * n);
 }
 

@@ -86,8 +86,9 @@ class ShardedMultiOutputGP(object):
     returning ``(mean, unc, deriv)`` with (n_local, m) arrays, and -- optional -- ``fit_record()`` returning
     ``{"fit_ok", "logpost", "nugget", "theta"}`` lists of length n_local (``MultiOutputGP_GPU.fit_record``).  A model
     without ``fit_record`` is reported through ``get_indices_fit()`` / ``get_indices_not_fit()`` alone (log-posterior,
-    nugget and theta_hat then stay nan / None).  A model that also has ``_mogp_gpu.predict_variance_batch_dev`` (the default
-    one) predicts into device buffers and the gather runs on them directly: one D2H copy of the gathered result per call.
+    nugget and theta_hat then stay nan / None).  The default model with the zero mean function predicts into device buffers
+    (``_mogp_gpu.predict_variance_batch_dev``) and the gather runs on them directly: one D2H copy of the gathered result
+    per call; with a mean function (``mean=`` / ``analytic_mean=``) the host arrays of ``predict`` are gathered.
 
     Failure on one rank: the local work runs inside try / except and the rank ALWAYS joins the collective with an error
     flag in its record (or payload); after the gather every rank raises ``ShardError`` -- a raising rank can therefore
@@ -119,6 +120,12 @@ class ShardedMultiOutputGP(object):
                     torch.cuda.set_device(int(device_index))
             except ImportError:
                 pass
+            # the device-resident predict entry point covers the zero mean function only (capi.hip,
+            # mogp_mogp_predict_variance_batch_dev); decided from the constructor arguments, which are the same on every
+            # rank -- all ranks must gather on the same path, also a rank that holds no emulator
+            self._dev_predict = kwargs.get("mean") is None and not kwargs.get("analytic_mean", False)
+        else:
+            self._dev_predict = False
         self.local = factory(inputs, targets[self.lo:self.hi], **kwargs) if self.hi > self.lo else None
         self.fit_ok = np.zeros(self.n_emulators, dtype=bool)
         self.logpost = np.full(self.n_emulators, np.nan)
@@ -213,9 +220,7 @@ class ShardedMultiOutputGP(object):
     def _device_path(self):
         """The default per-rank model with RCCL: predictions stay in HBM until after the gather."""
         import torch.distributed as dist
-        mo = getattr(self.local, "_mogp_gpu", None)
-        return (dist.is_initialized() and dist.get_backend(self.group) == "nccl"
-                and (self.local is None or hasattr(mo, "predict_variance_batch_dev")))
+        return self._dev_predict and dist.is_initialized() and dist.get_backend(self.group) == "nccl"
 
     def predict(self, testing, device=None, include_nugget=True, **kwargs):
         """(mean, unc) of ALL emulators, (n_emulators, m) each, on every rank.  ``unc`` = predictive variance (clipped at

@@ -116,6 +116,28 @@ def pivot_section():
     np.savez_compressed(os.path.join(HERE, "pivot.npz"), **out)
 
 
+def pivot65_section():
+    """---- 15b. nugget="pivot", n = 65 with TWO repeated design points (rank 63: dpstrf stops inside its first 64-column block) ----
+    The inputs are case 1026 of `tests/tools/fuzz_parity.py 1500 311` (UniformSqExp, D = 2), the one class the randomised
+    device-vs-oracle test reports (missing 5).  The two skipped rows keep what LAPACK left below their diagonal
+    (linalg/cholesky.py:315-325 only replaces the diagonal): rounding residue ~1e-15 .. 1e-21, divided by replacement diagonals of
+    7e-6 and 1e-7 in the forward substitution -- so y[63], y[64] and with them the log-posterior depend on the LAPACK build
+    (this file: the reference under its conda environment's MKL).  Stored next to the raw outputs: the parts that do NOT depend on
+    it (pivot order, the leading 63 x 63 block, log-determinant, the quadratic form of the 63 accepted pivots)."""
+    from mogp_emulator.Kernel import UniformSqExp
+    src = np.load(os.path.join(HERE, "pivot65_inputs.npz"))
+    X, t, Xs, theta = src["X"], src["t"], src["Xs"], src["theta"]
+    gp = GaussianProcess(X, t, kernel=UniformSqExp(), nugget="pivot", priors=GPPriors(n_corr=1, nugget_type="pivot"))
+    gp.fit(theta)
+    L, P = gp.Kinv.L, np.asarray(gp.Kinv.P, dtype=np.int64)
+    y = np.linalg.solve(np.tril(L), t[P])
+    mean, var, _ = gp.predict(Xs)
+    out = dict(X=X, t=t, Xs=Xs, theta=theta, L=L, P=P, logpost=np.array(gp.current_logpost), Kinv_t=gp.Kinv_t, y=y,
+               logdet=np.array(2. * np.sum(np.log(np.diag(L)))), quad_lead=np.array(y[:63] @ y[:63]), quad=np.array(y @ y),
+               mean=mean, var=var, grad=gp.logpost_deriv(theta))
+    np.savez_compressed(os.path.join(HERE, "pivot65.npz"), **out)
+
+
 def validation_section():
     """---- 16. validation.py (consumer of predict(full_cov=True)): standard / pivoted errors, Mahalanobis ----"""
     from mogp_emulator.validation import mahalanobis, standard_errors, pivoted_errors, generate_mahal_dist
@@ -212,6 +234,9 @@ def main():
         return
     if sys.argv[1:] == ["pivot"]:
         pivot_section()
+        return
+    if sys.argv[1:] == ["pivot65"]:
+        pivot65_section()
         return
     if sys.argv[1:] == ["validation"]:
         validation_section()
@@ -523,6 +548,7 @@ def main():
                 out[pre + "cov_full"] = gp.predict(Xs, full_cov=True)[1]
     np.savez_compressed(os.path.join(HERE, "meanpriors.npz"), **out)
     pivot_section()
+    pivot65_section()
     validation_section()
     tsunami_section()
     branin_pivot_section()

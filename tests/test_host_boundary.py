@@ -326,3 +326,13 @@ def test_one_launch_cholesky_task_order_is_topological(n):
             deps.append((0, c, 0))
         for d in deps:
             assert d in pos and pos[d] < p, "task %r (position %d) depends on %r (position %s)" % ((t, c, r), p, d, pos.get(d))
+
+
+def test_bench_refuses_a_world_size_that_disagrees_with_gpus():
+    """bench.py --gpus N starts N ranks itself when no launcher set WORLD_SIZE, and refuses a launcher whose world size differs
+    (--gpus used to be parsed and ignored).  Decided before torch is imported: runs without a GPU."""
+    import subprocess
+    import sys
+    env = dict(os.environ, WORLD_SIZE="3", RANK="0")
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True, timeout=60)
+    assert res.returncode != 0 and "WORLD_SIZE=3" in res.stderr

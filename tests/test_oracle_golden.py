@@ -465,6 +465,31 @@ def test_pivot_emulators_vs_reference(tag, kern, mtag):
     assert bool(g[pre + "nugget_is_none"]) and gp.nugget is None
 
 
+def test_pivot65_two_repeats_inside_the_first_block_vs_reference():
+    """n = 65, two repeated points, rank 63 (make_golden.py pivot65; the reference ran under MKL, this oracle runs the same calls
+    on SciPy's OpenBLAS): everything the reference defines agrees; y[63], y[64] -- LAPACK's rounding residue below the replaced
+    diagonals, divided by 7e-6 and 1e-7 -- do not, and move the log-posterior by 3.1e-4 relative between the two LAPACK builds."""
+    g = load_golden("pivot65.npz")
+    X, t, theta = g["X"], g["t"], g["theta"]
+    gp = R.GPRef(X, t, kernel="UniformSqExp", nugget="pivot", priors=R.GPPriorsRef(1, "pivot"))
+    lp = gp.fit(theta)
+    L, P = gp.L.L, np.asarray(gp.L.P)
+    canon = lambda p: [{63: 0, 64: 1}.get(int(i), int(i)) for i in p]
+    assert canon(P[:63]) == canon(g["P"][:63]) and sorted(canon(P[63:])) == sorted(canon(g["P"][63:]))
+    assert_allclose(L[:63, :63], g["L"][:63, :63], rtol=1e-9, atol=1e-12)
+    assert_allclose(np.diag(L)[63:], np.diag(g["L"])[63:], rtol=1e-9)
+    assert_allclose(2. * np.sum(np.log(np.diag(L))), float(g["logdet"]), rtol=1e-10)
+    y = np.linalg.solve(np.tril(L), t[P])
+    assert_allclose(y[:63] @ y[:63], float(g["quad_lead"]), rtol=1e-8)
+    spread = abs(float(g["quad"]) - float(g["quad_lead"]))             # 5.52: the residue-driven share in the fixture
+    assert y[63:] @ y[63:] <= 10. * spread
+    assert_allclose(lp, float(g["logpost"]), rtol=1e-3)                # LAPACK-dependent beyond that (3.1e-4 here)
+    mean, var, _ = gp.predict(g["Xs"])
+    # (alpha carries y[63], y[64] back through L^-T, so the means move with the residue too: 3.3e-4 between the two LAPACK builds)
+    assert_allclose(mean, g["mean"], rtol=5e-3, atol=5e-3)
+    assert_allclose(var, g["var"], rtol=1e-4, atol=1e-6)
+
+
 # ---- validation.py (SURVEY 8f row 3): standard / pivoted errors and the Mahalanobis distance -------------------------
 @pytest.mark.parametrize("kern", KERNELS)
 @pytest.mark.parametrize("mode", ["fixed", "fit"])
