@@ -225,6 +225,10 @@ int mogp_profile_get(const char* kernel_tag, double* total_ms, long long* launch
    `capacity` entries, returns the number of tasks.  Host-only (no device needed): the CPU suite checks that the order is
    topological, which is what the kernel's forward-progress argument rests on. */
 int mogp_mchol_task_table(int n_plus_rhs, int* out, int capacity);
+/* The same for throughput-bound launches (large batches / matrices): the bulk of block column c, row tiles r >= 2c + 8, is listed as
+   type 3 entries TT(r, c), r even = the row tiles r and r + 1 as ONE task with a 128 x 128 GEMM tile (two thirds of the operand bytes
+   per flop); all other entries as above. */
+int mogp_mchol_task_table_paired(int n_plus_rhs, int* out, int capacity);
 /* process-wide diagnostic counters: "backsolve_timeouts" = back substitutions that were repeated with the multi-launch
    path because a wait of the one-launch chain timed out (0 in normal operation); "mchol_aborts" = factorisations the
    one-launch Cholesky gave up on and a multi-launch schedule repeated (0 in normal operation); "objective_evals" / "gradient_evals" =

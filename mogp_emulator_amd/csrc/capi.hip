@@ -585,6 +585,14 @@ int mogp_mchol_task_table(int n_plus_rhs, int* out, int capacity) {
     for (int i = 0; i < (int)tb.size() && i < capacity; ++i) out[i] = tb[i];
   return (int)tb.size();
 }
+int mogp_mchol_task_table_paired(int n_plus_rhs, int* out, int capacity) {
+  // the table of throughput-bound launches: type 3 TT(r, c) = the row tiles r, r + 1 of block column c as one 128 x 128 task
+  const int NP = (n_plus_rhs + TILE - 1) / TILE * TILE;
+  const std::vector<int> tb = mchol_task_table(NP, true);
+  if (out)
+    for (int i = 0; i < (int)tb.size() && i < capacity; ++i) out[i] = tb[i];
+  return (int)tb.size();
+}
 int mogp_profile_counter(const char* name, long long* out) {
   const long long v = prof_counter(name);
   if (v < 0 || !out) {

@@ -136,8 +136,8 @@ class Engine {
   bool can_waitval = false;      // hipDeviceAttributeCanUseStreamWaitValue of the engine's device
   int device = 0;                // HIP device the engine was created on
   // one-launch Cholesky (kernels_mchol.hip): task table, control words, per-column packs
-  int* dMcTable = nullptr;
-  int mc_ntasks = 0;
+  int* dMcTable[2] = {nullptr, nullptr};     // [0] 64 x 128 bulk tasks, [1] paired 128 x 128 bulk tasks (mchol_use_pairs)
+  int mc_ntasks[2] = {0, 0};
   unsigned* dMcCtrl = nullptr;
   size_t mc_ctrl_ints = 0;
   int mc_slots = 0;              // batch slots dMcCtrl / dMcPacks are sized for (grown to the largest one-launch batch seen)

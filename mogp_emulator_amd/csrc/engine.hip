@@ -225,7 +225,7 @@ Engine::~Engine() {
     if (p) hipFree(p);
   if (hRes) hipHostFree(hRes);
   if (dBsFlags) hipFree(dBsFlags);
-  for (void* p : {(void*)dMcTable, (void*)dMcCtrl, (void*)dMcPacks})
+  for (void* p : {(void*)dMcTable[0], (void*)dMcTable[1], (void*)dMcCtrl, (void*)dMcPacks})
     if (p) hipFree(p);
   if (sigU1) hipFree(sigU1);
   for (auto& kv : w2) hipFree(kv.second);
@@ -479,11 +479,12 @@ void Engine::factorize_blocked(const std::vector<int>& ids, std::vector<int>& in
   mc_used = schedule == 4;
   if (schedule == 4) {
     // ONE LAUNCH: persistent workgroups take the tasks of all block columns from a dependency-ordered queue (kernels_mchol.hip)
-    if (!dMcTable) {
-      const std::vector<int> tb = mchol_task_table(NP);
-      mc_ntasks = (int)tb.size();
-      dMcTable = dalloc<int>(tb.size());
-      HIPCK(hipMemcpy(dMcTable, tb.data(), tb.size() * sizeof(int), hipMemcpyHostToDevice));
+    const int pv = mchol_use_pairs(nb, NP) ? 1 : 0;          // which task table: 64 x 128 bulk tasks, or 128 x 128 (throughput-bound launches)
+    if (!dMcTable[pv]) {
+      const std::vector<int> tb = mchol_task_table(NP, pv != 0);
+      mc_ntasks[pv] = (int)tb.size();
+      dMcTable[pv] = dalloc<int>(tb.size());
+      HIPCK(hipMemcpy(dMcTable[pv], tb.data(), tb.size() * sizeof(int), hipMemcpyHostToDevice));
     }
     if (nb > mc_slots) {
       // control rows and packs are per batch SLOT of a launch, sized for the largest launch seen so far -- not for the engine's B: a
@@ -501,7 +502,7 @@ void Engine::factorize_blocked(const std::vector<int>& ids, std::vector<int>& in
     }
     HIPCK(hipMemsetAsync(dInfo, 0, B * sizeof(int), stream));
     launch_cov_build(v, stream);
-    launch_mchol(v, dMcCtrl, mchol_ctrl_ints(NP, nb), dMcTable, mc_ntasks, dMcPacks, dInfo, n_cu, stream);
+    launch_mchol(v, dMcCtrl, mchol_ctrl_ints(NP, nb), dMcTable[pv], mc_ntasks[pv], pv != 0, dMcPacks, dInfo, n_cu, stream);
     if (!defer_info) {
       read_info(info, false);
       unsigned aborted = 0;

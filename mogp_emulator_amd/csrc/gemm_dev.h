@@ -196,7 +196,9 @@ __device__ __forceinline__ void mainloop_w(const double* __restrict__ Ag, int ld
 template <int BM, int BN, int WR, int WC, int PD>
 __device__ __forceinline__ void mainloop_pf(const double* __restrict__ Ag, int lda, const double* __restrict__ Bg, int ldb, int nk,
                                             v4d (&acc)[WCfg<BM, BN, WR, WC>::TI][WCfg<BM, BN, WR, WC>::TJ], double* smem,
-                                            const unsigned* park = nullptr, int* park_lds = nullptr, int park_spins = 0) {
+                                            const unsigned* park = nullptr, int* park_lds = nullptr, int park_spins = 0, int kmask = -1) {
+  // kmask (measurement only, MOGP_MC_NOTRAFFIC): k-step kt reads the operand columns of step kt & kmask -- with kmask = 3 every task
+  // re-reads its first 64 columns from the caches: the same instruction stream without the memory traffic (results are garbage)
   using C = WCfg<BM, BN, WR, WC>;
   const int t = mogp_tid(), lane = t & 63, wave = t >> 6;
   const int wr = wave / WC, wc = wave % WC;
@@ -206,7 +208,8 @@ __device__ __forceinline__ void mainloop_pf(const double* __restrict__ Ag, int l
   // one 32-bit byte offset per operand and thread against wave-uniform bases (as in mainloop_w)
   const unsigned offA = (unsigned)(((t >> 3) * lda + (t & 7) * 2) * (int)sizeof(double));
   const unsigned offB = (unsigned)(((t >> 3) * ldb + (t & 7) * 2) * (int)sizeof(double));
-  auto load = [&](int u, int kt) {
+  auto load = [&](int u, int kt_) {
+    const int kt = kt_ & kmask;
 #pragma unroll
     for (int q = 0; q < C::CHA; ++q)
       ra[u][q] = *reinterpret_cast<const v2d*>(reinterpret_cast<const char*>(Ag + (size_t)q * (C::NT / 8) * lda + (size_t)kt * BK) + offA);

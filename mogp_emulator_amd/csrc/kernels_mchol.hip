@@ -68,7 +68,7 @@ struct McCtx {
 // [0] pulled, [1] last operand wait begins, [2] ends (D: its inputs are complete), [3] after the GEMM main loop, [4] after the
 // tile has been written back, [5] published, [6] hardware id, [7] task word | queue position << 32, [8] pack seen (T), [9] sum
 // of all waits of the task; 100 MHz clock (s_memrealtime)
-constexpr int MC_TRW = 10;
+constexpr int MC_TRW = 30;      // [10..12] inside the panel solve of a bulk task (trsm128_tile_dev), [13] its stores drained, [14 + 2b] / [15 + 2b] block step b: wave 0's chain done / all waves through
 template <bool TRACE>
 __device__ __forceinline__ void mc_stamp(unsigned long long* tr, int i) {
   if (TRACE && tr && threadIdx.x == 0) tr[i] = __builtin_amdgcn_s_memrealtime();
@@ -76,16 +76,17 @@ __device__ __forceinline__ void mc_stamp(unsigned long long* tr, int i) {
 
 // All 256 threads call.  Lane 0 polls until min(*a, *b, *c) >= want (b, c may equal a); returns that minimum, or -1 after a
 // timeout / when another workgroup has aborted.
-__device__ __forceinline__ int mc_wait_min3(const McCtx& cx, const unsigned* a, const unsigned* b, const unsigned* c, unsigned want,
+__device__ __forceinline__ int mc_wait_min4(const McCtx& cx, const unsigned* a, const unsigned* b, const unsigned* c, const unsigned* d, unsigned want,
                                             unsigned long long* waited = nullptr) {
   if (threadIdx.x == 0) {
     const unsigned long long w0 = waited ? __builtin_amdgcn_s_memrealtime() : 0ull;
     int res, spins = 0;
     for (;;) {
       unsigned m = ldu(a);
-      const unsigned mb = ldu(b), mc = ldu(c);
+      const unsigned mb = ldu(b), mc = ldu(c), md = ldu(d);
       m = m < mb ? m : mb;
       m = m < mc ? m : mc;
+      m = m < md ? m : md;
       if (m >= want) {
         res = (int)m;
         break;
@@ -110,6 +111,11 @@ __device__ __forceinline__ int mc_wait_min3(const McCtx& cx, const unsigned* a, 
   const int r = cx.shi[1];
   __syncthreads();
   return r;
+}
+
+__device__ __forceinline__ int mc_wait_min3(const McCtx& cx, const unsigned* a, const unsigned* b, const unsigned* c, unsigned want,
+                                            unsigned long long* waited = nullptr) {
+  return mc_wait_min4(cx, a, b, c, c, want, waited);
 }
 
 // chol128_dev<.., PRE>'s view of the panel to its left: piece j (columns 16j .. 16j+15 of both 64-row tiles) is there once both
@@ -270,6 +276,76 @@ __global__ __launch_bounds__(256, SOLO ? 1 : 2) void mchol_kernel(BatchView v, u
         __builtin_amdgcn_s_setprio(0);
         continue;
       }
+      if (type == 3) {
+        // ---- TT(R, c): BULK task over the two row tiles r, r + 1 (r even, >= 2c + 8) of block column c at once -- a 128 x 128 GEMM tile.
+        // Why: a 64 x 128 tile reads (64 + 128) operand rows per 16-deep k-step for 32 MFMAs per wave; without L2 hits (free-running
+        // tasks rarely share a k slice while it is cached) that is 12 bytes per clock and CU at full matrix-core rate -- more than the
+        // fabric delivers, the 64-emulator launch was bound by it (MFMA-busy 0.685, 18 GB of L2 misses per launch at 4.8 TB/s).  128 x 128
+        // needs 8.  Same k order per element as two T tasks: bit-identical results.  Only listed for throughput-bound launches.
+        const int r0 = 64 * r;
+        const int kend = c;
+        v4d acc[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[i][j] = (v4d){0., 0., 0., 0.};
+        int kb = 0;
+        while (kb < kend) {
+          mc_stamp<TRACE>(tr, 1);
+          int m = mc_wait_min4(cx, rowdone + r, rowdone + r + 1, rowdone + 2 * c, rowdone + 2 * c + 1, (unsigned)(kb + 1), tr);
+          if (m < 0) return;
+          mc_stamp<TRACE>(tr, 2);
+          m = m < kend ? m : kend;
+          mainloop_pf<128, 128, 2, 2, 2>(A + (size_t)r0 * ld + 128 * kb, ld, A + (size_t)c0 * ld + 128 * kb, ld, 8 * (m - kb), acc, lds,
+                                         use_park ? cuword : nullptr, shi + 2, 1 << 14, (tile_solve & 2) ? 3 : -1);
+          kb = m;
+        }
+        mc_stamp<TRACE>(tr, 3);
+        draw_next();
+        // C -= acc, one 16-row sub-tile of the wave's 64 x 64 piece at a time (all loads of a sub-tile, then its stores; the next
+        // sub-tile's loads are requested before the stores of the current one)
+        {
+          const int lane = t & 63, wave = t >> 6, wr = wave >> 1, wc = wave & 1;
+          double* pc0 = A + (size_t)(r0 + wr * 64 + (lane >> 4)) * ld + (c0 + wc * 64 + (lane & 15));
+          double cv[2][4][4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) cv[0][j][q] = pc0[(size_t)(4 * q) * ld + j * 16];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            if (i + 1 < 4) {
+#pragma unroll
+              for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) cv[(i + 1) & 1][j][q] = pc0[(size_t)((i + 1) * 16 + 4 * q) * ld + j * 16];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+              for (int q = 0; q < 4; ++q) pc0[(size_t)(i * 16 + 4 * q) * ld + j * 16] = cv[i & 1][j][q] - acc[i][j][q];      // (read back by this workgroup's panel solves)
+          }
+        }
+        drain_stores();
+        mc_stamp<TRACE>(tr, 4);
+        __syncthreads();
+        if (mc_wait_min3(cx, ddone + c, ddone + c, ddone + c, 8u, tr) < 0) return;
+        mc_stamp<TRACE>(tr, 8);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll 1
+        for (int h = 0; h < 2; ++h) {
+          trsm128_lds_dev<true, true>(v, c0, r0, pk, emu, h, lds);
+          drain_stores();
+          __syncthreads();
+          if (t == 0) {
+            stu(rowprog + r + h, 8u * (unsigned)(c + 1));
+            stu(rowdone + r + h, (unsigned)(c + 1));
+          }
+        }
+        mc_stamp<TRACE>(tr, 5);
+        __builtin_amdgcn_s_setprio(0);
+        continue;
+      }
       // ---- T: 64 rows x 128 columns receive the panels 0 .. c-1 -----------------------------------------------------
       const int r0 = 64 * r;
       // tasks of the dependent chain (diagonal tiles, the two row blocks of the next diagonal block) issue ahead of the
@@ -291,12 +367,48 @@ __global__ __launch_bounds__(256, SOLO ? 1 : 2) void mchol_kernel(BatchView v, u
           mc_stamp<TRACE>(tr, 2);
           m = m < kend ? m : kend;
           mainloop_pf<64, 128, 2, 2, MC_PD>(A + (size_t)r0 * ld + 128 * kb, ld, A + (size_t)c0 * ld + 128 * kb, ld, 8 * (m - kb), acc, lds,
-                                            (use_park && !urgent) ? cuword : nullptr, shi + 2, 1 << 14);
+                                            (use_park && !urgent) ? cuword : nullptr, shi + 2, 1 << 14, (tile_solve & 2) ? 3 : -1);
           kb = m;
         }
         mc_stamp<TRACE>(tr, 3);
         draw_next();
-        if (!urgent && tile_solve) {
+        if (!urgent && (tile_solve & 5) == 5) {
+          // bulk task, round 4: the tile is re-dealt to the solving waves through LDS BEFORE the solve (trsm128_tile2_dev); the first
+          // pack images are requested before the C tile is read
+          if (mc_wait_min3(cx, ddone + c, ddone + c, ddone + c, 8u, tr) < 0) return;       // (a formality for a bulk task)
+          TrsmSlabPre SP;
+          trsm128_slab_request(pk, SP);
+          const int lane = t & 63, wave = t >> 6, wr = wave >> 1, wc = wave & 1;
+          const double* pc0 = A + (size_t)(r0 + wr * 32 + (lane >> 4)) * ld + (c0 + wc * 64 + (lane & 15));
+          double cv[2][4][4];
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+              for (int q = 0; q < 4; ++q) cv[i][j][q] = pc0[(size_t)(i * 16 + 4 * q) * ld + j * 16];
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+              for (int q = 0; q < 4; ++q) acc[i][j][q] = cv[i][j][q] - acc[i][j][q];
+          mc_stamp<TRACE>(tr, 4);
+          mc_stamp<TRACE>(tr, 8);
+          __builtin_amdgcn_s_setprio(1);
+          trsm128_tile2_dev<true>(v, c0, r0, pk, emu, lds, acc, SP, TRACE ? tr + 10 : nullptr);
+          drain_stores();
+          mc_stamp<TRACE>(tr, 13);
+          __syncthreads();
+          if (t == 0) {
+            stu(rowprog + r, 8u * (unsigned)(c + 1));
+            stu(rowdone + r, (unsigned)(c + 1));
+          }
+          mc_stamp<TRACE>(tr, 5);
+          __builtin_amdgcn_s_setprio(0);
+          continue;
+        }
+        if (!urgent && (tile_solve & 1)) {
           // bulk task: the tile C - acc goes to the panel solve through LDS, not through global memory (trsm128_tile_dev)
           const int lane = t & 63, wave = t >> 6, wr = wave >> 1, wc = wave & 1;
           const double* pc0 = A + (size_t)(r0 + wr * 32 + (lane >> 4)) * ld + (c0 + wc * 64 + (lane & 15));
@@ -317,8 +429,9 @@ __global__ __launch_bounds__(256, SOLO ? 1 : 2) void mchol_kernel(BatchView v, u
           if (mc_wait_min3(cx, ddone + c, ddone + c, ddone + c, 8u, tr) < 0) return;
           mc_stamp<TRACE>(tr, 8);
           __builtin_amdgcn_s_setprio(1);
-          trsm128_tile_dev<true>(v, c0, r0, pk, emu, lds, acc);
+          trsm128_tile_dev<true>(v, c0, r0, pk, emu, lds, acc, TRACE ? tr + 10 : nullptr);
           drain_stores();
+          mc_stamp<TRACE>(tr, 13);
           __syncthreads();
           if (t == 0) {
             stu(rowprog + r, 8u * (unsigned)(c + 1));
@@ -405,7 +518,9 @@ __global__ __launch_bounds__(256, SOLO ? 1 : 2) void mchol_kernel(BatchView v, u
 //   for c = 0, 1, ...:  D(c+1);  T(2c+4, c+1), T(2c+5, c+1);  G(0..2, c+2);  T(2c+6, c), T(2c+7, c);  T(2c+6, c+1), T(2c+7, c+1);
 //                       T(r, c) for r >= 2c+8
 // (a workgroup that draws a chain task early does its GEMM and then waits: at most a handful of waiting workgroups per emulator).
-std::vector<int> mchol_task_table(int NP) {
+// paired: the bulk of a column, r >= 2c + 8, is listed as TT(R, c) tasks over the row-tile pairs (r, r + 1), r = 2R even (type 3, r in
+// the row field): half as many tasks with 128 x 128 GEMM tiles, for throughput-bound launches (see the kernel).
+std::vector<int> mchol_task_table(int NP, bool paired) {
   const int K = NP / 128, K2 = NP / 64;
   auto word = [](int type, int c, int r) { return (type << 30) | (c << 15) | r; };
   std::vector<int> tb;
@@ -427,7 +542,12 @@ std::vector<int> mchol_task_table(int NP) {
     T(2 * c + 7, c);
     T(2 * c + 6, c + 1);
     T(2 * c + 7, c + 1);
-    for (int r = 2 * c + 8; r < K2; ++r) T(r, c);
+    if (paired) {
+      for (int r = 2 * c + 8; r + 1 < K2; r += 2)
+        if (c < K) tb.push_back(word(3, c, r));
+    } else {
+      for (int r = 2 * c + 8; r < K2; ++r) T(r, c);
+    }
   }
   return tb;
 }
@@ -436,7 +556,24 @@ int mchol_emu_stride(int NP) { return (2 * (NP / 64) + 2 * (NP / 128) + MC_LINE 
 size_t mchol_ctrl_ints(int NP, int B) { return MC_EMU0 + (size_t)B * mchol_emu_stride(NP); }
 size_t mchol_pack_doubles(int NP, int B) { return (size_t)B * (NP / 128) * PACK128_STRIDE; }
 
-void launch_mchol(const BatchView& v, unsigned* ctrl, size_t ctrl_ints, const int* table, int ntasks, double* packs, int* info, int n_cu,
+// rho = (time the matrix cores need at ~45 TFLOP/s) / (length of the dependent chain, ~55 us per block column)
+static double mchol_rho(int nb, int NP) {
+  const double npd = NP;
+  return ((double)nb * npd * npd * npd / 3.0 / 45e12) / ((npd / 128.0) * 55e-6);
+}
+
+// MOGP_MC_PAIR=1: the paired 128 x 128 bulk tasks (with MOGP_MC_PAIR_RHO=<rho>: from that rho on).  OFF by default -- measured
+// (round 4, same box, ms per launch, paired / 64 x 128): 64 x n=2000 4.10 / 3.89, 32 x 2.28 / 2.07, 16 x n=5000 13.75 / 13.05, n=16000
+// 26.26 / 25.27; bit-identical results.  The GEMM phase is 5 % faster per flop (3.8 us per 64-MFMA k-step against 2 x 2.0), the two
+// solves of a pair run one after the other from global memory; and the premise did not hold: with the operand traffic removed
+// altogether (MOGP_MC_NOTRAFFIC) the kernel changes by < 1 % in the per-task stamps -- it is not bound by the fabric.
+bool mchol_use_pairs(int nb, int NP) {
+  static const int force = [] { const char* e = getenv("MOGP_MC_PAIR"); return e ? atoi(e) : 0; }();
+  static const double thr = [] { const char* e = getenv("MOGP_MC_PAIR_RHO"); return e ? atof(e) : 0.0; }();
+  return force != 0 && mchol_rho(nb, NP) >= thr;
+}
+
+void launch_mchol(const BatchView& v, unsigned* ctrl, size_t ctrl_ints, const int* table, int ntasks, bool paired, double* packs, int* info, int n_cu,
                   hipStream_t s) {
   // MOGP_MC_SPIN: polls before a wait gives up (default 2^22: seconds)
   static const int spin_limit = [] { const char* e = getenv("MOGP_MC_SPIN"); return e ? atoi(e) : (1 << 22); }();
@@ -448,17 +585,24 @@ void launch_mchol(const BatchView& v, unsigned* ctrl, size_t ctrl_ints, const in
   // blocks have slack and a parked workgroup is only lost capacity.  MOGP_MC_WGS = 1 / 2 and MOGP_MC_PARK = 0 / 1 force either.
   static const int force_wgs = [] { const char* e = getenv("MOGP_MC_WGS"); return e ? std::max(1, atoi(e)) : 0; }();
   static const int force_park = [] { const char* e = getenv("MOGP_MC_PARK"); return e ? atoi(e) : -1; }();
-  const double npd = v.NP;
-  const double rho = ((double)v.nb * npd * npd * npd / 3.0 / 45e12) / ((npd / 128.0) * 55e-6);
-  const int per_cu = force_wgs ? force_wgs : (rho < 1.0 ? 1 : 2);
+  const double rho = mchol_rho(v.nb, v.NP);
+  const int per_cu = (force_wgs && !(paired && force_wgs == 1)) ? force_wgs : ((rho < 1.0 && !paired) ? 1 : 2);      // (the paired tasks' LDS excludes the one-per-CU padding)
   const int park_on = force_park >= 0 ? force_park : ((per_cu > 1 && rho < 2.0) ? 1 : 0);
   // MOGP_MC_TILE=0: bulk tasks write C - acc back and solve from global memory (rounds 3a-3c) instead of handing the tile over in LDS
-  static const int tile_solve = [] { const char* e = getenv("MOGP_MC_TILE"); return e ? atoi(e) : 1; }();
+  // MOGP_MC_NOTRAFFIC=1 (measurement only, garbage results): the bulk GEMM tasks re-read their first 64 operand columns -- the traffic A/B
+  static const int tile_solve = [] {
+    const char* e = getenv("MOGP_MC_TILE");
+    const char* f = getenv("MOGP_MC_NOTRAFFIC");
+    const char* g = getenv("MOGP_MC_SLAB");          // 0: the half-tile stage of round 3 (trsm128_tile_dev) instead of the re-deal (trsm128_tile2_dev)
+    return ((e ? atoi(e) : 1) & 1) | ((f && atoi(f)) ? 2 : 0) | ((!g || atoi(g)) ? 4 : 0);
+  }();
+
   (void)hipMemsetAsync(ctrl, 0, ctrl_ints * sizeof(unsigned), s);
   const int nq = (v.nb % 8 == 0) ? 8 : 1;
   // one workgroup per CU is enforced through the LDS request: more than half of the 160 KB
   const size_t lds_doubles = (per_cu == 1 ? (size_t)11 * 1024 : 0) + MC_LDS_HDR + std::max<size_t>({(size_t)WCfg<64, 128, 2, 2>::SMEM_DOUBLES, (size_t)TRSM128L_LDS, (size_t)C128_LDS_PRE_DOUBLES,
-                                                                                                                   tile_solve ? (size_t)TRSM128T_LDS : (size_t)0});
+                                                                                                                   (tile_solve & 1) ? (size_t)TRSM128T_LDS : (size_t)0,
+                                                                                                                   paired ? (size_t)WCfg<128, 128, 2, 2>::SMEM_DOUBLES : (size_t)0});
   const int total = ntasks * v.nb;
   const int grid = std::min(per_cu * n_cu, total);
   // MOGP_MC_TRACE=<file>: per-task time stamps of EVERY launch are appended to the file (analysis only: synchronises)

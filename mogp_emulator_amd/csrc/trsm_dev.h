@@ -177,9 +177,123 @@ __device__ __forceinline__ bool trsm128_lds_dev(const BatchView& v, int c0, int 
 // the waves wc = 0) is deposited first, block steps 0 - 3 run, then the waves wc = 1 deposit the other half into the same slots.  Same
 // arithmetic in the same order as trsm128_lds_dev: bit-identical results.  lds: TRSM128T_LDS doubles.
 constexpr int TRSM128T_LDS = 2 * TL_PK + 16 * TL_TS;
+// The images of block steps 0 and 1 of a FINISHED diagonal block's pack, requested by a bulk task BEFORE it reads its C tile (their
+// latency then runs under the tile's loads and the subtraction); trsm128_tile2_dev deposits them.
+struct TrsmSlabPre {
+  v2d_p pr[2][4], pinv[2];
+};
+__device__ __forceinline__ void trsm128_slab_request(const double* __restrict__ pk, TrsmSlabPre& P) {
+  const int t = mogp_tid();
+  const double* LT = pk + PACK128_LT;
+  // step 0 needs inv(L_00) only; step 1 the 16 pieces of row block 1 (128 chunks: q = 0, t < 128) and inv(L_11)
+  if (t < 128) P.pr[1][0] = *reinterpret_cast<const v2d_p*>(LT + (size_t)(t >> 3) * 128 + 16 + (t & 7) * 2);
+  if (t < 128) P.pinv[0] = *reinterpret_cast<const v2d_p*>(pk + PACK128_INV + 2 * t);
+  if (t < 128) P.pinv[1] = *reinterpret_cast<const v2d_p*>(pk + PACK128_INV + 256 + 2 * t);
+}
+
+// Round 4 (default for bulk tasks): the tile is RE-DEALT to the solving waves before the solve.  All four waves put their 32 x 64 piece of
+// x = C - acc into a whole-tile stage at once ([slab][block][16 x 17]: 8704 doubles, exactly the LDS of the round-3 form), one barrier, and
+// wave w takes the eight blocks of ITS slab as transposed fragments T[b] into the registers x used to occupy; the pack images move in
+// afterwards.  From then on nothing but the images is shared.  Round 3 (trsm128_tile_dev, MOGP_MC_SLAB=0) staged half a tile and
+// deposited the column half 64 .. 127 after block step 3: its 32 values per lane had to survive four block steps in the registers of two
+// waves, the compiler spilled 18 of them to scratch, and the mid-solve deposit -- reload from scratch memory under load, two barriers --
+// took 5.5 - 6 us of a 30 us solve next to a GEMM partner (per-step stamps); the first deposit of a block waited for three other waves
+// (10 us before the first block step).  Tried on the way: GEMM on 4 x 1 waves, so that every wave already holds its slab (no re-deal at
+// all): solve 30 -> 20 us, but 9 instead of 6 LDS fragment reads per 8 MFMAs made the GEMM phase 4 % slower (n=16000: +3 % overall);
+// the whole pack requested before the C tile (24 loads per thread): no gain, more spills; the operands of a block step all requested
+// in front of its first MFMA with the sign flips folded into the stage: slower (the chain is not LDS-latency-bound: 160 cycles per MFMA
+// next to a GEMM partner whichever way the operands arrive -- the partner's MFMAs take their share of the SIMD's pipe).
+// Same arithmetic in the same order as trsm128_lds_dev: bit-identical.  x: C - acc in the accumulator layout of trsm128_tile_dev;
+// P: trsm128_slab_request.  lds: TRSM128T_LDS doubles.
+constexpr int TL_TS17 = 16 * 17;
+static_assert(32 * TL_TS17 <= TRSM128T_LDS, "whole-tile stage must fit the LDS of the half-tile form");
+template <bool SC1_OUT>
+__device__ __forceinline__ void trsm128_tile2_dev(const BatchView& v, int c0, int r0, const double* __restrict__ pk, int emu, double* lds,
+                                                  const v4d_t (&x)[2][4], TrsmSlabPre& P, unsigned long long* stamps = nullptr) {
+  Sc1Buf ab;
+  if (SC1_OUT) ab = sc1_buf(v.A + (size_t)emu * v.MS, (unsigned)(v.MS * sizeof(double)));
+  const int ld = v.LD;
+  const int t = mogp_tid(), lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int g = lane >> 4, i = lane & 15;
+  const int wr = wave >> 1, wc = wave & 1;
+  double* slab = v.A + (size_t)emu * v.MS + (size_t)(r0 + wave * 16) * ld + c0;   // 16 rows x 128 columns
+  double* pkb[2] = {lds, lds + TL_PK};
+  double* ts = lds + 2 * TL_PK + wave * TL_TS;           // (after the re-deal: this wave's private 16 x 18 stage for the way out)
+  const double* LT = pk + PACK128_LT;
+  const int sr0 = lane >> 3, sp = (lane & 7) * 2;
+  auto pack_request = [&](int b) {
+    const int u = b & 1;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int ch = t + 256 * q;
+      if (ch < 128 * b) P.pr[u][q] = *reinterpret_cast<const v2d_p*>(LT + (size_t)(ch >> 3) * 128 + 16 * b + (ch & 7) * 2);
+    }
+    if (t < 128) P.pinv[u] = *reinterpret_cast<const v2d_p*>(pk + PACK128_INV + b * 256 + 2 * t);
+  };
+  auto pack_deposit = [&](int b, double* img) {
+    const int u = b & 1;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int ch = t + 256 * q;
+      if (ch < 128 * b) *reinterpret_cast<v2d_p*>(img + (ch >> 3) * 16 + (ch & 7) * 2) = P.pr[u][q];
+    }
+    if (t < 128) *reinterpret_cast<v2d_p*>(img + 112 * 16 + 2 * t) = P.pinv[u];
+  };
+  // whole-tile stage over ALL of lds: [slab 2 wr + ii][block 4 wc + j][16 x 17]
+#pragma unroll
+  for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) lds[((2 * wr + ii) * 8 + 4 * wc + j) * TL_TS17 + (g + 4 * q) * 17 + i] = x[ii][j][q];
+  __syncthreads();
+  v4d_t T[8];
+#pragma unroll
+  for (int b = 0; b < 8; ++b)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) T[b][r] = lds[(wave * 8 + b) * TL_TS17 + i * 17 + g + 4 * r];
+  __syncthreads();               // every wave has taken its slab: the images move in
+  pack_deposit(0, pkb[0]);
+  __syncthreads();
+  if (stamps && t == 0) stamps[0] = __builtin_amdgcn_s_memrealtime();
+  v4d_t X[8];
+#pragma unroll
+  for (int b = 0; b < 8; ++b) {
+    const double* img = pkb[b & 1];
+    if (b + 2 < 8) pack_request(b + 2);
+    v4d_t Tb = T[b];
+#pragma unroll
+    for (int a = 0; a < b; ++a)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Tb = __builtin_amdgcn_mfma_f64_16x16x4f64(-img[(16 * a + g + 4 * r) * 16 + i], X[a][r], Tb, 0, 0, 0);
+    const double* inv = img + 112 * 16;
+    X[b] = (v4d_t){0., 0., 0., 0.};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) X[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(inv[(g + 4 * r) * 16 + i], Tb[r], X[b], 0, 0, 0);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) ts[i * 18 + g + 4 * r] = X[b][r];
+    __builtin_amdgcn_wave_barrier();
+    if (stamps && t == 0) stamps[4 + 2 * b] = __builtin_amdgcn_s_memrealtime();
+    {
+      const v2d_p o0 = *reinterpret_cast<const v2d_p*>(ts + sr0 * 18 + sp);
+      const v2d_p o1 = *reinterpret_cast<const v2d_p*>(ts + (sr0 + 8) * 18 + sp);
+      st16<SC1_OUT>(ab, slab + (size_t)sr0 * ld + 16 * b + sp, o0);
+      st16<SC1_OUT>(ab, slab + (size_t)(sr0 + 8) * ld + 16 * b + sp, o1);
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (b == 3 && stamps && t == 0) stamps[1] = __builtin_amdgcn_s_memrealtime();
+    if (b < 7) pack_deposit(b + 1, pkb[(b + 1) & 1]);
+    __syncthreads();
+    if (stamps && t == 0) stamps[5 + 2 * b] = __builtin_amdgcn_s_memrealtime();
+  }
+  if (stamps && t == 0) stamps[2] = __builtin_amdgcn_s_memrealtime();
+}
+
+// stamps (analysis only, MOGP_MC_TRACE): [0] after the first barrier, [1] after block step 3, [2] after block step 7
 template <bool SC1_OUT>
 __device__ __forceinline__ void trsm128_tile_dev(const BatchView& v, int c0, int r0, const double* __restrict__ pk, int emu, double* lds,
-                                                 const v4d_t (&x)[2][4]) {
+                                                 const v4d_t (&x)[2][4], unsigned long long* stamps = nullptr) {
   Sc1Buf ab;
   if (SC1_OUT) ab = sc1_buf(v.A + (size_t)emu * v.MS, (unsigned)(v.MS * sizeof(double)));
   const int ld = v.LD;
@@ -226,6 +340,7 @@ __device__ __forceinline__ void trsm128_tile_dev(const BatchView& v, int c0, int
   tile_deposit(0);
   pack_deposit(0, pkb[0]);
   __syncthreads();
+  if (stamps && t == 0) stamps[0] = __builtin_amdgcn_s_memrealtime();
   v4d_t X[8];
 #pragma unroll
   for (int b = 0; b < 8; ++b) {
@@ -247,6 +362,7 @@ __device__ __forceinline__ void trsm128_tile_dev(const BatchView& v, int c0, int
 #pragma unroll
     for (int r = 0; r < 4; ++r) ts[i * 18 + g + 4 * r] = X[b][r];
     __builtin_amdgcn_wave_barrier();
+    if (stamps && t == 0) stamps[4 + 2 * b] = __builtin_amdgcn_s_memrealtime();      // X_b of wave 0 is in LDS: its MFMA chain has completed
     {
       const v2d_p o0 = *reinterpret_cast<const v2d_p*>(ts + sr0 * 18 + sp);
       const v2d_p o1 = *reinterpret_cast<const v2d_p*>(ts + (sr0 + 8) * 18 + sp);
@@ -255,11 +371,14 @@ __device__ __forceinline__ void trsm128_tile_dev(const BatchView& v, int c0, int
     }
     if (b == 3) {
       __syncthreads();                // every slab has read block 3 and taken X_3 out of its slot
+      if (stamps && t == 0) stamps[1] = __builtin_amdgcn_s_memrealtime();
       tile_deposit(1);
     }
     if (b < 7) pack_deposit(b + 1, pkb[(b + 1) & 1]);
     __syncthreads();
+    if (stamps && t == 0) stamps[5 + 2 * b] = __builtin_amdgcn_s_memrealtime();      // all four waves are through step b
   }
+  if (stamps && t == 0) stamps[2] = __builtin_amdgcn_s_memrealtime();
 }
 
 }  // namespace mogp

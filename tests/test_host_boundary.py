@@ -285,47 +285,63 @@ def test_native_meanpriors_prior_dists_and_sample():
     assert len(pri.sample()) == 2 + 1 + 1                               # mean parameters first (gppriors.hpp:458-471)
 
 
+@pytest.mark.parametrize("paired", [False, True])
 @pytest.mark.parametrize("n", [1, 100, 128, 129, 300, 640, 2000, 5000, 16000])
-def test_one_launch_cholesky_task_order_is_topological(n):
+def test_one_launch_cholesky_task_order_is_topological(n, paired):
     """The forward-progress argument of the one-launch Cholesky (csrc/kernels_mchol.hip) rests on ONE property of its task table:
-    every task only depends on tasks with a smaller number.  Replay the dependency rules of the kernel against the table the
-    library builds (host-only entry point, no device needed):
-      D(c)    needs G(0, c), G(1, c), G(2, c) (c >= 2) and T(2c, c-1), T(2c+1, c-1) (c >= 1)
-      G(s, c) (lower 64 x 64 tile (ti, tj) = (0,0), (1,0), (1,1) of the diagonal block) needs T(2c+ti, k), T(2c+tj, k) for every k <= c-2
-      T(r, c) needs D(c) and T(r', k) for r' in {r, 2c, 2c+1} and every k <= c-1
+    every task only depends on tasks with a smaller number.  Replay the dependency rules of the kernel against the tables the
+    library builds (host-only entry points, no device needed):
+      D(c)     needs G(0, c), G(1, c), G(2, c) (c >= 2) and the row tiles 2c, 2c+1 of column c-1 (c >= 1)
+      G(s, c)  (lower 64 x 64 tile (ti, tj) = (0,0), (1,0), (1,1) of the diagonal block) needs the row tiles 2c+ti, 2c+tj of every column k <= c-2
+      T(r, c)  needs D(c) and the row tiles r, 2c, 2c+1 of every column k <= c-1
+      TT(r, c) (paired table: row tiles r, r+1 as one 128 x 128 task) needs D(c) and the row tiles r, r+1, 2c, 2c+1 of every column k <= c-1
     and check that every tile of the lower block triangle is produced exactly once."""
     import ctypes
     lib = _capi.load()
-    cnt = lib.mogp_mchol_task_table(n + 1, None, 0)
+    fn = lib.mogp_mchol_task_table_paired if paired else lib.mogp_mchol_task_table
+    cnt = fn(n + 1, None, 0)
     buf = (ctypes.c_int * cnt)()
-    assert lib.mogp_mchol_task_table(n + 1, buf, cnt) == cnt
+    assert fn(n + 1, buf, cnt) == cnt
     NP = (n + 1 + 127) // 128 * 128
     K, K2 = NP // 128, NP // 64
     pos = {}
+    tile = {}                                   # (row tile, column) -> position of the task that produces it
     for p, w in enumerate(buf):
-        key = ((w >> 30) & 3, (w >> 15) & 0x7fff, (w & 0x7fff) if (w >> 30) & 3 else 0)
+        w &= 0xffffffff
+        t, c, r = (w >> 30) & 3, (w >> 15) & 0x7fff, w & 0x7fff
+        key = (t, c, r if t else 0)
         assert key not in pos, "task listed twice: %r" % (key,)
         pos[key] = p
+        for rr in ([r] if t == 2 else [r, r + 1] if t == 3 else []):
+            assert (rr, c) not in tile, "tile produced twice: %r" % ((rr, c),)
+            tile[(rr, c)] = p
+        if t == 3:
+            assert paired and r % 2 == 0 and r >= 2 * c + 8 and r + 1 < K2
     assert sorted(c for (t, c, r) in pos if t == 0) == list(range(K))
-    assert sorted((r, c) for (t, c, r) in pos if t == 2) == sorted((r, c) for c in range(K) for r in range(2 * c + 2, K2))
+    assert sorted(tile) == sorted((r, c) for c in range(K) for r in range(2 * c + 2, K2))
     assert sorted((r, c) for (t, c, r) in pos if t == 1) == sorted((sub, c) for c in range(2, K) for sub in range(3))
+    if not paired:
+        assert not any(t == 3 for (t, c, r) in pos)
     for (t, c, r), p in pos.items():
-        deps = []
+        need_tiles, deps = [], []
         if t == 0:
             if c >= 2:
                 deps += [(1, c, 0), (1, c, 1), (1, c, 2)]
             if c >= 1:
-                deps += [(2, c - 1, 2 * c), (2, c - 1, 2 * c + 1)]
+                need_tiles += [(2 * c, c - 1), (2 * c + 1, c - 1)]
         elif t == 1:
             ti, tj = (1 if r > 0 else 0), (1 if r > 1 else 0)
             for k in range(c - 1):
-                deps += [(2, k, rr) for rr in {2 * c + ti, 2 * c + tj}]
+                need_tiles += [(rr, k) for rr in {2 * c + ti, 2 * c + tj}]
         else:
+            rows = {r, 2 * c, 2 * c + 1} | ({r + 1} if t == 3 else set())
             for k in range(c):
-                deps += [(2, k, rr) for rr in {r, 2 * c, 2 * c + 1}]
+                need_tiles += [(rr, k) for rr in rows]
             deps.append((0, c, 0))
         for d in deps:
             assert d in pos and pos[d] < p, "task %r (position %d) depends on %r (position %s)" % ((t, c, r), p, d, pos.get(d))
+        for d in need_tiles:
+            assert d in tile and tile[d] < p, "task %r (position %d) needs tile %r (position %s)" % ((t, c, r), p, d, tile.get(d))
 
 
 def test_bench_refuses_a_world_size_that_disagrees_with_gpus():

@@ -50,7 +50,7 @@ for c in range(K):
 dur = (tr[:, :, 5] - tr[:, :, 0]) / 100.0
 wait = tr[:, :, 9] / 100.0
 print("# by task type (all emulators): count, sum of durations, of which waiting; mean duration / wait / last GEMM segment / write-back / solve")
-for ty, name in ((0, "D"), (1, "G"), (2, "T")):
+for ty, name in ((0, "D"), (1, "G"), (2, "T"), (3, "TT")):
     m = typ == ty
     if not m.any():
         continue
@@ -61,6 +61,29 @@ for ty, name in ((0, "D"), (1, "G"), (2, "T")):
     sol = np.where(x[:, :, 8] > 0, (x[:, :, 5] - x[:, :, 8]) / 100.0, 0.)
     print("#   %s: %6d tasks, %10.0f us total, %10.0f us waiting (%.0f %%); mean %.1f / %.1f / %.1f / %.1f / %.1f us" % (
         name, d.size, d.sum(), wv.sum(), 100 * wv.sum() / d.sum(), d.mean(), wv.mean(), seg.mean(), wb.mean(), sol.mean()))
+    if ty == 2 and x.shape[2] >= 14:
+        bm = (x[:, :, 10] > 0) & (x[:, :, 13] > 0)
+        if bm.any():
+            ph = [((x[:, :, b] - x[:, :, a]) / 100.0)[bm].mean() for a, b in ((8, 10), (10, 11), (11, 12), (12, 13), (13, 5))]
+            print("#      bulk solve phases (us): pack seen -> first barrier %.1f | steps 0-3 %.1f | steps 4-7 %.1f | drain %.1f | barrier + publish %.1f   (%d tasks)" % (
+                ph[0], ph[1], ph[2], ph[3], ph[4], int(bm.sum())))
+    if ty == 2 and x.shape[2] >= 30:
+        bm = (x[:, :, 10] > 0) & (x[:, :, 29] > 0)
+        if bm.any():
+            prev = x[:, :, 10]
+            parts = []
+            for b in range(8):
+                ch = ((x[:, :, 14 + 2 * b] - prev) / 100.0)[bm].mean()
+                al = ((x[:, :, 15 + 2 * b] - x[:, :, 14 + 2 * b]) / 100.0)[bm].mean()
+                parts.append("%d: %.2f + %.2f" % (b, ch, al))
+                prev = x[:, :, 15 + 2 * b]
+            print("#      bulk solve per block step (us): wave 0's chain + until all waves are through the step's barrier | " + " | ".join(parts))
+    if ty >= 2:
+        # GEMM time per 16-deep k-step (all segments: duration - waits - write-back - solve, over 8 c steps), by block column
+        cc = col[m]
+        gemm = d - wv - wb - sol
+        per = [(int(c), float(gemm[:, cc == c].mean() / (8 * c))) for c in sorted(set(cc.tolist())) if c > 0 and (cc == c).any()]
+        print("#      GEMM us per k-step by block column: " + " ".join("%d:%.2f" % pc for pc in per))
 busy = (dur - wait).sum()
 print("# busy (not waiting) workgroup time %.0f us = %.1f of %d workgroups over the kernel's %.1f us" % (busy, busy / total_us, grid, total_us))
 # busy workgroups over time (20 bins): a task counts as busy outside its waits -- approximated by its busy fraction
