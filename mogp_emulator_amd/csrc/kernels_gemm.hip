@@ -213,7 +213,93 @@ __global__ __launch_bounds__(256, 3) void trsm128_lds_kernel(BatchView v, int c0
 // trtri merge, level h:  node q covers [base, base+2h), base = q*2h
 //   STEP 0:  T     = L21 * Linv11          (T kept in scratch at the position of block 21)
 //   STEP 1:  Linv21 = -Linv22 * T
+// Round 4: both products skip the structural zeros of their triangular operand at the 16 x 16 sub-tile level (merge_mainloop), as the
+// predictive variance and K^-1 do, and the upper levels can use 128 x 128 tiles (launch_trtri_merges).
 // ---------------------------------------------------------------------------------------------
+// A K-major, B M-major, 2 x 2 waves, sub-tiles dealt round-robin (row sub-tile 2 i + wr, column sub-tile 2 j + wc).
+// MODE 0 (T = L21 Linv11, k from j0): the first BM values of k are the DIAGONAL block of Linv11 [k][j]: column sub-tile b has non-zeros
+//         from its step kd = b on -- the set of active column sub-tiles [0, E) GROWS.
+// MODE 1 (Linv21 = -Linv22 T, k up to i0 + BM): the LAST nd steps are the diagonal block of Linv22 [i][k]: row sub-tile a has non-zeros up
+//         to step a of that block -- the set of active row sub-tiles [S, WT) SHRINKS (nk_full = steps in front of the block).
+// The k loop is cut into consecutive loops, one per set; skipped products are exact zeros (entries unchanged bit for bit).
+template <int WT, int MODE>
+__device__ __forceinline__ void merge_mainloop(const double* __restrict__ Ag, int lda, const double* __restrict__ Bg, int ldb, int nk, int nk_full,
+                                               v4d (&acc)[WT][WT], double* smem, int wr, int wc) {
+  using C = Cfg<WT>;
+  const int lane = threadIdx.x & 63;
+  const int fr = lane & 15, fk = lane >> 4;
+#pragma unroll
+  for (int i = 0; i < WT; ++i)
+#pragma unroll
+    for (int j = 0; j < WT; ++j) acc[i][j] = (v4d){0., 0., 0., 0.};
+  if (nk <= 0) return;
+  const size_t stepB = (size_t)BK * ldb;
+  v2d ra[C::CH], rb[C::CH];
+  const unsigned offA = g2r_off<WT, true>(lda), offB = g2r_off<WT, false>(ldb);
+  g2r<WT, true>(Ag, lda, offA, ra);
+  g2r<WT, false>(Bg, ldb, offB, rb);
+  r2s<WT, true>(smem, ra);
+  r2s<WT, false>(smem + C::OPSZ, rb);
+  __syncthreads();
+  // one k-step with the row sub-tiles [S, WT) and the column sub-tiles [0, E)
+  auto step = [&](int kt, auto S_, auto E_) {
+    constexpr int S = decltype(S_)::value, E = decltype(E_)::value;
+    const double* sA = smem + (kt & 1) * 2 * C::OPSZ;
+    const double* sB = sA + C::OPSZ;
+    const bool more = (kt + 1 < nk);
+    if (more) {
+      Ag += BK;
+      Bg += stepB;
+      g2r<WT, true>(Ag, lda, offA, ra);
+      g2r<WT, false>(Bg, ldb, offB, rb);
+    }
+    if (S < WT && E > 0) {
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        double a[WT], b[WT];
+        const int k = kk * 4 + fk;
+#pragma unroll
+        for (int i = S; i < WT; ++i) a[i] = sA[((2 * i + wr) * 16 + fr) * LDK + k];
+#pragma unroll
+        for (int j = 0; j < E; ++j) b[j] = sB[k * C::LDM + (2 * j + wc) * 16 + fr];
+#pragma unroll
+        for (int i = S; i < WT; ++i)
+#pragma unroll
+          for (int j = 0; j < E; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+      }
+    }
+    if (more) {
+      double* dA = smem + ((kt + 1) & 1) * 2 * C::OPSZ;
+      r2s<WT, true>(dA, ra);
+      r2s<WT, false>(dA + C::OPSZ, rb);
+    }
+    __syncthreads();
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using IW = std::integral_constant<int, WT>;
+  int kt = 0;
+  static_assert(WT == 2 || WT == 4, "phase lists are written for two or four sub-tiles per wave");
+  if (MODE == 0) {
+    // column sub-tile 2 j + wc is active from step 2 j + wc on
+    for (const int end = min(nk, wc); kt < end; ++kt) step(kt, I0(), I0());
+    for (const int end = min(nk, 2 + wc); kt < end; ++kt) step(kt, I0(), std::integral_constant<int, 1>());
+    if (WT == 4) {
+      for (const int end = min(nk, 4 + wc); kt < end; ++kt) step(kt, I0(), std::integral_constant<int, 2>());
+      for (const int end = min(nk, 6 + wc); kt < end; ++kt) step(kt, I0(), std::integral_constant<int, 3>());
+    }
+    for (; kt < nk; ++kt) step(kt, I0(), IW());
+  } else {
+    // row sub-tile 2 i + wr is active up to step nk_full + 2 i + wr
+    for (const int end = min(nk, nk_full + wr + 1); kt < end; ++kt) step(kt, I0(), IW());
+    for (const int end = min(nk, nk_full + 2 + wr + 1); kt < end; ++kt) step(kt, std::integral_constant<int, 1>(), IW());
+    if (WT == 4) {
+      for (const int end = min(nk, nk_full + 4 + wr + 1); kt < end; ++kt) step(kt, std::integral_constant<int, 2>(), IW());
+      for (const int end = min(nk, nk_full + 6 + wr + 1); kt < end; ++kt) step(kt, std::integral_constant<int, 3>(), IW());
+    }
+    for (; kt < nk; ++kt) step(kt, IW(), IW());
+  }
+}
+
 template <int WT, int STEP>
 __global__ __launch_bounds__(256, 2) void trtri_merge_kernel(BatchView v, int h, int tiles_per_dim, int nodes) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -245,26 +331,105 @@ __global__ __launch_bounds__(256, 2) void trtri_merge_kernel(BatchView v, int h,
   const double* L = v.A + (size_t)emu * v.MS;
   double* Li = v.Linv + (size_t)emu * v.MS;
   double* S = v.Kinv + (size_t)emu * v.MS;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
   v4d acc[WT][WT];
+  // entry (row sub-tile 2 i + wr, column sub-tile 2 j + wc) of the tile
+  auto store = [&](double* dst, double sign) {
+#pragma unroll
+    for (int i = 0; i < WT; ++i)
+#pragma unroll
+      for (int j = 0; j < WT; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          dst[(size_t)((2 * i + wr) * 16 + (lane >> 4) + 4 * r) * ld + (2 * j + wc) * 16 + (lane & 15)] = sign * acc[i][j][r];
+  };
   if (STEP == 0) {
     // T[i,j] = sum_{k >= j0} L21[i,k] Linv11[k,j]
     const double* Ag = L + (size_t)(base + h + i0) * ld + base + j0;       // K-major, k from j0
     const double* Bg = Li + (size_t)(base + j0) * ld + base + j0;          // M-major: [k][j], k from j0
-    gemm_mainloop<WT, true, false>(Ag, ld, Bg, ld, (h - j0) / BK, acc, smem);
-    for_each_acc<WT>(acc, [&](int r, int c, double x) { S[(size_t)(base + h + i0 + r) * ld + base + j0 + c] = x; });
+    merge_mainloop<WT, 0>(Ag, ld, Bg, ld, (h - j0) / BK, 0, acc, smem, wr, wc);
+    store(S + (size_t)(base + h + i0) * ld + base + j0, 1.0);
   } else {
     // Linv21[i,j] = - sum_{k < i0+BM} Linv22[i,k] T[k,j]
     const double* Ag = Li + (size_t)(base + h + i0) * ld + base + h;       // K-major, k from 0
     const double* Bg = S + (size_t)(base + h) * ld + base + j0;            // M-major: T[k][j]
     const int kend = min(i0 + C::BM, m2);
-    gemm_mainloop<WT, true, false>(Ag, ld, Bg, ld, kend / BK, acc, smem);
-    for_each_acc<WT>(acc, [&](int r, int c, double x) { Li[(size_t)(base + h + i0 + r) * ld + base + j0 + c] = -x; });
+    merge_mainloop<WT, 1>(Ag, ld, Bg, ld, kend / BK, i0 / BK, acc, smem, wr, wc);
+    store(Li + (size_t)(base + h + i0) * ld + base + j0, -1.0);
   }
 }
 
 // ---------------------------------------------------------------------------------------------
 // Kinv = Linv^T Linv (lower tiles):  Kinv[i,j] = sum_{k >= i0} Linv[k,i] Linv[k,j]
 // ---------------------------------------------------------------------------------------------
+// Structural zeros (round 4).  The k range of tile (ti, tj) starts at i0 = 128 ti, i.e. with the DIAGONAL block of L^-1's row panel:
+// in its k-step kd = 0 .. 7 the A operand L^-1[k][i0 + row] is zero for the 16-row sub-tiles a > kd (28 of the 64 (sub-tile, step)
+// pairs), and of a diagonal tile only the sub-tile pairs a >= b are ever read (gradient reduction, get_invQ: entries j <= i).  The
+// dense kernel issued these products all the same: 0.844 MFMA-busy at 0.69 of the peak in algorithmic flops.  As in the
+// predictive variance (mainloop_w<.., TRIA>) the sub-tiles are dealt to the wave rows / columns ROUND-ROBIN (a = 2 i + wr, b = 2 j + wc),
+// so that every wave owns early and late sub-tiles, and the k loop is cut into CONSECUTIVE loops, one per set of active row sub-tiles
+// [0, E) -- each the dense straight-line step restricted to that set; waves meet at the step barriers whatever their set.
+// TRI: 0 every column sub-tile; 1 pairs j <= i; 2 pairs j < i (diagonal tiles: b <= a for the wave's residues).
+// All skipped products are exact zeros or never read: the sums of the products that remain are unchanged (bit-identical entries).
+template <int TRI>
+__device__ __forceinline__ void kinv_mainloop(const double* __restrict__ Ag, const double* __restrict__ Bg, int ld, int nk, v4d (&acc)[4][4],
+                                              double* smem, int wr, int wc) {
+  using C = Cfg<4>;
+  const int lane = threadIdx.x & 63;
+  const int fr = lane & 15, fk = lane >> 4;
+  const size_t stepA = (size_t)BK * ld;
+  v2d ra[C::CH], rb[C::CH];
+  const unsigned offA = g2r_off<4, false>(ld);
+  g2r<4, false>(Ag, ld, offA, ra);
+  g2r<4, false>(Bg, ld, offA, rb);
+  r2s<4, false>(smem, ra);
+  r2s<4, false>(smem + C::OPSZ, rb);
+  __syncthreads();
+  auto step = [&](int kt, auto E_) {
+    constexpr int E = decltype(E_)::value;
+    const double* sA = smem + (kt & 1) * 2 * C::OPSZ;
+    const double* sB = sA + C::OPSZ;
+    const bool more = (kt + 1 < nk);
+    if (more) {
+      Ag += stepA;
+      Bg += stepA;
+      g2r<4, false>(Ag, ld, offA, ra);
+      g2r<4, false>(Bg, ld, offA, rb);
+    }
+    constexpr int JN = (TRI == 0) ? 4 : ((TRI == 1) ? E : E - 1);      // column sub-tiles any active row sub-tile pairs with
+    if (E > 0 && JN > 0) {
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        double a[4], b[4];
+        const int k = kk * 4 + fk;
+#pragma unroll
+        for (int i = 0; i < E; ++i) a[i] = sA[k * C::LDM + (2 * i + wr) * 16 + fr];
+#pragma unroll
+        for (int j = 0; j < JN; ++j) b[j] = sB[k * C::LDM + (2 * j + wc) * 16 + fr];
+#pragma unroll
+        for (int i = 0; i < E; ++i)
+#pragma unroll
+          for (int j = 0; j < JN; ++j)
+            if (TRI == 0 || (TRI == 1 && j <= i) || (TRI == 2 && j < i)) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+      }
+    }
+    if (more) {
+      double* dA = smem + ((kt + 1) & 1) * 2 * C::OPSZ;
+      r2s<4, false>(dA, ra);
+      r2s<4, false>(dA + C::OPSZ, rb);
+    }
+    __syncthreads();
+  };
+  // row sub-tile a = 2 i + wr has non-zeros from step kd = a on
+  int kt = 0;
+  for (const int end = min(nk, wr); kt < end; ++kt) step(kt, std::integral_constant<int, 0>());
+  for (const int end = min(nk, 2 + wr); kt < end; ++kt) step(kt, std::integral_constant<int, 1>());
+  for (const int end = min(nk, 4 + wr); kt < end; ++kt) step(kt, std::integral_constant<int, 2>());
+  for (const int end = min(nk, 6 + wr); kt < end; ++kt) step(kt, std::integral_constant<int, 3>());
+  for (; kt < nk; ++kt) step(kt, std::integral_constant<int, 4>());
+}
+
 __global__ __launch_bounds__(256, 2) void kinv_kernel(BatchView v, int ntiles, int kend) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   using C = Cfg<4>;
@@ -280,9 +445,31 @@ __global__ __launch_bounds__(256, 2) void kinv_kernel(BatchView v, int ntiles, i
   const double* Li = v.Linv + (size_t)emu * v.MS;
   double* Ki = v.Kinv + (size_t)emu * v.MS;
   const int i0 = ti * C::BM, j0 = tj * C::BM;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
   v4d acc[4][4];
-  gemm_mainloop<4, false, false>(Li + (size_t)i0 * ld + i0, ld, Li + (size_t)i0 * ld + j0, ld, (kend - i0) / BK, acc, smem);
-  for_each_acc<4>(acc, [&](int r, int c, double x) { Ki[(size_t)(i0 + r) * ld + j0 + c] = x; });
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (v4d){0., 0., 0., 0.};
+  const double* Ag = Li + (size_t)i0 * ld + i0;
+  const double* Bg = Li + (size_t)i0 * ld + j0;
+  const int nk = (kend - i0) / BK;
+  // (entry (row sub-tile 2 i + wr, column sub-tile 2 j + wc) of the tile; a diagonal tile keeps the pairs b <= a)
+  const int tri = (ti != tj) ? 0 : (wr < wc ? 2 : 1);
+  if (tri == 0) kinv_mainloop<0>(Ag, Bg, ld, nk, acc, smem, wr, wc);
+  else if (tri == 1) kinv_mainloop<1>(Ag, Bg, ld, nk, acc, smem, wr, wc);
+  else kinv_mainloop<2>(Ag, Bg, ld, nk, acc, smem, wr, wc);
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (tri == 0 || (tri == 1 && j <= i) || (tri == 2 && j < i)) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          Ki[(size_t)(i0 + (2 * i + wr) * 16 + (lane >> 4) + 4 * r) * ld + j0 + (2 * j + wc) * 16 + (lane & 15)] = acc[i][j][r];
+      }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -550,17 +737,35 @@ void launch_update_trailing(const BatchView& v, int c0, int k0, int k1, hipStrea
 }
 
 void launch_trtri_merges(const BatchView& v, hipStream_t s) {
-  // 64 x 64 tiles at every level (128 x 128 tiles for the upper levels measured slower: trtri 4.9 vs 4.1 ms at 64 x n=2000)
+  // Tile size per level.  Rounds 1 - 3: 64 x 64 tiles at every level (128 x 128 for the upper levels measured slower then: 4.9 vs 4.1 ms
+  // at 64 x n=2000 -- a 128-wide tile multiplied the whole diagonal block of its triangular operand).  With the zeros skipped per 16 x 16
+  // sub-tile (merge_mainloop) the wide tile no longer pays for them.  Measured, fit + gradient, ms (64 x 64 everywhere / 128 x 128 from
+  // h = 1024 / 512 / 256 / 128; before the round: 12.56): 64 x n=2000 12.10 / 11.82 / 11.94 / 11.98 / 11.85; 16 x n=5000 37.83 / 37.30 / 37.51 /
+  // 37.44 (38.24); n=16000 70.95 / - / 68.16 / 68.02 (70.85); 8 x n=2000 2.006 / - / 2.083 / 2.094 (2.057): wide tiles where a level has
+  // thousands of them.  MOGP_TRTRI_WT4_FROM=<h> forces 128 x 128 tiles from level h on (a huge value: never).
+  static const int wt4_from = [] { const char* e = getenv("MOGP_TRTRI_WT4_FROM"); return e ? atoi(e) : -1; }();
+  const double alg = ((double)v.n / v.NP) * ((double)v.n / v.NP) * ((double)v.n / v.NP);
   for (int h = 64; h < v.NP; h *= 2) {
     const int nodes = (v.NP + 2 * h - 1) / (2 * h);
-    const int tpd = h / 64;
-    // algorithmic flops per node: two triangular-times-dense products of size h, h^3 flops each (h^3 / 2 multiply-adds)
+    // algorithmic flops of the level: per node two triangular-times-dense products, m2 h^2 + m2^2 h (m2 = rows of the lower block:
+    // h, less in the last node when NP is not a power of two); scaled to the n x n matrix (the levels of the padded matrix sum to NP^3 / 3)
+    double fl = 0.;
+    for (int q = 0; q < nodes; ++q) {
+      const double m2 = std::min<double>(h, (double)v.NP - (double)q * 2 * h - h);
+      if (m2 > 0) fl += m2 * h * (double)h + m2 * m2 * h;
+    }
     if (h > 64) prof_begin("trtri_merge", s);
-    hipLaunchKernelGGL((trtri_merge_kernel<2, 0>), dim3(padded_grid(v.nb, tpd * tpd * nodes)), dim3(256), smem_bytes<2>(), s, v, h, tpd, nodes);
-    hipLaunchKernelGGL((trtri_merge_kernel<2, 1>), dim3(padded_grid(v.nb, tpd * tpd * nodes)), dim3(256), smem_bytes<2>(), s, v, h, tpd, nodes);
-    // tagged with the ALGORITHMIC share: the levels sum to NP^3 / 3 on the padded matrix, the inverse of the n x n factor is n^3 / 3
-    const double alg = ((double)v.n / v.NP) * ((double)v.n / v.NP) * ((double)v.n / v.NP);
-    if (h > 64) prof_end("trtri_merge", s, (double)v.nb * nodes * 2.0 * h * h * h * alg, 0.);
+    const long wide_tiles = (long)v.nb * nodes * (h / 128) * (h / 128);
+    if (wt4_from >= 0 ? (h >= wt4_from && h >= 128) : (h >= 512 && wide_tiles >= 3000)) {
+      const int tpd = h / 128;
+      hipLaunchKernelGGL((trtri_merge_kernel<4, 0>), dim3(padded_grid(v.nb, tpd * tpd * nodes)), dim3(256), smem_bytes<4>(), s, v, h, tpd, nodes);
+      hipLaunchKernelGGL((trtri_merge_kernel<4, 1>), dim3(padded_grid(v.nb, tpd * tpd * nodes)), dim3(256), smem_bytes<4>(), s, v, h, tpd, nodes);
+    } else {
+      const int tpd = h / 64;
+      hipLaunchKernelGGL((trtri_merge_kernel<2, 0>), dim3(padded_grid(v.nb, tpd * tpd * nodes)), dim3(256), smem_bytes<2>(), s, v, h, tpd, nodes);
+      hipLaunchKernelGGL((trtri_merge_kernel<2, 1>), dim3(padded_grid(v.nb, tpd * tpd * nodes)), dim3(256), smem_bytes<2>(), s, v, h, tpd, nodes);
+    }
+    if (h > 64) prof_end("trtri_merge", s, (double)v.nb * fl * alg, 0.);
   }
 }
 

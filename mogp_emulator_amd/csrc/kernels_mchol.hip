@@ -141,7 +141,10 @@ struct PieceWait {
 // table[p] = (type << 30) | (c << 15) | r;  type 0: D(c), 1: G(s, c) with s in the r field, 2: T(r, c)
 // SOLO: the launch runs ONE workgroup per CU (chain-bound batches): the kernel may then use the whole register file of a SIMD for its one
 // wave -- the diagonal block's spills go to AGPRs instead of scratch memory
-template <bool TRACE, bool SOLO = false>
+// PAIRS: the instantiation that also holds the paired 128 x 128 bulk task (type 3, MOGP_MC_PAIR=1; a measurement switch) -- kept out of the
+// default kernels: its 128 accumulator registers per wave made the compiler spill in the task prologues of every path (632 instead
+// of ~140 bytes of scratch per lane)
+template <bool TRACE, bool SOLO = false, bool PAIRS = false>
 __global__ __launch_bounds__(256, SOLO ? 1 : 2) void mchol_kernel(BatchView v, unsigned* __restrict__ ctrl, const int* __restrict__ table, int ntasks,
                                                        int emu_stride, double* __restrict__ packs, int* __restrict__ info, int nq, int spin_limit,
                                                        int park_on, unsigned long long* __restrict__ trace, int tile_solve) {
@@ -276,7 +279,7 @@ __global__ __launch_bounds__(256, SOLO ? 1 : 2) void mchol_kernel(BatchView v, u
         __builtin_amdgcn_s_setprio(0);
         continue;
       }
-      if (type == 3) {
+      if (PAIRS && type == 3) {
         // ---- TT(R, c): BULK task over the two row tiles r, r + 1 (r even, >= 2c + 8) of block column c at once -- a 128 x 128 GEMM tile.
         // Why: a 64 x 128 tile reads (64 + 128) operand rows per 16-deep k-step for 32 MFMAs per wave; without L2 hits (free-running
         // tasks rarely share a k slice while it is cached) that is 12 bytes per clock and CU at full matrix-core rate -- more than the
@@ -614,8 +617,12 @@ void launch_mchol(const BatchView& v, unsigned* ctrl, size_t ctrl_ints, const in
   }
   if (trace_file && dtr) {
     (void)hipMemsetAsync(dtr, 0, words * 8, s);
-    hipLaunchKernelGGL(mchol_kernel<true>, dim3(grid), dim3(256), lds_doubles * sizeof(double), s, v, ctrl, table, ntasks, mchol_emu_stride(v.NP), packs,
-                       info, nq, spin_limit, park_on, dtr, tile_solve);
+    if (paired)
+      hipLaunchKernelGGL((mchol_kernel<true, false, true>), dim3(grid), dim3(256), lds_doubles * sizeof(double), s, v, ctrl, table, ntasks, mchol_emu_stride(v.NP), packs,
+                         info, nq, spin_limit, park_on, dtr, tile_solve);
+    else
+      hipLaunchKernelGGL(mchol_kernel<true>, dim3(grid), dim3(256), lds_doubles * sizeof(double), s, v, ctrl, table, ntasks, mchol_emu_stride(v.NP), packs,
+                         info, nq, spin_limit, park_on, dtr, tile_solve);
     std::vector<unsigned long long> h(words);
     (void)hipStreamSynchronize(s);
     (void)hipMemcpy(h.data(), dtr, words * 8, hipMemcpyDeviceToHost);
@@ -630,7 +637,10 @@ void launch_mchol(const BatchView& v, unsigned* ctrl, size_t ctrl_ints, const in
   }
   prof_begin("mchol", s);
   static const int solo_ok = [] { const char* e = getenv("MOGP_MC_SOLO"); return e ? atoi(e) : 1; }();
-  if (per_cu == 1 && solo_ok)
+  if (paired)
+    hipLaunchKernelGGL((mchol_kernel<false, false, true>), dim3(grid), dim3(256), lds_doubles * sizeof(double), s, v, ctrl, table, ntasks, mchol_emu_stride(v.NP), packs,
+                       info, nq, spin_limit, park_on, (unsigned long long*)nullptr, tile_solve);
+  else if (per_cu == 1 && solo_ok)
     hipLaunchKernelGGL((mchol_kernel<false, true>), dim3(grid), dim3(256), lds_doubles * sizeof(double), s, v, ctrl, table, ntasks, mchol_emu_stride(v.NP), packs,
                      info, nq, spin_limit, park_on, (unsigned long long*)nullptr, tile_solve);
   else
