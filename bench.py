@@ -307,7 +307,10 @@ def main():
     ap.add_argument("--m", type=int, default=10000, help="prediction points per emulator")
     ap.add_argument("--kernel", default="SquaredExponential")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-other-configs", action="store_true", help="skip the C4 / C5 block (other_configs)")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the C2 / C4 / C5 block (other_configs)")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="only the timed steps (+ the single-stream pass): none of the untimed extras (host-buffer predict, deriv, full_cov, "
+                         "fit_GP_MAP, pivot, tsunami) -- for kernel traces whose per-kernel averages should be those of the timed steps")
     args = ap.parse_args()
 
     # `python bench.py --gpus N` outside a launcher: start the N ranks ourselves (one process per GPU, the launch line the
@@ -441,7 +444,7 @@ def main():
                                 np.array([-2. * np.log(0.3 * np.sqrt(20))] * 20 + [0., np.log(1e-4)]), 3))
         extras["shard_sweep"] = sweep
         extras["fit_GP_MAP_15_starts_64_emulators"] = time_fit_map(M, X, T, args.kernel, nugget, 15, 10)
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not args.no_extras:
         means_h = np.zeros((B, m)); vars_h = np.zeros((B, m))
         mo.predict_variance_batch(Xs, means_h, vars_h)
         t0 = time.perf_counter()
@@ -574,7 +577,7 @@ def main():
             traffic = None
             try:
                 if (n, d, B, m, args.kernel, world) == (2000, 10, 64, 10000, "SquaredExponential", 1):
-                    with open(os.path.join(ROOT, "profiles", "r03_traffic.json")) as fh:
+                    with open(os.path.join(ROOT, "profiles", "r04_traffic.json")) as fh:
                         traffic = json.load(fh).get(dom, {}).get("traffic_bytes_per_launch")
             except (OSError, ValueError):
                 traffic = None

@@ -37,5 +37,10 @@ def run(tag, cid, n, d, B, m, kernel, nugget, theta):
     fp, _, _ = mo.eval(np.tile(theta + e, (B, 1)), grad=False); fm, _, _ = mo.eval(np.tile(theta - e, (B, 1)), grad=False)
     print("     grad[0] analytic %.8e  FD %.8e" % (g[0, p], (fp[0] - fm[0]) / (2 * h)))
 
+only = os.environ.get("ONLY", "")
+theta10 = np.array([-2. * np.log(0.3 * np.sqrt(10))] * 10 + [0.])
+if only == "C2": run("C2", 2, 2000, 10, 1, 10000, "SquaredExponential", 1e-6, theta10)          # BASELINE's single-output case
+if only == "S8": run("S8", 2, 2000, 10, 8, 10000, "SquaredExponential", 1e-6, theta10)          # the per-GPU shard of C3 on 8 GPUs
+if only in ("C2", "S8"): sys.exit(0)
 if os.environ.get("ONLY","") != "C5": run("C4", 4, 5000, 20, 16, 10000, "Matern52", "fit", np.array([-2. * np.log(0.3 * np.sqrt(20))] * 20 + [0., np.log(1e-4)]))
 if os.environ.get("ONLY","") != "C4": run("C5", 5, 16000, 8, 1, 10000, "SquaredExponential", 1e-6, np.array([-2. * np.log(0.3 * np.sqrt(8))] * 8 + [0.]))

@@ -4,8 +4,8 @@
 out=$1; shift
 cd /tmp && export TMPDIR=/tmp
 rm -rf /root/repo/gpurun_out/pmc_f /root/repo/gpurun_out/pmc_w
-env "$@" PMC_M=10000 timeout 300 rocprofv3 --pmc FETCH_SIZE -d /root/repo/gpurun_out/pmc_f -- python /root/repo/tools/pmc_step.py > /dev/null 2>&1
-env "$@" PMC_M=10000 timeout 300 rocprofv3 --pmc WRITE_SIZE -d /root/repo/gpurun_out/pmc_w -- python /root/repo/tools/pmc_step.py > /dev/null 2>&1
+env PMC_M=10000 "$@" timeout 300 rocprofv3 --pmc FETCH_SIZE -d /root/repo/gpurun_out/pmc_f -- python /root/repo/tools/pmc_step.py > /dev/null 2>&1
+env PMC_M=10000 "$@" timeout 300 rocprofv3 --pmc WRITE_SIZE -d /root/repo/gpurun_out/pmc_w -- python /root/repo/tools/pmc_step.py > /dev/null 2>&1
 cd /root/repo
 python tools/pmc_summary.py $(find gpurun_out/pmc_f gpurun_out/pmc_w -name "*.db") > "$out"
 head -6 "$out"

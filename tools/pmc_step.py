@@ -1,4 +1,4 @@
-"""One warm + one measured pass of the hot path for rocprofv3 --pmc collection (64 x n=2000 x d=10)."""
+"""Two passes of the hot path (fit + gradient, predict) for rocprofv3 --pmc collection.  env: PMC_B (64), PMC_N (2000), PMC_D (10), PMC_M (2048)."""
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -6,7 +6,7 @@ sys.path.insert(0, ROOT)
 import mogp_emulator_amd as M
 from mogp_emulator_amd.Priors import GPPriors
 from bench import synth
-n, d, B, m = 2000, 10, 64, int(os.environ.get("PMC_M", "2048"))
+n, d, B, m = (int(os.environ.get(k, v)) for k, v in (("PMC_N", 2000), ("PMC_D", 10), ("PMC_B", 64), ("PMC_M", 2048)))
 X, T, Xs = synth(2, n, d, B, m)
 theta = np.array([-2. * np.log(0.3 * np.sqrt(d))] * d + [0.])
 gp = M.MultiOutputGP_GPU(X, T, nugget=1e-6, priors=GPPriors(n_corr=d, nugget_type="fixed"))
