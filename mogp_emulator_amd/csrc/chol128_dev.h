@@ -27,7 +27,7 @@
 // owned trailing sub-blocks (independent accumulators interleaved), the owner publishes the next diagonal sub-block,
 // one barrier.
 //
-// Measured on MI355X (tools/chol128_probe.hip): see DESIGN.md section 3.  History: lane = row with pivots and multipliers
+// Measured on MI355X (tools/chol128_probe.hip): see DESIGN.md section 3 and HISTORY.md.  History: lane = row with pivots and multipliers
 // by v_readlane, 2 x 64 dependent column steps and a global-memory round trip between the halves: 58 us; first MFMA
 // version (LDS-staged load / store phases at one CU's ~10 B/cycle, MFMA results read back after every instruction): 57 us.
 #pragma once

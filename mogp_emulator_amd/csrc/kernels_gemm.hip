@@ -570,10 +570,13 @@ struct PvStepSync {
 template <int WR, int WC, bool TRI, bool SYNC>
 __global__ __launch_bounds__(64 * WR * WC, (WR * WC >= 8 ? 4 : 2)) void predict_var_w_kernel(
     BatchView v, const double* __restrict__ Ks, int MP, int nti, int ntj, double* __restrict__ partial, int lgc, int desc, unsigned* __restrict__ sync,
-    int sync_spins) {
+    int sync_spins, int single) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   using C = WCfg<128, 128, WR, WC>;
-  const int npairs = (nti + 1) / 2;
+  // single (launches of fewer than a few rounds of workgroups, e.g. ONE emulator): a workgroup takes one row tile instead of a complementary
+  // pair, longest tiles first in dispatch order -- equally long pair tasks that fill the device 1.23 times cost two full rounds (C2,
+  // m = 10^4: 632 tasks on 512 slots), unequal single tiles dealt longest-first pack to within a tile of the average
+  const int npairs = single ? nti : (nti + 1) / 2;
   const int SC = 1 << lgc, SR = 64 >> lgc;           // super-tile = SR pairs x SC column tiles
   const int nsr = (npairs + SR - 1) / SR, nsc = (ntj + SC - 1) / SC;
   const int t = threadIdx.x, lane = t & 63, wave = TRI ? __builtin_amdgcn_readfirstlane(t >> 6) : (t >> 6);
@@ -595,7 +598,7 @@ __global__ __launch_bounds__(64 * WR * WC, (WR * WC >= 8 ? 4 : 2)) void predict_
   const double* Li = v.Linv + (size_t)emu * v.MS;
   const double* K = Ks + (size_t)z * MP * ld;
   const int j0 = tj * 128;
-  const int ti_long = nti - 1 - pr, ti_short = pr;
+  const int ti_long = nti - 1 - pr, ti_short = single ? ti_long : pr;
   PvStepSync sy{sync + (size_t)z * (nsr * nsc) + st, (unsigned)(min(SR, npairs - (st / nsc) * SR) * min(SC, ntj - (st % nsc) * SC)), 0, sync_spins, 0u};
   // K* traffic: the long row tile walks k UP from 0, the short one DOWN to 0.  All workgroups of a super-tile are equally long
   // (nti + 1 blocks of 128) and start together, so at block step s every long pass is at k = s and every short pass at
@@ -794,9 +797,21 @@ void launch_predict_var(const BatchView& v, const double* Ks, int m, int MP, dou
   // (default: with the lock-step only -- free-running it changes neither time nor traffic).
   static const int sync_spins = [] { const char* e = getenv("MOGP_PV_SYNC"); return e ? std::max(0, std::min(atoi(e), 0xffff)) : 0; }();
   static const int desc = [] { const char* e = getenv("MOGP_PV_DESC"); return e ? atoi(e) : (sync_spins > 0 ? 1 : 0); }();
+  // MOGP_PV_SINGLE = 0 / 1 forces pairs / single row tiles; default: single row tiles when the pair tasks fill the device fewer than twice.
+  // Measured (predict incl. host copies, m = 10^4, ms, pairs / single): 1 x n=2000 1.080 / 1.031, 2 x 1.82 / 1.84, 3 x 2.44 / 2.50, 4 x 3.05 /
+  // 3.27, 1 x n=5000 5.36 / 4.86, 1 x n=700 (m = 3000) 0.213 / 0.187; bit-identical
+  static const int force_single = [] { const char* e = getenv("MOGP_PV_SINGLE"); return e ? atoi(e) : -1; }();
+  static const int n_cu_dev = [] {
+    int dev = 0, n = 256;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+    return n;
+  }();
   {
     const int SC = 1 << lgc, SR = 64 >> lgc;
     const int nst = (((nti + 1) / 2 + SR - 1) / SR) * ((ntj + SC - 1) / SC);
+    const long pair_tasks = (long)v.nb * ((nti + 1) / 2) * ntj;
+    const bool single = sync_spins == 0 && (force_single >= 0 ? force_single != 0 : pair_tasks < 2L * 2 * n_cu_dev);
     // the super-tile counters sit behind the partial sums (predict_sync_words)
     unsigned* sync = reinterpret_cast<unsigned*>(partial + (size_t)v.nb * nti * MP);
     if (sync_spins > 0) (void)hipMemsetAsync(sync, 0, (size_t)v.nb * nst * sizeof(unsigned), s);
@@ -806,10 +821,14 @@ void launch_predict_var(const BatchView& v, const double* Ks, int m, int MP, dou
       (void)hipGetDevice(&dev);
       (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
       hipLaunchKernelGGL((predict_var_w_kernel<2, 4, true, true>), dim3(std::min(2 * n_cu, v.nb * nst * 64)), dim3(512), smem_bytes<4>(), s, v, Ks, MP, nti, ntj, partial,
-                         lgc, desc, sync, sync_spins);
+                         lgc, desc, sync, sync_spins, 0);
+    } else if (single) {
+      const int nst1 = ((nti + SR - 1) / SR) * ((ntj + SC - 1) / SC);
+      hipLaunchKernelGGL((predict_var_w_kernel<2, 4, true, false>), dim3(padded_grid(v.nb, nst1 * 64)), dim3(512), smem_bytes<4>(), s, v, Ks, MP, nti, ntj, partial, lgc,
+                         0, sync, 0, 1);
     } else
       hipLaunchKernelGGL((predict_var_w_kernel<2, 4, true, false>), dim3(padded_grid(v.nb, nst * 64)), dim3(512), smem_bytes<4>(), s, v, Ks, MP, nti, ntj, partial, lgc,
-                         desc, sync, sync_spins);
+                         desc, sync, sync_spins, 0);
   }
   prof_end("predict_var", s, (double)v.nb * (double)m * v.n * v.n, 0.);
   hipLaunchKernelGGL(predict_var_finish_kernel, dim3((m + 255) / 256, v.nb), dim3(256), 0, s, v, partial, m, MP, nti, var, var_ld);

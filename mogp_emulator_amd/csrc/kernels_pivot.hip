@@ -17,7 +17,7 @@
 // that were never chosen hold, below the diagonal, what the factorisation left there -- the interchanged input entries
 // minus the rank-64 updates of the COMPLETED block columns (for n <= 64: the input entries, as the unblocked dpstf2) -- and the
 // diagonal l_{r-1,r-1} / ((r+1)(r+2)...(i+1)); the forward substitution of the right-hand-side rows is continued through
-// that block so that rows n.. of A hold L^-1 [t, H] for the complete factor (pstrf_tail_kernel).
+// that block so that rows n.. of A hold L^-1 [t, H] for the complete factor (pstrf_tail_kernel, HISTORY.md section 3d).
 #include <cfloat>
 #include <cmath>
 #include <cstdlib>

@@ -563,13 +563,15 @@ print("SWITCH-OK", repr(float(f[0])))
 
 @pytest.mark.parametrize("env", [{"MOGP_CHOL": "mchol"}, {"MOGP_CHOL": "mchol", "MOGP_MC_WGS": "2", "MOGP_MC_PARK": "1"},
                                  {"MOGP_CHOL": "mchol", "MOGP_MC_WGS": "2", "MOGP_MC_PARK": "0"}, {"MOGP_MCHOL": "0"}, {"MOGP_CHOL": "mchol", "MOGP_MC_TILE": "0"}, {"MOGP_CHOL": "mchol", "MOGP_MC_SOLO": "0"},
+                                 {"MOGP_CHOL": "mchol", "MOGP_MC_SLAB": "0"}, {"MOGP_CHOL": "mchol", "MOGP_MC_PAIR": "1"}, {"MOGP_CHOL": "mchol", "MOGP_MC_PAIR": "1", "MOGP_MC_WGS": "2"},
+                                 {"MOGP_TRTRI_WT4_FROM": "128"}, {"MOGP_TRTRI_WT4_FROM": "100000"},
                                  {"MOGP_CHOL": "la"}, {"MOGP_CHOL": "left"}, {"MOGP_CHOL": "left", "MOGP_GROUPS": "1"},
                                  {"MOGP_CHOL": "right"}, {"MOGP_CHOL": "right", "MOGP_OUTER": "128"}, {"MOGP_TAIL": "0"},
                                  {"MOGP_BACKSOLVE": "1"}, {"MOGP_WAITVAL": "0"}, {"MOGP_CHOL": "la", "MOGP_WAITVAL": "1"}, {"MOGP_KS_BUDGET_GB": "0.05"},
                                  {"MOGP_PV_SYNC": "1000"}, {"MOGP_PV_SYNC": "1"}, {"MOGP_PV_SYNC": "1000", "MOGP_PV_DESC": "0"}, {"MOGP_PV_DESC": "1"}],
                          ids=lambda e: ",".join(k + "=" + v for k, v in e.items()))
 def test_cholesky_schedules_and_switches(env):
-    """Every A/B switch libmogp_hip.so still reads goes through the C2 full-size parity check in its own
+    """Every A/B switch libmogp_hip.so still reads (HISTORY.md section 5) goes through the C2 full-size parity check in its own
     process (the library reads its environment once); with the Cholesky schedule forced, batching is bit-invisible."""
     import subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -675,6 +677,63 @@ def test_one_launch_cholesky_abort_falls_back_to_the_multi_launch_schedule():
     out = subprocess.run([sys.executable, "-c", script], env=dict(os.environ, MOGP_CHOL="mchol", MOGP_MC_SPIN="0"), capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "MC-ABORTS" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
     assert int(out.stdout.split("MC-ABORTS")[1].split()[0]) > 0, "the forced timeouts never happened: the fallback was not exercised"
+
+
+def test_in_kernel_hand_offs_are_bit_stable_under_uneven_load():
+    """The hand-offs inside the one-launch Cholesky and the chained back substitution (write-through stores, drained, then a relaxed
+    agent-scope flag; consumers never touch an address before its final value is published) rest on an argument, not on acquire /
+    release fences.  This is the mechanical check MI355X_MICROARCH.md prescribes: every hand-off under UNEVEN load, every
+    word compared.  Both kernels are bit-reproducible by construction (fixed k order per tile), so ONE stale word anywhere shows up as a bit
+    difference: 60 evaluations of 24 x n=1000 (three per XCD queue, two workgroups per CU) and 60 of 3 x n=1300 (single queue, one workgroup
+    per CU) while a second engine on another stream keeps part of the chip busy with predictions of varying size; the log-posteriors,
+    alpha and the whole factor of two emulators must equal the undisturbed first evaluation bit for bit, and no launch may have aborted."""
+    import ctypes
+    import threading
+    lib = _capi.load()
+
+    def aborts():
+        c = ctypes.c_longlong()
+        lib.mogp_profile_counter(b"mchol_aborts", ctypes.byref(c))
+        t = ctypes.c_longlong()
+        lib.mogp_profile_counter(b"backsolve_timeouts", ctypes.byref(t))
+        return c.value + t.value
+    Xn, Tn, Xsn = synth(77, 1500, 6, 6, 3000)
+    noise = M.MultiOutputGP_GPU(Xn, Tn, nugget=1e-6, priors=weak(6, 1e-6))
+    noise.fit(np.tile(np.array([1.0] * 6 + [0.]), (6, 1)))
+    stop = threading.Event()
+
+    def make_noise():
+        k = 0
+        while not stop.is_set():
+            m = (300, 3000, 900, 1700)[k % 4]                       # bursts of different length: the load on the CUs keeps changing
+            noise.predict(Xsn[:m], deriv=False)
+            k += 1
+    a0 = aborts()
+    for n, d, B in ((1000, 5, 24), (1300, 4, 3)):
+        X, T, _ = synth(500 + n, n, d, B, 4)
+        theta = np.tile(np.array([-2. * np.log(0.3 * np.sqrt(d))] * d + [0.]), (B, 1)) + 0.02 * np.arange(B)[:, None]
+        mo = M.MultiOutputGP_GPU(X, T, nugget=1e-6, priors=weak(d, 1e-6))
+
+        def snapshot():
+            f, _, ok = mo._mogp_gpu.eval(theta, grad=False)
+            assert ok.all()
+            mo.fit(theta)
+            return f.copy(), [mo.emulators[k].L.copy() for k in (0, B - 1)], [mo.emulators[k].Kinv_t.copy() for k in (0, B - 1)]
+        f0, L0, a0_ = snapshot()
+        th = threading.Thread(target=make_noise)
+        th.start()
+        try:
+            for it in range(60):
+                f, L, a = snapshot()
+                assert np.array_equal(f, f0), "log-posterior differs in evaluation %d (n=%d)" % (it, n)
+                for k in range(2):
+                    assert np.array_equal(L[k], L0[k]), "factor differs in evaluation %d (n=%d)" % (it, n)
+                    assert np.array_equal(a[k], a0_[k]), "alpha differs in evaluation %d (n=%d)" % (it, n)
+        finally:
+            stop.set()
+            th.join()
+            stop.clear()
+    assert aborts() == a0, "a bounded wait gave up under load"
 
 
 def test_backsolve_chain_timeout_is_retried_not_reported_as_failure():

@@ -1,4 +1,4 @@
-"""Context for the numbers in DESIGN.md: the same linear algebra through PyTorch-ROCm's vendor path (rocSOLVER / rocBLAS /
+"""Context for the numbers in DESIGN.md / HISTORY.md: the same linear algebra through PyTorch-ROCm's vendor path (rocSOLVER / rocBLAS /
 hipSOLVER via torch.linalg) on the benchmark shape -- 64 matrices of n=2000, fp64.  Not part of the product or the tests."""
 import sys, time
 import numpy as np
