@@ -371,22 +371,34 @@ __global__ __launch_bounds__(256) void combine_rows_kernel(BatchView v, const do
 // alpha = Linv^T y (fit+gradient path, Linv already available): alpha_i = sum_{i<=k<n} Linv[k][i] y_k.
 // One workgroup per 64-column strip; the 4 waves split the k range, rows are 512-byte coalesced reads.
 __global__ __launch_bounds__(256) void alpha_linv_kernel(BatchView v) {
-  __shared__ double red[4][64];
+  // a workgroup takes 128 columns of L^-1, a lane two of them (16-byte loads: 8-byte accesses run at 0.54 - 0.70 of that rate on this
+  // part), a wave every fourth row; sixteen loads in flight per lane
+  __shared__ double red[4][128];
+  typedef double a2 __attribute__((ext_vector_type(2)));
   const int emu = slot_emu(v.idx, blockIdx.y);
   const int ld = v.LD, n = v.n, R = v.R;
   const double* Li = v.Linv + (size_t)emu * v.MS;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int i0 = blockIdx.x * 64, i = i0 + lane;
+  const int i0 = blockIdx.x * 128, i = i0 + 2 * lane;
   for (int r = 0; r < R; ++r) {
     const double* y = v.A + (size_t)emu * v.MS + (size_t)(n + r) * ld;
-    double s = 0.;
+    a2 s = {0., 0.};
     if (i0 < n) {
-#pragma unroll 8
-      for (int k = i0 + wave; k < n; k += 4) s = __builtin_fma(Li[(size_t)k * ld + i], y[k], s);   // Linv[k][i] = 0 for k < i
+#pragma unroll 16
+      for (int k = i0 + wave; k < n; k += 4) {                 // Linv[k][i] = 0 for k < i
+        const a2 l = *reinterpret_cast<const a2*>(Li + (size_t)k * ld + i);
+        const double yk = y[k];
+        s[0] = __builtin_fma(l[0], yk, s[0]);
+        s[1] = __builtin_fma(l[1], yk, s[1]);
+      }
     }
-    red[wave][lane] = s;
+    red[wave][2 * lane] = s[0];
+    red[wave][2 * lane + 1] = s[1];
     __syncthreads();
-    if (wave == 0) v.Z[((size_t)emu * R + r) * ld + i] = (i < n) ? red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane] : 0.0;
+    if (threadIdx.x < 128) {
+      const int c = i0 + (int)threadIdx.x, t = threadIdx.x;
+      v.Z[((size_t)emu * R + r) * ld + c] = (c < n) ? red[0][t] + red[1][t] + red[2][t] + red[3][t] : 0.0;
+    }
     __syncthreads();
   }
 }
@@ -538,7 +550,7 @@ void launch_backsolve(const BatchView& v, hipStream_t s) {
 }
 
 void launch_alpha_from_linv(const BatchView& v, hipStream_t s) {
-  hipLaunchKernelGGL(alpha_linv_kernel, dim3(v.NP / 64, v.nb), dim3(256), 0, s, v);
+  hipLaunchKernelGGL(alpha_linv_kernel, dim3(v.NP / 128, v.nb), dim3(256), 0, s, v);
 }
 
 void launch_loo_variance(const BatchView& v, double* out, int out_ld, hipStream_t s) {

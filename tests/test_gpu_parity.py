@@ -15,7 +15,7 @@ import pytest
 from numpy.testing import assert_allclose
 
 import mogp_emulator_amd as M
-from mogp_emulator_amd import LibGPGPU
+from mogp_emulator_amd import LibGPGPU, _capi
 from mogp_emulator_amd.Priors import GPPriors, InvGammaPrior
 from oracle import cpu_ref as R
 from conftest import load_golden
@@ -684,7 +684,7 @@ def test_in_kernel_hand_offs_are_bit_stable_under_uneven_load():
     agent-scope flag; consumers never touch an address before its final value is published) rest on an argument, not on acquire /
     release fences.  This is the mechanical check MI355X_MICROARCH.md prescribes: every hand-off under UNEVEN load, every
     word compared.  Both kernels are bit-reproducible by construction (fixed k order per tile), so ONE stale word anywhere shows up as a bit
-    difference: 60 evaluations of 24 x n=1000 (three per XCD queue, two workgroups per CU) and 60 of 3 x n=1300 (single queue, one workgroup
+    difference: 150 evaluations of 24 x n=1000 (three per XCD queue, two workgroups per CU) and 150 of 3 x n=1300 (single queue, one workgroup
     per CU) while a second engine on another stream keeps part of the chip busy with predictions of varying size; the log-posteriors,
     alpha and the whole factor of two emulators must equal the undisturbed first evaluation bit for bit, and no launch may have aborted."""
     import ctypes
@@ -723,7 +723,7 @@ def test_in_kernel_hand_offs_are_bit_stable_under_uneven_load():
         th = threading.Thread(target=make_noise)
         th.start()
         try:
-            for it in range(60):
+            for it in range(150):
                 f, L, a = snapshot()
                 assert np.array_equal(f, f0), "log-posterior differs in evaluation %d (n=%d)" % (it, n)
                 for k in range(2):
