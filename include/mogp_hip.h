@@ -213,8 +213,6 @@ int mogp_kernel_eval(int kernel_type, int what, const double* x1, int n1, const 
 /* when enabled, HIP events are recorded on the launch stream around every launch of the tagged kernels */
 int mogp_profile_enable(int on);
 int mogp_profile_reset(void);
-/* the commit the library was built from: "<7 hex digits>", "<commit>-dirty" when the kernel sources differed from it, "unknown" */
-const char* mogp_build_commit(void);
 /* force the Cholesky schedule (0 two emulator groups, 1 right-looking, 3 look-ahead, 4 one launch / task queue, 5 the multi-launch
    schedule the library would pick without the one-launch kernel, -1 the library's choice) and / or
    serialise it onto one stream, so that the HIP-event time of a kernel is its time alone on the device */

@@ -128,7 +128,6 @@ SIGNATURES = {
     "mogp_profile_schedule": (c_int, [c_int, c_int]),
     "mogp_profile_get": (c_int, [c_char_p, c_double_p, POINTER(c_longlong), c_double_p, c_double_p]),
     "mogp_profile_counter": (c_int, [c_char_p, POINTER(c_longlong)]),
-    "mogp_build_commit": (c_char_p, []),
     "mogp_mchol_task_table": (c_int, [c_int, c_int_p, c_int]),
     "mogp_mchol_task_table_paired": (c_int, [c_int, c_int_p, c_int]),
     "mogp_dev_malloc": (c_void_p, [c_ulonglong]),

@@ -1,6 +1,6 @@
 """File the outputs of tools/jobs/r4_final.sh (gpurun_out/final_<commit>/) under profiles/r04_<commit>_* with explanatory headers and derive
 profiles/r04_traffic.json (what bench.py reports as roofline.traffic).  usage: collect_profiles.py <commit>
-REFUSES when <commit> is not the checked-out HEAD or the library that ran the job was not built from it (mogp_build_commit)."""
+REFUSES when <commit> is not the checked-out HEAD or the library that ran the job was not built from it (mogp_emulator_amd/libmogp_hip.build, written by the Makefile)."""
 import json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1]

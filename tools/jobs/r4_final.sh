@@ -8,7 +8,7 @@ TAG=${TAG:-head}
 O=$R/gpurun_out/final_$TAG
 rm -rf $O; mkdir -p $O
 cd $R
-python -c "from mogp_emulator_amd import _capi; print(_capi.load().mogp_build_commit().decode())" > $O/build_commit.txt; cat $O/build_commit.txt
+cp mogp_emulator_amd/libmogp_hip.build $O/build_commit.txt; cat $O/build_commit.txt        # written by the Makefile next to the library
 # 1. the GPU suite + smoke
 timeout 2400 python -m pytest tests -m gpu -x -q --durations=10 2>&1 | tail -22 > $O/gpu_tests.txt
 tail -3 $O/gpu_tests.txt
