@@ -372,19 +372,19 @@ __global__ __launch_bounds__(256, 2) void trtri_merge_kernel(BatchView v, int h,
 // [0, E) -- each the dense straight-line step restricted to that set; waves meet at the step barriers whatever their set.
 // TRI: 0 every column sub-tile; 1 pairs j <= i; 2 pairs j < i (diagonal tiles: b <= a for the wave's residues).
 // All skipped products are exact zeros or never read: the sums of the products that remain are unchanged (bit-identical entries).
-template <int TRI>
-__device__ __forceinline__ void kinv_mainloop(const double* __restrict__ Ag, const double* __restrict__ Bg, int ld, int nk, v4d (&acc)[4][4],
+template <int WT, int TRI>
+__device__ __forceinline__ void kinv_mainloop(const double* __restrict__ Ag, const double* __restrict__ Bg, int ld, int nk, v4d (&acc)[WT][WT],
                                               double* smem, int wr, int wc) {
-  using C = Cfg<4>;
+  using C = Cfg<WT>;
   const int lane = threadIdx.x & 63;
   const int fr = lane & 15, fk = lane >> 4;
   const size_t stepA = (size_t)BK * ld;
   v2d ra[C::CH], rb[C::CH];
-  const unsigned offA = g2r_off<4, false>(ld);
-  g2r<4, false>(Ag, ld, offA, ra);
-  g2r<4, false>(Bg, ld, offA, rb);
-  r2s<4, false>(smem, ra);
-  r2s<4, false>(smem + C::OPSZ, rb);
+  const unsigned offA = g2r_off<WT, false>(ld);
+  g2r<WT, false>(Ag, ld, offA, ra);
+  g2r<WT, false>(Bg, ld, offA, rb);
+  r2s<WT, false>(smem, ra);
+  r2s<WT, false>(smem + C::OPSZ, rb);
   __syncthreads();
   auto step = [&](int kt, auto E_) {
     constexpr int E = decltype(E_)::value;
@@ -394,14 +394,14 @@ __device__ __forceinline__ void kinv_mainloop(const double* __restrict__ Ag, con
     if (more) {
       Ag += stepA;
       Bg += stepA;
-      g2r<4, false>(Ag, ld, offA, ra);
-      g2r<4, false>(Bg, ld, offA, rb);
+      g2r<WT, false>(Ag, ld, offA, ra);
+      g2r<WT, false>(Bg, ld, offA, rb);
     }
-    constexpr int JN = (TRI == 0) ? 4 : ((TRI == 1) ? E : E - 1);      // column sub-tiles any active row sub-tile pairs with
+    constexpr int JN = (TRI == 0) ? WT : ((TRI == 1) ? E : E - 1);      // column sub-tiles any active row sub-tile pairs with
     if (E > 0 && JN > 0) {
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) {
-        double a[4], b[4];
+        double a[WT], b[WT];
         const int k = kk * 4 + fk;
 #pragma unroll
         for (int i = 0; i < E; ++i) a[i] = sA[k * C::LDM + (2 * i + wr) * 16 + fr];
@@ -416,23 +416,29 @@ __device__ __forceinline__ void kinv_mainloop(const double* __restrict__ Ag, con
     }
     if (more) {
       double* dA = smem + ((kt + 1) & 1) * 2 * C::OPSZ;
-      r2s<4, false>(dA, ra);
-      r2s<4, false>(dA + C::OPSZ, rb);
+      r2s<WT, false>(dA, ra);
+      r2s<WT, false>(dA + C::OPSZ, rb);
     }
     __syncthreads();
   };
+  static_assert(WT == 2 || WT == 4, "phase list written for two or four sub-tiles per wave");
   // row sub-tile a = 2 i + wr has non-zeros from step kd = a on
   int kt = 0;
   for (const int end = min(nk, wr); kt < end; ++kt) step(kt, std::integral_constant<int, 0>());
   for (const int end = min(nk, 2 + wr); kt < end; ++kt) step(kt, std::integral_constant<int, 1>());
-  for (const int end = min(nk, 4 + wr); kt < end; ++kt) step(kt, std::integral_constant<int, 2>());
-  for (const int end = min(nk, 6 + wr); kt < end; ++kt) step(kt, std::integral_constant<int, 3>());
-  for (; kt < nk; ++kt) step(kt, std::integral_constant<int, 4>());
+  if (WT == 4) {
+    for (const int end = min(nk, 4 + wr); kt < end; ++kt) step(kt, std::integral_constant<int, 2>());
+    for (const int end = min(nk, 6 + wr); kt < end; ++kt) step(kt, std::integral_constant<int, 3>());
+  }
+  for (; kt < nk; ++kt) step(kt, std::integral_constant<int, WT>());
 }
 
+// WT = 4: 128 x 128 tiles; WT = 2: 64 x 64 tiles for launches whose 128-tiles would not fill the device (one or a few emulators: the
+// longest tile alone, 125 k-steps at n = 2000, then bounds the kernel)
+template <int WT>
 __global__ __launch_bounds__(256, 2) void kinv_kernel(BatchView v, int ntiles, int kend) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
-  using C = Cfg<4>;
+  using C = Cfg<WT>;
   int z, tile;
   decode_block(v.nb, ntiles, z, tile);
   if (z >= v.nb) return;
@@ -447,23 +453,24 @@ __global__ __launch_bounds__(256, 2) void kinv_kernel(BatchView v, int ntiles, i
   const int i0 = ti * C::BM, j0 = tj * C::BM;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wr = wave >> 1, wc = wave & 1;
-  v4d acc[4][4];
+  v4d acc[WT][WT];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < WT; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (v4d){0., 0., 0., 0.};
+    for (int j = 0; j < WT; ++j) acc[i][j] = (v4d){0., 0., 0., 0.};
   const double* Ag = Li + (size_t)i0 * ld + i0;
   const double* Bg = Li + (size_t)i0 * ld + j0;
   const int nk = (kend - i0) / BK;
+  if (nk <= 0) return;
   // (entry (row sub-tile 2 i + wr, column sub-tile 2 j + wc) of the tile; a diagonal tile keeps the pairs b <= a)
   const int tri = (ti != tj) ? 0 : (wr < wc ? 2 : 1);
-  if (tri == 0) kinv_mainloop<0>(Ag, Bg, ld, nk, acc, smem, wr, wc);
-  else if (tri == 1) kinv_mainloop<1>(Ag, Bg, ld, nk, acc, smem, wr, wc);
-  else kinv_mainloop<2>(Ag, Bg, ld, nk, acc, smem, wr, wc);
+  if (tri == 0) kinv_mainloop<WT, 0>(Ag, Bg, ld, nk, acc, smem, wr, wc);
+  else if (tri == 1) kinv_mainloop<WT, 1>(Ag, Bg, ld, nk, acc, smem, wr, wc);
+  else kinv_mainloop<WT, 2>(Ag, Bg, ld, nk, acc, smem, wr, wc);
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < WT; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < WT; ++j) {
       if (tri == 0 || (tri == 1 && j <= i) || (tri == 2 && j < i)) {
 #pragma unroll
         for (int r = 0; r < 4; ++r)
@@ -773,11 +780,25 @@ void launch_trtri_merges(const BatchView& v, hipStream_t s) {
 }
 
 void launch_kinv(const BatchView& v, hipStream_t s) {
+  const int kend = ((v.n + 15) / 16) * 16;
   const int nt = (v.n + 127) / 128;      // tiles that contain real rows
   const int ntiles = nt * (nt + 1) / 2;
-  const int kend = ((v.n + 15) / 16) * 16;
+  // 64 x 64 tiles when the 128 x 128 ones would fill the device less than twice (MOGP_KINV_WT = 2 / 4 forces either)
+  static const int force_wt = [] { const char* e = getenv("MOGP_KINV_WT"); return e ? atoi(e) : 0; }();
+  static const int n_cu_dev = [] {
+    int dev = 0, n = 256;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+    return n;
+  }();
+  const bool small = force_wt ? force_wt == 2 : ((long)v.nb * ntiles < 2L * 2 * n_cu_dev);
   prof_begin("kinv", s);
-  hipLaunchKernelGGL(kinv_kernel, dim3(padded_grid(v.nb, ntiles)), dim3(256), smem_bytes<4>(), s, v, ntiles, kend);
+  if (small) {
+    const int nt2 = (v.n + 63) / 64;
+    const int ntiles2 = nt2 * (nt2 + 1) / 2;
+    hipLaunchKernelGGL(kinv_kernel<2>, dim3(padded_grid(v.nb, ntiles2)), dim3(256), smem_bytes<2>(), s, v, ntiles2, kend);
+  } else
+    hipLaunchKernelGGL(kinv_kernel<4>, dim3(padded_grid(v.nb, ntiles)), dim3(256), smem_bytes<4>(), s, v, ntiles, kend);
   prof_end("kinv", s, (double)v.nb * (double)v.n * v.n * v.n / 3.0, 0.);
 }
 

@@ -486,7 +486,15 @@ __global__ __launch_bounds__(256, SOLO ? 1 : 2) void mchol_kernel(BatchView v, u
         auto pub = [&](int b) {
           if (t == 0) stu(rowprog + r, 8u * (unsigned)c + (unsigned)b + 1u);
         };
-        if (!trsm128_lds_dev<true, false, true>(v, c0, r0, pk, emu, 0, lds, wait, pub)) return;
+        // Late block columns of chain-bound launches: the task's own GEMM ends AFTER the diagonal block has finished (per-task stamps: pack
+        // seen 10 - 24 us after D).  The pipelined form then still fetches every row-block image behind its (satisfied) wait, one exposed
+        // memory round trip per block step: 15 us per solve against 8 - 9 with the images requested two steps ahead.
+        const int prog = mc_wait_min3(cx, ddone + c, ddone + c, ddone + c, 0u);
+        if (prog < 0) return;
+        if (prog >= 8 && (tile_solve & 32)) {
+          mc_stamp<TRACE>(tr, 8);
+          trsm128_lds_dev<true, true, false>(v, c0, r0, pk, emu, 0, lds, TrsmNoWait(), pub);
+        } else if (!trsm128_lds_dev<true, false, true>(v, c0, r0, pk, emu, 0, lds, wait, pub)) return;
       } else {
         if (mc_wait_min3(cx, ddone + c, ddone + c, ddone + c, 8u, tr) < 0) return;
         mc_stamp<TRACE>(tr, 8);
@@ -597,7 +605,8 @@ void launch_mchol(const BatchView& v, unsigned* ctrl, size_t ctrl_ints, const in
     const char* e = getenv("MOGP_MC_TILE");
     const char* f = getenv("MOGP_MC_NOTRAFFIC");
     const char* g = getenv("MOGP_MC_SLAB");          // 0: the half-tile stage of round 3 (trsm128_tile_dev) instead of the re-deal (trsm128_tile2_dev)
-    return ((e ? atoi(e) : 1) & 1) | ((f && atoi(f)) ? 2 : 0) | ((!g || atoi(g)) ? 4 : 0);
+    return ((e ? atoi(e) : 1) & 1) | ((f && atoi(f)) ? 2 : 0) | ((!g || atoi(g)) ? 4 : 0) |
+           ((!getenv("MOGP_MC_LATE") || atoi(getenv("MOGP_MC_LATE"))) ? 32 : 0);      // 0: chain tasks always solve in the pipelined form
   }();
 
   (void)hipMemsetAsync(ctrl, 0, ctrl_ints * sizeof(unsigned), s);

@@ -56,7 +56,9 @@ struct TrsmNoPub {
 template <bool SC1_OUT = false, bool DEEP = false, bool PIPE = false, class WAIT = TrsmNoWait, class PUB = TrsmNoPub>
 __device__ __forceinline__ bool trsm128_lds_dev(const BatchView& v, int c0, int r0, const double* __restrict__ pk, int emu, int rowblock,
                                                 double* lds, WAIT wait = WAIT(), PUB pub = PUB()) {
-  constexpr bool PUBLISH = PIPE && !std::is_same<PUB, TrsmNoPub>::value;
+  // (PUB without PIPE -- with DEEP: the pack is complete, the images are requested two steps ahead, and the solved rows are still
+  // published piece by piece for the next diagonal block: a chain task whose GEMM ended after its diagonal block had finished)
+  constexpr bool PUBLISH = (PIPE || DEEP) && !std::is_same<PUB, TrsmNoPub>::value;
   Sc1Buf ab;
   if (SC1_OUT) ab = sc1_buf(v.A + (size_t)emu * v.MS, (unsigned)(v.MS * sizeof(double)));
   const int ld = v.LD;
