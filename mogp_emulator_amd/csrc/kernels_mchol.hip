@@ -444,6 +444,53 @@ __global__ __launch_bounds__(256, SOLO ? 1 : 2) void mchol_kernel(BatchView v, u
           __builtin_amdgcn_s_setprio(0);
           continue;
         }
+        if (urgent && (tile_solve & 69) == 69) {
+          // chain task, round 4: x = C - acc stays in registers and is re-dealt to the solving waves through LDS (trsm128_tile2_chain_dev)
+          // instead of being written back and re-read by the pipelined solve
+          {
+            const int lane = t & 63, wave = t >> 6, wr = wave >> 1, wc = wave & 1;
+            const double* pc0 = A + (size_t)(r0 + wr * 32 + (lane >> 4)) * ld + (c0 + wc * 64 + (lane & 15));
+            double cv[2][4][4];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+              for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) cv[i][j][q] = pc0[(size_t)(i * 16 + 4 * q) * ld + j * 16];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+              for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[i][j][q] = cv[i][j][q] - acc[i][j][q];
+          }
+          mc_stamp<TRACE>(tr, 4);
+          bool first = true;
+          auto wait = [&](int b) {
+            const bool ok = mc_wait_min3(cx, ddone + c, ddone + c, ddone + c, (unsigned)(b + 1), tr) >= 0;
+            if (first) mc_stamp<TRACE>(tr, 8);
+            first = false;
+            return ok;
+          };
+          auto pub = [&](int b) {
+            if (t == 0) stu(rowprog + r, 8u * (unsigned)c + (unsigned)b + 1u);
+          };
+          const int prog = mc_wait_min3(cx, ddone + c, ddone + c, ddone + c, 0u);
+          if (prog < 0) return;
+          if (prog >= 8 && (tile_solve & 32)) {
+            mc_stamp<TRACE>(tr, 8);
+            trsm128_tile2_chain_dev<true, true>(v, c0, r0, pk, emu, lds, acc, TrsmNoWait(), pub);
+          } else if (!trsm128_tile2_chain_dev<true, false>(v, c0, r0, pk, emu, lds, acc, wait, pub)) return;
+          drain_stores();
+          __syncthreads();
+          if (t == 0) {
+            stu(rowprog + r, 8u * (unsigned)(c + 1));
+            stu(rowdone + r, (unsigned)(c + 1));
+          }
+          mc_stamp<TRACE>(tr, 5);
+          __builtin_amdgcn_s_setprio(0);
+          continue;
+        }
         // C -= acc.  All 32 loads of a thread first, then the stores: written as load / subtract / store per element the
         // compiler keeps program order between a store and the next load (they might alias), and the write-back of a 64 KB
         // tile was 32 dependent memory round trips (23 - 31 us per task, tools/mchol_trace.py).
@@ -606,7 +653,8 @@ void launch_mchol(const BatchView& v, unsigned* ctrl, size_t ctrl_ints, const in
     const char* f = getenv("MOGP_MC_NOTRAFFIC");
     const char* g = getenv("MOGP_MC_SLAB");          // 0: the half-tile stage of round 3 (trsm128_tile_dev) instead of the re-deal (trsm128_tile2_dev)
     return ((e ? atoi(e) : 1) & 1) | ((f && atoi(f)) ? 2 : 0) | ((!g || atoi(g)) ? 4 : 0) |
-           ((!getenv("MOGP_MC_LATE") || atoi(getenv("MOGP_MC_LATE"))) ? 32 : 0);      // 0: chain tasks always solve in the pipelined form
+           ((!getenv("MOGP_MC_LATE") || atoi(getenv("MOGP_MC_LATE"))) ? 32 : 0) |
+           ((!getenv("MOGP_MC_CHAINX") || atoi(getenv("MOGP_MC_CHAINX"))) ? 64 : 0);      // 0: chain tasks write x back and solve from global memory      // 0: chain tasks always solve in the pipelined form
   }();
 
   (void)hipMemsetAsync(ctrl, 0, ctrl_ints * sizeof(unsigned), s);

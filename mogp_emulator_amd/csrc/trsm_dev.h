@@ -292,6 +292,106 @@ __device__ __forceinline__ void trsm128_tile2_dev(const BatchView& v, int c0, in
   if (stamps && t == 0) stamps[2] = __builtin_amdgcn_s_memrealtime();
 }
 
+// The re-dealt solve for a CHAIN task (round 4): x never goes to global memory -- it is re-dealt as in trsm128_tile2_dev -- and the block
+// steps follow the diagonal block that is still being factored (LATE = false: wait(b) as in trsm128_lds_dev<PIPE>, image b requested behind
+// its wait) or, when that block has already finished (LATE = true), run with the images requested two steps ahead.  pub(b) after the 16
+// columns of block step b are visible (b = 0 .. 6), as trsm128_lds_dev<PUB>.  Before: x written back (32 stores per lane, drain, barrier)
+// and re-read by the solve as 16-byte pieces: ~5 us of the row-band path that is one of the two critical paths of a single-matrix
+// factorisation (HISTORY.md).  Same arithmetic in the same order: bit-identical.  Returns false when the launch has been aborted.
+template <bool SC1_OUT, bool LATE, class WAIT, class PUB>
+__device__ __forceinline__ bool trsm128_tile2_chain_dev(const BatchView& v, int c0, int r0, const double* __restrict__ pk, int emu, double* lds,
+                                                        const v4d_t (&x)[2][4], WAIT wait, PUB pub) {
+  Sc1Buf ab;
+  if (SC1_OUT) ab = sc1_buf(v.A + (size_t)emu * v.MS, (unsigned)(v.MS * sizeof(double)));
+  const int ld = v.LD;
+  const int t = mogp_tid(), lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int g = lane >> 4, i = lane & 15;
+  const int wr = wave >> 1, wc = wave & 1;
+  double* slab = v.A + (size_t)emu * v.MS + (size_t)(r0 + wave * 16) * ld + c0;   // 16 rows x 128 columns
+  double* pkb[2] = {lds, lds + TL_PK};
+  double* ts = lds + 2 * TL_PK + wave * TL_TS;
+  const double* LT = pk + PACK128_LT;
+  const int sr0 = lane >> 3, sp = (lane & 7) * 2;
+  v2d_p pr[2][4], pinv[2];
+  auto pack_request = [&](int b) {
+    const int u = b & 1;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int ch = t + 256 * q;
+      if (ch < 128 * b) pr[u][q] = *reinterpret_cast<const v2d_p*>(LT + (size_t)(ch >> 3) * 128 + 16 * b + (ch & 7) * 2);
+    }
+    if (t < 128) pinv[u] = *reinterpret_cast<const v2d_p*>(pk + PACK128_INV + b * 256 + 2 * t);
+  };
+  auto pack_deposit = [&](int b, double* img) {
+    const int u = b & 1;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int ch = t + 256 * q;
+      if (ch < 128 * b) *reinterpret_cast<v2d_p*>(img + (ch >> 3) * 16 + (ch & 7) * 2) = pr[u][q];
+    }
+    if (t < 128) *reinterpret_cast<v2d_p*>(img + 112 * 16 + 2 * t) = pinv[u];
+  };
+#pragma unroll
+  for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) lds[((2 * wr + ii) * 8 + 4 * wc + j) * TL_TS17 + (g + 4 * q) * 17 + i] = x[ii][j][q];
+  __syncthreads();
+  v4d_t T[8];
+#pragma unroll
+  for (int b = 0; b < 8; ++b)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) T[b][r] = lds[(wave * 8 + b) * TL_TS17 + i * 17 + g + 4 * r];
+  if (LATE) {
+    pack_request(0);
+    pack_request(1);
+  } else {
+    if (!wait(0)) return false;        // (contains barriers: every wave has taken its slab by the time the image is written)
+    pack_request(0);
+  }
+  __syncthreads();
+  pack_deposit(0, pkb[0]);
+  __syncthreads();
+  v4d_t X[8];
+#pragma unroll
+  for (int b = 0; b < 8; ++b) {
+    const double* img = pkb[b & 1];
+    if (LATE && b + 2 < 8) pack_request(b + 2);
+    v4d_t Tb = T[b];
+#pragma unroll
+    for (int a = 0; a < b; ++a)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Tb = __builtin_amdgcn_mfma_f64_16x16x4f64(-img[(16 * a + g + 4 * r) * 16 + i], X[a][r], Tb, 0, 0, 0);
+    const double* inv = img + 112 * 16;
+    X[b] = (v4d_t){0., 0., 0., 0.};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) X[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(inv[(g + 4 * r) * 16 + i], Tb[r], X[b], 0, 0, 0);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) ts[i * 18 + g + 4 * r] = X[b][r];
+    __builtin_amdgcn_wave_barrier();
+    {
+      const v2d_p o0 = *reinterpret_cast<const v2d_p*>(ts + sr0 * 18 + sp);
+      const v2d_p o1 = *reinterpret_cast<const v2d_p*>(ts + (sr0 + 8) * 18 + sp);
+      st16<SC1_OUT>(ab, slab + (size_t)sr0 * ld + 16 * b + sp, o0);
+      st16<SC1_OUT>(ab, slab + (size_t)(sr0 + 8) * ld + 16 * b + sp, o1);
+    }
+    if (b < 7) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      pub(b);
+      if (!LATE) {
+        if (!wait(b + 1)) return false;
+        pack_request(b + 1);
+      }
+      pack_deposit(b + 1, pkb[(b + 1) & 1]);
+    }
+    __syncthreads();
+  }
+  return true;
+}
+
 // stamps (analysis only, MOGP_MC_TRACE): [0] after the first barrier, [1] after block step 3, [2] after block step 7
 template <bool SC1_OUT>
 __device__ __forceinline__ void trsm128_tile_dev(const BatchView& v, int c0, int r0, const double* __restrict__ pk, int emu, double* lds,
