@@ -144,7 +144,11 @@ struct PieceWait {
 // PAIRS: the instantiation that also holds the paired 128 x 128 bulk task (type 3, MOGP_MC_PAIR=1; a measurement switch) -- kept out of the
 // default kernels: its 128 accumulator registers per wave made the compiler spill in the task prologues of every path (632 instead
 // of ~140 bytes of scratch per lane)
-template <bool TRACE, bool SOLO = false, bool PAIRS = false>
+// LEGACY: the instantiation that still holds the round-3 forms behind MOGP_MC_TILE=0 / MOGP_MC_SLAB=0 / MOGP_MC_CHAINX=0 (x written back and
+// solved from global memory, the half-tile stage).  The default kernels are compiled without them: in this one function every extra path
+// costs registers in ALL paths (an experiment that added one more GEMM instantiation took the 64 x n=2000 launch from 3.9 to 5.4 ms through
+// spills alone, round 4).
+template <bool TRACE, bool SOLO = false, bool PAIRS = false, bool LEGACY = false>
 __global__ __launch_bounds__(256, SOLO ? 1 : 2) void mchol_kernel(BatchView v, unsigned* __restrict__ ctrl, const int* __restrict__ table, int ntasks,
                                                        int emu_stride, double* __restrict__ packs, int* __restrict__ info, int nq, int spin_limit,
                                                        int park_on, unsigned long long* __restrict__ trace, int tile_solve) {
@@ -375,7 +379,7 @@ __global__ __launch_bounds__(256, SOLO ? 1 : 2) void mchol_kernel(BatchView v, u
         }
         mc_stamp<TRACE>(tr, 3);
         draw_next();
-        if (!urgent && (tile_solve & 5) == 5) {
+        if (!urgent && (LEGACY ? (tile_solve & 5) == 5 : true)) {
           // bulk task, round 4: the tile is re-dealt to the solving waves through LDS BEFORE the solve (trsm128_tile2_dev); the first
           // pack images are requested before the C tile is read
           if (mc_wait_min3(cx, ddone + c, ddone + c, ddone + c, 8u, tr) < 0) return;       // (a formality for a bulk task)
@@ -411,7 +415,7 @@ __global__ __launch_bounds__(256, SOLO ? 1 : 2) void mchol_kernel(BatchView v, u
           __builtin_amdgcn_s_setprio(0);
           continue;
         }
-        if (!urgent && (tile_solve & 1)) {
+        if (LEGACY && !urgent && (tile_solve & 1)) {
           // bulk task: the tile C - acc goes to the panel solve through LDS, not through global memory (trsm128_tile_dev)
           const int lane = t & 63, wave = t >> 6, wr = wave >> 1, wc = wave & 1;
           const double* pc0 = A + (size_t)(r0 + wr * 32 + (lane >> 4)) * ld + (c0 + wc * 64 + (lane & 15));
@@ -444,7 +448,7 @@ __global__ __launch_bounds__(256, SOLO ? 1 : 2) void mchol_kernel(BatchView v, u
           __builtin_amdgcn_s_setprio(0);
           continue;
         }
-        if (urgent && (tile_solve & 69) == 69) {
+        if (urgent && (LEGACY ? (tile_solve & 69) == 69 : true)) {
           // chain task, round 4: x = C - acc stays in registers and is re-dealt to the solving waves through LDS (trsm128_tile2_chain_dev)
           // instead of being written back and re-read by the pipelined solve
           {
@@ -661,7 +665,7 @@ void launch_mchol(const BatchView& v, unsigned* ctrl, size_t ctrl_ints, const in
   const int nq = (v.nb % 8 == 0) ? 8 : 1;
   // one workgroup per CU is enforced through the LDS request: more than half of the 160 KB
   const size_t lds_doubles = (per_cu == 1 ? (size_t)11 * 1024 : 0) + MC_LDS_HDR + std::max<size_t>({(size_t)WCfg<64, 128, 2, 2>::SMEM_DOUBLES, (size_t)TRSM128L_LDS, (size_t)C128_LDS_PRE_DOUBLES,
-                                                                                                                   (tile_solve & 1) ? (size_t)TRSM128T_LDS : (size_t)0,
+                                                                                                                   (size_t)TRSM128T_LDS,
                                                                                                                    paired ? (size_t)WCfg<128, 128, 2, 2>::SMEM_DOUBLES : (size_t)0});
   const int total = ntasks * v.nb;
   const int grid = std::min(per_cu * n_cu, total);
@@ -669,13 +673,15 @@ void launch_mchol(const BatchView& v, unsigned* ctrl, size_t ctrl_ints, const in
   static const char* trace_file = getenv("MOGP_MC_TRACE");
   const size_t words = (size_t)total * MC_TRW;
   unsigned long long* dtr = nullptr;
-  if (trace_file) {
+  // the round-3 forms live in their own instantiations (LEGACY); the traced kernel is the default one (or the paired one)
+  const bool legacy = (tile_solve & 69) != 69;
+  if (trace_file && !(legacy && !paired)) {
     if (hipMalloc(reinterpret_cast<void**>(&dtr), words * 8) != hipSuccess) dtr = nullptr;   // no room for the stamps: factorise untraced
   }
   if (trace_file && dtr) {
     (void)hipMemsetAsync(dtr, 0, words * 8, s);
     if (paired)
-      hipLaunchKernelGGL((mchol_kernel<true, false, true>), dim3(grid), dim3(256), lds_doubles * sizeof(double), s, v, ctrl, table, ntasks, mchol_emu_stride(v.NP), packs,
+      hipLaunchKernelGGL((mchol_kernel<true, false, true, true>), dim3(grid), dim3(256), lds_doubles * sizeof(double), s, v, ctrl, table, ntasks, mchol_emu_stride(v.NP), packs,
                          info, nq, spin_limit, park_on, dtr, tile_solve);
     else
       hipLaunchKernelGGL(mchol_kernel<true>, dim3(grid), dim3(256), lds_doubles * sizeof(double), s, v, ctrl, table, ntasks, mchol_emu_stride(v.NP), packs,
@@ -695,8 +701,14 @@ void launch_mchol(const BatchView& v, unsigned* ctrl, size_t ctrl_ints, const in
   prof_begin("mchol", s);
   static const int solo_ok = [] { const char* e = getenv("MOGP_MC_SOLO"); return e ? atoi(e) : 1; }();
   if (paired)
-    hipLaunchKernelGGL((mchol_kernel<false, false, true>), dim3(grid), dim3(256), lds_doubles * sizeof(double), s, v, ctrl, table, ntasks, mchol_emu_stride(v.NP), packs,
+    hipLaunchKernelGGL((mchol_kernel<false, false, true, true>), dim3(grid), dim3(256), lds_doubles * sizeof(double), s, v, ctrl, table, ntasks, mchol_emu_stride(v.NP), packs,
                        info, nq, spin_limit, park_on, (unsigned long long*)nullptr, tile_solve);
+  else if (legacy && per_cu == 1 && solo_ok)
+    hipLaunchKernelGGL((mchol_kernel<false, true, false, true>), dim3(grid), dim3(256), lds_doubles * sizeof(double), s, v, ctrl, table, ntasks, mchol_emu_stride(v.NP), packs,
+                     info, nq, spin_limit, park_on, (unsigned long long*)nullptr, tile_solve);
+  else if (legacy)
+    hipLaunchKernelGGL((mchol_kernel<false, false, false, true>), dim3(grid), dim3(256), lds_doubles * sizeof(double), s, v, ctrl, table, ntasks, mchol_emu_stride(v.NP), packs,
+                     info, nq, spin_limit, park_on, (unsigned long long*)nullptr, tile_solve);
   else if (per_cu == 1 && solo_ok)
     hipLaunchKernelGGL((mchol_kernel<false, true>), dim3(grid), dim3(256), lds_doubles * sizeof(double), s, v, ctrl, table, ntasks, mchol_emu_stride(v.NP), packs,
                      info, nq, spin_limit, park_on, (unsigned long long*)nullptr, tile_solve);
