@@ -27,6 +27,11 @@
 // owned trailing sub-blocks (independent accumulators interleaved), the owner publishes the next diagonal sub-block,
 // one barrier.
 //
+// Round 4: the 16 columns of a block step run as four GROUPS of four (c128_column_groups below; the column-at-a-time form
+// described above is kept as c128_column_steps, -DC128_RANK1): all four k-slices of the MFMA carry a column, the 4 x 4 diagonal
+// piece of a group is factored on the vector ALU.  Stand-alone kernel 34.9 -> 27.3 us (column steps 18.7 -> 12.0 us of it), the
+// diagonal-block task of the one-launch Cholesky 27.7 -> 20.8 us.
+//
 // Measured on MI355X (tools/chol128_probe.hip): see DESIGN.md section 3 and HISTORY.md.  History: lane = row with pivots and multipliers
 // by v_readlane, 2 x 64 dependent column steps and a global-memory round trip between the halves: 58 us; first MFMA
 // version (LDS-staged load / store phases at one CU's ~10 B/cycle, MFMA results read back after every instruction): 57 us.
@@ -170,6 +175,69 @@ __device__ __forceinline__ void c128_column_steps(c128_v4d& Dn, c128_v4d& Xn, c1
   }
   rs_last = rs;
 }
+
+// The same 16 columns in four GROUPS of four (the default; -DC128_RANK1 keeps the column-at-a-time form above): the four k-slices of
+// one MFMA carry four columns, so a group costs 2 + 2 NSLOT MFMAs instead of 4 (1 + NSLOT).  Per group g (columns j0 = 4g .. j0+3):
+//   * the 4 x 4 diagonal piece G of the group -- register g of the lanes (rg, cl = j0 + b) -- is fetched with v_readlane and factored
+//     on the vector ALU with wave-uniform values (G = L44 L44^T: four dependent reciprocal square roots);
+//   * lane (rg, cl) forms W[cl][rg], W = inv(L44), by forward substitution on the unit vector e_rg (lanes cl >= 4: zero);
+//   * rows j0 .. j0+3 of the symmetric accumulator ARE the MFMA's B operand as they lie (k = rg): one MFMA with A = -W gives
+//     L[cl][j0 + rg] = sum_m W[rg][m] D[j0 + m][cl] in output register 0 -- exactly the layout of the rank-4 update's operands --,
+//     and the same MFMA on the carried sub-blocks gives their four solved columns;
+//   * D += V V^T, X += V UX^T, Y += V UY^T: one MFMA each with all four k-slices used (skipped after the last group).
+// The arithmetic differs from the column-at-a-time recurrence by the explicit 4 x 4 inverse (the panel solve below the block uses
+// explicit 16 x 16 inverses of the same matrices) and by the MFMA's summation of four products at once.
+template <int NSLOT>
+__device__ __forceinline__ void c128_column_groups(c128_v4d& Dn, c128_v4d& Xn, c128_v4d& Yn, c128_v4d& Lv, c128_v4d& UX, c128_v4d& UY, double& rs_last,
+                                                   int rg, int cl) {
+  const c128_v4d zero4 = {0., 0., 0., 0.};
+  const double e0 = rg == 0 ? 1.0 : 0.0, e1 = rg == 1 ? 1.0 : 0.0, e2 = rg == 2 ? 1.0 : 0.0, e3 = rg == 3 ? 1.0 : 0.0;
+  const double c0 = cl == 0 ? -1.0 : 0.0, c1 = cl == 1 ? -1.0 : 0.0, c2 = cl == 2 ? -1.0 : 0.0, c3 = cl == 3 ? -1.0 : 0.0;
+  double rs3 = 1.0;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int j0 = 4 * g;
+    const double g00 = -readlane_f64(Dn[g], j0), g10 = -readlane_f64(Dn[g], 16 + j0), g11 = -readlane_f64(Dn[g], 16 + j0 + 1);
+    const double g20 = -readlane_f64(Dn[g], 32 + j0), g21 = -readlane_f64(Dn[g], 32 + j0 + 1), g22 = -readlane_f64(Dn[g], 32 + j0 + 2);
+    const double g30 = -readlane_f64(Dn[g], 48 + j0), g31 = -readlane_f64(Dn[g], 48 + j0 + 1), g32 = -readlane_f64(Dn[g], 48 + j0 + 2),
+                 g33 = -readlane_f64(Dn[g], 48 + j0 + 3);
+    const double rs0 = rsqrt_fast(g00);
+    const double l10 = g10 * rs0, l20 = g20 * rs0, l30 = g30 * rs0;
+    const double rs1 = rsqrt_fast(__builtin_fma(-l10, l10, g11));
+    const double l21 = __builtin_fma(-l20, l10, g21) * rs1, l31 = __builtin_fma(-l30, l10, g31) * rs1;
+    const double rs2 = rsqrt_fast(__builtin_fma(-l21, l21, __builtin_fma(-l20, l20, g22)));
+    const double l32 = __builtin_fma(-l31, l21, __builtin_fma(-l30, l20, g32)) * rs2;
+    rs3 = rsqrt_fast(__builtin_fma(-l32, l32, __builtin_fma(-l31, l31, __builtin_fma(-l30, l30, g33))));
+    // column rg of W = inv(L44)
+    const double w0 = e0 * rs0;
+    const double w1 = __builtin_fma(-l10, w0, e1) * rs1;
+    const double w2 = __builtin_fma(-l21, w1, __builtin_fma(-l20, w0, e2)) * rs2;
+    const double w3 = __builtin_fma(-l32, w2, __builtin_fma(-l31, w1, __builtin_fma(-l30, w0, e3))) * rs3;
+    const double nW = __builtin_fma(c3, w3, __builtin_fma(c2, w2, __builtin_fma(c1, w1, c0 * w0)));     // -W[cl][rg]
+    __builtin_amdgcn_sched_barrier(0);
+    const c128_v4d oD = __builtin_amdgcn_mfma_f64_16x16x4f64(nW, Dn[g], zero4, 0, 0, 0);
+    const c128_v4d oX = __builtin_amdgcn_mfma_f64_16x16x4f64(nW, Xn[g], zero4, 0, 0, 0);
+    c128_v4d oY = zero4;
+    if (NSLOT > 1) oY = __builtin_amdgcn_mfma_f64_16x16x4f64(nW, Yn[g], zero4, 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    Lv[g] = oD[0];
+    UX[g] = oX[0];
+    if (NSLOT > 1) UY[g] = oY[0];
+    if (g < 3) {
+      Dn = __builtin_amdgcn_mfma_f64_16x16x4f64(oD[0], oD[0], Dn, 0, 0, 0);
+      Xn = __builtin_amdgcn_mfma_f64_16x16x4f64(oD[0], oX[0], Xn, 0, 0, 0);
+      if (NSLOT > 1) Yn = __builtin_amdgcn_mfma_f64_16x16x4f64(oD[0], oY[0], Yn, 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  rs_last = rs3;
+}
+
+#ifdef C128_RANK1
+#define C128_COLUMNS c128_column_steps
+#else
+#define C128_COLUMNS c128_column_groups
+#endif
 
 // A: origin of the 128 x 128 block (row stride ld); only its lower triangle is read.  On return A holds L (upper
 // triangle of the two 64 x 64 diagonal tiles zeroed), pk the pack above, *info_slot = c0 + 1 if it was 0 and the block is not
@@ -338,11 +406,11 @@ __device__ __forceinline__ bool chol128_dev(double* __restrict__ A, int ld, doub
         if (b < 3 && p1) X = R1[b < 3 ? b : 0];
         if (inv) X = nident;                 // (inv implies !p1)
         c128_v4d Y = R2[b];                  // r2 >= 4 > b
-        c128_column_steps<2>(Dn, X, Y, Lv, UX, UY, rs_last, rg, cl);
+        C128_COLUMNS<2>(Dn, X, Y, Lv, UX, UY, rs_last, rg, cl);
       } else {
         // one slot: sub-block (r2, b), or the inverse in the wave that owns the diagonal sub-block
         c128_v4d X = p2 ? R2[b] : nident, Y = zero4;
-        c128_column_steps<1>(Dn, X, Y, Lv, UX, UY, rs_last, rg, cl);
+        C128_COLUMNS<1>(Dn, X, Y, Lv, UX, UY, rs_last, rg, cl);
         UY = UX;                             // uniform naming below: UY belongs to block row r2
       }
       C128_STAMPW(4 * b + 1);
@@ -419,9 +487,11 @@ __device__ __forceinline__ bool chol128_dev(double* __restrict__ A, int ld, doub
       }
     }
     if (b == 7) break;
-    // rank-16 update of the owned sub-blocks to the right of block column b.  Branch-free: sub-blocks the wave does
-    // not own (k > r) are updated with a zero operand, so that no control flow touches an accumulator; with k == r the
-    // A operand is the wave's own panel sub-block, i.e. the symmetric update of the diagonal sub-block.
+    C128_STAMPW(32 + 4 * b);
+    // rank-16 update of the owned sub-blocks to the right of block column b.  All operands are requested from the LDS image
+    // first; sub-blocks the wave does not own (k > r) are skipped with wave-uniform branches (wave 0 -- block rows 0 and 7 -- is
+    // the longest in every block step: 7 - b sub-blocks instead of 10 - b issued); with k == r the A operand is the wave's own
+    // panel sub-block, i.e. the symmetric update of the diagonal sub-block.
     {
       double bo1[4], bo2[4];
       const double* pb1 = Sb + (16 * r1 + cl) * C128_LD + rg;
@@ -431,20 +501,26 @@ __device__ __forceinline__ bool chol128_dev(double* __restrict__ A, int ld, doub
         bo1[s] = pb1[4 * s];
         bo2[s] = pb2[4 * s];
       }
+      double aa[7][4];
 #pragma unroll
       for (int k = b + 1; k < 8; ++k) {
         const double* pa = Sb + (16 * k + cl) * C128_LD + rg;
-        double ak[4];
 #pragma unroll
-        for (int s = 0; s < 4; ++s) ak[s] = pa[4 * s];
-        if (k < 4) {
+        for (int s = 0; s < 4; ++s) aa[k - b - 1][s] = pa[4 * s];
+      }
 #pragma unroll
-          for (int s = 0; s < 4; ++s) R1[k < 4 ? k : 0] = __builtin_amdgcn_mfma_f64_16x16x4f64(k <= r1 ? ak[s] : 0.0, bo1[s], R1[k < 4 ? k : 0], 0, 0, 0);
+      for (int k = b + 1; k < 8; ++k) {
+        if (k < 4 && k <= r1) {
+#pragma unroll
+          for (int s = 0; s < 4; ++s) R1[k < 4 ? k : 0] = __builtin_amdgcn_mfma_f64_16x16x4f64(aa[k - b - 1][s], bo1[s], R1[k < 4 ? k : 0], 0, 0, 0);
         }
+        if (k <= r2) {
 #pragma unroll
-        for (int s = 0; s < 4; ++s) R2[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(k <= r2 ? ak[s] : 0.0, bo2[s], R2[k], 0, 0, 0);
+          for (int s = 0; s < 4; ++s) R2[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(aa[k - b - 1][s], bo2[s], R2[k], 0, 0, 0);
+        }
       }
     }
+    C128_STAMPW(33 + 4 * b);
     // the owner of the next diagonal sub-block publishes it
     {
       const bool own = (b + 1 < 4) ? (r1 == b + 1) : (r2 == b + 1);
@@ -455,6 +531,7 @@ __device__ __forceinline__ bool chol128_dev(double* __restrict__ A, int ld, doub
       }
     }
     __syncthreads();
+    C128_STAMPW(34 + 4 * b);
     C128_STAMP(3 + 2 * b);
   }
   // wave 0 took part in every block step: its last reciprocal square root is NaN iff some pivot was not a positive finite number

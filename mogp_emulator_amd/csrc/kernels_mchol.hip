@@ -357,7 +357,8 @@ __global__ __launch_bounds__(256, SOLO ? 1 : 2) void mchol_kernel(BatchView v, u
       const int r0 = 64 * r;
       // tasks of the dependent chain (diagonal tiles, the two row blocks of the next diagonal block) issue ahead of the
       // workgroup they share the CU with
-      const bool urgent = r < 2 * c + 4;
+      // (tile_solve bits 8, 9: 4 + 2 x rows below the diagonal block are chain tasks -- chain-bound launches take three pairs)
+      const bool urgent = LEGACY ? r < 2 * c + 4 : r < 2 * c + 4 + 2 * ((tile_solve >> 8) & 3);
       if (urgent) __builtin_amdgcn_s_setprio(2);
       const int kend = c;
       if (kend > 0) {
@@ -366,16 +367,36 @@ __global__ __launch_bounds__(256, SOLO ? 1 : 2) void mchol_kernel(BatchView v, u
         for (int i = 0; i < 2; ++i)
 #pragma unroll
           for (int j = 0; j < 4; ++j) acc[i][j] = (v4d){0., 0., 0., 0.};
-        int kb = 0;
-        while (kb < kend) {
-          mc_stamp<TRACE>(tr, 1);
-          int m = mc_wait_min3(cx, rowdone + r, rowdone + 2 * c, rowdone + 2 * c + 1, (unsigned)(kb + 1), tr);
-          if (m < 0) return;
-          mc_stamp<TRACE>(tr, 2);
-          m = m < kend ? m : kend;
-          mainloop_pf<64, 128, 2, 2, MC_PD>(A + (size_t)r0 * ld + 128 * kb, ld, A + (size_t)c0 * ld + 128 * kb, ld, 8 * (m - kb), acc, lds,
-                                            (use_park && !urgent) ? cuword : nullptr, shi + 2, 1 << 14, (tile_solve & 2) ? 3 : -1);
-          kb = m;
+        if (LEGACY || !(tile_solve & 128)) {
+          int kb = 0;
+          while (kb < kend) {
+            mc_stamp<TRACE>(tr, 1);
+            int m = mc_wait_min3(cx, rowdone + r, rowdone + 2 * c, rowdone + 2 * c + 1, (unsigned)(kb + 1), tr);
+            if (m < 0) return;
+            mc_stamp<TRACE>(tr, 2);
+            m = m < kend ? m : kend;
+            mainloop_pf<64, 128, 2, 2, MC_PD>(A + (size_t)r0 * ld + 128 * kb, ld, A + (size_t)c0 * ld + 128 * kb, ld, 8 * (m - kb), acc, lds,
+                                              (use_park && !urgent) ? cuword : nullptr, shi + 2, 1 << 14, (tile_solve & 2) ? 3 : -1);
+            kb = m;
+          }
+        } else {
+          // The k range is consumed in 16-column PIECES as they become visible (rowprog counts them: whole block columns of finished
+          // tiles plus what a chain task has published of the tile it is solving), MC_PD pieces at a time.  Why: every tile of block
+          // column c needs the rows of the diagonal block -- the chain tasks of column c-1 -- for its last 128 columns; waiting for those
+          // tiles to be complete put the whole 8-step GEMM (13 us on one CU) behind them, in the dependent chain of the next column
+          // (per-task stamps of one n = 2000 matrix: operands 1.2 us after the chain task, GEMM 13.4, solve 16.4 = the 34 us period).
+          int ks = 0;
+          const int kse = 8 * kend;
+          while (ks < kse) {
+            mc_stamp<TRACE>(tr, 1);
+            int have = mc_wait_min3(cx, rowprog + r, rowprog + 2 * c, rowprog + 2 * c + 1, (unsigned)(ks + MC_PD), tr);
+            if (have < 0) return;
+            mc_stamp<TRACE>(tr, 2);
+            have = (have < kse ? have : kse) & ~(MC_PD - 1);
+            mainloop_pf<64, 128, 2, 2, MC_PD>(A + (size_t)r0 * ld + 16 * ks, ld, A + (size_t)c0 * ld + 16 * ks, ld, have - ks, acc, lds,
+                                              (use_park && !urgent) ? cuword : nullptr, shi + 2, 1 << 14, (tile_solve & 2) ? 3 : -1);
+            ks = have;
+          }
         }
         mc_stamp<TRACE>(tr, 3);
         draw_next();
@@ -657,9 +678,12 @@ void launch_mchol(const BatchView& v, unsigned* ctrl, size_t ctrl_ints, const in
     const char* f = getenv("MOGP_MC_NOTRAFFIC");
     const char* g = getenv("MOGP_MC_SLAB");          // 0: the half-tile stage of round 3 (trsm128_tile_dev) instead of the re-deal (trsm128_tile2_dev)
     return ((e ? atoi(e) : 1) & 1) | ((f && atoi(f)) ? 2 : 0) | ((!g || atoi(g)) ? 4 : 0) |
-           ((!getenv("MOGP_MC_LATE") || atoi(getenv("MOGP_MC_LATE"))) ? 32 : 0) |
-           ((!getenv("MOGP_MC_CHAINX") || atoi(getenv("MOGP_MC_CHAINX"))) ? 64 : 0);      // 0: chain tasks write x back and solve from global memory      // 0: chain tasks always solve in the pipelined form
+           ((!getenv("MOGP_MC_LATE") || atoi(getenv("MOGP_MC_LATE"))) ? 32 : 0) |         // 0: chain tasks always solve in the pipelined form
+           ((!getenv("MOGP_MC_CHAINX") || atoi(getenv("MOGP_MC_CHAINX"))) ? 64 : 0) |     // 0: chain tasks write x back and solve from global memory
+           ((!getenv("MOGP_MC_PIECES") || atoi(getenv("MOGP_MC_PIECES"))) ? 128 : 0);     // 0: a GEMM task waits for whole tiles of its last block column
   }();
+  // MOGP_MC_URG = 0 / 1 / 2: two, four or six row tiles below the diagonal block are chain tasks (pipelined solve, pieces published)
+  static const int force_urg = [] { const char* e = getenv("MOGP_MC_URG"); return e ? atoi(e) & 3 : -1; }();
 
   (void)hipMemsetAsync(ctrl, 0, ctrl_ints * sizeof(unsigned), s);
   const int nq = (v.nb % 8 == 0) ? 8 : 1;
@@ -675,6 +699,7 @@ void launch_mchol(const BatchView& v, unsigned* ctrl, size_t ctrl_ints, const in
   unsigned long long* dtr = nullptr;
   // the round-3 forms live in their own instantiations (LEGACY); the traced kernel is the default one (or the paired one)
   const bool legacy = (tile_solve & 69) != 69;
+  const int ts = tile_solve | ((force_urg >= 0 ? force_urg : (rho < 1.0 ? 2 : 0)) << 8);
   if (trace_file && !(legacy && !paired)) {
     if (hipMalloc(reinterpret_cast<void**>(&dtr), words * 8) != hipSuccess) dtr = nullptr;   // no room for the stamps: factorise untraced
   }
@@ -682,10 +707,10 @@ void launch_mchol(const BatchView& v, unsigned* ctrl, size_t ctrl_ints, const in
     (void)hipMemsetAsync(dtr, 0, words * 8, s);
     if (paired)
       hipLaunchKernelGGL((mchol_kernel<true, false, true, true>), dim3(grid), dim3(256), lds_doubles * sizeof(double), s, v, ctrl, table, ntasks, mchol_emu_stride(v.NP), packs,
-                         info, nq, spin_limit, park_on, dtr, tile_solve);
+                         info, nq, spin_limit, park_on, dtr, ts);
     else
       hipLaunchKernelGGL(mchol_kernel<true>, dim3(grid), dim3(256), lds_doubles * sizeof(double), s, v, ctrl, table, ntasks, mchol_emu_stride(v.NP), packs,
-                         info, nq, spin_limit, park_on, dtr, tile_solve);
+                         info, nq, spin_limit, park_on, dtr, ts);
     std::vector<unsigned long long> h(words);
     (void)hipStreamSynchronize(s);
     (void)hipMemcpy(h.data(), dtr, words * 8, hipMemcpyDeviceToHost);
@@ -702,19 +727,19 @@ void launch_mchol(const BatchView& v, unsigned* ctrl, size_t ctrl_ints, const in
   static const int solo_ok = [] { const char* e = getenv("MOGP_MC_SOLO"); return e ? atoi(e) : 1; }();
   if (paired)
     hipLaunchKernelGGL((mchol_kernel<false, false, true, true>), dim3(grid), dim3(256), lds_doubles * sizeof(double), s, v, ctrl, table, ntasks, mchol_emu_stride(v.NP), packs,
-                       info, nq, spin_limit, park_on, (unsigned long long*)nullptr, tile_solve);
+                       info, nq, spin_limit, park_on, (unsigned long long*)nullptr, ts);
   else if (legacy && per_cu == 1 && solo_ok)
     hipLaunchKernelGGL((mchol_kernel<false, true, false, true>), dim3(grid), dim3(256), lds_doubles * sizeof(double), s, v, ctrl, table, ntasks, mchol_emu_stride(v.NP), packs,
-                     info, nq, spin_limit, park_on, (unsigned long long*)nullptr, tile_solve);
+                     info, nq, spin_limit, park_on, (unsigned long long*)nullptr, ts);
   else if (legacy)
     hipLaunchKernelGGL((mchol_kernel<false, false, false, true>), dim3(grid), dim3(256), lds_doubles * sizeof(double), s, v, ctrl, table, ntasks, mchol_emu_stride(v.NP), packs,
-                     info, nq, spin_limit, park_on, (unsigned long long*)nullptr, tile_solve);
+                     info, nq, spin_limit, park_on, (unsigned long long*)nullptr, ts);
   else if (per_cu == 1 && solo_ok)
     hipLaunchKernelGGL((mchol_kernel<false, true>), dim3(grid), dim3(256), lds_doubles * sizeof(double), s, v, ctrl, table, ntasks, mchol_emu_stride(v.NP), packs,
-                     info, nq, spin_limit, park_on, (unsigned long long*)nullptr, tile_solve);
+                     info, nq, spin_limit, park_on, (unsigned long long*)nullptr, ts);
   else
     hipLaunchKernelGGL(mchol_kernel<false>, dim3(grid), dim3(256), lds_doubles * sizeof(double), s, v, ctrl, table, ntasks, mchol_emu_stride(v.NP), packs,
-                     info, nq, spin_limit, park_on, (unsigned long long*)nullptr, tile_solve);
+                     info, nq, spin_limit, park_on, (unsigned long long*)nullptr, ts);
   const double n = v.n;                 // ALGORITHMIC work (n^3 / 3 per emulator), not the padded NP the tiles cover
   prof_end("mchol", s, (double)v.nb * n * n * n / 3.0, (double)v.nb * 8.0 * n * n);
 }

@@ -1,0 +1,42 @@
+"""
+ORACLE -- TEST INFRASTRUCTURE ONLY.  Not part of the product path.
+
+The likelihood part of the negative log-posterior (GaussianProcess.py:657-685 with H = n x 0:
+0.5 (t^T K^-1 t + log|K| + n log 2 pi)) of a GIVEN fp64 matrix K and targets t, evaluated in 80-bit long double
+(numpy longdouble on x86-64: 64-bit mantissa, ~2000 x finer than fp64) by an unblocked-in-the-block Cholesky without BLAS.
+
+Why it exists: for the ill-conditioned matrices GP fits produce (cond(K) ~ 1e9 with a 1e-6 nugget) two backward-stable fp64
+factorisations of the same K differ from the exact value -- and from each other -- by ~1e-3 cond(K) eps.  LAPACK's own result sits
+1e-11 ... 5e-10 (relative) from the exact one at n = 1500, d = 6 (tools/logpost_truth.py), so "rtol 1e-10 against LAPACK" is a
+tighter bar than LAPACK itself meets.  The tests that run such matrices compare the device result AND the fp64 oracle with this
+value, to a tolerance stated in units of cond(K) eps.
+"""
+import numpy as np
+
+
+def loglike_longdouble(K, T, nb=64):
+    """K: (n, n) fp64 SPD matrix (nugget already on the diagonal); T: (B, n) targets.  Returns a longdouble array (B,)."""
+    n = K.shape[0]
+    A = np.asarray(K, dtype=np.longdouble)
+    L = np.zeros_like(A)
+    for c in range(0, n, nb):
+        e = min(c + nb, n)
+        S = A[c:, c:e] - L[c:, :c] @ L[c:e, :c].T
+        for j in range(e - c):
+            S[j, j] = np.sqrt(S[j, j])
+            S[j + 1:, j] /= S[j, j]
+            S[j + 1:, j + 1:e - c] -= np.outer(S[j + 1:, j], S[j + 1:e - c, j])
+        L[c:, c:e] = S
+        L[c:e, c:e] = np.tril(S[:e - c])
+    logdet = 2 * np.sum(np.log(np.diag(L)))
+    T = np.atleast_2d(np.asarray(T, dtype=np.longdouble))
+    Y = T.T.copy()                                   # forward substitution for all right-hand sides at once
+    for i in range(n):
+        Y[i] = (Y[i] - L[i, :i] @ Y[:i]) / L[i, i]
+    return 0.5 * (np.sum(Y * Y, axis=0) + logdet + n * np.log(np.longdouble(2) * np.pi))
+
+
+def cond_eps(K):
+    """cond_2(K) * 2^-52 of a symmetric positive definite fp64 matrix."""
+    w = np.linalg.eigvalsh(K)
+    return float(w[-1] / w[0]) * 2.0 ** -52

@@ -531,3 +531,26 @@ def test_tsunami_reference_optimum_is_reproduced_by_the_oracle():
         mu, var, _ = gp.predict(g["Xs"])
         assert_allclose(mu, g["mean"][k], rtol=1e-6, atol=1e-8)
         assert_allclose(var, g["var"][k], rtol=1e-5, atol=1e-10)
+
+
+def test_long_double_likelihood_brackets_the_fp64_oracle():
+    """oracle/exact.py (the bar of the ill-conditioned GPU tests): on a well-conditioned matrix the 80-bit value and the LAPACK oracle
+    agree to fp64 rounding; on an ill-conditioned one (d = 6, nugget 1e-6) the oracle sits within 0.02 cond(K) eps of it -- and
+    visibly further than 1e-13, which is why those tests do not use "rtol 1e-10 against LAPACK"."""
+    from oracle.exact import loglike_longdouble, cond_eps
+    rng = np.random.default_rng(5)
+    for n, d, nug, scale in ((120, 3, 1e-2, 0.05), (400, 6, 1e-6, 0.3)):
+        X = rng.uniform(0, 1, (n, d))
+        T = np.sin(X @ rng.normal(size=(d, 2))).T + 0.01 * rng.normal(size=(2, n))
+        theta = np.array([-2. * np.log(scale * np.sqrt(d))] * d + [0.])
+        ref = R.GPRef(X, T[0], nugget=nug)
+        ref.fit(theta)
+        Kn = ref.get_K_matrix() + nug * np.eye(n)
+        exact = loglike_longdouble(Kn, T)
+        ce = cond_eps(Kn)
+        for k in range(2):
+            r = R.GPRef(X, T[k], nugget=nug)
+            r.fit(theta)
+            like = 0.5 * (np.dot(r.t, r.Kinv_t) + R.logdet_L(r.L) + n * np.log(2. * np.pi))
+            assert abs(like - float(exact[k])) <= max(0.02 * ce, 4e-16) * abs(float(exact[k])), (n, k, like, exact[k], ce)
+        assert (ce < 1e-12) == (n == 120)

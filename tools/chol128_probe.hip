@@ -118,6 +118,11 @@ int main(int argc, char** argv) {
       if (q[4 * b] && q[4 * b + 1]) printf("b%d: steps %llu put %llu bar %llu syrk %llu | ", b, q[4 * b + 1] - q[4 * b], q[4 * b + 2] - q[4 * b + 1],
                                            q[4 * b + 3] > q[4 * b + 2] ? q[4 * b + 3] - q[4 * b + 2] : 0ULL, (b < 7 && q[4 * b + 4] > q[4 * b + 3]) ? q[4 * b + 4] - q[4 * b + 3] : 0ULL);
     printf("\n");
+    printf("  wave %d update phase (x10 ns): ", w);
+    for (int b = 0; b < 7; ++b)
+      if (q[32 + 4 * b] && q[4 * b + 3]) printf("b%d: copy-out %llu mfma %llu publish+barrier %llu read-D %llu | ", b, q[32 + 4 * b] - q[4 * b + 3], q[33 + 4 * b] - q[32 + 4 * b],
+                                                q[34 + 4 * b] - q[33 + 4 * b], q[4 * b + 4] > q[34 + 4 * b] ? q[4 * b + 4] - q[34 + 4 * b] : 0ULL);
+    printf("\n");
   }
   return 0;
 }
