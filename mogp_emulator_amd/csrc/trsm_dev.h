@@ -331,6 +331,22 @@ __device__ __forceinline__ bool trsm128_tile2_chain_dev(const BatchView& v, int 
     }
     if (t < 128) *reinterpret_cast<v2d_p*>(img + 112 * 16 + 2 * t) = pinv[u];
   };
+  auto rows_request = [&](int b) {
+    const int u = b & 1;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int ch = t + 256 * q;
+      if (ch < 128 * b) pr[u][q] = *reinterpret_cast<const v2d_p*>(LT + (size_t)(ch >> 3) * 128 + 16 * b + (ch & 7) * 2);
+    }
+  };
+  auto rows_deposit = [&](int b, double* img) {
+    const int u = b & 1;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int ch = t + 256 * q;
+      if (ch < 128 * b) *reinterpret_cast<v2d_p*>(img + (ch >> 3) * 16 + (ch & 7) * 2) = pr[u][q];
+    }
+  };
 #pragma unroll
   for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
@@ -346,27 +362,38 @@ __device__ __forceinline__ bool trsm128_tile2_chain_dev(const BatchView& v, int 
   if (LATE) {
     pack_request(0);
     pack_request(1);
-  } else {
-    if (!wait(0)) return false;        // (contains barriers: every wave has taken its slab by the time the image is written)
-    pack_request(0);
+    __syncthreads();
+    pack_deposit(0, pkb[0]);
   }
-  __syncthreads();
-  pack_deposit(0, pkb[0]);
-  __syncthreads();
+  __syncthreads();                       // (every wave has taken its slab)
   v4d_t X[8];
 #pragma unroll
   for (int b = 0; b < 8; ++b) {
     const double* img = pkb[b & 1];
     if (LATE && b + 2 < 8) pack_request(b + 2);
+    // Pipelined form: the updates of block step b only need row block b of L, i.e. the pieces < b: they run BEFORE piece b is
+    // waited for, on an image requested during block step b - 1 (behind that step's wait); only inv(L_bb) -- fetched straight
+    // into the MFMA operand layout, no LDS image, no barrier -- is read behind the wait for piece b.  (Before: the whole image
+    // of step b was requested behind the wait: per block step one exposed round trip plus the deposit plus up to 28 MFMAs.)
     v4d_t Tb = T[b];
 #pragma unroll
     for (int a = 0; a < b; ++a)
 #pragma unroll
       for (int r = 0; r < 4; ++r) Tb = __builtin_amdgcn_mfma_f64_16x16x4f64(-img[(16 * a + g + 4 * r) * 16 + i], X[a][r], Tb, 0, 0, 0);
-    const double* inv = img + 112 * 16;
+    double invr[4];
+    if (LATE) {
+      const double* inv = img + 112 * 16;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) invr[r] = inv[(g + 4 * r) * 16 + i];
+    } else {
+      if (!wait(b)) return false;        // (contains barriers)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) invr[r] = pk[PACK128_INV + b * 256 + (g + 4 * r) * 16 + i];
+      if (b + 1 < 8) rows_request(b + 1);      // (row block b + 1 needs the pieces <= b)
+    }
     X[b] = (v4d_t){0., 0., 0., 0.};
 #pragma unroll
-    for (int r = 0; r < 4; ++r) X[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(inv[(g + 4 * r) * 16 + i], Tb[r], X[b], 0, 0, 0);
+    for (int r = 0; r < 4; ++r) X[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(invr[r], Tb[r], X[b], 0, 0, 0);
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int r = 0; r < 4; ++r) ts[i * 18 + g + 4 * r] = X[b][r];
@@ -381,11 +408,8 @@ __device__ __forceinline__ bool trsm128_tile2_chain_dev(const BatchView& v, int 
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       pub(b);
-      if (!LATE) {
-        if (!wait(b + 1)) return false;
-        pack_request(b + 1);
-      }
-      pack_deposit(b + 1, pkb[(b + 1) & 1]);
+      if (LATE) pack_deposit(b + 1, pkb[(b + 1) & 1]);
+      else rows_deposit(b + 1, pkb[(b + 1) & 1]);
     }
     __syncthreads();
   }
