@@ -367,7 +367,7 @@ __global__ __launch_bounds__(256, SOLO ? 1 : 2) void mchol_kernel(BatchView v, u
         for (int i = 0; i < 2; ++i)
 #pragma unroll
           for (int j = 0; j < 4; ++j) acc[i][j] = (v4d){0., 0., 0., 0.};
-        if (LEGACY || !(tile_solve & 128)) {
+        if (LEGACY) {                   // (MOGP_MC_PIECES=0 selects the LEGACY instantiation)
           int kb = 0;
           while (kb < kend) {
             mc_stamp<TRACE>(tr, 1);
@@ -698,7 +698,7 @@ void launch_mchol(const BatchView& v, unsigned* ctrl, size_t ctrl_ints, const in
   const size_t words = (size_t)total * MC_TRW;
   unsigned long long* dtr = nullptr;
   // the round-3 forms live in their own instantiations (LEGACY); the traced kernel is the default one (or the paired one)
-  const bool legacy = (tile_solve & 69) != 69;
+  const bool legacy = (tile_solve & 197) != 197;
   const int ts = tile_solve | ((force_urg >= 0 ? force_urg : (rho < 1.0 ? 2 : 0)) << 8);
   if (trace_file && !(legacy && !paired)) {
     if (hipMalloc(reinterpret_cast<void**>(&dtr), words * 8) != hipSuccess) dtr = nullptr;   // no room for the stamps: factorise untraced
