@@ -235,7 +235,14 @@ __global__ __launch_bounds__(256) void backsolve_gemv4_kernel(BatchView v, int k
 __device__ __forceinline__ double ld_agent(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_agent(double* p, double x) { __hip_atomic_store(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-__global__ __launch_bounds__(256) void backsolve_chain_kernel(BatchView v, int* __restrict__ flags, int epoch, int nch, int* __restrict__ status, int spin_limit) {
+// SENT (round 4, the default; MOGP_BS_SENTINEL=0 keeps the flag form): no flag and no second round trip -- the solution vector was
+// preset to all-ones bit patterns by the K build, a chunk's entries are published by their own agent-scope stores, and a consumer's
+// lanes poll the 128 VALUES they need until they are no longer that pattern.  Per chain step this removes the producer's drain +
+// barrier + flag store and the consumer's payload load behind its flag poll (~2.5 of 7 us), and the lower half of a chunk (solved
+// first) is folded while its producer still solves the upper half.  A lane that gives up takes 0.0 (never the pattern, which an fma
+// would propagate into its own results and make every chunk behind it time out too) and the emulator is re-solved by the engine.
+template <bool SENT>
+__global__ __launch_bounds__(256, 2) void backsolve_chain_kernel(BatchView v, int* __restrict__ flags, int epoch, int nch, int* __restrict__ status, int spin_limit) {
   __shared__ double Ld[2][64 * 65];        // the two diagonal blocks of this chunk: [row][column], row stride 65
   __shared__ double w[128], xs[128];
   __shared__ v2d part[3][64];
@@ -247,7 +254,7 @@ __global__ __launch_bounds__(256) void backsolve_chain_kernel(BatchView v, int* 
   const double* A = v.A + (size_t)emu * v.MS;
   double* alpha = v.Z + (size_t)emu * ld;
   int* fl = flags + (size_t)emu * nch;
-  const int t = threadIdx.x, lane = t & 63, rg = t >> 6;
+  const int t = threadIdx.x, lane = t & 63, rg = __builtin_amdgcn_readfirstlane(t >> 6);      // (wave-uniform: row addresses are scalar)
   const int j0 = 128 * c;
   if (t == 0) timed_out = 0;
   if (t < 128) w[t] = (j0 + t < n) ? A[(size_t)n * ld + j0 + t] : 0.0;
@@ -269,7 +276,10 @@ __global__ __launch_bounds__(256) void backsolve_chain_kernel(BatchView v, int* 
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int row = k0 + 16 * rg + i;
-      tv[i] = (row < n) ? *reinterpret_cast<const v2d*>(A + (size_t)row * ld + j0 + 2 * lane) : (v2d){0., 0.};
+      // (SENT: unpredicated -- rows n .. NP-1 exist, hold finite values (forward-solved targets, identity padding) and meet x = 0; with the
+      // predicate every row became a basic block of its own in that form and the register allocator spilled 500 bytes per lane)
+      if (SENT) tv[i] = *reinterpret_cast<const v2d*>(A + (size_t)row * ld + j0 + 2 * lane);
+      else tv[i] = (row < n) ? *reinterpret_cast<const v2d*>(A + (size_t)row * ld + j0 + 2 * lane) : (v2d){0., 0.};
     }
   };
   // w[cols] -= tile^T x, x = xs[xoff .. xoff+64); ncols = 128 (a block below the chunk) or 64 (inside the chunk)
@@ -308,7 +318,26 @@ __global__ __launch_bounds__(256) void backsolve_chain_kernel(BatchView v, int* 
         b = __builtin_fma(-Lb[j * 65 + lane], xj, b);      // L[k0+j][k0+lane]; only lanes < j use it afterwards
       }
       xs[64 * blk + lane] = xout;
+      if (SENT && __double_as_longlong(xout) == -1ll) xout = __builtin_nan("");      // (only garbage can be the "not there yet" pattern)
       st_agent(alpha + k0 + lane, xout);
+    }
+    __syncthreads();
+  };
+  // SENT: lanes [lo, lo + 64) of the workgroup fetch entries lo .. lo+63 of chunk cc into xs, each polling its own value
+  auto poll_values = [&](int cc, int lo) {
+    if (t >= lo && t < lo + 64) {
+      const double* p = alpha + 128 * cc + t;
+      double x = ld_agent(p);
+      int spins = 0;
+      while (__double_as_longlong(x) == -1ll && spins++ < spin_limit) {
+        __builtin_amdgcn_s_sleep(1);
+        x = ld_agent(p);
+      }
+      if (__double_as_longlong(x) == -1ll) {
+        timed_out = 1;
+        x = 0.0;
+      }
+      xs[t] = x;
     }
     __syncthreads();
   };
@@ -321,6 +350,16 @@ __global__ __launch_bounds__(256) void backsolve_chain_kernel(BatchView v, int* 
     load_tile(tA, j0 + 64);                    // rightmost chunk: only its own off-diagonal tile
   }
   for (int cc = nch - 1; cc > c; --cc) {
+    if (SENT) {
+      poll_values(cc, 64);                     // the lower half of chunk cc is solved (and stored) first
+      apply_tile(tA, 64, 128);                 // rows 128cc+64 ..
+      if (cc - 1 > c) load_tile(tA, 128 * (cc - 1) + 64);
+      else load_tile(tA, j0 + 64);
+      poll_values(cc, 0);
+      apply_tile(tB, 0, 128);                  // rows 128cc ..
+      if (cc - 1 > c) load_tile(tB, 128 * (cc - 1));
+      continue;
+    }
     if (t == 0) {
       int spins = 0;
       bool seen = false;
@@ -340,6 +379,10 @@ __global__ __launch_bounds__(256) void backsolve_chain_kernel(BatchView v, int* 
   solve_diag(1);
   apply_tile(tA, 64, 64);
   solve_diag(0);
+  if (SENT) {                                  // (the stores of solve_diag are the publication)
+    if (t == 0 && timed_out) __hip_atomic_store(status + emu, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return;
+  }
   // publish: payload drained, then the flag
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -530,7 +573,9 @@ void launch_backsolve_chain(const BatchView& v, int* flags, int epoch, int* stat
   // MOGP_BS_SPIN: polls before a wait gives up (default 2^20, about a second); 0 makes every unsatisfied wait a timeout,
   // which is how the GPU suite exercises the fallback
   static const int spin_limit = [] { const char* e = getenv("MOGP_BS_SPIN"); return e ? atoi(e) : (1 << 20); }();
-  hipLaunchKernelGGL(backsolve_chain_kernel, dim3(v.nb * nch), dim3(256), 0, s, v, flags, epoch, nch, status, spin_limit);
+  static const int sent = [] { const char* e = getenv("MOGP_BS_SENTINEL"); return e ? atoi(e) : 1; }();
+  if (sent) hipLaunchKernelGGL(backsolve_chain_kernel<true>, dim3(v.nb * nch), dim3(256), 0, s, v, flags, epoch, nch, status, spin_limit);
+  else hipLaunchKernelGGL(backsolve_chain_kernel<false>, dim3(v.nb * nch), dim3(256), 0, s, v, flags, epoch, nch, status, spin_limit);
 }
 
 void launch_backsolve(const BatchView& v, hipStream_t s) {

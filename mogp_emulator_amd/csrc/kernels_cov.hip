@@ -142,6 +142,10 @@ __global__ __launch_bounds__(256) void cov_build_kernel(BatchView v) {
     *reinterpret_cast<double2*>(p) = make_double2(out[0], out[1]);
     *reinterpret_cast<double2*>(p + 2) = make_double2(out[2], out[3]);
   }
+  // single right-hand side: the solution vector starts as all-ones bit patterns -- the "not there yet" value the chunks of the
+  // one-launch back substitution poll for (backsolve_chain_kernel<SENT>, kernels_chol.hip); every other solve overwrites it
+  if (ti == tj && v.R == 1 && v.Z && threadIdx.x < 64)
+    reinterpret_cast<unsigned long long*>(v.Z + (size_t)emu * ld)[i0 + threadIdx.x] = ~0ull;
 }
 
 // full (n,n) sigma^2 k(X,X) without nugget for get_K (GaussianProcessGPU.py:504-513)

@@ -569,7 +569,7 @@ print("SWITCH-OK", repr(float(f[0])))
                                  {"MOGP_CHOL": "mchol", "MOGP_MC_PIECES": "0"}, {"MOGP_CHOL": "mchol", "MOGP_MC_URG": "0"}, {"MOGP_CHOL": "mchol", "MOGP_MC_URG": "1", "MOGP_MC_WGS": "2"}, {"MOGP_PV_SINGLE": "1"}, {"MOGP_PV_SINGLE": "0"},
                                  {"MOGP_CHOL": "la"}, {"MOGP_CHOL": "left"}, {"MOGP_CHOL": "left", "MOGP_GROUPS": "1"},
                                  {"MOGP_CHOL": "right"}, {"MOGP_CHOL": "right", "MOGP_OUTER": "128"}, {"MOGP_TAIL": "0"},
-                                 {"MOGP_BACKSOLVE": "1"}, {"MOGP_WAITVAL": "0"}, {"MOGP_CHOL": "la", "MOGP_WAITVAL": "1"}, {"MOGP_KS_BUDGET_GB": "0.05"},
+                                 {"MOGP_BACKSOLVE": "1"}, {"MOGP_BS_SENTINEL": "0"}, {"MOGP_WAITVAL": "0"}, {"MOGP_CHOL": "la", "MOGP_WAITVAL": "1"}, {"MOGP_KS_BUDGET_GB": "0.05"},
                                  {"MOGP_PV_SYNC": "1000"}, {"MOGP_PV_SYNC": "1"}, {"MOGP_PV_SYNC": "1000", "MOGP_PV_DESC": "0"}, {"MOGP_PV_DESC": "1"}],
                          ids=lambda e: ",".join(k + "=" + v for k, v in e.items()))
 def test_cholesky_schedules_and_switches(env):
