@@ -138,6 +138,33 @@ SIGNATURES = {
 }
 
 
+def _one_hip_runtime_per_process():
+    """A PyTorch-ROCm wheel bundles its own libamdhip64.so.7 / libhsa-runtime64.so and loads them by absolute path.  If this
+    library has already pulled in the system copies (/opt/rocm), the process ends up with TWO HIP / HSA runtimes, and on some
+    hosts the second one finds no device ("No HIP GPUs are available" from torch.cuda after a fit; seen on MI355X boxes in
+    round 4).  Loaded the other way round, libmogp_hip.so's NEEDED libamdhip64.so.7 binds to the copy that is already there.
+    So: when a torch wheel with a bundled runtime is installed, its copy is loaded first -- whichever of the two packages is
+    imported first, there is one runtime (the configuration bench.py and the sharded path always ran in).  torch itself is NOT
+    imported.  MOGP_HIP_RUNTIME=system skips this."""
+    if os.environ.get("MOGP_HIP_RUNTIME", "") == "system":
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        return
+    if spec is None or not spec.origin:
+        return
+    libdir = os.path.join(os.path.dirname(spec.origin), "lib")
+    for name in ("libhsa-runtime64.so", "libamdhip64.so"):
+        path = os.path.join(libdir, name)
+        if os.path.exists(path):
+            try:
+                ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
+            except OSError:
+                return
+
+
 def load():
     """Load libmogp_hip.so (once) and attach the prototypes.  Raises OSError /
     AttributeError if the library or one of its symbols is missing."""
@@ -147,6 +174,7 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise OSError("libmogp_hip.so not found at %s -- run `python -c 'import __graft_entry__ as g; g.build()'` "
                       "or `make -C mogp_emulator_amd/csrc`" % LIB_PATH)
+    _one_hip_runtime_per_process()
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)

@@ -309,13 +309,25 @@ __global__ __launch_bounds__(256, 2) void backsolve_chain_kernel(BatchView v, in
       const double* Lb = Ld[blk];
       const double dg = Lb[lane * 65 + lane];
       const double rdg = (k0 + lane < n) ? 1.0 / dg : 0.0;
-      double b = w[64 * blk + lane];
       double xout = 0.0;
+      if (SENT) {
+        // the lane carries b / L_ll instead of b: per step readlane -> fma (the multiply by 1 / L_ll left the chain; the scaled column
+        // entries L[j][lane] / L_ll do not depend on the right-hand side)
+        double bs = w[64 * blk + lane] * rdg;
+#pragma unroll
+        for (int j = 63; j >= 0; --j) {
+          const double xj = readlane_f64(bs, j);           // rows >= n: rdg = 0 -> xj = 0 (identity padding, right-hand-side rows)
+          if (lane == j) xout = xj;
+          bs = __builtin_fma(-(Lb[j * 65 + lane] * rdg), xj, bs);
+        }
+      } else {
+      double b = w[64 * blk + lane];
 #pragma unroll
       for (int j = 63; j >= 0; --j) {
         const double xj = readlane_f64(b * rdg, j);       // rows >= n: rdg = 0 -> xj = 0 (identity padding, right-hand-side rows)
         if (lane == j) xout = xj;
         b = __builtin_fma(-Lb[j * 65 + lane], xj, b);      // L[k0+j][k0+lane]; only lanes < j use it afterwards
+      }
       }
       xs[64 * blk + lane] = xout;
       if (SENT && __double_as_longlong(xout) == -1ll) xout = __builtin_nan("");      // (only garbage can be the "not there yet" pattern)
