@@ -352,3 +352,29 @@ def test_bench_refuses_a_world_size_that_disagrees_with_gpus():
     env = dict(os.environ, WORLD_SIZE="3", RANK="0")
     res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True, timeout=60)
     assert res.returncode != 0 and "WORLD_SIZE=3" in res.stderr
+
+
+def test_one_hip_runtime_per_process_after_loading_the_library():
+    """_capi.load() must leave ONE libamdhip64 in the process -- the copy bundled with an installed PyTorch-ROCm wheel when there is one,
+    so that torch (imported later, or earlier) and the library share a runtime (round 4: with two runtimes torch.cuda found no device
+    after a fit on some MI355X hosts).  Checked in a fresh interpreter, in both import orders; needs no GPU."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r"""
+import sys, os
+sys.path.insert(0, %r)
+order = sys.argv[1]
+for w in order:
+    if w == "t":
+        import torch
+    else:
+        from mogp_emulator_amd import _capi
+        _capi.load()
+libs = sorted({l.split()[-1] for l in open("/proc/self/maps") if "libamdhip64" in l})
+print("HIPLIBS", len(libs), libs)
+""" % root
+    for order in ("l", "lt", "tl"):
+        out = subprocess.run([sys.executable, "-c", code, order], capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        line = [l for l in out.stdout.splitlines() if l.startswith("HIPLIBS")][0]
+        assert line.split()[1] == "1", (order, line)
