@@ -1,6 +1,7 @@
 """File the outputs of tools/jobs/r4_final.sh (gpurun_out/final_<commit>/) under profiles/r04_<commit>_* with explanatory headers and derive
 profiles/r04_traffic.json (what bench.py reports as roofline.traffic).  usage: collect_profiles.py <commit>
-REFUSES when <commit> is not the checked-out HEAD or the library that ran the job was not built from it (mogp_emulator_amd/libmogp_hip.build, written by the Makefile)."""
+REFUSES when the library that ran the job was not built from <commit> (mogp_emulator_amd/libmogp_hip.build, written by the Makefile), or when HEAD differs
+from <commit> in anything the job executed (library, package, bench.py, tools)."""
 import json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1]
@@ -8,8 +9,13 @@ src = os.path.join(ROOT, "gpurun_out", "final_" + tag)
 dst = os.path.join(ROOT, "profiles")
 head = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short=7", "HEAD"], capture_output=True, text=True).stdout.strip()
 built = open(os.path.join(src, "build_commit.txt")).read().strip()
-if not (tag == head == built) and "--force" not in sys.argv:
-    sys.exit("refusing: argument %s, HEAD %s, library build stamp %s must agree (commit, rebuild, run the job, then collect)" % (tag, head, built))
+# HEAD may have moved on from the commit the job ran on -- but only by commits that leave everything the job executed untouched
+# (library sources, headers, the Python package, bench.py, the tools the job calls): documentation, tests, profiles
+EXECUTED = ["mogp_emulator_amd", "include", "bench.py", "__graft_entry__.py", "oracle", "tools"]
+same_code = tag == built and subprocess.run(["git", "-C", ROOT, "diff", "--quiet", built, "HEAD", "--"] + EXECUTED).returncode == 0
+if not (tag == head == built) and not same_code and "--force" not in sys.argv:
+    sys.exit("refusing: argument %s, HEAD %s, library build stamp %s must agree, or HEAD must differ from the build commit by documentation / "
+             "tests / profiles only (commit, rebuild, run the job, then collect)" % (tag, head, built))
 
 
 def rd(name):
