@@ -313,13 +313,27 @@ __global__ __launch_bounds__(256, 2) void backsolve_chain_kernel(BatchView v, in
       if (SENT) {
         // the lane carries b / L_ll instead of b: per step readlane -> fma (the multiply by 1 / L_ll left the chain; the scaled column
         // entries L[j][lane] / L_ll do not depend on the right-hand side)
+        // ... and the lane's 64 scaled column entries are in REGISTERS before the chain starts: read inside the loop (as the compiler
+        // scheduled it) every second step waited for an LDS round trip -- 1.7 of the 2.3 us of a 64-entry substitution
+        double Lc[64];
+#pragma unroll
+        for (int j = 0; j < 64; ++j) Lc[j] = Lb[j * 65 + lane];
         double bs = w[64 * blk + lane] * rdg;
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 64; ++j) Lc[j] *= -rdg;
+        __builtin_amdgcn_sched_barrier(0);
+        int xlo = 0, xhi = 0;
 #pragma unroll
         for (int j = 63; j >= 0; --j) {
-          const double xj = readlane_f64(bs, j);           // rows >= n: rdg = 0 -> xj = 0 (identity padding, right-hand-side rows)
-          if (lane == j) xout = xj;
-          bs = __builtin_fma(-(Lb[j * 65 + lane] * rdg), xj, bs);
+          // x_j: lane j's value, to every lane through two scalar registers -- and back into lane j of the result with v_writelane
+          // (a compare + selects per step were five of the eight instructions of a step)
+          const int lo = __builtin_amdgcn_readlane(__double2loint(bs), j), hi = __builtin_amdgcn_readlane(__double2hiint(bs), j);
+          asm("v_writelane_b32 %0, %1, %2" : "+v"(xlo) : "s"(lo), "n"(j));
+          asm("v_writelane_b32 %0, %1, %2" : "+v"(xhi) : "s"(hi), "n"(j));
+          bs = __builtin_fma(Lc[j], __hiloint2double(hi, lo), bs);      // rows >= n: rdg = 0 -> x_j = 0 (identity padding, right-hand-side rows)
         }
+        xout = __hiloint2double(xhi, xlo);
       } else {
       double b = w[64 * blk + lane];
 #pragma unroll
