@@ -138,31 +138,81 @@ SIGNATURES = {
 }
 
 
-def _one_hip_runtime_per_process():
-    """A PyTorch-ROCm wheel bundles its own libamdhip64.so.7 / libhsa-runtime64.so and loads them by absolute path.  If this
-    library has already pulled in the system copies (/opt/rocm), the process ends up with TWO HIP / HSA runtimes, and on some
-    hosts the second one finds no device ("No HIP GPUs are available" from torch.cuda after a fit; seen on MI355X boxes in
-    round 4).  Loaded the other way round, libmogp_hip.so's NEEDED libamdhip64.so.7 binds to the copy that is already there.
-    So: when a torch wheel with a bundled runtime is installed, its copy is loaded first -- whichever of the two packages is
-    imported first, there is one runtime (the configuration bench.py and the sharded path always ran in).  torch itself is NOT
-    imported.  MOGP_HIP_RUNTIME=system skips this."""
-    if os.environ.get("MOGP_HIP_RUNTIME", "") == "system":
-        return
+def elf_dynamic(path):
+    """(DT_SONAME or None, [DT_NEEDED ...]) of a little-endian ELF64 shared object, read with struct -- no external tool."""
+    import struct
+    with open(path, "rb") as f:
+        data = f.read()
+    if data[:6] != b"\x7fELF\x02\x01":
+        raise OSError("%s is not a little-endian ELF64 file" % path)
+    e_phoff, = struct.unpack_from("<Q", data, 0x20)
+    e_phentsize, e_phnum = struct.unpack_from("<HH", data, 0x36)
+    loads, dyn = [], None
+    for k in range(e_phnum):
+        p_type, _, p_offset, p_vaddr, _, p_filesz = struct.unpack_from("<IIQQQQ", data, e_phoff + k * e_phentsize)
+        if p_type == 1:
+            loads.append((p_vaddr, p_offset, p_filesz))
+        elif p_type == 2:
+            dyn = (p_offset, p_filesz)
+    if dyn is None:
+        return None, []
+    entries = [struct.unpack_from("<qQ", data, dyn[0] + 16 * k) for k in range(dyn[1] // 16)]
+    strtab = next((v for t, v in entries if t == 5), None)
+    if strtab is None:
+        return None, []
+    stroff = next((off + strtab - va for va, off, sz in loads if va <= strtab < va + sz), strtab)
+
+    def name(o):
+        return data[stroff + o:data.index(b"\0", stroff + o)].decode()
+    soname = next((name(v) for t, v in entries if t == 14), None)
+    return soname, [name(v) for t, v in entries if t == 1]
+
+
+def _bundled_runtime_to_preload(lib_path):
+    """Paths of a PyTorch wheel's bundled HSA / HIP runtime to load before `lib_path`, or [] -- only when the bundled
+    libamdhip64's DT_SONAME is exactly the libamdhip64.so.N that `lib_path` was linked against (its DT_NEEDED): a wheel built for
+    another ROCm major is a different ABI and is left alone (then the system runtime serves this library, as the linker intended)."""
     try:
         import importlib.util
         spec = importlib.util.find_spec("torch")
     except (ImportError, ValueError):
-        return
+        return []
     if spec is None or not spec.origin:
-        return
+        return []
     libdir = os.path.join(os.path.dirname(spec.origin), "lib")
-    for name in ("libhsa-runtime64.so", "libamdhip64.so"):
-        path = os.path.join(libdir, name)
-        if os.path.exists(path):
-            try:
-                ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
-            except OSError:
-                return
+    hip = os.path.join(libdir, "libamdhip64.so")
+    if not os.path.exists(hip):
+        return []
+    try:
+        needed = [n for n in elf_dynamic(lib_path)[1] if n.startswith("libamdhip64.so")]
+        soname = elf_dynamic(hip)[0]
+    except (OSError, ValueError, IndexError):
+        return []
+    if not needed or soname != needed[0]:
+        return []
+    hsa = os.path.join(libdir, "libhsa-runtime64.so")
+    return ([hsa] if os.path.exists(hsa) else []) + [hip]
+
+
+def _one_hip_runtime_per_process():
+    """A PyTorch-ROCm wheel bundles its own libamdhip64.so.N / libhsa-runtime64.so and loads them by absolute path.  If this
+    library has already pulled in the system copies (/opt/rocm), the process ends up with TWO HIP / HSA runtimes, and on some
+    hosts the second one finds no device ("No HIP GPUs are available" from torch.cuda after a fit; seen on MI355X boxes in
+    round 4).  Loaded the other way round, libmogp_hip.so's NEEDED libamdhip64.so.N binds to the copy that is already there.
+    So: when a torch wheel bundles a runtime WITH THE SAME SONAME as the one this library needs (`_bundled_runtime_to_preload`),
+    its copy is loaded first -- whichever of the two packages is imported first, there is one runtime (the configuration bench.py
+    and the sharded path always ran in).  torch itself is NOT imported.  MOGP_HIP_RUNTIME=system skips this.  Returns the paths
+    that were loaded (for the error message of a failing load)."""
+    if os.environ.get("MOGP_HIP_RUNTIME", "") == "system":
+        return []
+    done = []
+    for path in _bundled_runtime_to_preload(LIB_PATH):
+        try:
+            ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
+            done.append(path)
+        except OSError:
+            break
+    return done
 
 
 def load():
@@ -174,8 +224,15 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise OSError("libmogp_hip.so not found at %s -- run `python -c 'import __graft_entry__ as g; g.build()'` "
                       "or `make -C mogp_emulator_amd/csrc`" % LIB_PATH)
-    _one_hip_runtime_per_process()
-    lib = ctypes.CDLL(LIB_PATH)
+    preloaded = _one_hip_runtime_per_process()
+    try:
+        lib = ctypes.CDLL(LIB_PATH)
+    except OSError as e:
+        if preloaded:
+            raise OSError("%s failed to load after the HIP runtime bundled with PyTorch was loaded first (%s): %s -- "
+                          "set MOGP_HIP_RUNTIME=system to bind to the system ROCm runtime instead"
+                          % (LIB_PATH, ", ".join(preloaded), e)) from e
+        raise
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)
         fn.restype = res

@@ -1,23 +1,31 @@
-// Device helpers shared by the covariance kernels (kernels_cov.hip) and the Cholesky update kernel that generates the
-// covariance tile it touches first (kernels_gemm.hip): kernel functions, LDS staging of input rows, and the rule for
-// the entries of the augmented matrix (targets / design rows / padding).
+// Device helpers shared by the covariance kernels (kernels_cov.hip) and the pivoted Cholesky (kernels_pivot.hip): kernel
+// functions with their exponential, LDS staging of input rows, and the rule for the entries of the augmented matrix
+// (targets / design rows / padding).
 #pragma once
 #include "launch.h"
+#include "exp_dev.h"
 
 namespace mogp {
 
+// 2^(j/256): the exponential's table.  The tiled kernels copy it into LDS (stage_exp_tab); one-thread-per-pair kernels read it here.
+static __device__ const double EXP_TAB_G[256] = {MOGP_EXP_TAB_VALUES};
+
+__device__ __forceinline__ void stage_exp_tab(double* tab) {     // 256-thread workgroups; the caller's next barrier publishes it
+  if (threadIdx.x < 256) tab[threadIdx.x] = EXP_TAB_G[threadIdx.x];
+}
+
 template <int KT>
-__device__ __forceinline__ double kern_val(double r2) {
-  if (KT == 0) return exp(-0.5 * r2);
+__device__ __forceinline__ double kern_val(double r2, const double* tab) {
+  if (KT == 0) return lean_exp_neg<true>(r2, tab);
   const double s = sqrt(5.0 * r2);
-  return (1.0 + s + (5.0 / 3.0) * r2) * exp(-s);
+  return (1.0 + s + (5.0 / 3.0) * r2) * lean_exp_neg<false>(s, tab);
 }
 // dk/d(r2)
 template <int KT>
-__device__ __forceinline__ double kern_dr2(double r2) {
-  if (KT == 0) return -0.5 * exp(-0.5 * r2);
+__device__ __forceinline__ double kern_dr2(double r2, const double* tab) {
+  if (KT == 0) return -0.5 * lean_exp_neg<true>(r2, tab);
   const double s = sqrt(5.0 * r2);
-  return -(5.0 / 6.0) * (1.0 + s) * exp(-s);
+  return -(5.0 / 6.0) * (1.0 + s) * lean_exp_neg<false>(s, tab);
 }
 
 // stage rows [r0, r0+64) of Xg (nrows, D) into sx[d*64 + r]; rows >= nrows are zero filled
@@ -43,30 +51,6 @@ __device__ __forceinline__ double cov_entry(const BatchView& v, const double* __
     return (lo == hi) ? PAD_BIG : 0.0;
   }
   return (i == j) ? 1.0 : 0.0;
-}
-
-// sigma^2-free kernel value of ONE pair from LDS-staged coordinates (si / sj as written by stage_rows), with exactly the
-// operation order of micro_r2 / micro_k so that every entry is bit-identical wherever it is generated.
-//   KT: 0 squared exponential, 1 Matern-5/2, 2 product of one-dimensional Matern-5/2
-template <int KT>
-__device__ __forceinline__ double pair_kval(const double* si, const double* sj, const double* __restrict__ P, int D, int row, int col) {
-  if (KT < 2) {
-    double r2 = 0.0;
-    for (int d = 0; d < D; ++d) {
-      const double df = si[d * 64 + row] - sj[d * 64 + col];
-      r2 = __builtin_fma(P[d] * df, df, r2);
-    }
-    return kern_val<KT>(r2);
-  }
-  double k = 1.0, ssum = 0.0;
-  for (int d = 0; d < D; ++d) {
-    const double df = si[d * 64 + row] - sj[d * 64 + col];
-    const double r2 = P[d] * df * df;
-    const double sd = sqrt(5.0 * r2);
-    k *= 1.0 + sd + (5.0 / 3.0) * r2;
-    ssum += sd;
-  }
-  return k * exp(-ssum);
 }
 
 }  // namespace mogp

@@ -59,13 +59,13 @@ __device__ __forceinline__ double mat52_dlog(double r2) {
 // kernel values (without sigma^2) of the thread's 4x4 micro tile
 template <int KT>
 __device__ __forceinline__ void micro_k(const double* si, const double* sj, const double* __restrict__ P, int D, int ty, int tx,
-                                        double (&k)[4][4]) {
+                                        double (&k)[4][4], const double* etab) {
   if (KT < 2) {
     micro_r2(si, sj, P, D, ty, tx, k);
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
-      for (int b = 0; b < 4; ++b) k[a][b] = kern_val<KT>(k[a][b]);
+      for (int b = 0; b < 4; ++b) k[a][b] = kern_val<KT>(k[a][b], etab);
     return;
   }
   // prod_d (1 + s_d + s_d^2/3) * exp(-sum_d s_d): one exponential per pair
@@ -98,7 +98,7 @@ __device__ __forceinline__ void micro_k(const double* si, const double* sj, cons
 #pragma unroll
   for (int a = 0; a < 4; ++a)
 #pragma unroll
-    for (int b = 0; b < 4; ++b) k[a][b] *= exp(-ssum[a][b]);
+    for (int b = 0; b < 4; ++b) k[a][b] *= lean_exp_neg<false>(ssum[a][b], etab);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -108,6 +108,8 @@ __device__ __forceinline__ void micro_k(const double* si, const double* sj, cons
 template <int KT>
 __global__ __launch_bounds__(256) void cov_build_kernel(BatchView v) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
+  __shared__ double etab[256];
+  stage_exp_tab(etab);
   const int z = blockIdx.y;
   const int emu = slot_emu2(v.idx, z);
   const int tile = blockIdx.x;
@@ -127,7 +129,7 @@ __global__ __launch_bounds__(256) void cov_build_kernel(BatchView v) {
   __syncthreads();
   const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
   double kv[4][4];
-  micro_k<KT>(si, sj, P, D, ty, tx, kv);
+  micro_k<KT>(si, sj, P, D, ty, tx, kv, etab);
   const double sig2 = P[D], nug = P[D + 1];
   // INTERIOR: a tile strictly below the diagonal whose rows are all training points (15 of 16 tiles at n = 2000): every entry is
   // sigma^2 k -- no nugget, no target row, no padding; the per-entry selects of cov_entry were ~8 of the kernel's 92 vector-ALU
@@ -161,6 +163,8 @@ __global__ __launch_bounds__(256) void cov_build_kernel(BatchView v) {
 template <int KT>
 __global__ __launch_bounds__(256) void cov_full_kernel(BatchView v, int emu, const double* __restrict__ Xp, int n, double* __restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
+  __shared__ double etab[256];
+  stage_exp_tab(etab);
   const int i0 = blockIdx.y * 64, j0 = blockIdx.x * 64;
   const int D = v.D;
   if (emu < 0) {                     // batched form: one (n, n) matrix per slot
@@ -175,7 +179,7 @@ __global__ __launch_bounds__(256) void cov_full_kernel(BatchView v, int emu, con
   __syncthreads();
   const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
   double kv[4][4];
-  micro_k<KT>(si, sj, P, D, ty, tx, kv);
+  micro_k<KT>(si, sj, P, D, ty, tx, kv, etab);
   const double sig2 = P[D];
   for (int a = 0; a < 4; ++a)
     for (int b = 0; b < 4; ++b) {
@@ -195,6 +199,8 @@ template <int KT, int RB>
 __global__ __launch_bounds__(256) void cross_cov_mean_kernel(BatchView v, const double* __restrict__ Xs, int m, int MP,
                                                            double* __restrict__ Ks, double* __restrict__ mean, int mean_ld) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
+  __shared__ double etab[256];
+  stage_exp_tab(etab);
   const int z = blockIdx.y;
   const int emu = slot_emu2(v.idx, z);
   const int n = v.n, D = v.D, ld = v.LD, R = (RB == 1) ? 1 : v.R;
@@ -229,7 +235,7 @@ __global__ __launch_bounds__(256) void cross_cov_mean_kernel(BatchView v, const 
     }
     __syncthreads();
     double kv[4][4];
-    if (j0 < n) micro_k<KT>(si, sj, P, D, ty, tx, kv);
+    if (j0 < n) micro_k<KT>(si, sj, P, D, ty, tx, kv, etab);
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
       const int i = i0 + 4 * ty + a;
@@ -277,6 +283,8 @@ template <int KT>
 __global__ __launch_bounds__(256) void predict_deriv_kernel(BatchView v, const double* __restrict__ Xs, int m,
                                                           double* __restrict__ deriv, long deriv_stride) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
+  __shared__ double etab[256];
+  stage_exp_tab(etab);
   const int z = blockIdx.y;
   const int emu = slot_emu2(v.idx, z);
   const int n = v.n, D = v.D, ld = v.LD;
@@ -300,13 +308,13 @@ __global__ __launch_bounds__(256) void predict_deriv_kernel(BatchView v, const d
     // factor (dm52/dr2)/m52 of dimension d is applied in the contraction below
     double r2[4][4];
     if (KT < 2) micro_r2(si, sj, P, D, ty, tx, r2);
-    else micro_k<KT>(si, sj, P, D, ty, tx, r2);
+    else micro_k<KT>(si, sj, P, D, ty, tx, r2, etab);
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
       for (int b = 0; b < 4; ++b) {
         const int j = j0 + 4 * tx + b;
-        const double f = (KT < 2) ? kern_dr2<KT>(r2[a][b]) : r2[a][b];
+        const double f = (KT < 2) ? kern_dr2<KT>(r2[a][b], etab) : r2[a][b];
         G[(4 * ty + a) * 65 + 4 * tx + b] = (j < n) ? 2.0 * sig2 * f * alpha[j] : 0.0;
       }
     __syncthreads();
@@ -368,6 +376,8 @@ __global__ __launch_bounds__(256) void predict_deriv_kernel(BatchView v, const d
 template <int KT>
 __global__ __launch_bounds__(256) void grad_kernel(BatchView v, int ntiles, double* __restrict__ partial) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
+  __shared__ double etab[256];
+  stage_exp_tab(etab);
   const int z = blockIdx.y;
   const int emu = slot_emu2(v.idx, z);
   int tile = blockIdx.x;
@@ -403,7 +413,7 @@ __global__ __launch_bounds__(256) void grad_kernel(BatchView v, int ntiles, doub
   // KT < 2: r2 holds squared distances; product kernel: r2 holds the kernel values themselves
   double r2[4][4];
   if (KT < 2) micro_r2(si, sj, P, D, ty, tx, r2);
-  else micro_k<KT>(si, sj, P, D, ty, tx, r2);
+  else micro_k<KT>(si, sj, P, D, ty, tx, r2, etab);
   const double sig2 = P[D];
   double scov = 0., strace = 0., saa = 0.;
   // W = K^-1 - (rank-R correction sum_c g_c[i] g_c[j]; R = 1: alpha_i alpha_j) for the micro tile
@@ -447,10 +457,10 @@ __global__ __launch_bounds__(256) void grad_kernel(BatchView v, int ntiles, doub
         const bool live = INTERIOR || ((i < n) && (j <= i));
         const double w = INTERIOR ? 2.0 : (live ? ((j < i) ? 2.0 : 1.0) : 0.0);
         const double Wv = live ? kin + W[a][b] : 0.0;
-        const double kval = (KT < 2) ? kern_val<KT>(r2[a][b]) : r2[a][b];
+        const double kval = (KT < 2) ? kern_val<KT>(r2[a][b], etab) : r2[a][b];
         const double wk = w * Wv * sig2;
         scov = __builtin_fma(wk, kval, scov);
-        G[a][b] = (KT < 2) ? wk * kern_dr2<KT>(r2[a][b]) : wk * kval;
+        G[a][b] = (KT < 2) ? wk * kern_dr2<KT>(r2[a][b], etab) : wk * kval;
         if (!INTERIOR && live && i == j) {
           strace += kin;
           saa += gsq[a];
@@ -542,7 +552,7 @@ __global__ __launch_bounds__(256) void kernel_object_kernel(const double* __rest
       const double df = a[d] - b[d];
       r2 = __builtin_fma(P[d] * df, df, r2);
     }
-    const double k = sig2 * kern_val<KT>(r2), dk = sig2 * kern_dr2<KT>(r2);
+    const double k = sig2 * kern_val<KT>(r2, EXP_TAB_G), dk = sig2 * kern_dr2<KT>(r2, EXP_TAB_G);
     if (mode == 0) out[e] = k;
     else if (mode == 1) {
       for (int p = 0; p < D; ++p) {
@@ -559,7 +569,7 @@ __global__ __launch_bounds__(256) void kernel_object_kernel(const double* __rest
   double k = sig2;
   for (int d = 0; d < D; ++d) {
     const double df = a[d] - b[d];
-    k *= kern_val<1>(P[d] * df * df);
+    k *= kern_val<1>(P[d] * df * df, EXP_TAB_G);
   }
   if (mode == 0) {
     out[e] = k;
@@ -683,8 +693,8 @@ __global__ __launch_bounds__(LOWRANK_THREADS) void grad_lowrank_kernel(BatchView
           const double df = sxi[d * LOWRANK_THREADS + tid] - xj[d];
           r2 = __builtin_fma(P[d] * df, df, r2);
         }
-        g = sig2 * kern_dr2<KT>(r2);
-        kv = sig2 * kern_val<KT>(r2);
+        g = sig2 * kern_dr2<KT>(r2, EXP_TAB_G);
+        kv = sig2 * kern_val<KT>(r2, EXP_TAB_G);
       } else {
         double kk = 1.0, ssum = 0.0;
         for (int d = 0; d < D; ++d) {
@@ -694,7 +704,7 @@ __global__ __launch_bounds__(LOWRANK_THREADS) void grad_lowrank_kernel(BatchView
           kk *= 1.0 + sd + (5.0 / 3.0) * r2;
           ssum += sd;
         }
-        kv = sig2 * (kk * exp(-ssum));
+        kv = sig2 * (kk * lean_exp_neg<false>(ssum, EXP_TAB_G));
         g = kv;
       }
 #pragma unroll

@@ -246,7 +246,7 @@ __global__ __launch_bounds__(PSTRF_THREADS) void pstrf_panel_kernel(BatchView v,
   }
 }
 
-// sigma^2 k(x_a, x_b) with the operation order of the covariance build (cov_dev.h pair_kval)
+// sigma^2 k(x_a, x_b) with the operation order of the covariance build (kernels_cov.hip micro_k)
 __device__ __forceinline__ double cov_pair_global(const BatchView& v, const double* __restrict__ X, const double* __restrict__ P, int a, int b) {
   const int D = v.D;
   const double* xa = X + (size_t)a * D;
@@ -257,7 +257,7 @@ __device__ __forceinline__ double cov_pair_global(const BatchView& v, const doub
       const double df = xa[d] - xb[d];
       r2 = __builtin_fma(P[d] * df, df, r2);
     }
-    return P[D] * (v.kernel_type == 0 ? kern_val<0>(r2) : kern_val<1>(r2));
+    return P[D] * (v.kernel_type == 0 ? kern_val<0>(r2, EXP_TAB_G) : kern_val<1>(r2, EXP_TAB_G));
   }
   double k = 1.0, ssum = 0.0;
   for (int d = 0; d < D; ++d) {
@@ -267,7 +267,7 @@ __device__ __forceinline__ double cov_pair_global(const BatchView& v, const doub
     k *= 1.0 + sd + (5.0 / 3.0) * r2;
     ssum += sd;
   }
-  return P[D] * (k * exp(-ssum));
+  return P[D] * (k * lean_exp_neg<false>(ssum, EXP_TAB_G));
 }
 
 // Emulators whose factorisation stopped at rank r < n: set the replacement diagonal of the block that was skipped and take the

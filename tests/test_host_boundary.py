@@ -378,3 +378,58 @@ print("HIPLIBS", len(libs), libs)
         assert out.returncode == 0, out.stderr[-2000:]
         line = [l for l in out.stdout.splitlines() if l.startswith("HIPLIBS")][0]
         assert line.split()[1] == "1", (order, line)
+
+
+def test_lean_exp_matches_long_double(tmp_path):
+    """The covariance kernels' 14-instruction exponential (csrc/exp_dev.h; replaces ocml's exp, Kernel.py:772-791, 861-882 use np.exp):
+    the same source text compiled for the host, against long double expl.  <= 1.1 ulp on normal results, exp(-x/2) form bit-identical
+    to the exp(-x) form at x/2, libm's behaviour at 0 / underflow / inf / NaN."""
+    import shutil
+    import subprocess
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    exe = str(tmp_path / "exp_check")
+    subprocess.check_call(["g++", "-O2", "-ffp-contract=off", "-I", os.path.join(ROOT, "mogp_emulator_amd", "csrc"),
+                           os.path.join(ROOT, "tests", "c", "exp_check.cpp"), "-o", exe])
+    full, half, mismatch, ok = subprocess.check_output([exe, "4000000"]).decode().split()
+    assert float(full) <= 1.1 and float(half) <= 1.1, (full, half)
+    assert int(mismatch) == 0 and int(ok) == 1
+    # the table in the header is what tools/gen_exp_table.py would write
+    tab = open(os.path.join(ROOT, "mogp_emulator_amd", "csrc", "exp_tab.h")).read()
+    vals = [float.fromhex(h) for h in re.findall(r"0x1\.[0-9a-f]+p\+0", tab)]
+    assert len(vals) == 256
+    assert_allclose(vals, 2.0 ** (np.arange(256) / 256.0), rtol=3e-16)
+
+
+def test_hip_runtime_preload_only_for_matching_soname(tmp_path, monkeypatch):
+    """the loader puts a PyTorch wheel's bundled HIP runtime in front of libmogp_hip.so only when that copy's DT_SONAME is
+    the libamdhip64.so.N this library was linked against; another ROCm major is left alone."""
+    import importlib.util
+    import shutil
+    import subprocess
+    import types
+    soname, needed = _capi.elf_dynamic(_capi.LIB_PATH)
+    hip_needed = [n for n in needed if n.startswith("libamdhip64.so")]
+    assert len(hip_needed) == 1 and re.fullmatch(r"libamdhip64\.so\.\d+", hip_needed[0])
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    # a fake torch package whose lib/ holds a libamdhip64.so with a chosen SONAME
+    def fake_torch(tag, so):
+        root = tmp_path / tag / "torch"
+        (root / "lib").mkdir(parents=True)
+        (root / "__init__.py").write_text("")
+        src = tmp_path / (tag + ".c")
+        src.write_text("int mogp_fake_runtime(void) { return 1; }\n")
+        subprocess.check_call(["gcc", "-shared", "-fPIC", "-Wl,-soname," + so, str(src), "-o", str(root / "lib" / "libamdhip64.so")])
+        return types.SimpleNamespace(origin=str(root / "__init__.py"))
+    same, other = fake_torch("same", hip_needed[0]), fake_torch("other", "libamdhip64.so.6")
+    assert _capi.elf_dynamic(os.path.join(os.path.dirname(other.origin), "lib", "libamdhip64.so"))[0] == "libamdhip64.so.6"
+    monkeypatch.setattr(importlib.util, "find_spec", lambda name: same)
+    assert _capi._bundled_runtime_to_preload(_capi.LIB_PATH) == [os.path.join(os.path.dirname(same.origin), "lib", "libamdhip64.so")]
+    monkeypatch.setattr(importlib.util, "find_spec", lambda name: other)
+    assert _capi._bundled_runtime_to_preload(_capi.LIB_PATH) == []
+    monkeypatch.setattr(importlib.util, "find_spec", lambda name: None)
+    assert _capi._bundled_runtime_to_preload(_capi.LIB_PATH) == []
+    monkeypatch.setenv("MOGP_HIP_RUNTIME", "system")
+    monkeypatch.setattr(importlib.util, "find_spec", lambda name: same)
+    assert _capi._one_hip_runtime_per_process() == []
