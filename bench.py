@@ -165,13 +165,19 @@ def time_shard(M, GPPriors, cid, n, d, B, m, kernel, nugget, theta, reps, map_st
     t_fit = med(lambda it: mo.eval(th + 1e-3 * it, grad=False))
     t_fg = med(lambda it: mo.eval(th + 1e-3 * it, grad=True))
     t_pr = med(lambda it: mo.predict_variance_batch(Xs, means, vars_))
+    import torch
+    dev = torch.device("cuda", torch.cuda.current_device())
+    d_Xs = torch.from_numpy(Xs).to(dev)
+    d_mean = torch.empty((B, m), dtype=torch.float64, device=dev)
+    d_var = torch.empty((B, m), dtype=torch.float64, device=dev)
+    t_pr_dev = med(lambda it: mo.predict_variance_batch_dev(d_Xs.data_ptr(), m, d_mean.data_ptr(), d_var.data_ptr()))
     # the same fit through the multi-launch Cholesky schedule of this regime (rounds 1-2), for comparison
     from mogp_emulator_amd import _capi
     _capi.load().mogp_profile_schedule(5, 0)
     t_fit_ml = med(lambda it: mo.eval(th + 1e-3 * it, grad=False))
     _capi.load().mogp_profile_schedule(-1, 0)
     out = {"fit_ms_multi_launch_schedule": t_fit_ml, "n": n, "d": d, "emulators": B, "m": m, "kernel": kernel, "fit_ms": t_fit, "fit_grad_ms": t_fg, "predict_ms_host_buffers": t_pr,
-           "fit_ms_per_emulator": t_fit / B, "fit_TFLOPs": B * float(n) ** 3 / 3. / t_fit * 1e-9, "fit_grad_TFLOPs": B * float(n) ** 3 / t_fg * 1e-9}
+           "predict_ms": t_pr_dev, "fit_ms_per_emulator": t_fit / B, "fit_TFLOPs": B * float(n) ** 3 / 3. / t_fit * 1e-9, "fit_grad_TFLOPs": B * float(n) ** 3 / t_fg * 1e-9}
     if map_starts:
         out.update(time_fit_map(M, X, T, kernel, nugget, map_starts, map_iters))
     return out
@@ -209,9 +215,47 @@ def time_fit_map(M, X, T, kernel, nugget, n_tries, max_iter):
     return res
 
 
-def time_other_config(M, GPPriors, lib, read_kernels, tag, cid, n, d, B, m, kernel, nugget, theta, reps):
-    """One of BASELINE's other configurations (C4, C5) on this GPU: fit / fit+gradient / predict at the fixed theta of
-    SURVEY 8d, with the tagged kernels of the fit phase from HIP events (work per unit: SURVEY 8d table)."""
+def cpu_baseline_config(tag, X, T, Xs, theta, kernel, nugget, emus, chunk_rows, ms, dev):
+    """the CPU path "reported beside each GPU figure".  The oracle (NumPy / LAPACK restatement of the
+    reference CPU path; BLAS-threaded) fits `emus` outputs of one of the other configurations at the benchmark theta and predicts
+    `ms` points, OUTSIDE any timed region; the device results of the same outputs (`dev`: logpost, mean, var) give the
+    configuration's own parity block.  chunk_rows: the oracle builds distances in row chunks where the faithful (n, n, d)
+    temporary would not fit (same per-entry arithmetic, tests/test_oracle_golden.py)."""
+    from oracle import cpu_ref as R
+    try:
+        from threadpoolctl import threadpool_info
+        threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+    except Exception:
+        threads = os.cpu_count() or 1
+    t_fits, t_pred, err_lp, err_mean, err_var, kappa_eps = [], [], 0., 0., 0., 0.
+    for k in emus:
+        ref = R.GPRef(X, T[k], kernel=kernel, nugget=nugget, chunk_rows=chunk_rows)
+        t0 = time.perf_counter(); lp = ref.fit(theta); t_fits.append(time.perf_counter() - t0)
+        t0 = time.perf_counter(); mu, var, _ = ref.predict(Xs[:ms], include_nugget=False); t_pred.append(time.perf_counter() - t0)
+        dl = np.diag(ref.L)
+        kappa_eps = max(kappa_eps, float((dl.max() / dl.min()) ** 2 * np.finfo(float).eps))
+        err_lp = max(err_lp, abs(dev["logpost"][k] - lp) / abs(lp))
+        err_mean = max(err_mean, float(np.max(np.abs(dev["mean"][k, :ms] - mu) / np.maximum(np.abs(mu), 1e-2))))
+        err_var = max(err_var, float(np.max(np.abs(np.maximum(dev["var"][k, :ms], 0.) - var))))
+        del ref
+    # stated bars (DESIGN.md section 4): logpost 1e-10 -- conditioning-scaled max(1e-10, 32 kappa_L eps) where kappa_L eps > 1e-11
+    # (C5: two backward-stable factorisations of the same matrix differ by ~cond eps in the quadratic form) --, mean 1e-7, var 1e-7
+    lp_tol = max(1e-10, 32 * kappa_eps) if kappa_eps > 1e-11 else 1e-10
+    parity = {"emulators": list(emus), "predict_points": int(ms), "max_rel_logpost": float(err_lp), "max_rel_mean": err_mean,
+              "max_abs_var": err_var, "kappa_L_eps": kappa_eps,
+              "tolerances": {"logpost_rtol": lp_tol, "mean_rtol_floor_1e-2": 1e-7, "var_atol": 1e-7}}
+    parity["passed"] = bool(err_lp <= lp_tol and err_mean <= 1e-7 and err_var <= 1e-7)
+    t_fit = float(np.median(t_fits))
+    return {"value": 1.0 / t_fit, "unit": "fits/s", "cores": int(threads), "kind": "port",
+            "sample": "%s: BLAS-threaded oracle, %d of the configuration's outputs: fit %.2fs each (median), predict %d pts %.2fs%s" % (
+                tag, len(emus), t_fit, ms, float(np.median(t_pred)), ", distances in %d-row chunks" % chunk_rows if chunk_rows else ""),
+            "predict_pts_per_s": ms / float(np.median(t_pred)), "host_cpus": os.cpu_count()}, parity
+
+
+def time_other_config(M, GPPriors, lib, read_kernels, tag, cid, n, d, B, m, kernel, nugget, theta, reps, cpu=None):
+    """One of BASELINE's other configurations (C2, C4, C5) on this GPU: fit / fit+gradient / predict at the fixed theta of
+    SURVEY 8d, with the tagged kernels of the fit phase from HIP events (work per unit: SURVEY 8d table).  cpu = (emulators,
+    chunk_rows, points, budget): the oracle timed beside it (cpu_baseline_config) unless the budget (seconds left) is used up."""
     X, T, Xs = synth(cid, n, d, B, m)
     nt = nugget if isinstance(nugget, str) else "fixed"
     gp = M.MultiOutputGP_GPU(X, T, kernel=kernel, nugget=nugget, priors=GPPriors(n_corr=d, nugget_type=nt))
@@ -245,7 +289,22 @@ def time_other_config(M, GPPriors, lib, read_kernels, tag, cid, n, d, B, m, kern
     assert ok.all() and np.all(np.isfinite(means)) and np.all(np.isfinite(vars_))
     assert np.allclose(d_mean.cpu().numpy(), means, rtol=1e-12, atol=1e-12)
     fit_tf, fg_tf, pv_tf = B * float(n) ** 3 / 3. / t_fit * 1e-9, B * float(n) ** 3 / t_fg * 1e-9, B * float(m) * float(n) ** 2 / t_pr * 1e-9
-    return {"config": tag, "workload": "%d outputs x n=%d x d=%d, %s, nugget %s, predict m=%d" % (B, n, d, kernel, nugget, m),
+    cpu_out = {}
+    if cpu is not None:
+        emus, chunk_rows, ms, budget = cpu
+        if budget["left"] < budget["need"].get(tag, 0.):
+            cpu_out["cpu_baseline"] = {"skipped": "CPU time budget of this run used up (%.0f s left, ~%.0f s needed)" % (
+                budget["left"], budget["need"].get(tag, 0.))}
+        else:
+            t0 = time.perf_counter()
+            fdev, _, okd = mo.eval(th, grad=False)          # the benchmark theta itself (the timed evaluations perturb it)
+            mo.predict_variance_batch(Xs, means, vars_)
+            assert okd.all()
+            cpu_out["cpu_baseline"], cpu_out["parity"] = cpu_baseline_config(
+                tag, X, T, Xs, theta, kernel, nugget, emus, chunk_rows, ms, {"logpost": fdev, "mean": means, "var": vars_})
+            cpu_out["cpu_baseline"]["gpu_over_cpu_fit"] = (B / t_fit * 1e3) / cpu_out["cpu_baseline"]["value"]
+            budget["left"] -= time.perf_counter() - t0
+    return {**cpu_out, "config": tag, "workload": "%d outputs x n=%d x d=%d, %s, nugget %s, predict m=%d" % (B, n, d, kernel, nugget, m),
             "fit_ms": t_fit, "fit_grad_ms": t_fg, "predict_ms": t_pr, "predict_ms_host_buffers": t_pr_host,
             "fits_per_s": B / t_fit * 1e3, "fit_grad_per_s": B / t_fg * 1e3, "predict_pts_per_s": B * m / t_pr * 1e3,
             "fit_TFLOPs": fit_tf, "fit_frac_of_fp64_mfma_peak": fit_tf / FP64_MFMA_PEAK_TF,
@@ -307,6 +366,8 @@ def main():
     ap.add_argument("--m", type=int, default=10000, help="prediction points per emulator")
     ap.add_argument("--kernel", default="SquaredExponential")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget-s", type=float, default=240.,
+                    help="host seconds the CPU oracle may spend beside the other configurations (C2 / C4 / C5); what does not fit is reported as skipped")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the C2 / C4 / C5 block (other_configs)")
     ap.add_argument("--no-extras", action="store_true",
                     help="only the timed steps (+ the single-stream pass): none of the untimed extras (host-buffer predict, deriv, full_cov, "
@@ -501,6 +562,23 @@ def main():
         except OSError:
             pass
 
+    # The timed predict follows eval(grad=True), i.e. L^-1 exists (steady state: many predictions per fit).  The FIRST predict after a
+    # plain fit also builds L^-1 (the reference pays its invQ inside fit, densegp_gpu.hpp:576-582): reported next to it.
+    if rank == 0 and world == 1:
+        first, steady = [], []
+        for it in range(3):
+            mo.eval(thetas + 1e-3 * (it + 11), grad=False)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter(); mo.predict_variance_batch_dev(d_Xs.data_ptr(), m, d_mean.data_ptr(), d_var.data_ptr()); t1 = time.perf_counter()
+            mo.predict_variance_batch_dev(d_Xs.data_ptr(), m, d_mean.data_ptr(), d_var.data_ptr()); t2 = time.perf_counter()
+            first.append(t1 - t0); steady.append(t2 - t1)
+        extras["predict_first_call_ms"] = float(np.median(first)) * 1e3
+        extras["predict_steady_ms"] = float(np.median(steady)) * 1e3
+        extras["predict_first_call_note"] = ("first predict after a fit without gradient = steady-state predict + the one-off L^-1 build "
+                                             "(%.2f ms for %d emulators); predict_pts_per_s is the steady-state rate" % (
+                                                 (float(np.median(first)) - float(np.median(steady))) * 1e3, B))
+        extras["predict_pts_per_s_first_call"] = B * m / float(np.median(first))
+
     # per-kernel device times from HIP events on the launch stream
     def read_kernels():
         kern = {}
@@ -544,15 +622,19 @@ def main():
         # BASELINE's other configurations on this GPU (VERDICT r2, row (+)2): C4 = 16 outputs, Matern-5/2 + fitted nugget,
         # n=5000, d=20; C5 = one output, n=16000, d=8.  ~0.5 s of GPU time each.
         if not args.no_other_configs and (n, d, B) == (2000, 10, 64):
+            # CPU oracle beside each of them, bounded: ~1 s (C2), ~30 s (two of C4's outputs), ~80 s (C5's fit)
+            budget = {"left": 0. if args.no_cpu_baseline else float(args.cpu_budget_s), "need": {"C2": 2., "C4": 45., "C5": 100.}}
+            cpu_of = (lambda emus, chunk, pts: None) if args.no_cpu_baseline else (lambda emus, chunk, pts: (emus, chunk, pts, budget))
             extras["other_configs"] = [
                 # C2: the single-output fit + 10^4-point predict every GaussianProcessGPU.fit / .predict of the reference
                 # wrapper runs (GaussianProcessGPU.py:431-438, densegp_gpu.hpp:451-474): one matrix, chain-bound
                 time_other_config(M, GPPriors, lib, read_kernels, "C2", 2, 2000, 10, 1, m, "SquaredExponential", 1e-6,
-                                  np.array([-2. * np.log(0.3 * np.sqrt(10))] * 10 + [0.]), 9),
+                                  np.array([-2. * np.log(0.3 * np.sqrt(10))] * 10 + [0.]), 9, cpu=cpu_of([0], None, 2000)),
                 time_other_config(M, GPPriors, lib, read_kernels, "C4", 4, 5000, 20, 16, m, "Matern52", "fit",
-                                  np.array([-2. * np.log(0.3 * np.sqrt(20))] * 20 + [0., np.log(1e-4)]), 3),
+                                  np.array([-2. * np.log(0.3 * np.sqrt(20))] * 20 + [0., np.log(1e-4)]), 3, cpu=cpu_of([0, 15], 256, 500)),
                 time_other_config(M, GPPriors, lib, read_kernels, "C5", 5, 16000, 8, 1, m, "SquaredExponential", 1e-6,
-                                  np.array([-2. * np.log(0.3 * np.sqrt(8))] * 8 + [0.]), 3)]
+                                  np.array([-2. * np.log(0.3 * np.sqrt(8))] * 8 + [0.]), 3, cpu=cpu_of([0], 128, 256))]
+            extras["other_configs_cpu_budget_s"] = {"given": float(args.cpu_budget_s), "left": budget["left"]}
         # RCCL exercised on the single GPU: the exchange payloads of the N > 1 path through a world-size-1 nccl group
         if not dist.is_initialized():
             extras["nccl_world1"] = nccl_world1(mo, B, m, dev)
@@ -574,15 +656,20 @@ def main():
             peak = FP64_MFMA_PEAK_TF if kd["bound"] == "mfma" else HBM_PEAK_GBS
             # HBM-side bytes per launch from rocprofv3 PMC passes (cannot be collected from inside this process):
             # measured offline on this exact default workload and stored under profiles/; null for any other workload
-            traffic = None
+            traffic, traffic_source = None, "none: not the default workload"
             try:
                 if (n, d, B, m, args.kernel, world) == (2000, 10, 64, 10000, "SquaredExponential", 1):
-                    with open(os.path.join(ROOT, "profiles", "r04_traffic.json")) as fh:
+                    import glob
+                    tf = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))[-1]
+                    with open(tf) as fh:
                         traffic = json.load(fh).get(dom, {}).get("traffic_bytes_per_launch")
-            except (OSError, ValueError):
-                traffic = None
+                    traffic_source = ("committed file profiles/%s: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this exact workload, "
+                                      "collected offline (tools/pmc_fetch.sh) -- NOT measured in this run" % os.path.basename(tf))
+            except (OSError, ValueError, IndexError):
+                traffic, traffic_source = None, "none: no profiles/r*_traffic.json"
             roofline = {"kernel": dom, "bound": kd["bound"], "achieved": kd["achieved"], "peak": peak, "unit": kd["unit"],
-                        "frac": kd["achieved"] / peak, "traffic": traffic, "avg_launch_ms": kd["avg_ms"], "launches": kd["launches"]}
+                        "frac": kd["achieved"] / peak, "traffic": traffic, "traffic_source": traffic_source,
+                        "avg_launch_ms": kd["avg_ms"], "launches": kd["launches"]}
         # the fit phase as a whole against the fp64 MFMA peak: n^3/3 flops per emulator / phase time
         fit_tf = total_emus * K * float(n) ** 3 / 3. / t_fit * 1e-12
         fitgrad_tf = total_emus * K * float(n) ** 3 / t_fg * 1e-12
@@ -615,6 +702,22 @@ def main():
         for e in out.get("shard_sweep", []):
             if e["n"] == n:      # per-emulator fit time of the shard relative to the full batch on one GPU (2.0 = half the efficiency)
                 e["per_emulator_time_vs_full_batch"] = e["fit_ms_per_emulator"] / (t_fit / K * 1e3 / total_emus)
+        if world == 1 and out.get("shard_sweep"):
+            # No multi-GPU run can be made from a one-GPU box: what N GPUs would deliver under strong scaling, from the time ONE GPU
+            # takes for the shard a rank holds at that N (shards are independent; the only exchange is the gather measured in
+            # nccl_world1, microseconds).  efficiency = (one-GPU time / N) / shard time.
+            by_b = {e["emulators"]: e for e in out["shard_sweep"] if e["n"] == n}
+            proj = {}
+            for N in (2, 4, 8):
+                e = by_b.get(total_emus // N)
+                if e:
+                    proj[str(N)] = {"emulators_per_gpu": total_emus // N, "fit_ms": e["fit_ms"], "fits_per_s": total_emus / e["fit_ms"] * 1e3,
+                                    "fit_efficiency": (t_fit / K * 1e3 / N) / e["fit_ms"],
+                                    "fit_grad_efficiency": (t_fg / K * 1e3 / N) / e["fit_grad_ms"],
+                                    "predict_pts_per_s": total_emus * m / e["predict_ms"] * 1e3,
+                                    "predict_efficiency": (t_pr / K * 1e3 / N) / e["predict_ms"]}
+            out["projected_scaling"] = {"basis": "one-GPU time of the per-rank shard (shard_sweep) -- a projection, not a multi-GPU measurement",
+                                        "n_gpus": proj}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"], values = cpu_baseline(X, T, Xs, theta, nugget)
             out["parity_in_bench"] = parity_in_bench(mo, values, theta, Xs)

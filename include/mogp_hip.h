@@ -191,8 +191,12 @@ int mogp_mogp_predict_deriv(mogp_mogp*, const double* testing, int m, int D, dou
 int mogp_mogp_implausibility(mogp_mogp*, const double* testing, int m, int D, const double* obs, const double* obs_var,
                              const double* discrepancy, int include_nugget, int rank, double* out /* m */);
 int mogp_mogp_predict_full_cov(mogp_mogp*, const double* testing, int m, int D, double* means, double* covs);
-/* same, but testing / outputs are DEVICE pointers (inputs already resident in HBM; results stay in HBM) */
+/* predict_variance_batch (multioutputgp_gpu.hpp:182-192) with DEVICE pointers: inputs already resident in HBM, results stay in HBM
+ * (every mean function; rows of emulators that are not fit are filled with NaN, MultiOutputGP_GPU.py:288-296) */
 int mogp_mogp_predict_variance_batch_dev(mogp_mogp*, const double* d_testing, int m, int D, double* d_means, double* d_vars);
+/* the same with the input derivatives of predict_deriv (multioutputgp_gpu.hpp:195-203) in the same pass: d_derivs (n_out, m, D) device
+ * buffer; d_vars and d_derivs may be NULL.  What one rank of a sharded predict hands to the single RCCL gather (dist.py). */
+int mogp_mogp_predict_dev(mogp_mogp*, const double* d_testing, int m, int D, double* d_means, double* d_vars, double* d_derivs);
 /* fit_GP_MAP(MultiOutputGP_GPU&, n_tries, theta0) bindings.cu:604-605 / fitting.hpp:122-128.
  * All emulators advance in lock-step: each L-BFGS iteration is one batched device evaluation. */
 int mogp_fit_GP_MAP(mogp_mogp*, int n_tries, const double* theta0, int theta0_len);
@@ -225,10 +229,6 @@ int mogp_profile_get(const char* kernel_tag, double* total_ms, long long* launch
    `capacity` entries, returns the number of tasks.  Host-only (no device needed): the CPU suite checks that the order is
    topological, which is what the kernel's forward-progress argument rests on. */
 int mogp_mchol_task_table(int n_plus_rhs, int* out, int capacity);
-/* The same for throughput-bound launches (large batches / matrices): the bulk of block column c, row tiles r >= 2c + 8, is listed as
-   type 3 entries TT(r, c), r even = the row tiles r and r + 1 as ONE task with a 128 x 128 GEMM tile (two thirds of the operand bytes
-   per flop); all other entries as above. */
-int mogp_mchol_task_table_paired(int n_plus_rhs, int* out, int capacity);
 /* process-wide diagnostic counters: "backsolve_timeouts" = back substitutions that were repeated with the multi-launch
    path because a wait of the one-launch chain timed out (0 in normal operation); "mchol_aborts" = factorisations the
    one-launch Cholesky gave up on and a multi-launch schedule repeated (0 in normal operation); "objective_evals" / "gradient_evals" =

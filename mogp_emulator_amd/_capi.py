@@ -120,6 +120,7 @@ SIGNATURES = {
     "mogp_mogp_implausibility": (c_int, [c_void_p, c_double_p, c_int, c_int, c_double_p, c_double_p, c_double_p, c_int, c_int, c_double_p]),
     "mogp_mogp_predict_full_cov": (c_int, [c_void_p, c_double_p, c_int, c_int, c_double_p, c_double_p]),
     "mogp_mogp_predict_variance_batch_dev": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "mogp_mogp_predict_dev": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "mogp_fit_GP_MAP": (c_int, [c_void_p, c_int, c_double_p, c_int]),
     "mogp_set_fit_options": (c_int, [c_int, c_double, c_double, c_ulonglong]),
     "mogp_kernel_eval": (c_int, [c_int, c_int, c_double_p, c_int, c_double_p, c_int, c_int, c_double_p, c_int, c_double_p]),
@@ -129,7 +130,6 @@ SIGNATURES = {
     "mogp_profile_get": (c_int, [c_char_p, c_double_p, POINTER(c_longlong), c_double_p, c_double_p]),
     "mogp_profile_counter": (c_int, [c_char_p, POINTER(c_longlong)]),
     "mogp_mchol_task_table": (c_int, [c_int, c_int_p, c_int]),
-    "mogp_mchol_task_table_paired": (c_int, [c_int, c_int_p, c_int]),
     "mogp_dev_malloc": (c_void_p, [c_ulonglong]),
     "mogp_dev_free": (c_int, [c_void_p]),
     "mogp_dev_upload": (c_int, [c_void_p, c_void_p, c_ulonglong]),

@@ -3,6 +3,7 @@
 // with that message, matching the std::runtime_error -> RuntimeError mapping of pybind11 in the
 // reference (bindings.cu).
 #include <cstring>
+#include <limits>
 #include <memory>
 
 #include "../../include/mogp_hip.h"
@@ -534,15 +535,57 @@ int mogp_mogp_implausibility(mogp_mogp* h, const double* testing, int m, int D, 
     e->implausibility(ids, testing, m, obs, obs_var, discrepancy, include_nugget != 0, rank, out);
   });
 }
+// device-resident prediction: d_means / d_vars (n_emulators, m) and d_derivs (n_emulators, m, D) are device buffers (d_vars, d_derivs may be
+// null); rows of emulators that are not fit are filled with NaN (MultiOutputGP_GPU.py:288-296)
+#define HIPCK(x) hip_check((x), #x)
+static void mogp_predict_dev_common(mogp_mogp* h, const double* d_testing, int m, int D, double* d_means, double* d_vars, double* d_derivs) {
+  Engine* e = h->eng.get();
+  if (D != e->D) throw std::runtime_error("testing points must have D columns");
+  if (m <= 0) return;
+  std::vector<int> ids = fitted_ids(h);
+  if ((int)ids.size() == e->B) {
+    e->predict(ids, d_testing, m, true, d_means, d_vars, m, true, d_derivs);
+    return;
+  }
+  // some emulators are not fit: the fitted ones are predicted into scratch rows and copied to their places, the others become NaN
+  const size_t nf = ids.size(), row = (size_t)m, drow = (size_t)m * D;
+  std::vector<double> nan_row(std::max(row, d_derivs ? drow : row), std::numeric_limits<double>::quiet_NaN());
+  std::vector<char> fitted(e->B, 0);
+  for (int i : ids) fitted[i] = 1;
+  for (int i = 0; i < e->B; ++i) {
+    if (fitted[i]) continue;
+    HIPCK(hipMemcpy(d_means + (size_t)i * row, nan_row.data(), row * sizeof(double), hipMemcpyHostToDevice));
+    if (d_vars) HIPCK(hipMemcpy(d_vars + (size_t)i * row, nan_row.data(), row * sizeof(double), hipMemcpyHostToDevice));
+    if (d_derivs) HIPCK(hipMemcpy(d_derivs + (size_t)i * drow, nan_row.data(), drow * sizeof(double), hipMemcpyHostToDevice));
+  }
+  if (nf == 0) return;
+  double *tm = nullptr, *tv = nullptr, *td = nullptr;
+  auto release = [&] {
+    for (double* p : {tm, tv, td})
+      if (p) hipFree(p);
+  };
+  try {
+    HIPCK(hipMalloc((void**)&tm, nf * row * sizeof(double)));
+    if (d_vars) HIPCK(hipMalloc((void**)&tv, nf * row * sizeof(double)));
+    if (d_derivs) HIPCK(hipMalloc((void**)&td, nf * drow * sizeof(double)));
+    e->predict(ids, d_testing, m, true, tm, tv, m, true, td);
+    for (size_t k = 0; k < nf; ++k) {
+      HIPCK(hipMemcpy(d_means + (size_t)ids[k] * row, tm + k * row, row * sizeof(double), hipMemcpyDeviceToDevice));
+      if (d_vars) HIPCK(hipMemcpy(d_vars + (size_t)ids[k] * row, tv + k * row, row * sizeof(double), hipMemcpyDeviceToDevice));
+      if (d_derivs) HIPCK(hipMemcpy(d_derivs + (size_t)ids[k] * drow, td + k * drow, drow * sizeof(double), hipMemcpyDeviceToDevice));
+    }
+  } catch (...) {
+    release();
+    throw;
+  }
+  release();
+}
+#undef HIPCK
 int mogp_mogp_predict_variance_batch_dev(mogp_mogp* h, const double* d_testing, int m, int D, double* d_means, double* d_vars) {
-  GUARD({
-    Engine* e = h->eng.get();
-    if (D != e->D) throw std::runtime_error("testing points must have D columns");
-    std::vector<int> ids = fitted_ids(h);
-    if ((int)ids.size() != e->B) throw std::runtime_error("predict_variance_batch_dev requires every emulator to be fit");
-    if (e->mean.kind != 0) throw std::runtime_error("predict_variance_batch_dev supports the zero mean function only");
-    e->predict(ids, d_testing, m, true, d_means, d_vars, m, true, nullptr);
-  });
+  GUARD(mogp_predict_dev_common(h, d_testing, m, D, d_means, d_vars, nullptr));
+}
+int mogp_mogp_predict_dev(mogp_mogp* h, const double* d_testing, int m, int D, double* d_means, double* d_vars, double* d_derivs) {
+  GUARD(mogp_predict_dev_common(h, d_testing, m, D, d_means, d_vars, d_derivs));
 }
 int mogp_fit_GP_MAP(mogp_mogp* h, int n_tries, const double* theta0, int theta0_len) {
   GUARD({
@@ -581,14 +624,6 @@ int mogp_mchol_task_table(int n_plus_rhs, int* out, int capacity) {
   // host-only: the per-emulator task order of the one-launch Cholesky for a matrix of NP = roundup(n_plus_rhs, 128) rows
   const int NP = (n_plus_rhs + TILE - 1) / TILE * TILE;
   const std::vector<int> tb = mchol_task_table(NP);
-  if (out)
-    for (int i = 0; i < (int)tb.size() && i < capacity; ++i) out[i] = tb[i];
-  return (int)tb.size();
-}
-int mogp_mchol_task_table_paired(int n_plus_rhs, int* out, int capacity) {
-  // the table of throughput-bound launches: type 3 TT(r, c) = the row tiles r, r + 1 of block column c as one 128 x 128 task
-  const int NP = (n_plus_rhs + TILE - 1) / TILE * TILE;
-  const std::vector<int> tb = mchol_task_table(NP, true);
   if (out)
     for (int i = 0; i < (int)tb.size() && i < capacity; ++i) out[i] = tb[i];
   return (int)tb.size();

@@ -78,9 +78,10 @@ class Engine {
   void grad_current(const std::vector<int>& ids, double* grad, int grad_ld);
 
   // predictions for emulators `ids` (must be fitted). Xs host (m, D) unless xs_on_device.
-  // means/vars: (ids.size(), m) row-major with leading dimension out_ld; host unless out_on_device.
+  // means/vars: (ids.size(), m) row-major with leading dimension out_ld, derivs (ids.size(), m, D) or null; host unless
+  // out_on_device.  Mean-function terms (parametric or analytic) are added on the device either way.
   void predict(const std::vector<int>& ids, const double* Xs, int m, bool xs_on_device, double* means, double* vars,
-               long out_ld, bool out_on_device, double* derivs /* host (ids, m, D) or null */);
+               long out_ld, bool out_on_device, double* derivs);
 
   void get_K(int i, double* out);
   // HistoryMatching.get_implausibility (HistoryMatching.py:197-276) fused behind the batched prediction:
@@ -127,6 +128,8 @@ class Engine {
   void ensure_linv(const std::vector<int>& ids);
   void ensure_kinv(const std::vector<int>& ids, bool for_gradient = false);
   BatchView view(int nb) const;
+  void build_cov(const BatchView& v);
+  std::vector<char> z_armed;     // per emulator: its solution row holds the sentinel pattern of the one-launch back substitution
   void set_theta(int i, const double* theta);
   void ensure_predict_scratch(int nb, int MC);
 
@@ -136,8 +139,8 @@ class Engine {
   bool can_waitval = false;      // hipDeviceAttributeCanUseStreamWaitValue of the engine's device
   int device = 0;                // HIP device the engine was created on
   // one-launch Cholesky (kernels_mchol.hip): task table, control words, per-column packs
-  int* dMcTable[2] = {nullptr, nullptr};     // [0] 64 x 128 bulk tasks, [1] paired 128 x 128 bulk tasks (mchol_use_pairs)
-  int mc_ntasks[2] = {0, 0};
+  int* dMcTable = nullptr;       // the task order of one emulator (mchol_task_table)
+  int mc_ntasks = 0;
   unsigned* dMcCtrl = nullptr;
   size_t mc_ctrl_ints = 0;
   int mc_slots = 0;              // batch slots dMcCtrl / dMcPacks are sized for (grown to the largest one-launch batch seen)
@@ -163,6 +166,8 @@ class Engine {
   // predict scratch
   double *dXs = nullptr, *dKs = nullptr, *dMean = nullptr, *dVar = nullptr, *dVarPartial = nullptr, *dDeriv = nullptr;
   size_t capXs = 0, capKs = 0, capMean = 0, capVar = 0, capVarPartial = 0, capDeriv = 0;
+  double *dMeanFin = nullptr, *dMeanAux = nullptr;   // finished means when the dot products have their own rows; staging of the mean-function terms
+  size_t capMeanFin = 0, capMeanAux = 0;
   std::mt19937_64 rng;
 };
 

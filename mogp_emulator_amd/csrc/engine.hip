@@ -221,11 +221,11 @@ Engine::~Engine() {
   for (void* p : {(void*)dX, (void*)dP, (void*)dT, (void*)dA, (void*)dLinv, (void*)dKinv, (void*)dAlpha, (void*)dRes,
                   (void*)dGradOut, (void*)dGradPartial, (void*)dInfo, (void*)dIdx, (void*)dXs, (void*)dKs, (void*)dMean, (void*)dVar,
                   (void*)dVarPartial, (void*)dDeriv, (void*)dLpack, (void*)dH, (void*)dZ, (void*)dM, (void*)dXp, (void*)dPivWork,
-                  (void*)dPerm, (void*)dRank})
+                  (void*)dPerm, (void*)dRank, (void*)dMeanFin, (void*)dMeanAux})
     if (p) hipFree(p);
   if (hRes) hipHostFree(hRes);
   if (dBsFlags) hipFree(dBsFlags);
-  for (void* p : {(void*)dMcTable[0], (void*)dMcTable[1], (void*)dMcCtrl, (void*)dMcPacks})
+  for (void* p : {(void*)dMcTable, (void*)dMcCtrl, (void*)dMcPacks})
     if (p) hipFree(p);
   if (sigU1) hipFree(sigU1);
   for (auto& kv : w2) hipFree(kv.second);
@@ -242,6 +242,15 @@ double Engine::nugget_size(int i) const {
   const GPState& g = gp[i];
   if (g.nug_type == NUG_FIT) return std::exp(g.data[NC + 1]);   // zero-initialised data -> 1 before the first fit   // gpparams.hpp:176-182
   return g.nug_size;
+}
+
+// K build of the slots in dIdx.  With one right-hand side it also presets the solution rows to the all-ones pattern the one-launch
+// back substitution polls for (backsolve_chain_kernel<SENT>); `z_armed` records that, so that a chain launched on a row that has
+// not been preset since its last solve arms it itself instead of reading stale values as "already there".
+void Engine::build_cov(const BatchView& v) {
+  launch_cov_build(v, stream);
+  if (z_armed.size() != (size_t)B) z_armed.assign(B, 0);
+  for (int i : idx_on_device) z_armed[i] = (R == 1 && v.Z != nullptr) ? 1 : 0;
 }
 
 BatchView Engine::view(int nb) const {
@@ -362,7 +371,7 @@ void Engine::factorize_pivot(const std::vector<int>& ids, std::vector<int>& info
   BatchView v = view(nb);
   v.X = dX;          // the covariance is built in training order; the interchanges happen inside the factorisation
   v.XS = 0;
-  launch_cov_build(v, stream);
+  build_cov(v);
   launch_pstrf_begin(v, dPerm, dRank, dInfo, dPivWork, stream);
   std::vector<int> rank(B, 0), inf(B, 0);
   std::vector<int> active(ids), stopped;
@@ -479,12 +488,11 @@ void Engine::factorize_blocked(const std::vector<int>& ids, std::vector<int>& in
   mc_used = schedule == 4;
   if (schedule == 4) {
     // ONE LAUNCH: persistent workgroups take the tasks of all block columns from a dependency-ordered queue (kernels_mchol.hip)
-    const int pv = mchol_use_pairs(nb, NP) ? 1 : 0;          // which task table: 64 x 128 bulk tasks, or 128 x 128 (throughput-bound launches)
-    if (!dMcTable[pv]) {
-      const std::vector<int> tb = mchol_task_table(NP, pv != 0);
-      mc_ntasks[pv] = (int)tb.size();
-      dMcTable[pv] = dalloc<int>(tb.size());
-      HIPCK(hipMemcpy(dMcTable[pv], tb.data(), tb.size() * sizeof(int), hipMemcpyHostToDevice));
+    if (!dMcTable) {
+      const std::vector<int> tb = mchol_task_table(NP);
+      mc_ntasks = (int)tb.size();
+      dMcTable = dalloc<int>(tb.size());
+      HIPCK(hipMemcpy(dMcTable, tb.data(), tb.size() * sizeof(int), hipMemcpyHostToDevice));
     }
     if (nb > mc_slots) {
       // control rows and packs are per batch SLOT of a launch, sized for the largest launch seen so far -- not for the engine's B: a
@@ -501,8 +509,8 @@ void Engine::factorize_blocked(const std::vector<int>& ids, std::vector<int>& in
       dMcPacks = dalloc<double>(mchol_pack_doubles(NP, mc_slots));
     }
     HIPCK(hipMemsetAsync(dInfo, 0, B * sizeof(int), stream));
-    launch_cov_build(v, stream);
-    launch_mchol(v, dMcCtrl, mchol_ctrl_ints(NP, nb), dMcTable[pv], mc_ntasks[pv], pv != 0, dMcPacks, dInfo, n_cu, stream);
+    build_cov(v);
+    launch_mchol(v, dMcCtrl, mchol_ctrl_ints(NP, nb), dMcTable, mc_ntasks, dMcPacks, dInfo, n_cu, stream);
     if (!defer_info) {
       read_info(info, false);
       unsigned aborted = 0;
@@ -544,7 +552,7 @@ void Engine::factorize_blocked(const std::vector<int>& ids, std::vector<int>& in
     };
     hipStream_t pst = ovr.single_stream ? stream : pstream;
     HIPCK(hipMemsetAsync(dInfo, 0, B * sizeof(int), stream));
-    launch_cov_build(v, stream);
+    build_cov(v);
     HIPCK(hipEventRecord(evReady, stream));
     HIPCK(hipStreamWaitEvent(pst, evReady, 0));
     // "U1(c) done" in front of U2(c) sits in the dependent chain although U1(c) has normally finished a block column earlier, and
@@ -604,7 +612,7 @@ void Engine::factorize_blocked(const std::vector<int>& ids, std::vector<int>& in
       gstreams.push_back(st);
     }
     HIPCK(hipMemsetAsync(dInfo, 0, B * sizeof(int), stream));
-    launch_cov_build(v, stream);
+    build_cov(v);
     HIPCK(hipEventRecord(evReady, stream));
     std::vector<BatchView> gv(G, v);
     std::vector<hipStream_t> gs(G, stream);
@@ -638,7 +646,7 @@ void Engine::factorize_blocked(const std::vector<int>& ids, std::vector<int>& in
     return;
   }
   HIPCK(hipMemsetAsync(dInfo, 0, B * sizeof(int), stream));
-  launch_cov_build(v, stream);
+  build_cov(v);
   std::vector<int> starts;
   // outer block = K depth of the trailing update (MOGP_OUTER: 256 / 512 / 1024 -> C5 fit 45.7 / 41.7 / 44.3 ms)
   static const int OUTERW = [] { const char* e = getenv("MOGP_OUTER"); const int w = e ? atoi(e) : 512; return (w == 128 || w == 256 || w == 512 || w == 1024) ? w : 512; }();
@@ -717,6 +725,11 @@ void Engine::eval(const std::vector<int>& ids, const std::vector<const double*>&
           if (bs_epoch > 0x7FFFFF00) {                       // flags and status are compared with the epoch: start over before it wraps
             HIPCK(hipMemsetAsync(dBsFlags, 0, (nfl + B) * sizeof(int), stream));
             bs_epoch = 0;
+          }
+          if (z_armed.size() != (size_t)B) z_armed.assign(B, 0);
+          for (int i : todo) {
+            if (!z_armed[i]) HIPCK(hipMemsetAsync(dAlpha + (size_t)i * RA * LD, 0xFF, (size_t)LD * sizeof(double), stream));
+            z_armed[i] = 0;                                  // consumed by this solve
           }
           launch_backsolve_chain(v, dBsFlags, ++bs_epoch, dBsFlags + nfl, stream);
           chained = true;
@@ -1098,7 +1111,6 @@ void Engine::predict(const std::vector<int>& ids, const double* Xs, int m, bool 
   if (nb == 0 || m == 0) return;
   for (int i : ids)
     if (!gp[i].factored) throw std::runtime_error("emulator has not been fit");
-  if (R > 1 && out_on_device) throw std::runtime_error("device-resident outputs are not available with an analytic mean function");
   if (vars) ensure_linv(ids);
   upload_idx(ids);
   BatchView v = view(nb);
@@ -1108,16 +1120,32 @@ void Engine::predict(const std::vector<int>& ids, const double* Xs, int m, bool 
     HIPCK(hipMemcpyAsync(dXs, Xs, (size_t)m * D * sizeof(double), hipMemcpyHostToDevice, stream));
     dXsrc = dXs;
   }
-  // dm: R rows of dot products per emulator (row 0 = k*^T K^-1 (t - H beta), rows 1.. = k*^T K^-1 h_c)
-  double* dm = means;
-  double* dv = vars;
+  // dots: R rows of dot products per emulator (row 0 = k*^T K^-1 (t - H beta), rows 1.. = k*^T K^-1 h_c); with R = 1 that row IS
+  // the mean (before the mean-function term) and lands in the result rows directly.  fm / fv / fd: where the finished means /
+  // variances / derivatives live on the device -- the caller's buffers (out_on_device) or the engine's, copied out at the end.
+  double* fm = means;
+  double* fv = vars;
+  double* fd = derivs;
   long ld = out_ld;
   if (!out_on_device) {
-    grow(dMean, capMean, (size_t)nb * R * m);
-    grow(dVar, capVar, (size_t)nb * m);
-    dm = dMean;
-    dv = dVar;
+    grow(dMeanFin, capMeanFin, (size_t)nb * m);
+    fm = dMeanFin;
     ld = m;
+    if (vars) {
+      grow(dVar, capVar, (size_t)nb * m);
+      fv = dVar;
+    }
+    if (derivs) {
+      grow(dDeriv, capDeriv, (size_t)nb * m * D);
+      fd = dDeriv;
+    }
+  }
+  double* dots = fm;
+  long dots_ld = ld;
+  if (R > 1) {
+    grow(dMean, capMean, (size_t)nb * R * m);
+    dots = dMean;
+    dots_ld = m;
   }
   const int MPtot = roundup(m, 128);
   static const double budget = [] { const char* e = getenv("MOGP_KS_BUDGET_GB"); return (e ? atof(e) : 12.0) * 1e9; }();  // cross-covariance chunk (12 GB: one chunk for 64 x n=2000 x m=10^4)
@@ -1134,84 +1162,72 @@ void Engine::predict(const std::vector<int>& ids, const double* Xs, int m, bool 
   for (int c0 = 0; c0 < m; c0 += (int)MC) {
     const int mc = std::min<int>((int)MC, m - c0);
     const int MPc = roundup(mc, 128);
-    launch_cross_cov_mean(v, dXsrc + (size_t)c0 * D, mc, MPc, vars ? dKs : nullptr, dm + c0, (int)ld, stream);
-    if (vars) launch_predict_var(v, dKs, mc, MPc, dVarPartial, dv + c0, (int)ld, stream);
+    launch_cross_cov_mean(v, dXsrc + (size_t)c0 * D, mc, MPc, vars ? dKs : nullptr, dots + c0, (int)dots_ld, stream);
+    if (vars) launch_predict_var(v, dKs, mc, MPc, dVarPartial, fv + c0, (int)ld, stream);
   }
-  if (derivs) {
-    grow(dDeriv, capDeriv, (size_t)nb * m * D);
-    launch_predict_deriv(v, dXsrc, m, dDeriv, (long)m * D, stream);
-    HIPCK(hipMemcpyAsync(derivs, dDeriv, (size_t)nb * m * D * sizeof(double), hipMemcpyDeviceToHost, stream));
-  }
-  std::vector<double> dots;
-  if (!out_on_device) {
-    if (R > 1) {
-      dots.resize((size_t)nb * R * m);
-      HIPCK(hipMemcpyAsync(dots.data(), dm, dots.size() * sizeof(double), hipMemcpyDeviceToHost, stream));
+  if (derivs) launch_predict_deriv(v, dXsrc, m, fd, (long)m * D, stream);
+  if (mean.kind != 0 || R > 1) {
+    // mean-function terms, on the device (predict_mean_finish_kernel): the basis columns are evaluated here on the host (the one
+    // definition of the basis, hostmath.h) from the test points -- read back when they were handed over in device memory
+    std::vector<double> hx;
+    const double* xs_h = Xs;
+    if (xs_on_device) {
+      hx.resize((size_t)m * D);
+      HIPCK(hipMemcpyAsync(hx.data(), Xs, hx.size() * sizeof(double), hipMemcpyDeviceToHost, stream));
+      HIPCK(hipStreamSynchronize(stream));
+      xs_h = hx.data();
     }
+    const int nterm = (mean.kind == 3) ? (int)mean.dims.size() : 0;
+    const int nbasis = 1 + nterm;
+    const int qq = R - 1;
+    if (R > 1 && qq != nbasis) throw std::runtime_error("predict: analytic mean with an unexpected number of columns");
+    // one staging block: basis | dbasis | coef | LA | (ints) ddims, dpowers
+    const size_t o_basis = 0, o_dbasis = o_basis + (size_t)nbasis * m, o_coef = o_dbasis + (size_t)nterm * m,
+                 o_la = o_coef + (size_t)nb * nbasis, o_int = o_la + (size_t)nb * qq * qq, total = o_int + (size_t)nterm + 1;
+    std::vector<double> st(total, 0.);
+    for (int j = 0; j < m; ++j) st[o_basis + j] = 1.;
+    for (int t = 0; t < nterm; ++t)
+      for (int j = 0; j < m; ++j) {
+        const double x = xs_h[(size_t)j * D + mean.dims[t]];
+        st[o_basis + (size_t)(t + 1) * m + j] = std::pow(x, mean.powers[t]);
+        st[o_dbasis + (size_t)t * m + j] = std::pow(x, mean.powers[t] - 1);
+      }
+    for (int k = 0; k < nb; ++k) {
+      const GPState& g = gp[ids[k]];
+      double* c = st.data() + o_coef + (size_t)k * nbasis;
+      if (R > 1) {
+        for (int t = 0; t < qq; ++t) c[t] = g.beta[t];
+        for (int e = 0; e < qq * qq; ++e) st[o_la + (size_t)k * qq * qq + e] = g.LA[e];
+      } else if (mean.kind == 1) c[0] = mean.value;
+      else
+        for (int t = 0; t < nbasis; ++t) c[t] = g.meanp[t];
+    }
+    int* hi = reinterpret_cast<int*>(st.data() + o_int);
+    for (int t = 0; t < nterm; ++t) {
+      hi[t] = mean.dims[t];
+      hi[nterm + t] = mean.powers[t];
+    }
+    grow(dMeanAux, capMeanAux, total);
+    HIPCK(hipMemcpyAsync(dMeanAux, st.data(), total * sizeof(double), hipMemcpyHostToDevice, stream));
+    const int* di = reinterpret_cast<const int*>(dMeanAux + o_int);
+    launch_predict_mean_finish(nb, m, D, R, nbasis, dMeanAux + o_basis, dMeanAux + o_coef, R > 1 ? dots : nullptr, dMeanAux + o_la, fm,
+                               (R > 1 && vars) ? fv : nullptr, ld, derivs ? nterm : 0, dMeanAux + o_dbasis, di, di + nterm, fd, stream);
+    HIPCK(hipStreamSynchronize(stream));      // `st` is the source of an asynchronous copy
+  }
+  if (!out_on_device) {
     if (out_ld == m) {               // contiguous result arrays: one transfer each instead of one per emulator
-      if (R == 1) HIPCK(hipMemcpyAsync(means, dm, (size_t)nb * m * sizeof(double), hipMemcpyDeviceToHost, stream));
-      if (vars) HIPCK(hipMemcpyAsync(vars, dv, (size_t)nb * m * sizeof(double), hipMemcpyDeviceToHost, stream));
+      HIPCK(hipMemcpyAsync(means, fm, (size_t)nb * m * sizeof(double), hipMemcpyDeviceToHost, stream));
+      if (vars) HIPCK(hipMemcpyAsync(vars, fv, (size_t)nb * m * sizeof(double), hipMemcpyDeviceToHost, stream));
     } else {
       for (int k = 0; k < nb; ++k) {
-        if (R == 1) HIPCK(hipMemcpyAsync(means + (size_t)k * out_ld, dm + (size_t)k * m, m * sizeof(double), hipMemcpyDeviceToHost, stream));
-        if (vars) HIPCK(hipMemcpyAsync(vars + (size_t)k * out_ld, dv + (size_t)k * m, m * sizeof(double), hipMemcpyDeviceToHost, stream));
+        HIPCK(hipMemcpyAsync(means + (size_t)k * out_ld, fm + (size_t)k * m, m * sizeof(double), hipMemcpyDeviceToHost, stream));
+        if (vars) HIPCK(hipMemcpyAsync(vars + (size_t)k * out_ld, fv + (size_t)k * m, m * sizeof(double), hipMemcpyDeviceToHost, stream));
       }
     }
+    if (derivs) HIPCK(hipMemcpyAsync(derivs, fd, (size_t)nb * m * D * sizeof(double), hipMemcpyDeviceToHost, stream));
   }
   HIPCK(hipStreamSynchronize(stream));
   HIPCK(hipGetLastError());
-  if (out_on_device || (mean.kind == 0 && R == 1)) return;
-  std::vector<double> hx;
-  const double* xs_h = Xs;
-  if (xs_on_device) {
-    hx.resize((size_t)m * D);
-    HIPCK(hipMemcpy(hx.data(), Xs, hx.size() * sizeof(double), hipMemcpyDeviceToHost));
-    xs_h = hx.data();
-  }
-  std::vector<double> mv(m), mid((size_t)D * m);
-  if (R > 1) {
-    // analytic mean (GaussianProcess.py:906-935): mu = m(x*) + k*^T K^-1 (t - H beta),
-    // var += || LA^-1 (H*^T - H^T K^-1 k*) ||^2  with H* the design matrix of the test points
-    std::vector<double> Hs((size_t)q * m), rm(q);
-    std::vector<double> dummy(q, 0.);
-    mean.mean_deriv(xs_h, m, D, dummy.data(), q, Hs.data());
-    for (int k = 0; k < nb; ++k) {
-      const GPState& g = gp[ids[k]];
-      const double* dk = dots.data() + (size_t)k * R * m;
-      for (int j = 0; j < m; ++j) {
-        double mu = dk[j];
-        for (int c = 0; c < q; ++c) mu += g.beta[c] * Hs[(size_t)c * m + j];
-        means[(size_t)k * out_ld + j] = mu;
-        if (vars) {
-          double add = 0.;
-          for (int c = 0; c < q; ++c) {
-            double s = Hs[(size_t)c * m + j] - dk[(size_t)(1 + c) * m + j];
-            for (int p = 0; p < c; ++p) s -= g.LA[c * q + p] * rm[p];
-            rm[c] = s / g.LA[c * q + c];
-            add += rm[c] * rm[c];
-          }
-          vars[(size_t)k * out_ld + j] += add;
-        }
-      }
-      if (derivs) {
-        mean.mean_inputderiv(xs_h, m, D, g.beta.data(), q, mid.data());
-        for (int j = 0; j < m; ++j)
-          for (int d = 0; d < D; ++d) derivs[((size_t)k * m + j) * D + d] += mid[(size_t)d * m + j];
-      }
-    }
-    return;
-  }
-  // mean function contribution (host, O(m)): densegp_gpu.hpp:334-337, 402-405, 443-447
-  for (int k = 0; k < nb; ++k) {
-    const GPState& g = gp[ids[k]];
-    mean.mean_f(xs_h, m, D, g.meanp.data(), n_mean(), mv.data());
-    for (int j = 0; j < m; ++j) means[(size_t)k * out_ld + j] += mv[j];
-    if (derivs) {
-      mean.mean_inputderiv(xs_h, m, D, g.meanp.data(), n_mean(), mid.data());
-      for (int j = 0; j < m; ++j)
-        for (int d = 0; d < D; ++d) derivs[((size_t)k * m + j) * D + d] += mid[(size_t)d * m + j];
-    }
-  }
 }
 
 void Engine::predict_full_cov(const std::vector<int>& ids, const double* Xs, int m, double* means, double* covs) {

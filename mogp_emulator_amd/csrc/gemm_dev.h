@@ -279,6 +279,109 @@ __device__ __forceinline__ void mainloop_pf(const double* __restrict__ Ag, int l
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// mainloop_q (round 5): the k-step of mainloop_pf rebuilt so that ONE wave per SIMD keeps the matrix pipe busy -- in the one-launch
+// Cholesky a GEMM task runs alone on its CU's pipes whenever the co-resident workgroup is in a solve / load / wait phase (a third of
+// the time), and alone mainloop_pf reaches 63 - 72 % of the pipe (k-step 1.35 us against 0.85 - 0.97).  Three changes:
+//   * operand tiles UNPADDED [row][16] in LDS with the 16-byte chunk index XOR-swizzled by the row (chunk c of row R at
+//     c ^ sw(R & 15), sw(r) = ((r >> 1) & 1) | ((r >> 3) & 1) << 2): a lane's two k values of a half step are ONE ds_read_b128,
+//     conflict-free in the four 16-lane groups the instruction is served in (12 reads per k-step instead of 24 ds_read_b64, and
+//     ds_read_b128 reaches its rate from one wave per SIMD, ds_read_b64 only from four -- MI355X_MICROARCH.md, LDS);
+//     lane (fr, fk) therefore multiplies k = 4 fk + 2 h + e in the MFMA (h, e) of a step: the k order INSIDE a 16-deep step differs
+//     from mainloop_pf's (results agree to rounding, not bit for bit);
+//   * THREE LDS stages, one barrier per step: the stage a step writes was last read a whole step ago and is first read a whole step
+//     later, so neither the LDS writes nor the first fragment reads of a step sit next to the barrier -- the fragments of half step 0
+//     of step kt + 1 are requested BEFORE the barrier that ends step kt;
+//   * global loads G steps ahead of the LDS stage they fill (2 + G steps ahead of the matrix cores) through G register sets --
+//     with G = 2 the same four steps as mainloop_pf<.., 4> with half the staging registers.
+// The products are ADDED to acc.  nk: a positive multiple of G.  LDS: 3 * (BM + BN) * 16 doubles.
+// ---------------------------------------------------------------------------------------------
+template <int BM, int BN>
+struct QCfg {
+  static constexpr int STAGE = (BM + BN) * BK;           // doubles per stage: A tile, then B tile
+  static constexpr int SMEM_DOUBLES = 3 * STAGE;
+};
+__device__ __forceinline__ int q_swz(int row) { return ((row >> 1) & 1) | (((row >> 3) & 1) << 2); }
+
+template <int BM, int BN, int WR, int WC, int G>
+__device__ __forceinline__ void mainloop_q(const double* __restrict__ Ag, int lda, const double* __restrict__ Bg, int ldb, int nk,
+                                           v4d (&acc)[WCfg<BM, BN, WR, WC>::TI][WCfg<BM, BN, WR, WC>::TJ], double* smem) {
+  using C = WCfg<BM, BN, WR, WC>;
+  constexpr int STAGE = QCfg<BM, BN>::STAGE;
+  const int t = mogp_tid(), lane = t & 63, wave = t >> 6;
+  const int wr = wave / WC, wc = wave % WC;
+  const int fr = lane & 15, fk = lane >> 4;
+  if (nk <= 0) return;
+  v2d ra[G][C::CHA], rb[G][C::CHB];
+  const unsigned offA = (unsigned)(((t >> 3) * lda + (t & 7) * 2) * (int)sizeof(double));
+  const unsigned offB = (unsigned)(((t >> 3) * ldb + (t & 7) * 2) * (int)sizeof(double));
+  auto load = [&](int u, int kt) {
+#pragma unroll
+    for (int q = 0; q < C::CHA; ++q)
+      ra[u][q] = *reinterpret_cast<const v2d*>(reinterpret_cast<const char*>(Ag + (size_t)q * (C::NT / 8) * lda + (size_t)kt * BK) + offA);
+#pragma unroll
+    for (int q = 0; q < C::CHB; ++q)
+      rb[u][q] = *reinterpret_cast<const v2d*>(reinterpret_cast<const char*>(Bg + (size_t)q * (C::NT / 8) * ldb + (size_t)kt * BK) + offB);
+  };
+  // this thread's chunk of a staged row: row (t >> 3) + 32 q, 16-byte chunk (t & 7) ^ sw(row)
+  const int st_off = (t >> 3) * BK + (((t & 7) ^ q_swz((t >> 3) & 15)) << 1);
+  auto store = [&](int u, double* st) {
+#pragma unroll
+    for (int q = 0; q < C::CHA; ++q) *reinterpret_cast<v2d*>(st + st_off + q * (C::NT / 8) * BK) = ra[u][q];
+#pragma unroll
+    for (int q = 0; q < C::CHB; ++q) *reinterpret_cast<v2d*>(st + BM * BK + st_off + q * (C::NT / 8) * BK) = rb[u][q];
+  };
+  // fragment of half step h: the lane's k = 4 fk + 2 h, + 1 of row fr of a 16-row block
+  const int fo0 = fr * BK + (((2 * fk) ^ q_swz(fr)) << 1);
+  v2d fa[2][C::TI], fb[2][C::TJ];
+  auto frag = [&](int set, const double* st, int h) {
+    const int fo = fo0 ^ (h << 1);
+#pragma unroll
+    for (int i = 0; i < C::TI; ++i) fa[set][i] = *reinterpret_cast<const v2d*>(st + (wr * C::TI + i) * 16 * BK + fo);
+#pragma unroll
+    for (int j = 0; j < C::TJ; ++j) fb[set][j] = *reinterpret_cast<const v2d*>(st + BM * BK + (wc * C::TJ + j) * 16 * BK + fo);
+  };
+  auto mfmas = [&](int set) {
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+#pragma unroll
+      for (int i = 0; i < C::TI; ++i)
+#pragma unroll
+        for (int j = 0; j < C::TJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[set][i][e], fb[set][j][e], acc[i][j], 0, 0, 0);
+  };
+  // Branch-free body: loads, stores and fragment reads past the end of the k range are made harmless instead of skipped (a load
+  // re-reads the last step, a store fills a stage nobody reads any more) -- with conditions around them the compiler splits the step into
+  // a dozen basic blocks and serialises what should overlap.  nk must be a multiple of G.
+  const int last = nk - 1;
+  // prologue: stages 0 and 1 filled, register sets hold steps 2 .. 2 + G - 1
+  load(0, 0);
+  load(1 % G, min(1, last));
+  store(0, smem);
+  store(1 % G, smem + STAGE);
+#pragma unroll
+  for (int u = 0; u < G; ++u) load(u, min(2 + u, last));
+  __syncthreads();
+  frag(0, smem, 0);
+  int cur = 0;                                            // stage of step kt
+  for (int kt0 = 0; kt0 < nk; kt0 += G) {
+#pragma unroll
+    for (int u = 0; u < G; ++u) {
+      const int kt = kt0 + u;
+      const double* st = smem + cur * STAGE;
+      const int nxt = cur == 2 ? 0 : cur + 1, wrt = nxt == 2 ? 0 : nxt + 1;
+      frag(1, st, 1);
+      mfmas(0);
+      // the stage of step kt + 2 (last read during step kt - 1, a barrier ago) gets register set u; the set is then reloaded
+      store(u, smem + wrt * STAGE);
+      load(u, min(kt + 2 + G, last));
+      frag(0, smem + nxt * STAGE, 0);                      // written during step kt - 1: visible since the barrier that ended it
+      mfmas(1);
+      __syncthreads();
+      cur = nxt;
+    }
+  }
+}
+
 // f(row_in_tile, col_in_tile, value) over the accumulator fragment of mainloop_w
 template <int WC, int TI, int TJ, typename F>
 __device__ __forceinline__ void for_each_acc_w(v4d (&acc)[TI][TJ], F f) {

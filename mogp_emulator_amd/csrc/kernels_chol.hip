@@ -532,6 +532,86 @@ __global__ __launch_bounds__(256) void implausibility_kernel(int nb, const doubl
 }
 
 // ---------------------------------------------------------------------------------------------
+// Mean-function terms of a batched prediction, on the device (densegp_gpu.hpp:334-337, 402-405, 443-447; analytic mean:
+// GaussianProcess.py:906-935), so that predictions of models with a mean function can stay in HBM (the sharded predict gathers
+// them there) and the host path is the same code followed by one copy.
+//   basis (nbasis, m): row 0 = 1, row t = x[dims[t-1]]^powers[t-1] (std::pow on the host: the library's one definition of the
+//   basis);  coef (nb, nbasis): the emulator's mean parameters (fixed mean: the value), or beta with an analytic mean.
+//   R == 1:  mean[k][j] += coef_0 + sum_t coef_t basis_t[j]
+//   R  > 1:  dots (nb, R, m) = [k*^T K^-1 (t - H beta); k*^T K^-1 h_c]:  mean = dots_0 + sum_c beta_c basis_c,
+//            var += || LA^-1 (basis[:, j] - dots_{1..q}[:, j]) ||^2   (LA (nb, q, q) lower, row-major)
+//   dbasis (nterm, m) = powers[t] x^(powers[t]-1), ddims[t] = its input dimension: deriv[k][j][ddims[t]] += coef_{t+1} dbasis_t[j]
+// Products and sums are NOT contracted, in the order of the host loops this replaces (hostmath.h MeanFunc).
+// ---------------------------------------------------------------------------------------------
+constexpr int MEAN_MAXQ = RMAX;
+__device__ __forceinline__ double add_nc(double a, double b) {
+#pragma clang fp contract(off)
+  return a + b;
+}
+__device__ __forceinline__ double sub_nc(double a, double b) {
+#pragma clang fp contract(off)
+  return a - b;
+}
+__device__ __forceinline__ double mul_nc(double a, double b) {
+#pragma clang fp contract(off)
+  return a * b;
+}
+__global__ __launch_bounds__(256) void predict_mean_finish_kernel(int nb, int m, int D, int R, int nbasis, const double* __restrict__ basis,
+                                                                  const double* __restrict__ coef, const double* __restrict__ dots,
+                                                                  const double* __restrict__ LA, double* __restrict__ mean,
+                                                                  double* __restrict__ var, long ld, int nterm,
+                                                                  const double* __restrict__ dbasis, const int* __restrict__ ddims,
+                                                                  const int* __restrict__ dpowers, double* __restrict__ deriv) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  const int k = blockIdx.y;
+  if (j >= m) return;
+  const double* c = coef + (size_t)k * nbasis;
+  if (mean) {
+    if (R == 1) {
+      double v = c[0];
+      for (int t = 1; t < nbasis; ++t) v = add_nc(v, mul_nc(c[t], basis[(size_t)t * m + j]));
+      mean[(size_t)k * ld + j] = add_nc(mean[(size_t)k * ld + j], v);
+    } else {
+      const int q = R - 1;
+      const double* dk = dots + (size_t)k * R * m;
+      double mu = dk[j];
+      for (int t = 0; t < q; ++t) mu = add_nc(mu, mul_nc(c[t], basis[(size_t)t * m + j]));
+      mean[(size_t)k * ld + j] = mu;
+      if (var) {
+        const double* La = LA + (size_t)k * q * q;
+        double rm[MEAN_MAXQ], add = 0.;
+#pragma unroll
+        for (int t = 0; t < MEAN_MAXQ; ++t) {
+          if (t < q) {
+            double sres = sub_nc(basis[(size_t)t * m + j], dk[(size_t)(1 + t) * m + j]);
+#pragma unroll
+            for (int p = 0; p < MEAN_MAXQ; ++p)
+              if (p < t) sres = sub_nc(sres, mul_nc(La[t * q + p], rm[p]));
+            rm[t] = sres / La[t * q + t];
+            add = add_nc(add, mul_nc(rm[t], rm[t]));
+          }
+        }
+        var[(size_t)k * ld + j] = add_nc(var[(size_t)k * ld + j], add);
+      }
+    }
+  }
+  if (deriv && nterm > 0) {
+    // terms that share an input dimension are summed first (in term order), then added -- the host's mean_inputderiv
+    for (int t = 0; t < nterm; ++t) {
+      const int d = ddims[t];
+      bool first = true;
+      for (int u = 0; u < t; ++u) first = first && (ddims[u] != d);
+      if (!first) continue;
+      double mid = 0.;
+      for (int u = t; u < nterm; ++u)
+        if (ddims[u] == d) mid = add_nc(mid, mul_nc(mul_nc(c[u + 1], (double)dpowers[u]), dbasis[(size_t)u * m + j]));
+      double* o = deriv + ((size_t)k * m + j) * D + d;
+      *o = add_nc(*o, mid);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // trtri leaf: invert every 64x64 diagonal block of L; lane j produces column j of the inverse.
 // Also zeroes the block to the right inside the same 128-tile so that 128-granular consumers can
 // treat diagonal tiles of Linv as dense.
@@ -631,6 +711,13 @@ void launch_loo_variance(const BatchView& v, double* out, int out_ld, hipStream_
 void launch_implausibility(int nb, const double* mean, const double* var, int ld, int m, const double* prm, int rank, double* out,
                            hipStream_t s) {
   hipLaunchKernelGGL(implausibility_kernel, dim3((m + 255) / 256), dim3(256), 0, s, nb, mean, var, ld, m, prm, rank, out);
+}
+
+void launch_predict_mean_finish(int nb, int m, int D, int R, int nbasis, const double* basis, const double* coef, const double* dots,
+                                const double* LA, double* mean, double* var, long ld, int nterm, const double* dbasis, const int* ddims,
+                                const int* dpowers, double* deriv, hipStream_t s) {
+  hipLaunchKernelGGL(predict_mean_finish_kernel, dim3((m + 255) / 256, nb), dim3(256), 0, s, nb, m, D, R, nbasis, basis, coef, dots, LA,
+                     mean, var, ld, nterm, dbasis, ddims, dpowers, deriv);
 }
 
 void launch_trtri_merges(const BatchView& v, hipStream_t s);   // kernels_gemm.hip

@@ -25,24 +25,26 @@ typedef double v2d __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ int slot_emu2(const int* idx, int z) { return idx ? idx[z] : z; }
 
-// r2 for the thread's 4x4 micro tile (rows 4*ty.., cols 4*tx..)
+// r2 for the thread's RA x CB micro tile (rows RA*ty.., cols CB*tx..): 4 x 4 with (ty, tx) = (t >> 4, t & 15), or 8 x 2 with
+// (t >> 5, t & 31) -- the latter makes a wave's store instruction two whole 512-byte rows of the 64-column tile
+template <int RA, int CB>
 __device__ __forceinline__ void micro_r2(const double* si, const double* sj, const double* __restrict__ P, int D, int ty, int tx,
-                                         double (&r2)[4][4]) {
+                                         double (&r2)[RA][CB]) {
 #pragma unroll
-  for (int a = 0; a < 4; ++a)
+  for (int a = 0; a < RA; ++a)
 #pragma unroll
-    for (int b = 0; b < 4; ++b) r2[a][b] = 0.0;
+    for (int b = 0; b < CB; ++b) r2[a][b] = 0.0;
   for (int d = 0; d < D; ++d) {
     const double e = P[d];
-    double xi[4], xj[4];
+    double xi[RA], xj[CB];
 #pragma unroll
-    for (int a = 0; a < 4; ++a) xi[a] = si[d * 64 + 4 * ty + a];
+    for (int a = 0; a < RA; ++a) xi[a] = si[d * 64 + RA * ty + a];
 #pragma unroll
-    for (int b = 0; b < 4; ++b) xj[b] = sj[d * 64 + 4 * tx + b];
+    for (int b = 0; b < CB; ++b) xj[b] = sj[d * 64 + CB * tx + b];
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+    for (int a = 0; a < RA; ++a)
 #pragma unroll
-      for (int b = 0; b < 4; ++b) {
+      for (int b = 0; b < CB; ++b) {
         const double df = xi[a] - xj[b];
         r2[a][b] = __builtin_fma(e * df, df, r2[a][b]);
       }
@@ -56,38 +58,54 @@ __device__ __forceinline__ double mat52_dlog(double r2) {
   return -(5.0 / 6.0) * (1.0 + s) / (1.0 + s + (5.0 / 3.0) * r2);
 }
 
-// kernel values (without sigma^2) of the thread's 4x4 micro tile
-template <int KT>
+// Orders the work on a register tile in groups of four entries: group g's results and group g+1's inputs pass through ONE empty asm
+// statement, so nothing of group g+1 can start before group g is finished.  Left to itself the compiler interleaves all sixteen
+// exponentials (about ten live registers each: 107 instead of 60 VGPRs for the K build, half the waves per SIMD -- and these kernels
+// live on occupancy).  Entry e of the tile is t[e / CB][e % CB].
+template <int RA, int CB>
+__device__ __forceinline__ void group_fence(double (&t)[RA][CB], int g) {
+  static_assert(RA * CB == 16, "sixteen entries per thread");
+  double* f = &t[0][0];
+  if (g < 3)
+    asm volatile("" : "+v"(f[4 * g]), "+v"(f[4 * g + 1]), "+v"(f[4 * g + 2]), "+v"(f[4 * g + 3]), "+v"(f[4 * g + 4]), "+v"(f[4 * g + 5]),
+                 "+v"(f[4 * g + 6]), "+v"(f[4 * g + 7]));
+}
+
+// kernel values (without sigma^2) of the thread's micro tile
+template <int KT, int RA, int CB>
 __device__ __forceinline__ void micro_k(const double* si, const double* sj, const double* __restrict__ P, int D, int ty, int tx,
-                                        double (&k)[4][4], const double* etab) {
+                                        double (&k)[RA][CB], const double* etab) {
+  double* kf = &k[0][0];
   if (KT < 2) {
-    micro_r2(si, sj, P, D, ty, tx, k);
+    micro_r2<RA, CB>(si, sj, P, D, ty, tx, k);
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+    for (int g = 0; g < 4; ++g) {
 #pragma unroll
-      for (int b = 0; b < 4; ++b) k[a][b] = kern_val<KT>(k[a][b], etab);
+      for (int e = 4 * g; e < 4 * g + 4; ++e) kf[e] = kern_val<KT>(kf[e], etab);
+      group_fence<RA, CB>(k, g);
+    }
     return;
   }
   // prod_d (1 + s_d + s_d^2/3) * exp(-sum_d s_d): one exponential per pair
-  double ssum[4][4];
+  double ssum[RA][CB];
 #pragma unroll
-  for (int a = 0; a < 4; ++a)
+  for (int a = 0; a < RA; ++a)
 #pragma unroll
-    for (int b = 0; b < 4; ++b) {
+    for (int b = 0; b < CB; ++b) {
       k[a][b] = 1.0;
       ssum[a][b] = 0.0;
     }
   for (int d = 0; d < D; ++d) {
     const double e = P[d];
-    double xi[4], xj[4];
+    double xi[RA], xj[CB];
 #pragma unroll
-    for (int a = 0; a < 4; ++a) xi[a] = si[d * 64 + 4 * ty + a];
+    for (int a = 0; a < RA; ++a) xi[a] = si[d * 64 + RA * ty + a];
 #pragma unroll
-    for (int b = 0; b < 4; ++b) xj[b] = sj[d * 64 + 4 * tx + b];
+    for (int b = 0; b < CB; ++b) xj[b] = sj[d * 64 + CB * tx + b];
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+    for (int a = 0; a < RA; ++a)
 #pragma unroll
-      for (int b = 0; b < 4; ++b) {
+      for (int b = 0; b < CB; ++b) {
         const double df = xi[a] - xj[b];
         const double r2 = e * df * df;
         const double sd = sqrt(5.0 * r2);
@@ -95,10 +113,13 @@ __device__ __forceinline__ void micro_k(const double* si, const double* sj, cons
         ssum[a][b] += sd;
       }
   }
+  double* sf = &ssum[0][0];
 #pragma unroll
-  for (int a = 0; a < 4; ++a)
+  for (int g = 0; g < 4; ++g) {
 #pragma unroll
-    for (int b = 0; b < 4; ++b) k[a][b] *= lean_exp_neg<false>(ssum[a][b], etab);
+    for (int e = 4 * g; e < 4 * g + 4; ++e) kf[e] *= lean_exp_neg<false>(sf[e], etab);
+    group_fence<RA, CB>(ssum, g);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -127,31 +148,31 @@ __global__ __launch_bounds__(256) void cov_build_kernel(BatchView v) {
   stage_rows(v.X + (size_t)emu * v.XS, n, D, i0, si);
   stage_rows(v.X + (size_t)emu * v.XS, n, D, j0, sj);
   __syncthreads();
-  const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
-  double kv[4][4];
-  micro_k<KT>(si, sj, P, D, ty, tx, kv, etab);
+  // 8 x 2 micro tile: thread (ty, tx) = (t >> 5, t & 31) owns rows 8 ty .. 8 ty + 7 and columns 2 tx, 2 tx + 1, so that one store
+  // instruction of a wave is two whole 512-byte rows of the tile (with 4 x 4 micro tiles it was sixteen 16-byte pieces per row pair
+  // at a 32-byte stride: every 128-byte line written by two instructions, half each)
+  const int ty = threadIdx.x >> 5, tx = threadIdx.x & 31;
+  double kv[8][2];
+  micro_k<KT, 8, 2>(si, sj, P, D, ty, tx, kv, etab);
   const double sig2 = P[D], nug = P[D + 1];
   // INTERIOR: a tile strictly below the diagonal whose rows are all training points (15 of 16 tiles at n = 2000): every entry is
-  // sigma^2 k -- no nugget, no target row, no padding; the per-entry selects of cov_entry were ~8 of the kernel's 92 vector-ALU
-  // instructions per entry, and the kernel is bound by their issue (profiles/r04_*_pmc_sq_valu_B64.txt)
+  // sigma^2 k -- no nugget, no target row, no padding
   const bool interior = ti > tj && i0 + 64 <= n;
 #pragma unroll
-  for (int a = 0; a < 4; ++a) {
-    const int i = i0 + 4 * ty + a;
-    double out[4];
+  for (int a = 0; a < 8; ++a) {
+    const int i = i0 + 8 * ty + a;
+    double out[2];
     if (interior) {
 #pragma unroll
-      for (int b = 0; b < 4; ++b) out[b] = sig2 * kv[a][b];
+      for (int b = 0; b < 2; ++b) out[b] = sig2 * kv[a][b];
     } else {
 #pragma unroll
-      for (int b = 0; b < 4; ++b) {
-        const int j = j0 + 4 * tx + b;
+      for (int b = 0; b < 2; ++b) {
+        const int j = j0 + 2 * tx + b;
         out[b] = cov_entry(v, T, i, j, sig2 * kv[a][b], nug);
       }
     }
-    double* p = A + (size_t)i * ld + j0 + 4 * tx;
-    *reinterpret_cast<double2*>(p) = make_double2(out[0], out[1]);
-    *reinterpret_cast<double2*>(p + 2) = make_double2(out[2], out[3]);
+    *reinterpret_cast<double2*>(A + (size_t)i * ld + j0 + 2 * tx) = make_double2(out[0], out[1]);
   }
   // single right-hand side: the solution vector starts as all-ones bit patterns -- the "not there yet" value the chunks of the
   // one-launch back substitution poll for (backsolve_chain_kernel<SENT>, kernels_chol.hip); every other solve overwrites it
@@ -179,7 +200,7 @@ __global__ __launch_bounds__(256) void cov_full_kernel(BatchView v, int emu, con
   __syncthreads();
   const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
   double kv[4][4];
-  micro_k<KT>(si, sj, P, D, ty, tx, kv, etab);
+  micro_k<KT, 4, 4>(si, sj, P, D, ty, tx, kv, etab);
   const double sig2 = P[D];
   for (int a = 0; a < 4; ++a)
     for (int b = 0; b < 4; ++b) {
@@ -211,15 +232,16 @@ __global__ __launch_bounds__(256) void cross_cov_mean_kernel(BatchView v, const 
   double* si = sm;
   double* sj = sm + 64 * D;
   double* sa = sm + 128 * D;          // R x 64 operand tile
-  double* red = sa + RMAX * 64;       // 64 x 17
+  double* red = sa + RMAX * 64;       // 64 x 33
   stage_rows(Xs, m, D, i0, si);
-  const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
+  // 8 x 2 micro tile (see cov_build_kernel): a wave's store instruction is two whole 512-byte rows of the K* tile
+  const int ty = threadIdx.x >> 5, tx = threadIdx.x & 31;
   const double sig2 = P[D];
-  double macc[RB][4];
+  double macc[RB][8];
 #pragma unroll
   for (int c = 0; c < RB; ++c)
 #pragma unroll
-    for (int a = 0; a < 4; ++a) macc[c][a] = 0.;
+    for (int a = 0; a < 8; ++a) macc[c][a] = 0.;
   double* Kz = Ks ? Ks + (size_t)z * MP * ld : nullptr;
   const int ntj = v.NP / 64;
   for (int tj = 0; tj < ntj; ++tj) {
@@ -234,29 +256,25 @@ __global__ __launch_bounds__(256) void cross_cov_mean_kernel(BatchView v, const 
       }
     }
     __syncthreads();
-    double kv[4][4];
-    if (j0 < n) micro_k<KT>(si, sj, P, D, ty, tx, kv, etab);
+    double kv[8][2];
+    if (j0 < n) micro_k<KT, 8, 2>(si, sj, P, D, ty, tx, kv, etab);
 #pragma unroll
-    for (int a = 0; a < 4; ++a) {
-      const int i = i0 + 4 * ty + a;
-      double out[4];
+    for (int a = 0; a < 8; ++a) {
+      const int i = i0 + 8 * ty + a;
+      double out[2];
 #pragma unroll
-      for (int b = 0; b < 4; ++b) {
-        const int j = j0 + 4 * tx + b;
+      for (int b = 0; b < 2; ++b) {
+        const int j = j0 + 2 * tx + b;
         double x = 0.0;
         if (j < n && i < m) x = sig2 * kv[a][b];
         out[b] = x;
         if (j0 < n) {
 #pragma unroll
           for (int c = 0; c < RB; ++c)
-            if (c < R) macc[c][a] = __builtin_fma(x, sa[c * 64 + 4 * tx + b], macc[c][a]);
+            if (c < R) macc[c][a] = __builtin_fma(x, sa[c * 64 + 2 * tx + b], macc[c][a]);
         }
       }
-      if (Kz) {
-        double* p = Kz + (size_t)i * ld + j0 + 4 * tx;
-        *reinterpret_cast<double2*>(p) = make_double2(out[0], out[1]);
-        *reinterpret_cast<double2*>(p + 2) = make_double2(out[2], out[3]);
-      }
+      if (Kz) *reinterpret_cast<double2*>(Kz + (size_t)i * ld + j0 + 2 * tx) = make_double2(out[0], out[1]);
     }
   }
 #pragma unroll
@@ -264,11 +282,11 @@ __global__ __launch_bounds__(256) void cross_cov_mean_kernel(BatchView v, const 
     if (c < R) {
       __syncthreads();
 #pragma unroll
-      for (int a = 0; a < 4; ++a) red[(4 * ty + a) * 17 + tx] = macc[c][a];
+      for (int a = 0; a < 8; ++a) red[(8 * ty + a) * 33 + tx] = macc[c][a];
       __syncthreads();
       if (threadIdx.x < 64) {
         double s = 0.;
-        for (int q = 0; q < 16; ++q) s += red[threadIdx.x * 17 + q];
+        for (int q = 0; q < 32; ++q) s += red[threadIdx.x * 33 + q];
         const int i = i0 + threadIdx.x;
         if (i < m) mean[((size_t)z * R + c) * mean_ld + i] = s;
       }
@@ -307,8 +325,8 @@ __global__ __launch_bounds__(256) void predict_deriv_kernel(BatchView v, const d
     // KT < 2: G = 2 sigma^2 dk/dr2 alpha_j;  product kernel: G = 2 sigma^2 k alpha_j and the per-dimension
     // factor (dm52/dr2)/m52 of dimension d is applied in the contraction below
     double r2[4][4];
-    if (KT < 2) micro_r2(si, sj, P, D, ty, tx, r2);
-    else micro_k<KT>(si, sj, P, D, ty, tx, r2, etab);
+    if (KT < 2) micro_r2<4, 4>(si, sj, P, D, ty, tx, r2);
+    else micro_k<KT, 4, 4>(si, sj, P, D, ty, tx, r2, etab);
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
@@ -373,8 +391,9 @@ __global__ __launch_bounds__(256) void predict_deriv_kernel(BatchView v, const d
 // never materialised (the reference writes and re-reads (D+1) n x n planes).
 // partial[(z*ntiles + tile)*(D+3) + p]
 // ---------------------------------------------------------------------------------------------
+// three waves per SIMD (<= 168 VGPRs; the squared-exponential instantiation spills five dwords for it) -- the product kernel needs 255
 template <int KT>
-__global__ __launch_bounds__(256) void grad_kernel(BatchView v, int ntiles, double* __restrict__ partial) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KT == 2 ? 2 : 3))) void grad_kernel(BatchView v, int ntiles, double* __restrict__ partial) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   __shared__ double etab[256];
   stage_exp_tab(etab);
@@ -412,8 +431,8 @@ __global__ __launch_bounds__(256) void grad_kernel(BatchView v, int ntiles, doub
   const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
   // KT < 2: r2 holds squared distances; product kernel: r2 holds the kernel values themselves
   double r2[4][4];
-  if (KT < 2) micro_r2(si, sj, P, D, ty, tx, r2);
-  else micro_k<KT>(si, sj, P, D, ty, tx, r2, etab);
+  if (KT < 2) micro_r2<4, 4>(si, sj, P, D, ty, tx, r2);
+  else micro_k<KT, 4, 4>(si, sj, P, D, ty, tx, r2, etab);
   const double sig2 = P[D];
   double scov = 0., strace = 0., saa = 0.;
   // W = K^-1 - (rank-R correction sum_c g_c[i] g_c[j]; R = 1: alpha_i alpha_j) for the micro tile
@@ -630,7 +649,7 @@ void launch_cov_full(const BatchView& v, int emu, double* out, hipStream_t s) {
 }
 
 void launch_cross_cov_mean(const BatchView& v, const double* Xs, int m, int MP, double* Ks, double* mean, int mean_ld, hipStream_t s) {
-  const size_t sm = (size_t)(128 * v.D + RMAX * 64 + 64 * 17) * sizeof(double);
+  const size_t sm = (size_t)(128 * v.D + RMAX * 64 + 64 * 33) * sizeof(double);
   prof_begin("cross_cov", s);
 #define CALL(K)                                                                                                                      \
   do {                                                                                                                               \

@@ -138,17 +138,14 @@ struct PieceWait {
 
 }  // namespace
 
-// table[p] = (type << 30) | (c << 15) | r;  type 0: D(c), 1: G(s, c) with s in the r field, 2: T(r, c)
+// table[p] = (type << 30) | (c << 15) | r (built with unsigned arithmetic);  type 0: D(c), 1: G(s, c) with s in the r field, 2: T(r, c)
 // SOLO: the launch runs ONE workgroup per CU (chain-bound batches): the kernel may then use the whole register file of a SIMD for its one
 // wave -- the diagonal block's spills go to AGPRs instead of scratch memory
-// PAIRS: the instantiation that also holds the paired 128 x 128 bulk task (type 3, MOGP_MC_PAIR=1; a measurement switch) -- kept out of the
-// default kernels: its 128 accumulator registers per wave made the compiler spill in the task prologues of every path (632 instead
-// of ~140 bytes of scratch per lane)
-// LEGACY: the instantiation that still holds the round-3 forms behind MOGP_MC_TILE=0 / MOGP_MC_SLAB=0 / MOGP_MC_CHAINX=0 (x written back and
-// solved from global memory, the half-tile stage).  The default kernels are compiled without them: in this one function every extra path
-// costs registers in ALL paths (an experiment that added one more GEMM instantiation took the 64 x n=2000 launch from 3.9 to 5.4 ms through
-// spills alone, round 4).
-template <bool TRACE, bool SOLO = false, bool PAIRS = false, bool LEGACY = false>
+// (Round 5: the measurement instantiations of rounds 3 - 4 are gone -- PAIRS, the paired 128 x 128 bulk task behind MOGP_MC_PAIR, 5 % slower
+// everywhere; LEGACY, the round-3 forms behind MOGP_MC_TILE / MOGP_MC_SLAB / MOGP_MC_CHAINX / MOGP_MC_PIECES = 0.  Their measurements are in
+// HISTORY.md; in this one function every extra path costs registers in ALL paths, which is why they had lived in instantiations of
+// their own.)
+template <bool TRACE, bool SOLO = false>
 __global__ __launch_bounds__(256, SOLO ? 1 : 2) void mchol_kernel(BatchView v, unsigned* __restrict__ ctrl, const int* __restrict__ table, int ntasks,
                                                        int emu_stride, double* __restrict__ packs, int* __restrict__ info, int nq, int spin_limit,
                                                        int park_on, unsigned long long* __restrict__ trace, int tile_solve) {
@@ -283,82 +280,12 @@ __global__ __launch_bounds__(256, SOLO ? 1 : 2) void mchol_kernel(BatchView v, u
         __builtin_amdgcn_s_setprio(0);
         continue;
       }
-      if (PAIRS && type == 3) {
-        // ---- TT(R, c): BULK task over the two row tiles r, r + 1 (r even, >= 2c + 8) of block column c at once -- a 128 x 128 GEMM tile.
-        // Why: a 64 x 128 tile reads (64 + 128) operand rows per 16-deep k-step for 32 MFMAs per wave; without L2 hits (free-running
-        // tasks rarely share a k slice while it is cached) that is 12 bytes per clock and CU at full matrix-core rate -- more than the
-        // fabric delivers, the 64-emulator launch was bound by it (MFMA-busy 0.685, 18 GB of L2 misses per launch at 4.8 TB/s).  128 x 128
-        // needs 8.  Same k order per element as two T tasks: bit-identical results.  Only listed for throughput-bound launches.
-        const int r0 = 64 * r;
-        const int kend = c;
-        v4d acc[4][4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) acc[i][j] = (v4d){0., 0., 0., 0.};
-        int kb = 0;
-        while (kb < kend) {
-          mc_stamp<TRACE>(tr, 1);
-          int m = mc_wait_min4(cx, rowdone + r, rowdone + r + 1, rowdone + 2 * c, rowdone + 2 * c + 1, (unsigned)(kb + 1), tr);
-          if (m < 0) return;
-          mc_stamp<TRACE>(tr, 2);
-          m = m < kend ? m : kend;
-          mainloop_pf<128, 128, 2, 2, 2>(A + (size_t)r0 * ld + 128 * kb, ld, A + (size_t)c0 * ld + 128 * kb, ld, 8 * (m - kb), acc, lds,
-                                         use_park ? cuword : nullptr, shi + 2, 1 << 14, (tile_solve & 2) ? 3 : -1);
-          kb = m;
-        }
-        mc_stamp<TRACE>(tr, 3);
-        draw_next();
-        // C -= acc, one 16-row sub-tile of the wave's 64 x 64 piece at a time (all loads of a sub-tile, then its stores; the next
-        // sub-tile's loads are requested before the stores of the current one)
-        {
-          const int lane = t & 63, wave = t >> 6, wr = wave >> 1, wc = wave & 1;
-          double* pc0 = A + (size_t)(r0 + wr * 64 + (lane >> 4)) * ld + (c0 + wc * 64 + (lane & 15));
-          double cv[2][4][4];
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) cv[0][j][q] = pc0[(size_t)(4 * q) * ld + j * 16];
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            if (i + 1 < 4) {
-#pragma unroll
-              for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) cv[(i + 1) & 1][j][q] = pc0[(size_t)((i + 1) * 16 + 4 * q) * ld + j * 16];
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-              for (int q = 0; q < 4; ++q) pc0[(size_t)(i * 16 + 4 * q) * ld + j * 16] = cv[i & 1][j][q] - acc[i][j][q];      // (read back by this workgroup's panel solves)
-          }
-        }
-        drain_stores();
-        mc_stamp<TRACE>(tr, 4);
-        __syncthreads();
-        if (mc_wait_min3(cx, ddone + c, ddone + c, ddone + c, 8u, tr) < 0) return;
-        mc_stamp<TRACE>(tr, 8);
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll 1
-        for (int h = 0; h < 2; ++h) {
-          trsm128_lds_dev<true, true>(v, c0, r0, pk, emu, h, lds);
-          drain_stores();
-          __syncthreads();
-          if (t == 0) {
-            stu(rowprog + r + h, 8u * (unsigned)(c + 1));
-            stu(rowdone + r + h, (unsigned)(c + 1));
-          }
-        }
-        mc_stamp<TRACE>(tr, 5);
-        __builtin_amdgcn_s_setprio(0);
-        continue;
-      }
       // ---- T: 64 rows x 128 columns receive the panels 0 .. c-1 -----------------------------------------------------
       const int r0 = 64 * r;
       // tasks of the dependent chain (diagonal tiles, the two row blocks of the next diagonal block) issue ahead of the
       // workgroup they share the CU with
       // (tile_solve bits 8, 9: 4 + 2 x rows below the diagonal block are chain tasks -- chain-bound launches take three pairs)
-      const bool urgent = LEGACY ? r < 2 * c + 4 : r < 2 * c + 4 + 2 * ((tile_solve >> 8) & 3);
+      const bool urgent = r < 2 * c + 4 + 2 * ((tile_solve >> 8) & 3);
       if (urgent) __builtin_amdgcn_s_setprio(2);
       const int kend = c;
       if (kend > 0) {
@@ -367,19 +294,7 @@ __global__ __launch_bounds__(256, SOLO ? 1 : 2) void mchol_kernel(BatchView v, u
         for (int i = 0; i < 2; ++i)
 #pragma unroll
           for (int j = 0; j < 4; ++j) acc[i][j] = (v4d){0., 0., 0., 0.};
-        if (LEGACY) {                   // (MOGP_MC_PIECES=0 selects the LEGACY instantiation)
-          int kb = 0;
-          while (kb < kend) {
-            mc_stamp<TRACE>(tr, 1);
-            int m = mc_wait_min3(cx, rowdone + r, rowdone + 2 * c, rowdone + 2 * c + 1, (unsigned)(kb + 1), tr);
-            if (m < 0) return;
-            mc_stamp<TRACE>(tr, 2);
-            m = m < kend ? m : kend;
-            mainloop_pf<64, 128, 2, 2, MC_PD>(A + (size_t)r0 * ld + 128 * kb, ld, A + (size_t)c0 * ld + 128 * kb, ld, 8 * (m - kb), acc, lds,
-                                              (use_park && !urgent) ? cuword : nullptr, shi + 2, 1 << 14, (tile_solve & 2) ? 3 : -1);
-            kb = m;
-          }
-        } else {
+        {
           // The k range is consumed in 16-column PIECES as they become visible (rowprog counts them: whole block columns of finished
           // tiles plus what a chain task has published of the tile it is solving), MC_PD pieces at a time.  Why: every tile of block
           // column c needs the rows of the diagonal block -- the chain tasks of column c-1 -- for its last 128 columns; waiting for those
@@ -400,7 +315,7 @@ __global__ __launch_bounds__(256, SOLO ? 1 : 2) void mchol_kernel(BatchView v, u
         }
         mc_stamp<TRACE>(tr, 3);
         draw_next();
-        if (!urgent && (LEGACY ? (tile_solve & 5) == 5 : true)) {
+        if (!urgent) {
           // bulk task, round 4: the tile is re-dealt to the solving waves through LDS BEFORE the solve (trsm128_tile2_dev); the first
           // pack images are requested before the C tile is read
           if (mc_wait_min3(cx, ddone + c, ddone + c, ddone + c, 8u, tr) < 0) return;       // (a formality for a bulk task)
@@ -436,40 +351,7 @@ __global__ __launch_bounds__(256, SOLO ? 1 : 2) void mchol_kernel(BatchView v, u
           __builtin_amdgcn_s_setprio(0);
           continue;
         }
-        if (LEGACY && !urgent && (tile_solve & 1)) {
-          // bulk task: the tile C - acc goes to the panel solve through LDS, not through global memory (trsm128_tile_dev)
-          const int lane = t & 63, wave = t >> 6, wr = wave >> 1, wc = wave & 1;
-          const double* pc0 = A + (size_t)(r0 + wr * 32 + (lane >> 4)) * ld + (c0 + wc * 64 + (lane & 15));
-          double cv[2][4][4];
-#pragma unroll
-          for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-              for (int q = 0; q < 4; ++q) cv[i][j][q] = pc0[(size_t)(i * 16 + 4 * q) * ld + j * 16];
-#pragma unroll
-          for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-              for (int q = 0; q < 4; ++q) acc[i][j][q] = cv[i][j][q] - acc[i][j][q];
-          mc_stamp<TRACE>(tr, 4);
-          if (mc_wait_min3(cx, ddone + c, ddone + c, ddone + c, 8u, tr) < 0) return;
-          mc_stamp<TRACE>(tr, 8);
-          __builtin_amdgcn_s_setprio(1);
-          trsm128_tile_dev<true>(v, c0, r0, pk, emu, lds, acc, TRACE ? tr + 10 : nullptr);
-          drain_stores();
-          mc_stamp<TRACE>(tr, 13);
-          __syncthreads();
-          if (t == 0) {
-            stu(rowprog + r, 8u * (unsigned)(c + 1));
-            stu(rowdone + r, (unsigned)(c + 1));
-          }
-          mc_stamp<TRACE>(tr, 5);
-          __builtin_amdgcn_s_setprio(0);
-          continue;
-        }
-        if (urgent && (LEGACY ? (tile_solve & 69) == 69 : true)) {
+        {
           // chain task, round 4: x = C - acc stays in registers and is re-dealt to the solving waves through LDS (trsm128_tile2_chain_dev)
           // instead of being written back and re-read by the pipelined solve
           {
@@ -516,34 +398,8 @@ __global__ __launch_bounds__(256, SOLO ? 1 : 2) void mchol_kernel(BatchView v, u
           __builtin_amdgcn_s_setprio(0);
           continue;
         }
-        // C -= acc.  All 32 loads of a thread first, then the stores: written as load / subtract / store per element the
-        // compiler keeps program order between a store and the next load (they might alias), and the write-back of a 64 KB
-        // tile was 32 dependent memory round trips (23 - 31 us per task, tools/mchol_trace.py).
-        {
-          double cv[2][4][4];
-          const int lane = t & 63, wave = t >> 6, wr = wave >> 1, wc = wave & 1;
-          double* pc0 = A + (size_t)(r0 + wr * 32 + (lane >> 4)) * ld + (c0 + wc * 64 + (lane & 15));
-#pragma unroll
-          for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-              for (int q = 0; q < 4; ++q) cv[i][j][q] = pc0[(size_t)(i * 16 + 4 * q) * ld + j * 16];
-#pragma unroll
-          for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-              for (int q = 0; q < 4; ++q) {
-                double* pc = pc0 + (size_t)(i * 16 + 4 * q) * ld + j * 16;
-                const double x = cv[i][j][q] - acc[i][j][q];
-                *pc = x;                     // (read back by this workgroup's panel solve)
-              }
-        }
-        drain_stores();
-        mc_stamp<TRACE>(tr, 4);
-        __syncthreads();
       }
+      // (only block column 0 gets here: its tiles have no GEMM and are solved straight from the covariance entries in A)
       // ---- T: panel solve with the pack of D(c) ---------------------------------------------------------------------------
       if (urgent) {
         // chain task: one block step behind the diagonal block that is still being factored (chol128_dev<.., PROG>)
@@ -601,11 +457,9 @@ __global__ __launch_bounds__(256, SOLO ? 1 : 2) void mchol_kernel(BatchView v, u
 //   for c = 0, 1, ...:  D(c+1);  T(2c+4, c+1), T(2c+5, c+1);  G(0..2, c+2);  T(2c+6, c), T(2c+7, c);  T(2c+6, c+1), T(2c+7, c+1);
 //                       T(r, c) for r >= 2c+8
 // (a workgroup that draws a chain task early does its GEMM and then waits: at most a handful of waiting workgroups per emulator).
-// paired: the bulk of a column, r >= 2c + 8, is listed as TT(R, c) tasks over the row-tile pairs (r, r + 1), r = 2R even (type 3, r in
-// the row field): half as many tasks with 128 x 128 GEMM tiles, for throughput-bound launches (see the kernel).
-std::vector<int> mchol_task_table(int NP, bool paired) {
+std::vector<int> mchol_task_table(int NP) {
   const int K = NP / 128, K2 = NP / 64;
-  auto word = [](int type, int c, int r) { return (type << 30) | (c << 15) | r; };
+  auto word = [](int type, int c, int r) { return (int)(((unsigned)type << 30) | ((unsigned)c << 15) | (unsigned)r); };
   std::vector<int> tb;
   auto T = [&](int r, int c) {
     if (c < K && r < K2 && r >= 2 * c + 2) tb.push_back(word(2, c, r));
@@ -625,12 +479,7 @@ std::vector<int> mchol_task_table(int NP, bool paired) {
     T(2 * c + 7, c);
     T(2 * c + 6, c + 1);
     T(2 * c + 7, c + 1);
-    if (paired) {
-      for (int r = 2 * c + 8; r + 1 < K2; r += 2)
-        if (c < K) tb.push_back(word(3, c, r));
-    } else {
-      for (int r = 2 * c + 8; r < K2; ++r) T(r, c);
-    }
+    for (int r = 2 * c + 8; r < K2; ++r) T(r, c);
   }
   return tb;
 }
@@ -645,18 +494,7 @@ static double mchol_rho(int nb, int NP) {
   return ((double)nb * npd * npd * npd / 3.0 / 45e12) / ((npd / 128.0) * 55e-6);
 }
 
-// MOGP_MC_PAIR=1: the paired 128 x 128 bulk tasks (with MOGP_MC_PAIR_RHO=<rho>: from that rho on).  OFF by default -- measured
-// (round 4, same box, ms per launch, paired / 64 x 128): 64 x n=2000 4.10 / 3.89, 32 x 2.28 / 2.07, 16 x n=5000 13.75 / 13.05, n=16000
-// 26.26 / 25.27; bit-identical results.  The GEMM phase is 5 % faster per flop (3.8 us per 64-MFMA k-step against 2 x 2.0), the two
-// solves of a pair run one after the other from global memory; and the premise did not hold: with the operand traffic removed
-// altogether (MOGP_MC_NOTRAFFIC) the kernel changes by < 1 % in the per-task stamps -- it is not bound by the fabric.
-bool mchol_use_pairs(int nb, int NP) {
-  static const int force = [] { const char* e = getenv("MOGP_MC_PAIR"); return e ? atoi(e) : 0; }();
-  static const double thr = [] { const char* e = getenv("MOGP_MC_PAIR_RHO"); return e ? atof(e) : 0.0; }();
-  return force != 0 && mchol_rho(nb, NP) >= thr;
-}
-
-void launch_mchol(const BatchView& v, unsigned* ctrl, size_t ctrl_ints, const int* table, int ntasks, bool paired, double* packs, int* info, int n_cu,
+void launch_mchol(const BatchView& v, unsigned* ctrl, size_t ctrl_ints, const int* table, int ntasks, double* packs, int* info, int n_cu,
                   hipStream_t s) {
   // MOGP_MC_SPIN: polls before a wait gives up (default 2^22: seconds)
   static const int spin_limit = [] { const char* e = getenv("MOGP_MC_SPIN"); return e ? atoi(e) : (1 << 22); }();
@@ -669,18 +507,14 @@ void launch_mchol(const BatchView& v, unsigned* ctrl, size_t ctrl_ints, const in
   static const int force_wgs = [] { const char* e = getenv("MOGP_MC_WGS"); return e ? std::max(1, atoi(e)) : 0; }();
   static const int force_park = [] { const char* e = getenv("MOGP_MC_PARK"); return e ? atoi(e) : -1; }();
   const double rho = mchol_rho(v.nb, v.NP);
-  const int per_cu = (force_wgs && !(paired && force_wgs == 1)) ? force_wgs : ((rho < 1.0 && !paired) ? 1 : 2);      // (the paired tasks' LDS excludes the one-per-CU padding)
+  const int per_cu = force_wgs ? force_wgs : (rho < 1.0 ? 1 : 2);
   const int park_on = force_park >= 0 ? force_park : ((per_cu > 1 && rho < 2.0) ? 1 : 0);
-  // MOGP_MC_TILE=0: bulk tasks write C - acc back and solve from global memory (rounds 3a-3c) instead of handing the tile over in LDS
-  // MOGP_MC_NOTRAFFIC=1 (measurement only, garbage results): the bulk GEMM tasks re-read their first 64 operand columns -- the traffic A/B
+  // bit 1: MOGP_MC_NOTRAFFIC=1 (measurement only, garbage results): the bulk GEMM tasks re-read their first 64 operand columns -- the traffic A/B;
+  // bit 5: MOGP_MC_LATE=0: chain tasks always solve in the pipelined form, also when their diagonal block has already finished
   static const int tile_solve = [] {
-    const char* e = getenv("MOGP_MC_TILE");
     const char* f = getenv("MOGP_MC_NOTRAFFIC");
-    const char* g = getenv("MOGP_MC_SLAB");          // 0: the half-tile stage of round 3 (trsm128_tile_dev) instead of the re-deal (trsm128_tile2_dev)
-    return ((e ? atoi(e) : 1) & 1) | ((f && atoi(f)) ? 2 : 0) | ((!g || atoi(g)) ? 4 : 0) |
-           ((!getenv("MOGP_MC_LATE") || atoi(getenv("MOGP_MC_LATE"))) ? 32 : 0) |         // 0: chain tasks always solve in the pipelined form
-           ((!getenv("MOGP_MC_CHAINX") || atoi(getenv("MOGP_MC_CHAINX"))) ? 64 : 0) |     // 0: chain tasks write x back and solve from global memory
-           ((!getenv("MOGP_MC_PIECES") || atoi(getenv("MOGP_MC_PIECES"))) ? 128 : 0);     // 0: a GEMM task waits for whole tiles of its last block column
+    const char* l = getenv("MOGP_MC_LATE");
+    return ((f && atoi(f)) ? 2 : 0) | ((!l || atoi(l)) ? 32 : 0);
   }();
   // MOGP_MC_URG = 0 / 1 / 2: two, four or six row tiles below the diagonal block are chain tasks (pipelined solve, pieces published)
   static const int force_urg = [] { const char* e = getenv("MOGP_MC_URG"); return e ? atoi(e) & 3 : -1; }();
@@ -689,28 +523,24 @@ void launch_mchol(const BatchView& v, unsigned* ctrl, size_t ctrl_ints, const in
   const int nq = (v.nb % 8 == 0) ? 8 : 1;
   // one workgroup per CU is enforced through the LDS request: more than half of the 160 KB
   const size_t lds_doubles = (per_cu == 1 ? (size_t)11 * 1024 : 0) + MC_LDS_HDR + std::max<size_t>({(size_t)WCfg<64, 128, 2, 2>::SMEM_DOUBLES, (size_t)TRSM128L_LDS, (size_t)C128_LDS_PRE_DOUBLES,
-                                                                                                                   (size_t)TRSM128T_LDS,
-                                                                                                                   paired ? (size_t)WCfg<128, 128, 2, 2>::SMEM_DOUBLES : (size_t)0});
+                                                                                                                   (size_t)TRSM128T_LDS});
   const int total = ntasks * v.nb;
   const int grid = std::min(per_cu * n_cu, total);
   // MOGP_MC_TRACE=<file>: per-task time stamps of EVERY launch are appended to the file (analysis only: synchronises)
   static const char* trace_file = getenv("MOGP_MC_TRACE");
   const size_t words = (size_t)total * MC_TRW;
   unsigned long long* dtr = nullptr;
-  // the round-3 forms live in their own instantiations (LEGACY); the traced kernel is the default one (or the paired one)
-  const bool legacy = (tile_solve & 197) != 197;
   const int ts = tile_solve | ((force_urg >= 0 ? force_urg : (rho < 1.0 ? 2 : 0)) << 8);
-  if (trace_file && !(legacy && !paired)) {
-    if (hipMalloc(reinterpret_cast<void**>(&dtr), words * 8) != hipSuccess) dtr = nullptr;   // no room for the stamps: factorise untraced
+  if (trace_file) {
+    if (hipMalloc(reinterpret_cast<void**>(&dtr), words * 8) != hipSuccess) {
+      dtr = nullptr;                                        // no room for the stamps: factorise untraced, and say so
+      fprintf(stderr, "libmogp_hip: MOGP_MC_TRACE: no device memory for %zu stamp words, this factorisation is not traced\n", words);
+    }
   }
   if (trace_file && dtr) {
     (void)hipMemsetAsync(dtr, 0, words * 8, s);
-    if (paired)
-      hipLaunchKernelGGL((mchol_kernel<true, false, true, true>), dim3(grid), dim3(256), lds_doubles * sizeof(double), s, v, ctrl, table, ntasks, mchol_emu_stride(v.NP), packs,
-                         info, nq, spin_limit, park_on, dtr, ts);
-    else
-      hipLaunchKernelGGL(mchol_kernel<true>, dim3(grid), dim3(256), lds_doubles * sizeof(double), s, v, ctrl, table, ntasks, mchol_emu_stride(v.NP), packs,
-                         info, nq, spin_limit, park_on, dtr, ts);
+    hipLaunchKernelGGL(mchol_kernel<true>, dim3(grid), dim3(256), lds_doubles * sizeof(double), s, v, ctrl, table, ntasks, mchol_emu_stride(v.NP), packs,
+                       info, nq, spin_limit, park_on, dtr, ts);
     std::vector<unsigned long long> h(words);
     (void)hipStreamSynchronize(s);
     (void)hipMemcpy(h.data(), dtr, words * 8, hipMemcpyDeviceToHost);
@@ -725,16 +555,7 @@ void launch_mchol(const BatchView& v, unsigned* ctrl, size_t ctrl_ints, const in
   }
   prof_begin("mchol", s);
   static const int solo_ok = [] { const char* e = getenv("MOGP_MC_SOLO"); return e ? atoi(e) : 1; }();
-  if (paired)
-    hipLaunchKernelGGL((mchol_kernel<false, false, true, true>), dim3(grid), dim3(256), lds_doubles * sizeof(double), s, v, ctrl, table, ntasks, mchol_emu_stride(v.NP), packs,
-                       info, nq, spin_limit, park_on, (unsigned long long*)nullptr, ts);
-  else if (legacy && per_cu == 1 && solo_ok)
-    hipLaunchKernelGGL((mchol_kernel<false, true, false, true>), dim3(grid), dim3(256), lds_doubles * sizeof(double), s, v, ctrl, table, ntasks, mchol_emu_stride(v.NP), packs,
-                     info, nq, spin_limit, park_on, (unsigned long long*)nullptr, ts);
-  else if (legacy)
-    hipLaunchKernelGGL((mchol_kernel<false, false, false, true>), dim3(grid), dim3(256), lds_doubles * sizeof(double), s, v, ctrl, table, ntasks, mchol_emu_stride(v.NP), packs,
-                     info, nq, spin_limit, park_on, (unsigned long long*)nullptr, ts);
-  else if (per_cu == 1 && solo_ok)
+  if (per_cu == 1 && solo_ok)
     hipLaunchKernelGGL((mchol_kernel<false, true>), dim3(grid), dim3(256), lds_doubles * sizeof(double), s, v, ctrl, table, ntasks, mchol_emu_stride(v.NP), packs,
                      info, nq, spin_limit, park_on, (unsigned long long*)nullptr, ts);
   else

@@ -101,12 +101,10 @@ void launch_update_trailing(const BatchView& v, int c0, int k0, int k1, hipStrea
 // != 0 afterwards = a wait timed out and the factors are unusable: factorise again with a multi-launch schedule); packs:
 // mchol_pack_doubles(NP, B) doubles (one diagonal-block pack per emulator and block column); info as launch_panel128.
 // The matrix of one emulator must be smaller than 4 GB (write-through stores go through a buffer descriptor).
-std::vector<int> mchol_task_table(int NP, bool paired = false);
-// throughput-bound launches list the bulk of every block column as 128 x 128 tasks (the paired table): fewer operand bytes per flop
-bool mchol_use_pairs(int nb, int NP);
+std::vector<int> mchol_task_table(int NP);
 size_t mchol_ctrl_ints(int NP, int B);
 size_t mchol_pack_doubles(int NP, int B);
-void launch_mchol(const BatchView& v, unsigned* ctrl, size_t ctrl_ints, const int* table, int ntasks, bool paired, double* packs, int* info, int n_cu,
+void launch_mchol(const BatchView& v, unsigned* ctrl, size_t ctrl_ints, const int* table, int ntasks, double* packs, int* info, int n_cu,
                   hipStream_t s);
 constexpr int MCHOL_ABORTED = -3;     // status reported by launch_logdet for every emulator when ctrl[0] != 0
 
@@ -162,6 +160,13 @@ void launch_cross_cov_mean(const BatchView& v, const double* Xs, int m, int MP, 
 void launch_predict_var(const BatchView& v, const double* Ks, int m, int MP, double* partial, double* var, int var_ld, hipStream_t s);
 // deriv[z][m][d]
 void launch_predict_deriv(const BatchView& v, const double* Xs, int m, double* deriv, long deriv_stride, hipStream_t s);
+
+// mean-function terms of a batched prediction on device buffers (kernels_chol.hip predict_mean_finish_kernel): basis (nbasis, m),
+// coef (nb, nbasis), R > 1: dots (nb, R, m) and LA (nb, q, q); mean / var (nb rows of stride ld; either may be null); derivative terms
+// dbasis (nterm, m), ddims / dpowers (nterm) into deriv (nb, m, D) or null
+void launch_predict_mean_finish(int nb, int m, int D, int R, int nbasis, const double* basis, const double* coef, const double* dots,
+                                const double* LA, double* mean, double* var, long ld, int nterm, const double* dbasis, const int* ddims,
+                                const int* dpowers, double* deriv, hipStream_t s);
 
 // --- utilities -------------------------------------------------------------------------------
 // out (n,n) <- tile of src (NP,NP): mode 0 copy, mode 1 transpose, mode 2 symmetrise from lower

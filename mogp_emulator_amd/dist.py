@@ -79,16 +79,17 @@ class ShardedMultiOutputGP(object):
     fit / predict run on the local shard only.  ``fit_GP_MAP`` / ``fit`` end with ONE gather of the
     per-emulator fit records, so that every rank knows theta_hat, the log-posterior, the nugget and the
     fit status of ALL emulators (``theta_hat``, ``logpost``, ``nuggets``, ``get_indices_fit()``,
-    ``get_indices_not_fit()``: global emulator indices); ``predict`` ends with the single gather of
-    means / variances, every rank returns the full (n_emulators, m) arrays.
+    ``get_indices_not_fit()``: global emulator indices); ``predict`` has the reference's signature and result
+    (MultiOutputGP_GPU.py:185-297: ``unc``, ``deriv``, ``include_nugget``, ``allow_not_fit``) and ends with the single gather of
+    means / variances / input derivatives, every rank returns the full arrays.
 
-    Factory protocol (what a custom per-rank model must offer): ``fit(thetas)``, ``predict(testing, deriv=False, **kw)``
-    returning ``(mean, unc, deriv)`` with (n_local, m) arrays, and -- optional -- ``fit_record()`` returning
+    Factory protocol (what a custom per-rank model must offer): ``fit(thetas)``, ``predict(testing, unc=, deriv=,
+    include_nugget=, allow_not_fit=)`` returning ``(mean, unc, deriv)`` with (n_local, m) / (n_local, m, D) arrays (or None
+    for what was not asked for), and -- optional -- ``fit_record()`` returning
     ``{"fit_ok", "logpost", "nugget", "theta"}`` lists of length n_local (``MultiOutputGP_GPU.fit_record``).  A model
     without ``fit_record`` is reported through ``get_indices_fit()`` / ``get_indices_not_fit()`` alone (log-posterior,
-    nugget and theta_hat then stay nan / None).  The default model with the zero mean function predicts into device buffers
-    (``_mogp_gpu.predict_variance_batch_dev``) and the gather runs on them directly: one D2H copy of the gathered result
-    per call; with a mean function (``mean=`` / ``analytic_mean=``) the host arrays of ``predict`` are gathered.
+    nugget and theta_hat then stay nan / None).  The default model predicts into device buffers (``_mogp_gpu.predict_dev``,
+    any mean function) and the gather runs on them directly: one D2H copy of the gathered result per call.
 
     Failure on one rank: the local work runs inside try / except and the rank ALWAYS joins the collective with an error
     flag in its record (or payload); after the gather every rank raises ``ShardError`` -- a raising rank can therefore
@@ -120,12 +121,13 @@ class ShardedMultiOutputGP(object):
                     torch.cuda.set_device(int(device_index))
             except ImportError:
                 pass
-            # the device-resident predict entry point covers the zero mean function only (capi.hip,
-            # mogp_mogp_predict_variance_batch_dev); decided from the constructor arguments, which are the same on every
-            # rank -- all ranks must gather on the same path, also a rank that holds no emulator
-            self._dev_predict = kwargs.get("mean") is None and not kwargs.get("analytic_mean", False)
+            # the default per-rank model predicts into device buffers whatever its mean function is (capi.hip mogp_mogp_predict_dev)
+            self._dev_predict = True
         else:
             self._dev_predict = False
+        inputs_arr = np.asarray(inputs, dtype=np.float64)
+        self.D = 1 if inputs_arr.ndim == 1 else int(inputs_arr.shape[1])
+        self._fit_known = False        # fit_ok holds the outcome of a fit gather (every rank: the same values)
         self.local = factory(inputs, targets[self.lo:self.hi], **kwargs) if self.hi > self.lo else None
         self.fit_ok = np.zeros(self.n_emulators, dtype=bool)
         self.logpost = np.full(self.n_emulators, np.nan)
@@ -172,6 +174,7 @@ class ShardedMultiOutputGP(object):
             block[:, 4] = 1.0
         full = gather_rows(block, self.n_emulators, group=self.group).cpu().numpy()
         self.fit_ok = full[:, 0] > 0.5
+        self._fit_known = True
         self.logpost = np.where(self.fit_ok, full[:, 1], np.nan)
         self.nuggets = full[:, 2].copy()
         self.theta_hat = [full[k, 5:5 + int(full[k, 3])].copy() if self.fit_ok[k] and full[k, 3] > 0 else None
@@ -222,49 +225,92 @@ class ShardedMultiOutputGP(object):
         import torch.distributed as dist
         return self._dev_predict and dist.is_initialized() and dist.get_backend(self.group) == "nccl"
 
-    def predict(self, testing, device=None, include_nugget=True, **kwargs):
-        """(mean, unc) of ALL emulators, (n_emulators, m) each, on every rank.  ``unc`` = predictive variance (clipped at
-        0, + nugget iff include_nugget, as MultiOutputGP_GPU.predict).  With the nccl backend and the default per-rank
-        model the local predictions are written into device buffers (``predict_variance_batch_dev``), gathered there by
-        RCCL and copied to the host once; otherwise host arrays are gathered (gloo / custom factories)."""
-        testing = np.ascontiguousarray(np.atleast_2d(np.asarray(testing, dtype=np.float64)))
-        m = testing.shape[0]
+    def predict(self, testing, unc=True, deriv=True, include_nugget=True, allow_not_fit=False, processes=None, full_cov=False,
+                device=None):
+        """``MultiOutputGP_GPU.predict`` (MultiOutputGP_GPU.py:185-297) over ALL emulators, on every rank: ``PredictResult`` of
+        mean (n_emulators, m), unc (n_emulators, m) -- predictive variance, clipped at 0, + nugget iff include_nugget -- and deriv
+        (n_emulators, m, D); arrays that were not asked for are zeros, as in the reference.  ``allow_not_fit``: rows of
+        emulators that are not fit are NaN (on every rank) instead of a ``ValueError``.  ONE collective carries everything that
+        was asked for: per emulator ``[mean | unc | deriv | error flag]``.  With the nccl backend and the default per-rank model
+        the local predictions are written into device buffers (``_mogp_gpu.predict_dev``, any mean function), gathered there by
+        RCCL and copied to the host once; otherwise host arrays are gathered (gloo / custom factories).  ``full_cov`` is refused:
+        an (m, m) covariance per emulator is not something the single gather is sized for -- ask the per-rank model
+        (``.local.predict(..., full_cov=True)``) for the emulators ``[lo, hi)`` it holds."""
+        from .GaussianProcessGPU import PredictResult
+        if full_cov:
+            raise NotImplementedError("ShardedMultiOutputGP.predict(full_cov=True) is not supported: the (n_emulators, m, m) "
+                                      "covariances are not gathered across ranks; use .local.predict(..., full_cov=True) for "
+                                      "the emulators [%d, %d) of this rank" % (self.lo, self.hi))
+        testing = np.array(testing, dtype=np.float64)
+        if testing.ndim == 1:
+            testing = testing.reshape(-1, 1) if self.D == 1 else testing.reshape(1, -1)
+        assert testing.ndim == 2, "testing must be a 2D array"
+        assert testing.shape[1] == self.D, "second dimension of testing must be the same as the number of input parameters"
+        testing = np.ascontiguousarray(testing)
+        if not allow_not_fit and self._fit_known and not self.fit_ok.all():
+            # the same on every rank (fit_ok came out of the fit gather): nobody enters the collective
+            raise ValueError("Hyperparameters have not been fit for this Gaussian Process")
+        m, D = testing.shape
         n_local = self.hi - self.lo
+        # columns of one emulator's row in the single gather
+        o_unc = m
+        o_der = o_unc + (m if unc else 0)
+        o_flag = o_der + (m * D if deriv else 0)
+        width = o_flag + 1
         error = None
-        if device is None and self._device_path() and not kwargs:
+        if device is None and self._device_path():
             import torch
             dev = _collective_device(self.group)
-            payload = torch.zeros((n_local, 2, m), dtype=torch.float64, device=dev)
-            flag = torch.zeros((n_local, 1, m), dtype=torch.float64, device=dev)
+            payload = torch.zeros((n_local, width), dtype=torch.float64, device=dev)
             try:
                 if self.local is not None:
-                    if len(self.local.get_indices_not_fit()) > 0:
+                    if not allow_not_fit and len(self.local.get_indices_not_fit()) > 0:
                         raise ValueError("Hyperparameters have not been fit for this Gaussian Process")
                     d_x = torch.from_numpy(testing).to(dev)
                     d_mean = torch.empty((n_local, m), dtype=torch.float64, device=dev)
-                    d_var = torch.empty((n_local, m), dtype=torch.float64, device=dev)
-                    self.local._mogp_gpu.predict_variance_batch_dev(d_x.data_ptr(), m, d_mean.data_ptr(), d_var.data_ptr())
-                    if include_nugget:
-                        d_var += torch.from_numpy(np.asarray(self.local._nuggets())).to(dev)[:, None]
-                    payload[:, 0] = d_mean
-                    payload[:, 1] = torch.clamp_min(d_var, 0.)
+                    d_var = torch.empty((n_local, m), dtype=torch.float64, device=dev) if unc else None
+                    d_der = torch.empty((n_local, m * D), dtype=torch.float64, device=dev) if deriv else None
+                    self.local._mogp_gpu.predict_dev(d_x.data_ptr(), m, d_mean.data_ptr(), d_var.data_ptr() if unc else None,
+                                                     d_der.data_ptr() if deriv else None)
+                    payload[:, :m] = d_mean
+                    if unc:
+                        if include_nugget:
+                            d_var += torch.from_numpy(np.asarray(self.local._nuggets())).to(dev)[:, None]
+                        payload[:, o_unc:o_der] = torch.clamp_min(d_var, 0.)
+                    if deriv:
+                        payload[:, o_der:o_flag] = d_der
             except Exception as exc:           # noqa: BLE001
                 error = exc
                 payload.zero_()
-                flag.fill_(1.)
-            full = gather_rows(torch.cat([payload, flag], dim=1), self.n_emulators, device=dev, group=self.group).cpu().numpy()
+                payload[:, o_flag] = 1.
+            full = gather_rows(payload, self.n_emulators, device=dev, group=self.group).cpu().numpy()
         else:
-            payload = np.zeros((n_local, 3, m))
+            payload = np.zeros((n_local, width))
             try:
                 if self.local is not None:
-                    mean, unc, _ = self.local.predict(testing, deriv=False, include_nugget=include_nugget, **kwargs)
-                    payload[:, 0] = mean
-                    if unc is not None:
-                        payload[:, 1] = unc
+                    res = self.local.predict(testing, unc=unc, deriv=deriv, include_nugget=include_nugget,
+                                             allow_not_fit=allow_not_fit)
+                    payload[:, :m] = res[0]
+                    if unc and res[1] is not None:
+                        payload[:, o_unc:o_der] = res[1]
+                    if deriv and res[2] is not None:
+                        payload[:, o_der:o_flag] = np.asarray(res[2]).reshape(n_local, m * D)
             except Exception as exc:           # noqa: BLE001
                 error = exc
                 payload[:] = 0.
-                payload[:, 2] = 1.
+                payload[:, o_flag] = 1.
             full = gather_rows(payload, self.n_emulators, device=device, group=self.group).cpu().numpy()
-        self._raise_if_failed(full[:, 2, 0] > 0.5 if m > 0 else np.zeros(self.n_emulators, bool), error, "predict")
-        return full[:, 0, :], full[:, 1, :]
+        self._raise_if_failed(full[:, o_flag] > 0.5, error, "predict")
+        means = full[:, :m].copy()
+        uncs = full[:, o_unc:o_der].copy() if unc else np.zeros((self.n_emulators, m))
+        derivs = full[:, o_der:o_flag].reshape(self.n_emulators, m, D).copy() if deriv else np.zeros((self.n_emulators, m, D))
+        if allow_not_fit and self._fit_known:
+            # emulators the fit gather reported as not fit: NaN rows on every rank, whatever the per-rank model returned
+            bad = ~self.fit_ok
+            means[bad] = np.nan
+            uncs[bad] = np.nan
+            derivs[bad] = np.nan
+        return PredictResult(mean=means, unc=uncs, deriv=derivs)
+
+    def __call__(self, testing, processes=None):
+        return self.predict(testing, unc=False, deriv=False, processes=processes)[0]

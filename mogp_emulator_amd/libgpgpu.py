@@ -983,6 +983,12 @@ class MultiOutputGP_GPU(object):
         """Device-pointer variant: inputs already resident in HBM, results stay in HBM."""
         check(_lib.mogp_mogp_predict_variance_batch_dev(self._h, int(d_testing), int(m), self.D(), int(d_means), int(d_vars)))
 
+    def predict_dev(self, d_testing, m, d_means, d_vars=None, d_derivs=None):
+        """Device pointers throughout: means (+ variances, + input derivatives (n_emulators, m, D)) of every emulator in one pass,
+        results stay in HBM; any mean function; rows of emulators that are not fit are NaN."""
+        check(_lib.mogp_mogp_predict_dev(self._h, int(d_testing), int(m), self.D(), int(d_means),
+                                         int(d_vars) if d_vars else None, int(d_derivs) if d_derivs else None))
+
 
 def fit_GP_MAP(gp, n_tries=15, theta0=()):
     """bindings.cu:602-605 / fitting.hpp:61-128"""

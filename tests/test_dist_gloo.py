@@ -14,10 +14,12 @@ from mogp_emulator_amd.dist import ShardedMultiOutputGP, gather_rows, shard_boun
 
 
 class _LocalStub(object):
-    """Deterministic stand-in: 'prediction' of emulator k at x is (sum(targets_k) + sum(x), sum(x)^2)."""
-    def __init__(self, inputs, targets, **kw):
+    """Deterministic stand-in: 'prediction' of emulator k at x is (sum(targets_k) + sum(x), sum(x)^2), its input derivative
+    d/dx_d = (k + 1) * (d + 1) * sum(x); emulators with a negative first target count as not fit (NaN rows when allowed)."""
+    def __init__(self, inputs, targets, k0=0, **kw):
         self.t = np.asarray(targets)
         self.fitted = None
+        self.k0 = k0          # global index of the first local emulator (set by the test's factory wrapper)
 
     def fit(self, thetas):
         self.fitted = np.asarray(thetas)
@@ -30,12 +32,21 @@ class _LocalStub(object):
                 "nugget": [0.5 + float(self.t[k, 0]) for k in range(n)],
                 "theta": [self.fitted[k] if ok[k] else None for k in range(n)]}
 
-    def predict(self, testing, deriv=False, **kw):
-        s = np.asarray(testing).sum(axis=1)
+    def get_indices_not_fit(self):
+        return [k for k in range(self.t.shape[0]) if self.fitted is None or self.t[k, 0] < 0.]
+
+    def predict(self, testing, unc=True, deriv=False, include_nugget=True, allow_not_fit=False, **kw):
+        if not allow_not_fit and len(self.get_indices_not_fit()) > 0:
+            raise ValueError("Hyperparameters have not been fit for this Gaussian Process")
+        testing = np.asarray(testing)
+        s = testing.sum(axis=1)
         mean = self.t.sum(axis=1)[:, None] + s[None, :]
         if self.fitted is not None:
             mean = mean + self.fitted.sum(axis=1)[:, None]
-        return mean, np.tile(s ** 2, (self.t.shape[0], 1)), None
+        var = np.tile(s ** 2, (self.t.shape[0], 1)) + (0.25 if include_nugget else 0.)
+        D = testing.shape[1]
+        der = (self.k0 + np.arange(self.t.shape[0]) + 1.)[:, None, None] * s[None, :, None] * (np.arange(D) + 1.)[None, None, :]
+        return mean, (var if unc else None), (der if deriv else None)
 
 
 def _free_port():
@@ -48,12 +59,38 @@ def _worker(rank, world, port, n_out, q):
     rng = np.random.default_rng(0)
     X = rng.normal(size=(6, 2)); T = rng.normal(size=(n_out, 6)); Xs = rng.normal(size=(5, 2))
     thetas = rng.normal(size=(n_out, 3))
-    gp = ShardedMultiOutputGP(X, T, factory=_LocalStub)
+    lo, hi = shard_bounds(n_out, world, rank)
+    gp = ShardedMultiOutputGP(X, T, factory=lambda x, t, **kw: _LocalStub(x, t, k0=lo, **kw))
     gp.fit(thetas)
-    mean, unc = gp.predict(Xs)
     ref = _LocalStub(X, T); ref.fit(thetas)
-    rm, ru, _ = ref.predict(Xs)
-    ok = np.allclose(mean, rm) and np.allclose(unc, ru) and mean.shape == (n_out, 5)
+    not_fit = ref.get_indices_not_fit()
+    # the reference's surface (MultiOutputGP_GPU.py:185-297): unc / deriv / include_nugget / allow_not_fit, PredictResult of 3
+    ok = True
+    if not_fit:
+        try:
+            gp.predict(Xs)
+            ok = False
+        except ValueError as exc:                 # raised on every rank before the collective: fit_ok is global knowledge
+            ok = "have not been fit" in str(exc)
+    res = gp.predict(Xs, allow_not_fit=True)
+    rm, ru, rd = ref.predict(Xs, deriv=True, allow_not_fit=True)
+    for a in (rm, ru, rd):
+        a[not_fit] = np.nan
+    mean, unc, der = res
+    ok = ok and res.mean is mean and res.unc is unc and res.deriv is der
+    ok = ok and mean.shape == (n_out, 5) and unc.shape == (n_out, 5) and der.shape == (n_out, 5, 2)
+    ok = ok and np.allclose(mean, rm, equal_nan=True) and np.allclose(unc, ru, equal_nan=True) and np.allclose(der, rd, equal_nan=True)
+    ok = ok and bool(np.isnan(mean[not_fit]).all()) and bool(np.isfinite(np.delete(mean, not_fit, axis=0)).all())
+    m2, u2, d2 = gp.predict(Xs, unc=False, deriv=False, allow_not_fit=True)      # not asked for: zeros, as in the reference
+    ok = ok and np.allclose(m2, rm, equal_nan=True) and not np.delete(u2, not_fit, axis=0).any() and not np.delete(d2, not_fit, axis=0).any()
+    m3, u3, _ = gp.predict(Xs, deriv=False, include_nugget=False, allow_not_fit=True)
+    ok = ok and np.allclose(u3, ru - 0.25, equal_nan=True)
+    ok = ok and np.allclose(gp(Xs[0]) if not not_fit else m2[:, :1], m2[:, :1], equal_nan=True)     # __call__ and the (D,) input form
+    try:
+        gp.predict(Xs, full_cov=True)
+        ok = False
+    except NotImplementedError as exc:
+        ok = ok and "full_cov" in str(exc)
     # the fit exchange: every rank knows the record of every emulator after ONE gather
     rec = ref.fit_record()
     ok = ok and gp.get_indices_fit() == [k for k in range(n_out) if rec["fit_ok"][k]]
@@ -65,7 +102,6 @@ def _worker(rank, world, port, n_out, q):
             ok = ok and np.array_equal(gp.theta_hat[k], thetas[k]) and np.isclose(gp.logpost[k], rec["logpost"][k])
         else:
             ok = ok and gp.theta_hat[k] is None and np.isnan(gp.logpost[k])
-    lo, hi = shard_bounds(n_out, world, rank)
     g = gather_rows(np.arange(lo, hi, dtype=np.float64).reshape(-1, 1), n_out).numpy().ravel()
     ok = ok and np.array_equal(g, np.arange(n_out))
     q.put((rank, bool(ok), (gp.lo, gp.hi)))
@@ -98,10 +134,10 @@ class _FailingStub(_LocalStub):
             raise RuntimeError("boom in fit")
         super(_FailingStub, self).fit(thetas)
 
-    def predict(self, testing, deriv=False, **kw):
+    def predict(self, testing, **kw):
         if self.bad:
             raise RuntimeError("boom in predict")
-        return super(_FailingStub, self).predict(testing, deriv=deriv, **kw)
+        return super(_FailingStub, self).predict(testing, **kw)
 
 
 class _NoRecordStub(object):
@@ -116,7 +152,7 @@ class _NoRecordStub(object):
     def get_indices_not_fit(self):
         return [] if self.done else list(range(self.t.shape[0]))
 
-    def predict(self, testing, deriv=False, **kw):
+    def predict(self, testing, **kw):
         s = np.asarray(testing).sum(axis=1)
         return np.tile(s, (self.t.shape[0], 1)), np.tile(s ** 2, (self.t.shape[0], 1)), None
 
@@ -131,7 +167,7 @@ def _worker_failures(rank, world, port, q):
     T[4, 0] = 1000.                                   # emulator 4 lives on rank 1: that rank raises
     gp = ShardedMultiOutputGP(X, T, factory=_FailingStub)
     seen = []
-    for call in (lambda: gp.fit(rng.normal(size=(n_out, 3))), lambda: gp.predict(Xs)):
+    for call in (lambda: gp.fit(rng.normal(size=(n_out, 3))), lambda: gp.predict(Xs, allow_not_fit=True)):
         try:
             call()
             seen.append(None)
@@ -143,8 +179,8 @@ def _worker_failures(rank, world, port, q):
     gp2 = ShardedMultiOutputGP(X, T, factory=_NoRecordStub)
     gp2.fit(np.zeros((n_out, 3)))
     ok = ok and gp2.get_indices_fit() == list(range(n_out)) and all(t is None for t in gp2.theta_hat)
-    mean, unc = gp2.predict(Xs)
-    ok = ok and np.allclose(mean, np.tile(Xs.sum(axis=1), (n_out, 1)))
+    mean, unc, der = gp2.predict(Xs)               # a per-rank model that returns no derivatives: zeros
+    ok = ok and np.allclose(mean, np.tile(Xs.sum(axis=1), (n_out, 1))) and der.shape == (n_out, 5, 2) and not der.any()
     q.put((rank, bool(ok), seen))
     dist.barrier()
     dist.destroy_process_group()

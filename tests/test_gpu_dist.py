@@ -51,9 +51,9 @@ def _worker(rank, world, port, n_out, q, chol):
     sh = ShardedMultiOutputGP(X, T, nugget="fit")
     theta0 = np.array([1.0, 1.0, 1.0, 0.0, np.log(1e-3)])
     sh.fit_GP_MAP(n_tries=1, theta0=theta0)
-    mean, unc = sh.predict(Xs)
+    mean, unc, der = sh.predict(Xs)               # the reference's default: deriv=True (MultiOutputGP_GPU.py:185-186)
     q.put((rank, (sh.lo, sh.hi), sh.get_indices_fit(), sh.get_indices_not_fit(), [None if t is None else t.copy() for t in sh.theta_hat],
-           sh.logpost.copy(), sh.nuggets.copy(), mean, unc, _aborts()))
+           sh.logpost.copy(), sh.nuggets.copy(), mean, unc, _aborts(), der))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -86,10 +86,10 @@ def test_two_ranks_on_one_gpu_match_the_unsharded_model(n_out, chol):
     full = M.MultiOutputGP_GPU(X, T, nugget="fit")
     full = M.fit_GP_MAP(full, n_tries=1, theta0=np.array([1.0, 1.0, 1.0, 0.0, np.log(1e-3)]))
     rec = full.fit_record()
-    fmean, func, _ = full.predict(Xs, deriv=False)
+    fmean, func, fder = full.predict(Xs)
     assert res[0][1][0] == 0 and res[0][1][1] == res[1][1][0] and res[1][1][1] == n_out
     for r in res:                                   # every rank holds the records of ALL emulators
-        _, _, fit_idx, notfit_idx, theta_hat, logpost, nuggets, mean, unc, _ = r
+        _, _, fit_idx, notfit_idx, theta_hat, logpost, nuggets, mean, unc, _, der = r
         assert fit_idx == full.get_indices_fit() and notfit_idx == full.get_indices_not_fit()
         for k in range(n_out):
             if rec["fit_ok"][k]:
@@ -100,14 +100,16 @@ def test_two_ranks_on_one_gpu_match_the_unsharded_model(n_out, chol):
                 assert theta_hat[k] is None and np.isnan(logpost[k])
         np.testing.assert_allclose(mean, fmean, rtol=1e-8 * loose, atol=1e-10 * loose)
         np.testing.assert_allclose(unc, func, rtol=1e-6 * loose, atol=1e-9 * loose)
+        assert der.shape == (n_out, Xs.shape[0], X.shape[1])
+        np.testing.assert_allclose(der, fder, rtol=1e-7 * loose, atol=1e-8 * loose * np.abs(fder).max())
     # both ranks return the same bits
-    assert np.array_equal(res[0][7], res[1][7]) and np.array_equal(res[0][8], res[1][8])
+    assert np.array_equal(res[0][7], res[1][7]) and np.array_equal(res[0][8], res[1][8]) and np.array_equal(res[0][10], res[1][10])
 
 
 def _nccl_world1_worker(port, q):
     """ONE rank, nccl backend, on the one GPU: RCCL initialisation + all_gather_into_tensor on device memory with the real
-    payload shapes, and the device-resident predict path of ShardedMultiOutputGP (predict_variance_batch_dev -> gather ->
-    one D2H copy) against the plain model."""
+    payload shapes, and the device-resident predict path of ShardedMultiOutputGP (predict_dev -> gather -> one D2H copy) against
+    the plain model: means / variances / input derivatives, with and without a mean function, with an emulator that is not fit."""
     try:
         import torch
         import torch.distributed as dist
@@ -117,7 +119,7 @@ def _nccl_world1_worker(port, q):
         dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1, device_id=dev)
         assert dist.get_backend() == "nccl"
         out = {}
-        for name, shape in (("fit_records", (64, REC_WIDTH)), ("predictions", (64, 2, 10000))):
+        for name, shape in (("fit_records", (64, REC_WIDTH)), ("predictions", (64, 2 * 10000 + 1))):
             payload = torch.randn(shape, dtype=torch.float64, device=dev)
             got = gather_rows(payload, shape[0])                     # device defaults to the rank's GPU with nccl
             torch.cuda.synchronize()
@@ -127,26 +129,54 @@ def _nccl_world1_worker(port, q):
         sh = ShardedMultiOutputGP(X, T, nugget="fit")
         assert sh._device_path()
         sh.fit(theta)
-        mean, unc = sh.predict(Xs)
+        mean, unc, der = sh.predict(Xs)
         full = M.MultiOutputGP_GPU(X, T, nugget="fit")
         full.fit(theta)
-        fmean, func, _ = full.predict(Xs, deriv=False)
-        out["predict"] = bool(np.array_equal(mean, fmean) and np.allclose(unc, func, rtol=0, atol=1e-15))
+        fmean, func, fder = full.predict(Xs)
+        out["predict"] = bool(np.array_equal(mean, fmean) and np.allclose(unc, func, rtol=0, atol=1e-15) and np.array_equal(der, fder))
         out["fit"] = sh.get_indices_fit() == [0, 1, 2, 3, 4] and bool(np.allclose(sh.nuggets, 1e-3))
-        m2, u2 = sh.predict(Xs, include_nugget=False)
+        m2, u2, d2 = sh.predict(Xs, deriv=False, include_nugget=False)
         f2m, f2u, _ = full.predict(Xs, deriv=False, include_nugget=False)
-        out["predict_no_nugget"] = bool(np.array_equal(m2, f2m) and np.allclose(u2, f2u, rtol=0, atol=1e-15))
-        # a mean function: the device entry point does not cover it, every rank must take the host-array path
-        for tag, kw, n_mean in (("theta_mean", {"mean": "c+c*x[0]"}, 2), ("analytic_mean", {"mean": "c+c*x[0]", "analytic_mean": True}, 0)):
+        out["predict_no_nugget"] = bool(np.array_equal(m2, f2m) and np.allclose(u2, f2u, rtol=0, atol=1e-15) and not d2.any())
+        m3, u3, d3 = sh.predict(Xs, unc=False)
+        out["predict_no_unc"] = bool(np.array_equal(m3, fmean) and not u3.any() and np.array_equal(d3, fder))
+        try:
+            sh.predict(Xs, full_cov=True)
+            out["full_cov_refused"] = False
+        except NotImplementedError:
+            out["full_cov_refused"] = True
+        # a mean function (in theta, or integrated out analytically): the mean terms are added on the device, the gather still runs
+        # on device buffers (densegp_gpu.hpp:300-408, GaussianProcess.py:885-920)
+        for tag, kw, n_mean in (("theta_mean", {"mean": "c+c*x[0]+c*x[1]^2"}, 3), ("const_mean", {"mean": "c"}, 1),
+                                ("analytic_mean", {"mean": "c+c*x[0]", "analytic_mean": True}, 0)):
             shm = ShardedMultiOutputGP(X, T, nugget=1e-3, **kw)
-            assert not shm._device_path()
+            assert shm._device_path()
             fm = M.MultiOutputGP_GPU(X, T, nugget=1e-3, **kw)
-            th = np.tile(np.concatenate([np.full(n_mean, 0.3), [1.0, 1.0, 1.0, 0.0]]), (5, 1))
+            th = np.tile(np.concatenate([np.linspace(0.3, -0.2, n_mean), [1.0, 1.0, 1.0, 0.0]]), (5, 1))
             shm.fit(th)
             fm.fit(th)
-            mm, mu = shm.predict(Xs)
-            rm, ru, _ = fm.predict(Xs, deriv=False)
-            out["predict_" + tag] = bool(np.array_equal(mm, rm) and np.allclose(mu, ru, rtol=0, atol=1e-15))
+            mm, mu, md = shm.predict(Xs)
+            rm, ru, rd = fm.predict(Xs)
+            out["predict_" + tag] = bool(np.array_equal(mm, rm) and np.allclose(mu, ru, rtol=0, atol=1e-15) and np.array_equal(md, rd))
+        # an emulator that is not fit: ValueError unless allow_not_fit, then NaN rows (MultiOutputGP_GPU.py:267-296)
+        shn = ShardedMultiOutputGP(X, T, nugget=1e-3)
+        shn.fit(theta[:, :4])
+        shn.local.reset_fit_status()
+        shn.local.fit_emulator(0, theta[0, :4]); shn.local.fit_emulator(3, theta[3, :4])
+        shn._gather_fit_records()
+        out["not_fit_indices"] = shn.get_indices_not_fit() == [1, 2, 4]
+        try:
+            shn.predict(Xs)
+            out["not_fit_raises"] = False
+        except ValueError:
+            out["not_fit_raises"] = True
+        nm, nu, nd = shn.predict(Xs, allow_not_fit=True)
+        fn = M.MultiOutputGP_GPU(X, T, nugget=1e-3)
+        fn.fit(theta[:, :4])
+        rm, ru, rd = fn.predict(Xs)
+        out["not_fit_nan_rows"] = bool(np.isnan(nm[[1, 2, 4]]).all() and np.isnan(nu[[1, 2, 4]]).all() and np.isnan(nd[[1, 2, 4]]).all()
+                                       and np.array_equal(nm[[0, 3]], rm[[0, 3]]) and np.allclose(nu[[0, 3]], ru[[0, 3]], rtol=0, atol=1e-15)
+                                       and np.array_equal(nd[[0, 3]], rd[[0, 3]]))
         dist.destroy_process_group()
         q.put(out)
     except Exception as exc:                                          # noqa: BLE001

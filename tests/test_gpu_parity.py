@@ -906,9 +906,14 @@ def test_sharded_wrapper_on_one_gpu():
     sh = ShardedMultiOutputGP(g["X"], g["T"], nugget=1e-6, priors=weak(D, 1e-6))
     assert (sh.lo, sh.hi) == (0, 4)
     sh.fit(g["thetas"])
-    mean, unc = sh.predict(g["Xs"])
+    res = sh.predict(g["Xs"])                      # the reference's surface: PredictResult(mean, unc, deriv), deriv=True by default
+    mean, unc, der = res
     assert_allclose(mean, g["mean"], rtol=1e-7, atol=1e-9)
     assert_allclose(unc, g["var"], atol=1e-7)
+    plain = M.MultiOutputGP_GPU(g["X"], g["T"], nugget=1e-6, priors=weak(D, 1e-6))
+    plain.fit(g["thetas"])
+    assert np.array_equal(der, plain.predict(g["Xs"]).deriv) and der.shape == (4, g["Xs"].shape[0], D)
+    assert np.array_equal(sh(g["Xs"]), mean)
 
 
 @pytest.mark.parametrize("n", [1, 3, 63, 64, 65, 127, 128, 129, 191, 255, 256, 257, 383, 640])

@@ -285,20 +285,18 @@ def test_native_meanpriors_prior_dists_and_sample():
     assert len(pri.sample()) == 2 + 1 + 1                               # mean parameters first (gppriors.hpp:458-471)
 
 
-@pytest.mark.parametrize("paired", [False, True])
 @pytest.mark.parametrize("n", [1, 100, 128, 129, 300, 640, 2000, 5000, 16000])
-def test_one_launch_cholesky_task_order_is_topological(n, paired):
+def test_one_launch_cholesky_task_order_is_topological(n):
     """The forward-progress argument of the one-launch Cholesky (csrc/kernels_mchol.hip) rests on ONE property of its task table:
     every task only depends on tasks with a smaller number.  Replay the dependency rules of the kernel against the tables the
     library builds (host-only entry points, no device needed):
       D(c)     needs G(0, c), G(1, c), G(2, c) (c >= 2) and the row tiles 2c, 2c+1 of column c-1 (c >= 1)
       G(s, c)  (lower 64 x 64 tile (ti, tj) = (0,0), (1,0), (1,1) of the diagonal block) needs the row tiles 2c+ti, 2c+tj of every column k <= c-2
       T(r, c)  needs D(c) and the row tiles r, 2c, 2c+1 of every column k <= c-1
-      TT(r, c) (paired table: row tiles r, r+1 as one 128 x 128 task) needs D(c) and the row tiles r, r+1, 2c, 2c+1 of every column k <= c-1
     and check that every tile of the lower block triangle is produced exactly once."""
     import ctypes
     lib = _capi.load()
-    fn = lib.mogp_mchol_task_table_paired if paired else lib.mogp_mchol_task_table
+    fn = lib.mogp_mchol_task_table
     cnt = fn(n + 1, None, 0)
     buf = (ctypes.c_int * cnt)()
     assert fn(n + 1, buf, cnt) == cnt
@@ -312,16 +310,13 @@ def test_one_launch_cholesky_task_order_is_topological(n, paired):
         key = (t, c, r if t else 0)
         assert key not in pos, "task listed twice: %r" % (key,)
         pos[key] = p
-        for rr in ([r] if t == 2 else [r, r + 1] if t == 3 else []):
-            assert (rr, c) not in tile, "tile produced twice: %r" % ((rr, c),)
-            tile[(rr, c)] = p
-        if t == 3:
-            assert paired and r % 2 == 0 and r >= 2 * c + 8 and r + 1 < K2
+        assert t != 3
+        if t == 2:
+            assert (r, c) not in tile, "tile produced twice: %r" % ((r, c),)
+            tile[(r, c)] = p
     assert sorted(c for (t, c, r) in pos if t == 0) == list(range(K))
     assert sorted(tile) == sorted((r, c) for c in range(K) for r in range(2 * c + 2, K2))
     assert sorted((r, c) for (t, c, r) in pos if t == 1) == sorted((sub, c) for c in range(2, K) for sub in range(3))
-    if not paired:
-        assert not any(t == 3 for (t, c, r) in pos)
     for (t, c, r), p in pos.items():
         need_tiles, deps = [], []
         if t == 0:
@@ -334,7 +329,7 @@ def test_one_launch_cholesky_task_order_is_topological(n, paired):
             for k in range(c - 1):
                 need_tiles += [(rr, k) for rr in {2 * c + ti, 2 * c + tj}]
         else:
-            rows = {r, 2 * c, 2 * c + 1} | ({r + 1} if t == 3 else set())
+            rows = {r, 2 * c, 2 * c + 1}
             for k in range(c):
                 need_tiles += [(rr, k) for rr in rows]
             deps.append((0, c, 0))

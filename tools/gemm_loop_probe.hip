@@ -1,0 +1,117 @@
+// Probe of the GEMM main loops of the one-launch Cholesky's tasks (csrc/gemm_dev.h): time per 16-deep k-step of a 64 x 128 task tile with ONE
+// and with TWO workgroups per CU, operands resident in L2 / the infinity cache -- the loop alone, no dependencies, no solves.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I mogp_emulator_amd/csrc tools/gemm_loop_probe.hip -o tools/gemm_loop_probe.bin
+//   tools/gemm_loop_probe.bin [nk = 64] [reps = 40]
+// Floor: 32 MFMAs of 64 cycles per wave and step = 0.853 us at 2.4 GHz with one wave per SIMD, 1.707 us with two.
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include "gemm_dev.h"
+using namespace mogp;
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at line %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
+
+constexpr int LD = 2048;
+
+// V = 0: mainloop_pf<64,128,2,2,4> (round 3-4); V = 1: mainloop_q<64,128,2,2,2>; V = 2: mainloop_q with G = 3
+template <int V, int WGS>
+__global__ __launch_bounds__(256, WGS) void loop_kernel(const double* __restrict__ M, int nk, int reps, double* __restrict__ out, int write_tile) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int r0 = 64 * (blockIdx.x % 30 + 2), c0 = 128 * (blockIdx.x % 13);
+  v4d acc[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (v4d){0., 0., 0., 0.};
+  for (int rep = 0; rep < reps; ++rep) {
+    if (V == 0) mainloop_pf<64, 128, 2, 2, 4>(M + (size_t)r0 * LD, LD, M + (size_t)c0 * LD, LD, nk, acc, smem);
+    else if (V == 1) mainloop_q<64, 128, 2, 2, 2>(M + (size_t)r0 * LD, LD, M + (size_t)c0 * LD, LD, nk, acc, smem);
+    else mainloop_q<64, 128, 2, 2, 3>(M + (size_t)r0 * LD, LD, M + (size_t)c0 * LD, LD, nk, acc, smem);
+    __syncthreads();
+  }
+  if (write_tile) {
+    // the tile in the accumulator layout of for_each_acc_w
+    for_each_acc_w<2, 2, 4>(acc, [&](int row, int col, double x) { out[((size_t)blockIdx.x * 64 + row) * 128 + col] = x; });
+  } else {
+    double s = 0.;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) s += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+    if (s == 12345.678) out[0] = s;
+  }
+}
+
+template <int V, int WGS>
+static double run(const double* dM, int nk, int reps, double* dOut, int grid, size_t lds, int write_tile) {
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  hipFuncSetAttribute(reinterpret_cast<const void*>(&loop_kernel<V, WGS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  float best = 1e30f;
+  for (int it = 0; it < 4; ++it) {
+    hipEventRecord(e0);
+    hipLaunchKernelGGL((loop_kernel<V, WGS>), dim3(grid), dim3(256), lds, 0, dM, nk, reps, dOut, write_tile);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    if (it > 0 && ms < best) best = ms;
+  }
+  return best;
+}
+
+int main(int argc, char** argv) {
+  const int nk = argc > 1 ? atoi(argv[1]) : 64, reps = argc > 2 ? atoi(argv[2]) : 40;
+  hipDeviceProp_t p; CK(hipGetDeviceProperties(&p, 0));
+  const int ncu = p.multiProcessorCount;
+  std::vector<double> hM((size_t)LD * LD);
+  srand(3);
+  for (auto& x : hM) x = rand() / (double)RAND_MAX - 0.5;
+  double *dM, *dOut;
+  CK(hipMalloc(&dM, hM.size() * 8)); CK(hipMalloc(&dOut, (size_t)2 * ncu * 64 * 128 * 8));
+  CK(hipMemcpy(dM, hM.data(), hM.size() * 8, hipMemcpyHostToDevice));
+  const size_t lds_pf = (size_t)WCfg<64, 128, 2, 2>::SMEM_DOUBLES * 8, lds_q = (size_t)QCfg<64, 128>::SMEM_DOUBLES * 8;
+  const size_t solo = 88 * 1024;        // more than half of the CU's LDS: one workgroup per CU
+  // correctness: every variant against a host product of the same tile (one pass)
+  {
+    std::vector<double> ref((size_t)8 * 64 * 128), got(ref.size());
+    for (int b = 0; b < 8; ++b) {
+      const int r0 = 64 * (b % 30 + 2), c0 = 128 * (b % 13);
+      for (int i = 0; i < 64; ++i)
+        for (int j = 0; j < 128; ++j) {
+          double s = 0.;
+          for (int k = 0; k < nk * 16; ++k) s += hM[(size_t)(r0 + i) * LD + k] * hM[(size_t)(c0 + j) * LD + k];
+          ref[((size_t)b * 64 + i) * 128 + j] = s;
+        }
+    }
+    for (int v = 0; v < 3; ++v) {
+      if (v == 0) run<0, 2>(dM, nk, 1, dOut, 8, lds_pf, 1);
+      else if (v == 1) run<1, 2>(dM, nk, 1, dOut, 8, lds_q, 1);
+      else run<2, 2>(dM, nk, 1, dOut, 8, lds_q, 1);
+      CK(hipMemcpy(got.data(), dOut, got.size() * 8, hipMemcpyDeviceToHost));
+      double err = 0., mx = 0.;
+      for (size_t e = 0; e < ref.size(); ++e) { err = std::fmax(err, std::fabs(got[e] - ref[e])); mx = std::fmax(mx, std::fabs(ref[e])); }
+      printf("variant %d: max |tile - host product| = %.3e (max |entry| %.3e)  %s\n", v, err, mx, err < 1e-11 * mx * nk ? "OK" : "WRONG");
+    }
+  }
+  const double steps = (double)nk * reps;
+  for (int wgs = 1; wgs <= 2; ++wgs) {
+    const int grid = ncu * wgs;
+    double ms[3];
+    if (wgs == 1) {
+      ms[0] = run<0, 1>(dM, nk, reps, dOut, grid, solo, 0);
+      ms[1] = run<1, 1>(dM, nk, reps, dOut, grid, solo, 0);
+      ms[2] = run<2, 1>(dM, nk, reps, dOut, grid, solo, 0);
+    } else {
+      ms[0] = run<0, 2>(dM, nk, reps, dOut, grid, lds_pf, 0);
+      ms[1] = run<1, 2>(dM, nk, reps, dOut, grid, lds_q, 0);
+      ms[2] = run<2, 2>(dM, nk, reps, dOut, grid, lds_q, 0);
+    }
+    const char* names[3] = {"mainloop_pf<..,4>", "mainloop_q<..,2> ", "mainloop_q<..,3> "};
+    for (int v = 0; v < 3; ++v) {
+      const double us = ms[v] * 1e3 / steps;
+      const double tf = (double)grid * steps * 64. * 128. * 16. * 2. / (ms[v] * 1e-3) * 1e-12;
+      printf("%d workgroup(s) per CU, %s: %.3f us per k-step, %.1f TFLOP/s (%.2f of 78.6)\n", wgs, names[v], us, tf, tf / 78.6);
+    }
+  }
+  return 0;
+}
