@@ -1033,7 +1033,7 @@ void Engine::ensure_kinv(const std::vector<int>& ids, bool for_gradient) {
     }
   upload_idx(need);
   BatchView v = view((int)need.size());
-  launch_kinv(v, stream);
+  launch_kinv(v, n_cu, stream);
   for (int i : split) {
     double* rows = dLinv + (size_t)i * MS + (size_t)gp[i].rank * LD;
     HIPCK(hipMemcpy2DAsync(rows, rowb, w2[i], rowb, wb, n - gp[i].rank, hipMemcpyDeviceToDevice, stream));
@@ -1100,9 +1100,9 @@ void Engine::grad_current(const std::vector<int>& ids, double* grad, int grad_ld
 
 void Engine::ensure_predict_scratch(int nb, int MC) {
   grow(dKs, capKs, (size_t)nb * MC * LD);
-  // partial sums per row tile, then the super-tile counters of predict_var_w_kernel (launch_predict_var; unsigned words, counted generously)
+  // partial sums per row tile
   const size_t nti = (n + 127) / 128;
-  grow(dVarPartial, capVarPartial, (size_t)nb * nti * MC + (size_t)nb * (nti + 1) * (MC / 128 + 8));
+  grow(dVarPartial, capVarPartial, (size_t)nb * nti * MC);
 }
 
 void Engine::predict(const std::vector<int>& ids, const double* Xs, int m, bool xs_on_device, double* means, double* vars, long out_ld,
@@ -1163,7 +1163,7 @@ void Engine::predict(const std::vector<int>& ids, const double* Xs, int m, bool 
     const int mc = std::min<int>((int)MC, m - c0);
     const int MPc = roundup(mc, 128);
     launch_cross_cov_mean(v, dXsrc + (size_t)c0 * D, mc, MPc, vars ? dKs : nullptr, dots + c0, (int)dots_ld, stream);
-    if (vars) launch_predict_var(v, dKs, mc, MPc, dVarPartial, fv + c0, (int)ld, stream);
+    if (vars) launch_predict_var(v, dKs, mc, MPc, dVarPartial, fv + c0, (int)ld, n_cu, stream);
   }
   if (derivs) launch_predict_deriv(v, dXsrc, m, fd, (long)m * D, stream);
   if (mean.kind != 0 || R > 1) {
@@ -1335,7 +1335,7 @@ void Engine::implausibility(const std::vector<int>& ids, const double* Xs, int m
       const int MPc = roundup(mc, 128);
       HIPCK(hipMemcpyAsync(dXs, Xs + (size_t)c0 * D, (size_t)mc * D * sizeof(double), hipMemcpyHostToDevice, stream));
       launch_cross_cov_mean(v, dXs, mc, MPc, dKs, dMean, (int)MC, stream);
-      launch_predict_var(v, dKs, mc, MPc, dVarPartial, dVar, (int)MC, stream);
+      launch_predict_var(v, dKs, mc, MPc, dVarPartial, dVar, (int)MC, n_cu, stream);
       launch_implausibility(nb, dMean, dVar, (int)MC, mc, dPrm, rank, dOut, stream);
       HIPCK(hipMemcpyAsync(out + c0, dOut, (size_t)mc * sizeof(double), hipMemcpyDeviceToHost, stream));
       HIPCK(hipStreamSynchronize(stream));      // dXs is re-used by the next chunk

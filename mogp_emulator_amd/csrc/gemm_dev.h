@@ -41,19 +41,10 @@ struct WCfg {
 // around MFMA groups inside one loop costs more in register copies and exposed LDS latency than the skipped MFMAs save.)
 // Callers must not depend on the row -> accumulator map.
 // ZERO = false: the products are ADDED to what acc holds on entry (a k range continued after a wait).
-// DESC (with TRIA): the k range is walked from its END to its start -- the diagonal block first, with the set of active sub-tiles
-// growing instead of shrinking.  The predictive-variance kernel walks the short row tile of a pair this way, so that at any time all
-// workgroups of a super-tile that are in their short pass read the SAME k slice of the cross-covariance panel (see there).
-// SY: called by every thread at the start (after the step's global loads have been requested) and at the end (in front of the
-// barrier) of every k-step: the hook through which the predictive-variance kernel keeps the workgroups of a super-tile in step.
-struct StepNoSync {
-  __device__ __forceinline__ void begin_step(int) {}
-  __device__ __forceinline__ void end_step(int) {}
-};
-template <int BM, int BN, int WR, int WC, bool TRIA = false, bool ZERO = true, bool DESC = false, class SY = StepNoSync>
+template <int BM, int BN, int WR, int WC, bool TRIA = false, bool ZERO = true>
 __device__ __forceinline__ void mainloop_w(const double* __restrict__ Ag, int lda, const double* __restrict__ Bg, int ldb, int nk,
                                            v4d (&acc)[WCfg<BM, BN, WR, WC>::TI][WCfg<BM, BN, WR, WC>::TJ], double* smem,
-                                           int nk_full = 0, int a_rows = BM, SY* sy = nullptr) {
+                                           int nk_full = 0, int a_rows = BM) {
   using C = WCfg<BM, BN, WR, WC>;
   const int t = mogp_tid(), lane = t & 63;
   const int wave = TRIA ? __builtin_amdgcn_readfirstlane(t >> 6) : (t >> 6);
@@ -66,11 +57,6 @@ __device__ __forceinline__ void mainloop_w(const double* __restrict__ Ag, int ld
       for (int j = 0; j < C::TJ; ++j) acc[i][j] = (v4d){0., 0., 0., 0.};
   }
   if (nk <= 0) return;
-  static_assert(!DESC || TRIA, "the descending walk is only written for the triangular operand");
-  if (DESC) {
-    Ag += (size_t)(nk - 1) * BK;
-    Bg += (size_t)(nk - 1) * BK;
-  }
   v2d ra[C::CHA], rb[C::CHB];
   // chunk q of a thread = rows (t >> 3) + q NT/8: ONE 32-bit byte offset per operand and thread against wave-uniform bases (scalar
   // base + vector offset addressing: no 64-bit address arithmetic per load, three address registers fewer than per-thread pointers)
@@ -105,17 +91,16 @@ __device__ __forceinline__ void mainloop_w(const double* __restrict__ Ag, int ld
   // one k-step with the sub-tiles [S, E) of this wave
   auto step = [&](int kt, auto S_, auto E_) {
     constexpr int S = decltype(S_)::value, E = decltype(E_)::value;
-    const int par = DESC ? ((nk - 1 - kt) & 1) : (kt & 1);
+    const int par = kt & 1;
     const double* sA = smem + par * (C::OPA + C::OPB);
     const double* sB = sA + C::OPA;
-    const bool more = DESC ? (kt > 0) : (kt + 1 < nk);
+    const bool more = kt + 1 < nk;
     if (more) {
-      Ag += DESC ? -BK : BK;
-      Bg += DESC ? -BK : BK;
+      Ag += BK;
+      Bg += BK;
       loadA();
       loadB();
     }
-    if (!std::is_same<SY, StepNoSync>::value) sy->begin_step(t);
     if (S < E) {
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) {
@@ -135,7 +120,6 @@ __device__ __forceinline__ void mainloop_w(const double* __restrict__ Ag, int ld
       double* dA = smem + (par ^ 1) * (C::OPA + C::OPB);
       store(dA, dA + C::OPA);
     }
-    if (!std::is_same<SY, StepNoSync>::value) sy->end_step(t);
     __syncthreads();
   };
   using I0 = std::integral_constant<int, 0>;
@@ -157,25 +141,6 @@ __device__ __forceinline__ void mainloop_w(const double* __restrict__ Ag, int ld
   int n_act = 0;     // sub-tiles of this wave that contain real rows
 #pragma unroll
   for (int i = 0; i < C::TI; ++i) n_act += ((i * WR + wr) * 16 < a_rows) ? 1 : 0;
-  if (DESC) {
-    // sub-tile i is idle while kt >= nk_full + i WR + wr + 1: phase S (sub-tiles [S, E) active) lasts down to the first step of
-    // sub-tile S - 1; phase S = E only moves operands
-    kt = nk - 1;
-    auto phases_d = [&](auto E_) {
-      constexpr int E = decltype(E_)::value;
-      if (E >= 4) for (const int lo = nk_full + 3 * WR + wr + 1; kt >= lo; --kt) step(kt, std::integral_constant<int, 4>(), E_);
-      if (E >= 3) for (const int lo = nk_full + 2 * WR + wr + 1; kt >= lo; --kt) step(kt, std::integral_constant<int, 3>(), E_);
-      if (E >= 2) for (const int lo = nk_full + 1 * WR + wr + 1; kt >= lo; --kt) step(kt, std::integral_constant<int, 2>(), E_);
-      if (E >= 1) for (const int lo = nk_full + 0 * WR + wr + 1; kt >= lo; --kt) step(kt, std::integral_constant<int, 1>(), E_);
-      for (; kt >= 0; --kt) step(kt, I0(), E_);
-    };
-    if (n_act == 4) phases_d(std::integral_constant<int, 4>());
-    else if (n_act == 3) phases_d(std::integral_constant<int, 3>());
-    else if (n_act == 2) phases_d(std::integral_constant<int, 2>());
-    else if (n_act == 1) phases_d(std::integral_constant<int, 1>());
-    else phases_d(I0());
-    return;
-  }
   if (n_act == 4) phases(std::integral_constant<int, 4>());
   else if (n_act == 3) phases(std::integral_constant<int, 3>());
   else if (n_act == 2) phases(std::integral_constant<int, 2>());
@@ -303,9 +268,11 @@ struct QCfg {
 };
 __device__ __forceinline__ int q_swz(int row) { return ((row >> 1) & 1) | (((row >> 3) & 1) << 2); }
 
-template <int BM, int BN, int WR, int WC, int G>
+// park / park_lds / park_spins and kmask: as in mainloop_pf.
+template <int BM, int BN, int WR, int WC, int G, int ORDER = 0>
 __device__ __forceinline__ void mainloop_q(const double* __restrict__ Ag, int lda, const double* __restrict__ Bg, int ldb, int nk,
-                                           v4d (&acc)[WCfg<BM, BN, WR, WC>::TI][WCfg<BM, BN, WR, WC>::TJ], double* smem) {
+                                           v4d (&acc)[WCfg<BM, BN, WR, WC>::TI][WCfg<BM, BN, WR, WC>::TJ], double* smem,
+                                           const unsigned* park = nullptr, int* park_lds = nullptr, int park_spins = 0, int kmask = -1) {
   using C = WCfg<BM, BN, WR, WC>;
   constexpr int STAGE = QCfg<BM, BN>::STAGE;
   const int t = mogp_tid(), lane = t & 63, wave = t >> 6;
@@ -315,7 +282,8 @@ __device__ __forceinline__ void mainloop_q(const double* __restrict__ Ag, int ld
   v2d ra[G][C::CHA], rb[G][C::CHB];
   const unsigned offA = (unsigned)(((t >> 3) * lda + (t & 7) * 2) * (int)sizeof(double));
   const unsigned offB = (unsigned)(((t >> 3) * ldb + (t & 7) * 2) * (int)sizeof(double));
-  auto load = [&](int u, int kt) {
+  auto load = [&](int u, int kt_) {
+    const int kt = kt_ & kmask;
 #pragma unroll
     for (int q = 0; q < C::CHA; ++q)
       ra[u][q] = *reinterpret_cast<const v2d*>(reinterpret_cast<const char*>(Ag + (size_t)q * (C::NT / 8) * lda + (size_t)kt * BK) + offA);
@@ -363,23 +331,52 @@ __device__ __forceinline__ void mainloop_q(const double* __restrict__ Ag, int ld
   __syncthreads();
   frag(0, smem, 0);
   int cur = 0;                                            // stage of step kt
+  unsigned pword = 0;
   for (int kt0 = 0; kt0 < nk; kt0 += G) {
 #pragma unroll
     for (int u = 0; u < G; ++u) {
       const int kt = kt0 + u;
+      if (park) {
+        // slot kt & 1 was written during step kt - 1, before the barrier that ended it: every thread reads the same value
+        if (kt > 0 && park_lds[kt & 1] != 0) {
+          if (t == 0) {
+            int spins = 0;
+            while (__hip_atomic_load(park, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u && ++spins < park_spins) __builtin_amdgcn_s_sleep(16);
+            pword = 0;
+          }
+          __syncthreads();
+        }
+        if (t == 0) {
+          park_lds[(kt + 1) & 1] = (int)pword;            // value loaded a step ago; everybody reads it after this step's barrier
+          pword = __hip_atomic_load(park, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
       const double* st = smem + cur * STAGE;
       const int nxt = cur == 2 ? 0 : cur + 1, wrt = nxt == 2 ? 0 : nxt + 1;
-      frag(1, st, 1);
-      mfmas(0);
-      // the stage of step kt + 2 (last read during step kt - 1, a barrier ago) gets register set u; the set is then reloaded
-      store(u, smem + wrt * STAGE);
-      load(u, min(kt + 2 + G, last));
-      frag(0, smem + nxt * STAGE, 0);                      // written during step kt - 1: visible since the barrier that ended it
-      mfmas(1);
-      __syncthreads();
+      if (ORDER == 0) {
+        frag(1, st, 1);
+        mfmas(0);
+        // the stage of step kt + 2 (last read during step kt - 1, a barrier ago) gets register set u; the set is then reloaded
+        store(u, smem + wrt * STAGE);
+        load(u, min(kt + 2 + G, last));
+        frag(0, smem + nxt * STAGE, 0);                    // written during step kt - 1: visible since the barrier that ended it
+        mfmas(1);
+        __syncthreads();
+      } else {
+        // the barrier in the MIDDLE of the step: every LDS operation in flight at the barrier was issued half a step (16 MFMAs) earlier,
+        // and what is issued right behind it is needed half a step later
+        store(u, smem + wrt * STAGE);
+        load(u, min(kt + 2 + G, last));
+        frag(1, st, 1);
+        mfmas(0);
+        __syncthreads();
+        frag(0, smem + nxt * STAGE, 0);
+        mfmas(1);
+      }
       cur = nxt;
     }
   }
+  if (ORDER != 0) __syncthreads();                         // (the fragment reads behind the last barrier are complete: smem may be reused)
 }
 
 // f(row_in_tile, col_in_tile, value) over the accumulator fragment of mainloop_w

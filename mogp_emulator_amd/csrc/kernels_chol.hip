@@ -150,7 +150,7 @@ __global__ __launch_bounds__(BSG_THREADS) void backsolve_gemv_kernel(BatchView v
 #pragma unroll
   for (int r = 0; r < RT; ++r) s[r] = (v2d){0., 0.};
   const double* p = A + (size_t)k0 * ld + c;
-#pragma unroll(RT == 1 ? 32 : 8)
+#pragma clang loop unroll_count(RT == 1 ? 32 : 8)
   for (int i = 0; i < 64; ++i) {
     const v2d x = *reinterpret_cast<const v2d*>(p + (size_t)i * ld);
 #pragma unroll

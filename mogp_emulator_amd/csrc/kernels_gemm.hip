@@ -542,42 +542,12 @@ __global__ __launch_bounds__(512, 4) void update_tri8_kernel(BatchView v, int c0
 // VGPRs -> four waves per SIMD instead of the two of the 2 x 2 / 128-accumulator configuration):
 // 59.2 -> 61.1 TFLOP/s on 64 x n=2000 x m=10^4 (4 x 2 waves 60.7, 4 x 4 waves 57.3).
 // ---------------------------------------------------------------------------------------------
-// Soft lock-step of the workgroups of one super-tile (they share the k slices of 2^lgc cross-covariance panels and 64 / 2^lgc pairs of
-// L^-1 row tiles through one XCD's L2, but only while they are at the same k): every 8 k-steps a workgroup adds 1 to the super-tile's
-// counter (at step 3 of the block, fire and forget) and at step 7 waits -- bounded, a PERFORMANCE hint only, correctness never depends
-// on it -- until all active workgroups of the super-tile have arrived at that block; the counter's value is requested at the start of
-// step 7, so an in-step super-tile pays no exposed round trip.  A workgroup that leaves adds its remaining arrivals.
-struct PvStepSync {
-  unsigned* cnt;
-  unsigned per_sync;     // active workgroups of the super-tile
-  int gs, spin_limit;      // gs: k-steps done
-  unsigned val;
-  __device__ __forceinline__ int arrived() const { return (gs + 4) >> 3; }
-  __device__ __forceinline__ void begin_step(int t) {
-    if (t == 0) {
-      if ((gs & 7) == 3) {
-        __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-      if ((gs & 7) == 7) val = __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  }
-  __device__ __forceinline__ void end_step(int t) {
-    if (t == 0 && (gs & 7) == 7) {
-      const unsigned want = per_sync * (unsigned)((gs >> 3) + 1);
-      int spins = 0;
-      while (val < want && ++spins < spin_limit) {
-        __builtin_amdgcn_s_sleep(8);
-        val = __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-    }
-    ++gs;
-  }
-};
-
-template <int WR, int WC, bool TRI, bool SYNC>
+// (Round 5: the soft lock-step of a super-tile's workgroups -- MOGP_PV_SYNC, persistent workgroups that waited for each other every 8
+// k-steps: 3.4 x less L2-miss traffic, 1 - 7 % slower -- and the downward walk of the short row tile, MOGP_PV_DESC, are gone; their
+// measurements are in HISTORY.md.)
+template <int WR, int WC, bool TRI>
 __global__ __launch_bounds__(64 * WR * WC, (WR * WC >= 8 ? 4 : 2)) void predict_var_w_kernel(
-    BatchView v, const double* __restrict__ Ks, int MP, int nti, int ntj, double* __restrict__ partial, int lgc, int desc, unsigned* __restrict__ sync,
-    int sync_spins, int single) {
+    BatchView v, const double* __restrict__ Ks, int MP, int nti, int ntj, double* __restrict__ partial, int lgc, int single) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   using C = WCfg<128, 128, WR, WC>;
   // single (launches of fewer than a few rounds of workgroups, e.g. ONE emulator): a workgroup takes one row tile instead of a complementary
@@ -588,29 +558,19 @@ __global__ __launch_bounds__(64 * WR * WC, (WR * WC >= 8 ? 4 : 2)) void predict_
   const int nsr = (npairs + SR - 1) / SR, nsc = (ntj + SC - 1) / SC;
   const int t = threadIdx.x, lane = t & 63, wave = TRI ? __builtin_amdgcn_readfirstlane(t >> 6) : (t >> 6);
   const int wr = wave / WC, wc = wave % WC;
-  // SYNC: PERSISTENT workgroups (the grid is what the device holds at once, a multiple of 8 and of 64 per XCD), each walks the block
-  // numbers blockIdx.x + k gridDim.x: the 64 workgroups of a super-tile are then always resident together, and a wait for them ends
-  // as soon as they have caught up (with one workgroup per block number the dispatcher -- one in-order queue for all XCDs -- can hold
-  // back siblings for a workgroup's whole life: 45 instead of 64 TFLOP/s with the same waits)
-  const int nblocks = v.nb * nsr * nsc * 64;
-  for (int L = (int)blockIdx.x; L < (SYNC ? nblocks : (int)blockIdx.x + 1); L += (int)gridDim.x) {
   int z, tile;
-  decode_block(v.nb, nsr * nsc * 64, z, tile, L);
-  if (z >= v.nb) continue;
+  decode_block(v.nb, nsr * nsc * 64, z, tile);
+  if (z >= v.nb) return;
   const int st = tile >> 6, w = tile & 63;
   const int pr = (st / nsc) * SR + (w >> lgc), tj = (st % nsc) * SC + (w & (SC - 1));
-  if (pr >= npairs || tj >= ntj) continue;
+  if (pr >= npairs || tj >= ntj) return;
   const int emu = slot_to_emu(v.idx, z);
   const int ld = v.LD;
   const double* Li = v.Linv + (size_t)emu * v.MS;
   const double* K = Ks + (size_t)z * MP * ld;
   const int j0 = tj * 128;
   const int ti_long = nti - 1 - pr, ti_short = single ? ti_long : pr;
-  PvStepSync sy{sync + (size_t)z * (nsr * nsc) + st, (unsigned)(min(SR, npairs - (st / nsc) * SR) * min(SC, ntj - (st % nsc) * SC)), 0, sync_spins, 0u};
-  // K* traffic: the long row tile walks k UP from 0, the short one DOWN to 0.  All workgroups of a super-tile are equally long
-  // (nti + 1 blocks of 128) and start together, so at block step s every long pass is at k = s and every short pass at
-  // k = nti - s: two k slices of the 2^lgc column panels in flight instead of one per pair (both passes upward: the short pass of pair p
-  // is at k = s - (nti - p), different for every pair, and re-reads what the long passes have long evicted from the 4 MB L2).
+  // both row tiles of a pair walk k upward (free-running workgroups: the order changes neither time nor traffic, round 3)
   for (int pass = 0; pass < 2; ++pass) {
     if (pass == 1 && ti_short == ti_long) break;
     const int ti = pass == 0 ? ti_long : ti_short;
@@ -618,15 +578,7 @@ __global__ __launch_bounds__(64 * WR * WC, (WR * WC >= 8 ? 4 : 2)) void predict_
     v4d acc[C::TI][C::TJ];
     // L^-1 is lower triangular and its rows >= n are padding: TRI skips the structurally zero steps (mainloop_w)
     const int nk = TRI ? min(i0 + 128, (v.n + 15) & ~15) / BK : (i0 + 128) / BK;
-    if (TRI && SYNC) {
-      if (pass == 1 && desc)
-        mainloop_w<128, 128, WR, WC, TRI, true, TRI, PvStepSync>(Li + (size_t)i0 * ld, ld, K + (size_t)j0 * ld, ld, nk, acc, smem, i0 / BK, v.n - i0, &sy);
-      else
-        mainloop_w<128, 128, WR, WC, TRI, true, false, PvStepSync>(Li + (size_t)i0 * ld, ld, K + (size_t)j0 * ld, ld, nk, acc, smem, i0 / BK, v.n - i0, &sy);
-    } else if (TRI && pass == 1 && desc)
-      mainloop_w<128, 128, WR, WC, TRI, true, TRI>(Li + (size_t)i0 * ld, ld, K + (size_t)j0 * ld, ld, nk, acc, smem, i0 / BK, v.n - i0);
-    else
-      mainloop_w<128, 128, WR, WC, TRI>(Li + (size_t)i0 * ld, ld, K + (size_t)j0 * ld, ld, nk, acc, smem, i0 / BK, v.n - i0);
+    mainloop_w<128, 128, WR, WC, TRI>(Li + (size_t)i0 * ld, ld, K + (size_t)j0 * ld, ld, nk, acc, smem, i0 / BK, v.n - i0);
     // column sums of squares over the tile's 128 rows: red[wr][128]
     double* red = smem;
 #pragma unroll
@@ -648,9 +600,6 @@ __global__ __launch_bounds__(64 * WR * WC, (WR * WC >= 8 ? 4 : 2)) void predict_
       partial[((size_t)z * nti + ti) * MP + j0 + t] = s;
     }
     __syncthreads();                 // red aliases the operand buffers of the next pass
-  }
-  if (TRI && SYNC && t == 0 && sy.arrived() < nti + 1)     // (nti + 1 blocks of 8 steps per workgroup: nobody waits for a workgroup that has left)
-    __hip_atomic_fetch_add(sy.cnt, (unsigned)(nti + 1 - sy.arrived()), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
@@ -779,19 +728,13 @@ void launch_trtri_merges(const BatchView& v, hipStream_t s) {
   }
 }
 
-void launch_kinv(const BatchView& v, hipStream_t s) {
+void launch_kinv(const BatchView& v, int n_cu, hipStream_t s) {
   const int kend = ((v.n + 15) / 16) * 16;
   const int nt = (v.n + 127) / 128;      // tiles that contain real rows
   const int ntiles = nt * (nt + 1) / 2;
   // 64 x 64 tiles when the 128 x 128 ones would fill the device less than twice (MOGP_KINV_WT = 2 / 4 forces either)
   static const int force_wt = [] { const char* e = getenv("MOGP_KINV_WT"); return e ? atoi(e) : 0; }();
-  static const int n_cu_dev = [] {
-    int dev = 0, n = 256;
-    (void)hipGetDevice(&dev);
-    (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
-    return n;
-  }();
-  const bool small = force_wt ? force_wt == 2 : ((long)v.nb * ntiles < 2L * 2 * n_cu_dev);
+  const bool small = force_wt ? force_wt == 2 : ((long)v.nb * ntiles < 2L * 2 * n_cu);
   prof_begin("kinv", s);
   if (small) {
     const int nt2 = (v.n + 63) / 64;
@@ -802,7 +745,7 @@ void launch_kinv(const BatchView& v, hipStream_t s) {
   prof_end("kinv", s, (double)v.nb * (double)v.n * v.n * v.n / 3.0, 0.);
 }
 
-void launch_predict_var(const BatchView& v, const double* Ks, int m, int MP, double* partial, double* var, int var_ld, hipStream_t s) {
+void launch_predict_var(const BatchView& v, const double* Ks, int m, int MP, double* partial, double* var, int var_ld, int n_cu, hipStream_t s) {
   const int nti = (v.n + 127) / 128, ntj = MP / 128;
   prof_begin("predict_var", s);
   // 2 x 4 waves per 128 x 128 tile (measured, TFLOP/s, dense form: 2 x 2 waves 59.2, 2 x 4 waves 61.1, 4 x 2 waves 60.7, 4 x 4 waves 57.3).
@@ -810,46 +753,20 @@ void launch_predict_var(const BatchView& v, const double* Ks, int m, int MP, dou
   // TFLOP/s: 8x8 37 GB / 62.3, 4 pairs x 16 44 GB / 61.9, 2 x 32 53 GB / 60.4, 1 x 64 54 GB / 60.4; without the XCD-aware
   // block decode (workgroups of a super-tile spread over all eight L2s) 47 GB but only 52.1 TFLOP/s
   static const int lgc = [] { const char* e = getenv("MOGP_PV_LGC"); return e ? atoi(e) : 3; }();
-  // MOGP_PV_SYNC: polls a workgroup waits for the others of its super-tile every 8 k-steps (default 0: free-running, one workgroup per
-  // tile pair).  Measured, 64 x n=2000 x m=10^4, L2-miss bytes per launch / predict ms on the same box: free-running 103 GB / 44.9;
-  // lock-step (1000 polls) 28 GB / 45.4 - 45.7 (both passes upward: 51 GB); persistent but free-running 99 GB / 47.4 - 48.6 -- the
-  // static tile -> workgroup map costs 7 % (block numbers drawn from a counter instead: 45.6), the lock-step wins 4 - 6 % of it back.
-  // The miss traffic is not what limits the kernel; the switch stays for that measurement.  MOGP_PV_DESC: short pass downward
-  // (default: with the lock-step only -- free-running it changes neither time nor traffic).
-  static const int sync_spins = [] { const char* e = getenv("MOGP_PV_SYNC"); return e ? std::max(0, std::min(atoi(e), 0xffff)) : 0; }();
-  static const int desc = [] { const char* e = getenv("MOGP_PV_DESC"); return e ? atoi(e) : (sync_spins > 0 ? 1 : 0); }();
   // MOGP_PV_SINGLE = 0 / 1 forces pairs / single row tiles; default: single row tiles when the pair tasks fill the device fewer than twice.
   // Measured (predict incl. host copies, m = 10^4, ms, pairs / single): 1 x n=2000 1.080 / 1.031, 2 x 1.82 / 1.84, 3 x 2.44 / 2.50, 4 x 3.05 /
   // 3.27, 1 x n=5000 5.36 / 4.86, 1 x n=700 (m = 3000) 0.213 / 0.187; bit-identical
   static const int force_single = [] { const char* e = getenv("MOGP_PV_SINGLE"); return e ? atoi(e) : -1; }();
-  static const int n_cu_dev = [] {
-    int dev = 0, n = 256;
-    (void)hipGetDevice(&dev);
-    (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
-    return n;
-  }();
   {
     const int SC = 1 << lgc, SR = 64 >> lgc;
     const int nst = (((nti + 1) / 2 + SR - 1) / SR) * ((ntj + SC - 1) / SC);
     const long pair_tasks = (long)v.nb * ((nti + 1) / 2) * ntj;
-    const bool single = sync_spins == 0 && (force_single >= 0 ? force_single != 0 : pair_tasks < 2L * 2 * n_cu_dev);
-    // the super-tile counters sit behind the partial sums (predict_sync_words)
-    unsigned* sync = reinterpret_cast<unsigned*>(partial + (size_t)v.nb * nti * MP);
-    if (sync_spins > 0) (void)hipMemsetAsync(sync, 0, (size_t)v.nb * nst * sizeof(unsigned), s);
-    if (sync_spins > 0) {
-      // persistent: what the current device holds at once, two 512-thread workgroups per CU
-      int dev = 0, n_cu = 256;
-      (void)hipGetDevice(&dev);
-      (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
-      hipLaunchKernelGGL((predict_var_w_kernel<2, 4, true, true>), dim3(std::min(2 * n_cu, v.nb * nst * 64)), dim3(512), smem_bytes<4>(), s, v, Ks, MP, nti, ntj, partial,
-                         lgc, desc, sync, sync_spins, 0);
-    } else if (single) {
+    const bool single = force_single >= 0 ? force_single != 0 : pair_tasks < 2L * 2 * n_cu;
+    if (single) {
       const int nst1 = ((nti + SR - 1) / SR) * ((ntj + SC - 1) / SC);
-      hipLaunchKernelGGL((predict_var_w_kernel<2, 4, true, false>), dim3(padded_grid(v.nb, nst1 * 64)), dim3(512), smem_bytes<4>(), s, v, Ks, MP, nti, ntj, partial, lgc,
-                         0, sync, 0, 1);
+      hipLaunchKernelGGL((predict_var_w_kernel<2, 4, true>), dim3(padded_grid(v.nb, nst1 * 64)), dim3(512), smem_bytes<4>(), s, v, Ks, MP, nti, ntj, partial, lgc, 1);
     } else
-      hipLaunchKernelGGL((predict_var_w_kernel<2, 4, true, false>), dim3(padded_grid(v.nb, nst * 64)), dim3(512), smem_bytes<4>(), s, v, Ks, MP, nti, ntj, partial, lgc,
-                         desc, sync, sync_spins, 0);
+      hipLaunchKernelGGL((predict_var_w_kernel<2, 4, true>), dim3(padded_grid(v.nb, nst * 64)), dim3(512), smem_bytes<4>(), s, v, Ks, MP, nti, ntj, partial, lgc, 0);
   }
   prof_end("predict_var", s, (double)v.nb * (double)m * v.n * v.n, 0.);
   hipLaunchKernelGGL(predict_var_finish_kernel, dim3((m + 255) / 256, v.nb), dim3(256), 0, s, v, partial, m, MP, nti, var, var_ld);

@@ -58,6 +58,25 @@ __device__ __forceinline__ unsigned ldu(const unsigned* p) { return __hip_atomic
 __device__ __forceinline__ void stu(unsigned* p, unsigned x) { __hip_atomic_store(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
+#ifndef MOGP_MC_Q_ORDER
+#define MOGP_MC_Q_ORDER 0
+#endif
+// the GEMM main loop of the tasks: -DMOGP_MC_LOOP_PF keeps mainloop_pf (rounds 3 - 4), the default is mainloop_q (round 5, gemm_dev.h)
+template <int BM, int BN>
+__device__ __forceinline__ void MC_GEMM(const double* __restrict__ Ag, int lda, const double* __restrict__ Bg, int ldb, int nk, v4d (&acc)[BM / 32][BN / 32],
+                                        double* smem, const unsigned* park, int* park_lds, int park_spins, int kmask) {
+#ifdef MOGP_MC_LOOP_PF
+  mainloop_pf<BM, BN, 2, 2, MC_PD>(Ag, lda, Bg, ldb, nk, acc, smem, park, park_lds, park_spins, kmask);
+#else
+  mainloop_q<BM, BN, 2, 2, 2, MOGP_MC_Q_ORDER>(Ag, lda, Bg, ldb, nk, acc, smem, park, park_lds, park_spins, kmask);
+#endif
+}
+#ifdef MOGP_MC_LOOP_PF
+constexpr size_t MC_GEMM_LDS = WCfg<64, 128, 2, 2>::SMEM_DOUBLES;
+#else
+constexpr size_t MC_GEMM_LDS = QCfg<64, 128>::SMEM_DOUBLES;
+#endif
+
 struct McCtx {
   unsigned* ctrl;
   int spin_limit;
@@ -249,7 +268,7 @@ __global__ __launch_bounds__(256, SOLO ? 1 : 2) void mchol_kernel(BatchView v, u
           if (m < 0) return;
           mc_stamp<TRACE>(tr, 2);
           m = m < kend ? m : kend;
-          mainloop_pf<64, 64, 2, 2, MC_PD>(A + (size_t)gi0 * ld + 128 * kb, ld, A + (size_t)gj0 * ld + 128 * kb, ld, 8 * (m - kb), acc, lds);
+          MC_GEMM<64, 64>(A + (size_t)gi0 * ld + 128 * kb, ld, A + (size_t)gj0 * ld + 128 * kb, ld, 8 * (m - kb), acc, lds, nullptr, nullptr, 0, -1);
           kb = m;
         }
         mc_stamp<TRACE>(tr, 3);
@@ -308,8 +327,8 @@ __global__ __launch_bounds__(256, SOLO ? 1 : 2) void mchol_kernel(BatchView v, u
             if (have < 0) return;
             mc_stamp<TRACE>(tr, 2);
             have = (have < kse ? have : kse) & ~(MC_PD - 1);
-            mainloop_pf<64, 128, 2, 2, MC_PD>(A + (size_t)r0 * ld + 16 * ks, ld, A + (size_t)c0 * ld + 16 * ks, ld, have - ks, acc, lds,
-                                              (use_park && !urgent) ? cuword : nullptr, shi + 2, 1 << 14, (tile_solve & 2) ? 3 : -1);
+            MC_GEMM<64, 128>(A + (size_t)r0 * ld + 16 * ks, ld, A + (size_t)c0 * ld + 16 * ks, ld, have - ks, acc, lds,
+                             (use_park && !urgent) ? cuword : nullptr, shi + 2, 1 << 14, (tile_solve & 2) ? 3 : -1);
             ks = have;
           }
         }
@@ -522,8 +541,8 @@ void launch_mchol(const BatchView& v, unsigned* ctrl, size_t ctrl_ints, const in
   (void)hipMemsetAsync(ctrl, 0, ctrl_ints * sizeof(unsigned), s);
   const int nq = (v.nb % 8 == 0) ? 8 : 1;
   // one workgroup per CU is enforced through the LDS request: more than half of the 160 KB
-  const size_t lds_doubles = (per_cu == 1 ? (size_t)11 * 1024 : 0) + MC_LDS_HDR + std::max<size_t>({(size_t)WCfg<64, 128, 2, 2>::SMEM_DOUBLES, (size_t)TRSM128L_LDS, (size_t)C128_LDS_PRE_DOUBLES,
-                                                                                                                   (size_t)TRSM128T_LDS});
+  const size_t lds_need = MC_LDS_HDR + std::max<size_t>({(size_t)MC_GEMM_LDS, (size_t)TRSM128L_LDS, (size_t)C128_LDS_PRE_DOUBLES, (size_t)TRSM128T_LDS});
+  const size_t lds_doubles = per_cu == 1 ? std::max<size_t>(lds_need, 10 * 1024 + 64) : lds_need;
   const int total = ntasks * v.nb;
   const int grid = std::min(per_cu * n_cu, total);
   // MOGP_MC_TRACE=<file>: per-task time stamps of EVERY launch are appended to the file (analysis only: synchronises)

@@ -140,7 +140,7 @@ void launch_permute_rows(const BatchView& v, const double* X, const int* perm, d
 
 // --- L^-1, K^-1 ----------------------------------------------------------------------------
 void launch_trtri(const BatchView& v, hipStream_t s);        // A(L) -> Linv   (uses Kinv as scratch)
-void launch_kinv(const BatchView& v, hipStream_t s);         // Linv -> Kinv (lower tiles)
+void launch_kinv(const BatchView& v, int n_cu, hipStream_t s);   // Linv -> Kinv (lower tiles); n_cu: compute units of the engine's device
 void launch_alpha_from_linv(const BatchView& v, hipStream_t s);   // alpha = Linv^T y
 
 // --- gradient ------------------------------------------------------------------------------
@@ -157,7 +157,7 @@ void launch_grad_lowrank(const BatchView& v, int emu, const double* W2, int m, d
 // row stride mean_ld per emulator block of R rows).
 void launch_cross_cov_mean(const BatchView& v, const double* Xs, int m, int MP, double* Ks, double* mean, int mean_ld, hipStream_t s);
 // var[z][m] = sigma^2 - sum_i (Linv Ks^T)[i][m]^2 ; partial: nb * (NP/128) * MP scratch
-void launch_predict_var(const BatchView& v, const double* Ks, int m, int MP, double* partial, double* var, int var_ld, hipStream_t s);
+void launch_predict_var(const BatchView& v, const double* Ks, int m, int MP, double* partial, double* var, int var_ld, int n_cu, hipStream_t s);
 // deriv[z][m][d]
 void launch_predict_deriv(const BatchView& v, const double* Xs, int m, double* deriv, long deriv_stride, hipStream_t s);
 

@@ -562,15 +562,13 @@ print("SWITCH-OK", repr(float(f[0])))
 
 
 @pytest.mark.parametrize("env", [{"MOGP_CHOL": "mchol"}, {"MOGP_CHOL": "mchol", "MOGP_MC_WGS": "2", "MOGP_MC_PARK": "1"},
-                                 {"MOGP_CHOL": "mchol", "MOGP_MC_WGS": "2", "MOGP_MC_PARK": "0"}, {"MOGP_MCHOL": "0"}, {"MOGP_CHOL": "mchol", "MOGP_MC_TILE": "0"}, {"MOGP_CHOL": "mchol", "MOGP_MC_SOLO": "0"},
-                                 {"MOGP_CHOL": "mchol", "MOGP_MC_SLAB": "0"}, {"MOGP_CHOL": "mchol", "MOGP_MC_PAIR": "1"}, {"MOGP_CHOL": "mchol", "MOGP_MC_PAIR": "1", "MOGP_MC_WGS": "2"},
+                                 {"MOGP_CHOL": "mchol", "MOGP_MC_WGS": "2", "MOGP_MC_PARK": "0"}, {"MOGP_MCHOL": "0"}, {"MOGP_CHOL": "mchol", "MOGP_MC_SOLO": "0"},
                                  {"MOGP_TRTRI_WT4_FROM": "128"}, {"MOGP_TRTRI_WT4_FROM": "100000"}, {"MOGP_KINV_WT": "2"}, {"MOGP_KINV_WT": "4"},
-                                 {"MOGP_CHOL": "mchol", "MOGP_MC_LATE": "0"}, {"MOGP_CHOL": "mchol", "MOGP_MC_CHAINX": "0"},
-                                 {"MOGP_CHOL": "mchol", "MOGP_MC_PIECES": "0"}, {"MOGP_CHOL": "mchol", "MOGP_MC_URG": "0"}, {"MOGP_CHOL": "mchol", "MOGP_MC_URG": "1", "MOGP_MC_WGS": "2"}, {"MOGP_PV_SINGLE": "1"}, {"MOGP_PV_SINGLE": "0"},
+                                 {"MOGP_CHOL": "mchol", "MOGP_MC_LATE": "0"},
+                                 {"MOGP_CHOL": "mchol", "MOGP_MC_URG": "0"}, {"MOGP_CHOL": "mchol", "MOGP_MC_URG": "1", "MOGP_MC_WGS": "2"}, {"MOGP_PV_SINGLE": "1"}, {"MOGP_PV_SINGLE": "0"},
                                  {"MOGP_CHOL": "la"}, {"MOGP_CHOL": "left"}, {"MOGP_CHOL": "left", "MOGP_GROUPS": "1"},
                                  {"MOGP_CHOL": "right"}, {"MOGP_CHOL": "right", "MOGP_OUTER": "128"}, {"MOGP_TAIL": "0"},
-                                 {"MOGP_BACKSOLVE": "1"}, {"MOGP_BS_SENTINEL": "0"}, {"MOGP_WAITVAL": "0"}, {"MOGP_CHOL": "la", "MOGP_WAITVAL": "1"}, {"MOGP_KS_BUDGET_GB": "0.05"},
-                                 {"MOGP_PV_SYNC": "1000"}, {"MOGP_PV_SYNC": "1"}, {"MOGP_PV_SYNC": "1000", "MOGP_PV_DESC": "0"}, {"MOGP_PV_DESC": "1"}],
+                                 {"MOGP_BACKSOLVE": "1"}, {"MOGP_BS_SENTINEL": "0"}, {"MOGP_WAITVAL": "0"}, {"MOGP_CHOL": "la", "MOGP_WAITVAL": "1"}, {"MOGP_KS_BUDGET_GB": "0.05"}],
                          ids=lambda e: ",".join(k + "=" + v for k, v in e.items()))
 def test_cholesky_schedules_and_switches(env):
     """Every A/B switch libmogp_hip.so still reads (HISTORY.md section 5) goes through the C2 full-size parity check in its own
@@ -582,37 +580,51 @@ def test_cholesky_schedules_and_switches(env):
     assert out.returncode == 0 and "SWITCH-OK" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
 
 
-_PV_SYNC_SCRIPT = r"""
-import sys, numpy as np
-sys.path.insert(0, %(root)r); sys.path.insert(0, %(tests)r)
-import mogp_emulator_amd as M
-from oracle import cpu_ref as R
-from test_gpu_parity import synth, weak
-for n, d, B, m in ((600, 3, 3, 700), (129, 2, 1, 130), (900, 5, 16, 1100), (1300, 4, 5, 260)):
-    X, T, Xs = synth(900 + n, n, d, B, m)
-    theta = np.array([-2. * np.log(0.3 * np.sqrt(d))] * d + [0.])
-    mo = M.MultiOutputGP_GPU(X, T, nugget=1e-6, priors=weak(d, 1e-6))
-    mo.fit(np.tile(theta, (B, 1)))
-    mean, unc, _ = mo.predict(Xs, deriv=False)
-    for k in (0, B - 1):
-        ref = R.GPRef(X, T[k], nugget=1e-6); ref.fit(theta)
-        mu, var, _ = ref.predict(Xs)
-        np.testing.assert_allclose(mean[k], mu, rtol=1e-7, atol=1e-8)
-        np.testing.assert_allclose(unc[k], var, atol=1e-7)
-print("PV-SYNC-OK")
-"""
-
-
-@pytest.mark.parametrize("spins", ["1000", "1"])
-def test_predictive_variance_lockstep_form_on_ragged_shapes(spins):
-    """MOGP_PV_SYNC > 0 runs the predictive variance as persistent workgroups that wait (bounded) for the others of their
-    super-tile: odd numbers of row tiles (a pair with one tile), partial super-tiles, batches that are not a multiple of 8 and
-    a wait budget of one poll (every unsatisfied wait gives up) must all give the oracle's variances."""
-    import subprocess, sys
+def test_diagonal_block_grouped_columns_vs_column_at_a_time(tmp_path):
+    """the 128 x 128 diagonal block factors four columns per MFMA through an explicit 4 x 4 inverse (chol128_dev.h
+    c128_column_groups, round 4); the column-at-a-time form it replaced is still in the header behind -DC128_RANK1.  Both are built into
+    the stand-alone probe (tools/chol128_probe.hip) and factor the same blocks: backward error max|L L^T - A| / max|A| of each against a
+    host Cholesky on well-conditioned blocks (tight bar) and on nearly singular ones (shift 1e-10 on a rank-64 Gram matrix), where the
+    grouped form may cost a small factor but not an order of magnitude."""
+    import re
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc on this box")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    script = _PV_SYNC_SCRIPT % {"root": root, "tests": os.path.join(root, "tests")}
-    out = subprocess.run([sys.executable, "-c", script], env=dict(os.environ, MOGP_PV_SYNC=spins), capture_output=True, text=True, timeout=600)
-    assert out.returncode == 0 and "PV-SYNC-OK" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
+    res = {}
+    for tag, flags in (("grouped", []), ("rank1", ["-DC128_RANK1"])):
+        exe = str(tmp_path / ("probe_" + tag))
+        subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-mllvm", "-amdgpu-mfma-vgpr-form=1"] + flags +
+                              ["-I", os.path.join(root, "mogp_emulator_amd", "csrc"), os.path.join(root, "tools", "chol128_probe.hip"), "-o", exe],
+                              stderr=subprocess.DEVNULL)
+        for case, args in (("well", ["16", "8.0", "128"]), ("ill", ["16", "1e-10", "64"])):
+            out = subprocess.check_output([exe] + args, timeout=120).decode()
+            m = re.search(r"backward error.*device ([0-9.e+-]+), host Cholesky ([0-9.e+-]+)", out)
+            assert m, out[-500:]
+            res[(tag, case)] = (float(m.group(1)), float(m.group(2)))
+    for tag in ("grouped", "rank1"):
+        dev, host = res[(tag, "well")]
+        assert dev <= 1e-14 and dev <= 4 * host, (tag, res)
+    g, r1 = res[("grouped", "ill")][0], res[("rank1", "ill")][0]
+    assert g <= 1e-13 and g <= 16 * max(r1, res[("grouped", "ill")][1]), res
+
+
+def test_predictive_variance_on_ragged_shapes():
+    """Odd numbers of row tiles (a pair with one tile), partial super-tiles, batches that are not a multiple of 8: the variances of
+    the first and the last emulator against the oracle."""
+    for n, d, B, m in ((600, 3, 3, 700), (129, 2, 1, 130), (900, 5, 16, 1100), (1300, 4, 5, 260)):
+        X, T, Xs = synth(900 + n, n, d, B, m)
+        theta = np.array([-2. * np.log(0.3 * np.sqrt(d))] * d + [0.])
+        mo = M.MultiOutputGP_GPU(X, T, nugget=1e-6, priors=weak(d, 1e-6))
+        mo.fit(np.tile(theta, (B, 1)))
+        mean, unc, _ = mo.predict(Xs, deriv=False)
+        for k in (0, B - 1):
+            ref = R.GPRef(X, T[k], nugget=1e-6); ref.fit(theta)
+            mu, var, _ = ref.predict(Xs)
+            assert_allclose(mean[k], mu, rtol=1e-7, atol=1e-8)
+            assert_allclose(unc[k], var, atol=1e-7)
 
 
 _BS_TIMEOUT_SCRIPT = r"""

@@ -14,7 +14,8 @@ using namespace mogp;
 
 constexpr int LD = 2048;
 
-// V = 0: mainloop_pf<64,128,2,2,4> (round 3-4); V = 1: mainloop_q<64,128,2,2,2>; V = 2: mainloop_q with G = 3
+// V = 0: mainloop_pf<64,128,2,2,4> (round 3-4); V = 1: mainloop_q<64,128,2,2,2>; V = 2: mainloop_q G = 4; V = 3 / 4: G = 2 / 4 with the barrier in
+// the middle of the step (ORDER 1); V = 5: mainloop_pf with PD = 2
 template <int V, int WGS>
 __global__ __launch_bounds__(256, WGS) void loop_kernel(const double* __restrict__ M, int nk, int reps, double* __restrict__ out, int write_tile) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -25,9 +26,13 @@ __global__ __launch_bounds__(256, WGS) void loop_kernel(const double* __restrict
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (v4d){0., 0., 0., 0.};
   for (int rep = 0; rep < reps; ++rep) {
-    if (V == 0) mainloop_pf<64, 128, 2, 2, 4>(M + (size_t)r0 * LD, LD, M + (size_t)c0 * LD, LD, nk, acc, smem);
-    else if (V == 1) mainloop_q<64, 128, 2, 2, 2>(M + (size_t)r0 * LD, LD, M + (size_t)c0 * LD, LD, nk, acc, smem);
-    else mainloop_q<64, 128, 2, 2, 3>(M + (size_t)r0 * LD, LD, M + (size_t)c0 * LD, LD, nk, acc, smem);
+    const double *Ap = M + (size_t)r0 * LD, *Bp = M + (size_t)c0 * LD;
+    if (V == 0) mainloop_pf<64, 128, 2, 2, 4>(Ap, LD, Bp, LD, nk, acc, smem);
+    else if (V == 1) mainloop_q<64, 128, 2, 2, 2, 0>(Ap, LD, Bp, LD, nk, acc, smem);
+    else if (V == 2) mainloop_q<64, 128, 2, 2, 4, 0>(Ap, LD, Bp, LD, nk, acc, smem);
+    else if (V == 3) mainloop_q<64, 128, 2, 2, 2, 1>(Ap, LD, Bp, LD, nk, acc, smem);
+    else if (V == 4) mainloop_q<64, 128, 2, 2, 4, 1>(Ap, LD, Bp, LD, nk, acc, smem);
+    else mainloop_pf<64, 128, 2, 2, 2>(Ap, LD, Bp, LD, nk, acc, smem);
     __syncthreads();
   }
   if (write_tile) {
@@ -59,6 +64,19 @@ static double run(const double* dM, int nk, int reps, double* dOut, int grid, si
   return best;
 }
 
+constexpr int NV = 6;
+template <int WGS>
+static double run_v(int v, const double* dM, int nk, int reps, double* dOut, int grid, size_t lds, int write_tile) {
+  switch (v) {
+    case 0: return run<0, WGS>(dM, nk, reps, dOut, grid, lds, write_tile);
+    case 1: return run<1, WGS>(dM, nk, reps, dOut, grid, lds, write_tile);
+    case 2: return run<2, WGS>(dM, nk, reps, dOut, grid, lds, write_tile);
+    case 3: return run<3, WGS>(dM, nk, reps, dOut, grid, lds, write_tile);
+    case 4: return run<4, WGS>(dM, nk, reps, dOut, grid, lds, write_tile);
+    default: return run<5, WGS>(dM, nk, reps, dOut, grid, lds, write_tile);
+  }
+}
+
 int main(int argc, char** argv) {
   const int nk = argc > 1 ? atoi(argv[1]) : 64, reps = argc > 2 ? atoi(argv[2]) : 40;
   hipDeviceProp_t p; CK(hipGetDeviceProperties(&p, 0));
@@ -83,10 +101,8 @@ int main(int argc, char** argv) {
           ref[((size_t)b * 64 + i) * 128 + j] = s;
         }
     }
-    for (int v = 0; v < 3; ++v) {
-      if (v == 0) run<0, 2>(dM, nk, 1, dOut, 8, lds_pf, 1);
-      else if (v == 1) run<1, 2>(dM, nk, 1, dOut, 8, lds_q, 1);
-      else run<2, 2>(dM, nk, 1, dOut, 8, lds_q, 1);
+    for (int v = 0; v < NV; ++v) {
+      run_v<2>(v, dM, nk, 1, dOut, 8, v == 0 || v == 5 ? lds_pf : lds_q, 1);
       CK(hipMemcpy(got.data(), dOut, got.size() * 8, hipMemcpyDeviceToHost));
       double err = 0., mx = 0.;
       for (size_t e = 0; e < ref.size(); ++e) { err = std::fmax(err, std::fabs(got[e] - ref[e])); mx = std::fmax(mx, std::fabs(ref[e])); }
@@ -96,18 +112,13 @@ int main(int argc, char** argv) {
   const double steps = (double)nk * reps;
   for (int wgs = 1; wgs <= 2; ++wgs) {
     const int grid = ncu * wgs;
-    double ms[3];
-    if (wgs == 1) {
-      ms[0] = run<0, 1>(dM, nk, reps, dOut, grid, solo, 0);
-      ms[1] = run<1, 1>(dM, nk, reps, dOut, grid, solo, 0);
-      ms[2] = run<2, 1>(dM, nk, reps, dOut, grid, solo, 0);
-    } else {
-      ms[0] = run<0, 2>(dM, nk, reps, dOut, grid, lds_pf, 0);
-      ms[1] = run<1, 2>(dM, nk, reps, dOut, grid, lds_q, 0);
-      ms[2] = run<2, 2>(dM, nk, reps, dOut, grid, lds_q, 0);
+    double ms[NV];
+    for (int v = 0; v < NV; ++v) {
+      const size_t lds = wgs == 1 ? solo : (v == 0 || v == 5 ? lds_pf : lds_q);
+      ms[v] = wgs == 1 ? run_v<1>(v, dM, nk, reps, dOut, grid, lds, 0) : run_v<2>(v, dM, nk, reps, dOut, grid, lds, 0);
     }
-    const char* names[3] = {"mainloop_pf<..,4>", "mainloop_q<..,2> ", "mainloop_q<..,3> "};
-    for (int v = 0; v < 3; ++v) {
+    const char* names[NV] = {"mainloop_pf<..,4>    ", "mainloop_q<..,2,0>   ", "mainloop_q<..,4,0>   ", "mainloop_q<..,2,1>   ", "mainloop_q<..,4,1>   ", "mainloop_pf<..,2>    "};
+    for (int v = 0; v < NV; ++v) {
       const double us = ms[v] * 1e3 / steps;
       const double tf = (double)grid * steps * 64. * 128. * 16. * 2. / (ms[v] * 1e-3) * 1e-12;
       printf("%d workgroup(s) per CU, %s: %.3f us per k-step, %.1f TFLOP/s (%.2f of 78.6)\n", wgs, names[v], us, tf, tf / 78.6);
