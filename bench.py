@@ -235,16 +235,16 @@ def cpu_baseline_config(tag, X, T, Xs, theta, kernel, nugget, emus, chunk_rows, 
         dl = np.diag(ref.L)
         kappa_eps = max(kappa_eps, float((dl.max() / dl.min()) ** 2 * np.finfo(float).eps))
         err_lp = max(err_lp, abs(dev["logpost"][k] - lp) / abs(lp))
-        err_mean = max(err_mean, float(np.max(np.abs(dev["mean"][k, :ms] - mu) / np.maximum(np.abs(mu), 1e-2))))
+        err_mean = max(err_mean, float(np.max(np.abs(dev["mean"][k, :ms] - mu) / (1e-9 + 1e-7 * np.abs(mu)))))     # in units of the bar
         err_var = max(err_var, float(np.max(np.abs(np.maximum(dev["var"][k, :ms], 0.) - var))))
         del ref
     # stated bars: logpost 1e-10 -- conditioning-scaled max(1e-10, 32 kappa_L eps) where kappa_L eps > 1e-11
     # (C5: two backward-stable factorisations of the same matrix differ by ~cond eps in the quadratic form) --, mean 1e-7, var 1e-7
     lp_tol = max(1e-10, 32 * kappa_eps) if kappa_eps > 1e-11 else 1e-10
-    parity = {"emulators": list(emus), "predict_points": int(ms), "max_rel_logpost": float(err_lp), "max_rel_mean": err_mean,
+    parity = {"emulators": list(emus), "predict_points": int(ms), "max_rel_logpost": float(err_lp), "max_mean_err_over_bar": err_mean,
               "max_abs_var": err_var, "kappa_L_eps": kappa_eps,
-              "tolerances": {"logpost_rtol": lp_tol, "mean_rtol_floor_1e-2": 1e-7, "var_atol": 1e-7}}
-    parity["passed"] = bool(err_lp <= lp_tol and err_mean <= 1e-7 and err_var <= 1e-7)
+              "tolerances": {"logpost_rtol": lp_tol, "mean_bar": "1e-9 + 1e-7 |mean| (the GPU suite's)", "var_atol": 1e-7}}
+    parity["passed"] = bool(err_lp <= lp_tol and err_mean <= 1.0 and err_var <= 1e-7)
     t_fit = float(np.median(t_fits))
     return {"value": 1.0 / t_fit, "unit": "fits/s", "cores": int(threads), "kind": "port",
             "sample": "%s: BLAS-threaded oracle, %d of the configuration's outputs: fit %.2fs each (median), predict %d pts %.2fs%s" % (

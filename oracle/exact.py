@@ -40,3 +40,39 @@ def cond_eps(K):
     """cond_2(K) * 2^-52 of a symmetric positive definite fp64 matrix."""
     w = np.linalg.eigvalsh(K)
     return float(w[-1] / w[0]) * 2.0 ** -52
+
+
+def loglike_from_factor_longdouble(L, t):
+    """The same likelihood term from a GIVEN fp64 Cholesky factor L (lower, n x n) and targets t (n): forward substitution and
+    log-determinant in 80-bit long double, O(n^2).  What it isolates: the value the factor itself stands for -- exact for the matrix
+    L L^T = K + E -- so that (device value - this) is the error of the device's solve / reduction arithmetic alone, and the difference
+    of this quantity between two factors of the same K is the sensitivity of the likelihood to their backward errors E (~ cond eps)."""
+    n = L.shape[0]
+    y = np.zeros(n, dtype=np.longdouble)
+    tl = np.asarray(t, dtype=np.longdouble)
+    for i in range(n):
+        row = np.asarray(L[i, :i], dtype=np.longdouble)
+        y[i] = (tl[i] - row @ y[:i]) / np.longdouble(L[i, i])
+    logdet = 2 * np.sum(np.log(np.asarray(np.diag(L), dtype=np.longdouble)))
+    return 0.5 * (np.sum(y * y) + logdet + n * np.log(np.longdouble(2) * np.pi))
+
+
+def factor_backward_error(K_rows, L, probes=4, seed=0):
+    """max over a few random vectors v of ||(K - L L^T) v||_inf / (||K||_inf ||v||_inf), the products in long double; K_rows(i0, i1) returns
+    rows [i0, i1) of the fp64 matrix K (so that K need not be held as one array)."""
+    n = L.shape[0]
+    rng = np.random.default_rng(seed)
+    V = rng.standard_normal((n, probes))
+    Vl = np.asarray(V, dtype=np.longdouble)
+    W = np.zeros_like(Vl)                                # L^T V
+    for i0 in range(0, n, 512):
+        i1 = min(i0 + 512, n)
+        W[:i1] += np.asarray(L[i0:i1, :i1], dtype=np.longdouble).T @ Vl[i0:i1]
+    err, knorm = 0., 0.
+    for i0 in range(0, n, 512):
+        i1 = min(i0 + 512, n)
+        Kr = K_rows(i0, i1)
+        r = np.asarray(Kr, dtype=np.longdouble) @ Vl - np.asarray(L[i0:i1, :i1], dtype=np.longdouble) @ W[:i1]
+        err = max(err, float(np.max(np.abs(r))))
+        knorm = max(knorm, float(np.max(np.sum(np.abs(Kr), axis=1))))
+    return err / (knorm * float(np.max(np.abs(V))))

@@ -707,6 +707,37 @@ def test_one_launch_cholesky_abort_falls_back_to_the_multi_launch_schedule():
     assert int(out.stdout.split("MC-ABORTS")[1].split()[0]) > 0, "the forced timeouts never happened: the fallback was not exercised"
 
 
+def test_c5_like_conditioning_against_the_exact_value():
+    """at n = 16000 nothing independent of LAPACK can be computed in full, so the same family one size down, where it
+    can: n = 4000, d = 8, C5's theta and nugget.  The device AND the oracle against the likelihood of the same fp64 matrix evaluated
+    in 80-bit long double (oracle/exact.py), at 0.02 cond(K) eps -- the bar of the n = 1500 test -- and each factor's own long-double
+    value (loglike_from_factor_longdouble) against its fp64 result at 1e-11."""
+    from oracle.exact import loglike_longdouble, loglike_from_factor_longdouble, cond_eps
+    n, d = 4000, 8
+    X, T, Xs = synth(20240607 + 5, n, d, 2, 16)
+    theta = np.array([-2. * np.log(0.3 * np.sqrt(d))] * d + [0.])
+    eta = 1e-6
+    ref = R.GPRef(X, T[0], nugget=eta); ref.fit(theta)
+    Kn = ref.get_K_matrix() + eta * np.eye(n)
+    ce = cond_eps(Kn)
+    tol = 0.02 * ce
+    like = loglike_longdouble(Kn, T, nb=128)
+    for k in range(2):
+        gp = make_gp(X, T[k], nugget=eta)
+        f_dev = gp.logposterior(theta)
+        gp.fit(theta)
+        rk = R.GPRef(X, T[k], nugget=eta)
+        f_ref = rk.fit(theta)
+        prior = f_ref - 0.5 * (np.dot(rk.t, rk.Kinv_t) + R.logdet_L(rk.L) + n * np.log(2. * np.pi))
+        exact = float(like[k] + np.longdouble(prior))
+        assert_allclose(f_ref, exact, rtol=tol)
+        assert_allclose(f_dev, exact, rtol=tol)
+        own = float(loglike_from_factor_longdouble(gp.L, T[k]) + np.longdouble(prior))
+        assert abs(f_dev - own) <= 1e-11 * abs(own), (f_dev, own)
+        print("n=4000 k=%d: cond eps %.2e; (oracle - exact)/exact %.2e, (device - exact)/exact %.2e, device vs its own factor %.2e" % (
+            k, ce, (f_ref - exact) / exact, (f_dev - exact) / exact, (f_dev - own) / own))
+
+
 def test_in_kernel_hand_offs_are_bit_stable_under_uneven_load():
     """The hand-offs inside the one-launch Cholesky and the chained back substitution (write-through stores, drained, then a relaxed
     agent-scope flag; consumers never touch an address before its final value is published) rest on an argument, not on acquire /
@@ -908,6 +939,31 @@ def test_c5_full_size_vs_oracle():
     assert_allclose(gp.Kinv_t, ref.Kinv_t, rtol=1e-5, atol=1e-5 * np.abs(ref.Kinv_t).max())
     gref = ref.logpost_deriv_chunked(theta, chunk_rows=128)
     assert_allclose(grad, gref, rtol=1e-6, atol=max(1e-7, 64 * kappa_eps) * np.abs(gref).max())
+    # Arbitration independent of LAPACK's arithmetic.  Each factor L stands for a matrix L L^T = K + E; the likelihood
+    # of THAT matrix is computable in 80-bit long double from the factor in O(n^2) (oracle/exact.py).  Measured here, not argued:
+    #  (i)   both factors are backward stable: ||(K - L L^T) v|| <= 1e-14 ||K|| ||v|| on random probes (products in long double);
+    #  (ii)  each side's own fp64 solve + reductions reproduce the value of its factor to 1e-11 -- the arithmetic AFTER the factorisation
+    #        is not where the two log-posteriors part;
+    #  (iii) the two factors' exact values differ by what the conditioning allows, and the fp64 results differ by no more than that (+ (ii)):
+    #        the 32 kappa_L eps bar above is the measured sensitivity of the likelihood to a backward-stable factor's error, with headroom.
+    from oracle.exact import loglike_from_factor_longdouble, factor_backward_error
+    L_dev = gp.L
+    eta = 1e-6
+
+    def K_rows(i0, i1):
+        Kr = R.calc_K(R.calc_r2(X[i0:i1], X, theta[:d])) * np.exp(theta[d])
+        Kr[np.arange(i1 - i0), np.arange(i0, i1)] += eta
+        return Kr
+    be_dev, be_ref = factor_backward_error(K_rows, L_dev, probes=2), factor_backward_error(K_rows, ref.L, probes=2)
+    assert be_dev < 1e-14 and be_ref < 1e-14, (be_dev, be_ref)
+    prior = lp_ref - 0.5 * (np.dot(ref.t, ref.Kinv_t) + R.logdet_L(ref.L) + n * np.log(2. * np.pi))
+    ex_dev = float(loglike_from_factor_longdouble(L_dev, T[0]) + np.longdouble(prior))
+    ex_ref = float(loglike_from_factor_longdouble(ref.L, T[0]) + np.longdouble(prior))
+    assert abs(lp - ex_dev) <= 1e-11 * abs(ex_dev) and abs(lp_ref - ex_ref) <= 1e-11 * abs(ex_ref), (lp, ex_dev, lp_ref, ex_ref)
+    gap = abs(ex_dev - ex_ref) / abs(ex_ref)
+    assert gap <= 32 * kappa_eps and abs(lp - lp_ref) <= abs(ex_dev - ex_ref) + 2e-11 * abs(ex_ref), (gap, kappa_eps, lp, lp_ref)
+    print("C5 arbitration: backward errors %.2e / %.2e, |fp64 - factor value| %.2e / %.2e, factor-to-factor %.2e = %.1f kappa_L eps" % (
+        be_dev, be_ref, abs(lp - ex_dev) / abs(ex_dev), abs(lp_ref - ex_ref) / abs(ex_ref), gap, gap / kappa_eps))
 
 
 def test_sharded_wrapper_on_one_gpu():
