@@ -16,7 +16,11 @@ A "step" is one pass of the hot path over the rank's shard:
 fit+grad/s and predict pts/s are reported next to it from the same timed steps.
 
 other_configs (N = 1): BASELINE's C2 (one n=2000 emulator, predict m=10^4), C4 (16 x n=5000, Matern-5/2, fitted nugget) and
-C5 (n=16000) timed on this GPU with their tagged kernels; nccl_world1 (N = 1): the two exchange payloads through RCCL in a one-rank process group; shard_sweep also
+C5 (n=16000) timed on this GPU with their tagged kernels, each with the CPU oracle beside it (`cpu_baseline`: one / two / one of its outputs fitted
+on the host, outside every timed region, within --cpu-budget-s) and its own `parity` block from the values that run produces;
+predict_first_call_ms: the first predict after a fit without gradient (it also builds L^-1) next to the steady-state time the headline's
+predict rate is taken from; projected_scaling: what 2 / 4 / 8 GPUs would deliver, from the one-GPU time of the shard a rank holds (no
+multi-GPU measurement can be made on a one-GPU box); roofline.traffic_source: where `traffic` comes from (a committed PMC pass, not this run); nccl_world1 (N = 1): the two exchange payloads through RCCL in a one-rank process group; shard_sweep also
 times fit_GP_MAP with 15 concurrent starts per emulator (the workload users run at shard size).
 roofline: for the kernel with the largest share of device time; `achieved` = algorithmic flops (n^3/3 per
 Cholesky, m n^2 per predictive variance, ...) of all its launches in the timed steps / their total duration measured with

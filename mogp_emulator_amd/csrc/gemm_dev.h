@@ -12,6 +12,9 @@ typedef double v2d __attribute__((ext_vector_type(2)));
 
 constexpr int BK = 16;
 constexpr int LDK = BK + 2;
+// XOR swizzle of the 16-byte chunk index of an UNPADDED [row][16] operand tile (mainloop_q, mainloop_w<.., SWZ>): chunk c of row R lies at
+// c ^ q_swz(R & 15), which makes the ds_read_b128 fragment reads conflict-free in the four 16-lane groups the instruction is served in
+__device__ __forceinline__ int q_swz(int row) { return ((row >> 1) & 1) | (((row >> 3) & 1) << 2); }
 
 // ---------------------------------------------------------------------------------------------
 // Main loop with WR x WC waves per BM x BN block tile, both operands K-major (same LDS layout and k-step as
@@ -41,7 +44,10 @@ struct WCfg {
 // around MFMA groups inside one loop costs more in register copies and exposed LDS latency than the skipped MFMAs save.)
 // Callers must not depend on the row -> accumulator map.
 // ZERO = false: the products are ADDED to what acc holds on entry (a k range continued after a wait).
-template <int BM, int BN, int WR, int WC, bool TRIA = false, bool ZERO = true>
+// SWZ (round 5, the predictive variance): operand tiles unpadded and swizzled as in mainloop_q, fragments as ds_read_b128 -- half the LDS
+// instructions and no bank conflicts (the padded [row][18] layout spends 40 % of its LDS cycles in conflicts, profiles/r05_loop_probe_pmc.txt);
+// lane (fr, fk) then multiplies k = 4 fk + 2 h + e in the MFMA (h, e) of a step (results agree with the padded form to rounding).
+template <int BM, int BN, int WR, int WC, bool TRIA = false, bool ZERO = true, bool SWZ = false>
 __device__ __forceinline__ void mainloop_w(const double* __restrict__ Ag, int lda, const double* __restrict__ Bg, int ldb, int nk,
                                            v4d (&acc)[WCfg<BM, BN, WR, WC>::TI][WCfg<BM, BN, WR, WC>::TJ], double* smem,
                                            int nk_full = 0, int a_rows = BM) {
@@ -72,16 +78,20 @@ __device__ __forceinline__ void mainloop_w(const double* __restrict__ Ag, int ld
     for (int q = 0; q < C::CHB; ++q)
       rb[q] = *reinterpret_cast<const v2d*>(reinterpret_cast<const char*>(Bg + (size_t)q * (C::NT / 8) * ldb) + offB);
   };
+  // (SWZ: row (t >> 3) + (NT / 8) q, chunk (t & 7) ^ sw(row) -- NT / 8 is a multiple of 16, so the swizzle is the thread's own)
+  const int st_swz = (t >> 3) * BK + (((t & 7) ^ q_swz((t >> 3) & 15)) << 1);
   auto store = [&](double* sA, double* sB) {
 #pragma unroll
     for (int q = 0; q < C::CHA; ++q) {
       const int c = t + C::NT * q;
-      *reinterpret_cast<v2d*>(sA + (c >> 3) * LDK + (c & 7) * 2) = ra[q];
+      if (SWZ) *reinterpret_cast<v2d*>(sA + st_swz + q * (C::NT / 8) * BK) = ra[q];
+      else *reinterpret_cast<v2d*>(sA + (c >> 3) * LDK + (c & 7) * 2) = ra[q];
     }
 #pragma unroll
     for (int q = 0; q < C::CHB; ++q) {
       const int c = t + C::NT * q;
-      *reinterpret_cast<v2d*>(sB + (c >> 3) * LDK + (c & 7) * 2) = rb[q];
+      if (SWZ) *reinterpret_cast<v2d*>(sB + st_swz + q * (C::NT / 8) * BK) = rb[q];
+      else *reinterpret_cast<v2d*>(sB + (c >> 3) * LDK + (c & 7) * 2) = rb[q];
     }
   };
   loadA();
@@ -101,7 +111,23 @@ __device__ __forceinline__ void mainloop_w(const double* __restrict__ Ag, int ld
       loadA();
       loadB();
     }
-    if (S < E) {
+    if (S < E && SWZ) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        v2d a2[C::TI], b2[C::TJ];
+        const int fo = fr * BK + ((((2 * fk) ^ q_swz(fr)) << 1) ^ (h << 1));
+#pragma unroll
+        for (int i = S; i < E; ++i) a2[i] = *reinterpret_cast<const v2d*>(sA + (TRIA ? i * WR + wr : wr * C::TI + i) * 16 * BK + fo);
+#pragma unroll
+        for (int j = 0; j < C::TJ; ++j) b2[j] = *reinterpret_cast<const v2d*>(sB + (wc * C::TJ + j) * 16 * BK + fo);
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+#pragma unroll
+          for (int i = S; i < E; ++i)
+#pragma unroll
+            for (int j = 0; j < C::TJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2[i][e], b2[j][e], acc[i][j], 0, 0, 0);
+      }
+    } else if (S < E) {
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) {
         double a[C::TI], b[C::TJ];
@@ -266,10 +292,9 @@ struct QCfg {
   static constexpr int STAGE = (BM + BN) * BK;           // doubles per stage: A tile, then B tile
   static constexpr int SMEM_DOUBLES = 3 * STAGE;
 };
-__device__ __forceinline__ int q_swz(int row) { return ((row >> 1) & 1) | (((row >> 3) & 1) << 2); }
 
 // park / park_lds / park_spins and kmask: as in mainloop_pf.
-template <int BM, int BN, int WR, int WC, int G, int ORDER = 0>
+template <int BM, int BN, int WR, int WC, int G>
 __device__ __forceinline__ void mainloop_q(const double* __restrict__ Ag, int lda, const double* __restrict__ Bg, int ldb, int nk,
                                            v4d (&acc)[WCfg<BM, BN, WR, WC>::TI][WCfg<BM, BN, WR, WC>::TJ], double* smem,
                                            const unsigned* park = nullptr, int* park_lds = nullptr, int park_spins = 0, int kmask = -1) {
@@ -353,30 +378,19 @@ __device__ __forceinline__ void mainloop_q(const double* __restrict__ Ag, int ld
       }
       const double* st = smem + cur * STAGE;
       const int nxt = cur == 2 ? 0 : cur + 1, wrt = nxt == 2 ? 0 : nxt + 1;
-      if (ORDER == 0) {
-        frag(1, st, 1);
-        mfmas(0);
-        // the stage of step kt + 2 (last read during step kt - 1, a barrier ago) gets register set u; the set is then reloaded
-        store(u, smem + wrt * STAGE);
-        load(u, min(kt + 2 + G, last));
-        frag(0, smem + nxt * STAGE, 0);                    // written during step kt - 1: visible since the barrier that ended it
-        mfmas(1);
-        __syncthreads();
-      } else {
-        // the barrier in the MIDDLE of the step: every LDS operation in flight at the barrier was issued half a step (16 MFMAs) earlier,
-        // and what is issued right behind it is needed half a step later
-        store(u, smem + wrt * STAGE);
-        load(u, min(kt + 2 + G, last));
-        frag(1, st, 1);
-        mfmas(0);
-        __syncthreads();
-        frag(0, smem + nxt * STAGE, 0);
-        mfmas(1);
-      }
+      frag(1, st, 1);
+      mfmas(0);
+      // the stage of step kt + 2 (last read during step kt - 1, a barrier ago) gets register set u; the set is then reloaded
+      store(u, smem + wrt * STAGE);
+      load(u, min(kt + 2 + G, last));
+      frag(0, smem + nxt * STAGE, 0);                      // written during step kt - 1: visible since the barrier that ended it
+      mfmas(1);
+      __syncthreads();
+      // (tried: the barrier in the MIDDLE of the step, so that every LDS operation in flight at it was issued half a step earlier -- the
+      // same times, tools/gemm_loop_probe.hip round 5)
       cur = nxt;
     }
   }
-  if (ORDER != 0) __syncthreads();                         // (the fragment reads behind the last barrier are complete: smem may be reused)
 }
 
 // f(row_in_tile, col_in_tile, value) over the accumulator fragment of mainloop_w

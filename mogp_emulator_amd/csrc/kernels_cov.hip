@@ -216,7 +216,12 @@ __global__ __launch_bounds__(256) void cov_full_kernel(BatchView v, int emu, con
 // ---------------------------------------------------------------------------------------------
 // RB = compile-time bound of the right-hand-side rows: 1 for the plain path (8 instead of 64 accumulator registers,
 // five instead of three waves per SIMD), RMAX with an analytic mean.
-template <int KT, int RB>
+// NPF > 0 (round 5; D <= 4 NPF): the NEXT tile of training inputs (and of alpha) is requested into NPF registers per thread before the
+// current tile is computed and deposited into the other of two LDS buffers after it -- one barrier per tile, no exposed load.  Before,
+// every one of the NP / 64 tiles of a workgroup began with a global load between two barriers: 10 us per tile of which 1.4 us per wave
+// is arithmetic; with four waves per SIMD that is what bounded the kernel (3.2 TB/s of writes whatever the store pattern or the
+// instruction count).  NPF = 0: the synchronous form (D > 32: the register set would be larger than what it hides).
+template <int KT, int RB, int NPF>
 __global__ __launch_bounds__(256) void cross_cov_mean_kernel(BatchView v, const double* __restrict__ Xs, int m, int MP,
                                                            double* __restrict__ Ks, double* __restrict__ mean, int mean_ld) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
@@ -229,13 +234,16 @@ __global__ __launch_bounds__(256) void cross_cov_mean_kernel(BatchView v, const 
   const double* P = v.P + (size_t)emu * v.PS;
   const double* alpha0 = v.alpha + (size_t)emu * v.RA * ld;   // row 0: K^-1 (t - H beta)
   const double* Zr = v.Z + (size_t)emu * R * ld;              // rows 1..: K^-1 h_c
+  const double* Xtr = v.X + (size_t)emu * v.XS;
+  constexpr int NB = NPF > 0 ? 2 : 1;                         // LDS buffers of the training tile / the alpha tile
+  constexpr int NPA = RB == 1 ? 1 : (RMAX * 64 + 255) / 256;  // alpha values per thread
   double* si = sm;
-  double* sj = sm + 64 * D;
-  double* sa = sm + 128 * D;          // R x 64 operand tile
-  double* red = sa + RMAX * 64;       // 64 x 33
+  double* sj = sm + 64 * D;           // NB x [D][64]
+  double* sa = sj + NB * 64 * D;      // NB x [R][64] operand tile
+  double* red = sa + NB * RMAX * 64;  // 64 x 33
   stage_rows(Xs, m, D, i0, si);
   // 8 x 2 micro tile (see cov_build_kernel): a wave's store instruction is two whole 512-byte rows of the K* tile
-  const int ty = threadIdx.x >> 5, tx = threadIdx.x & 31;
+  const int t = threadIdx.x, ty = t >> 5, tx = t & 31;
   const double sig2 = P[D];
   double macc[RB][8];
 #pragma unroll
@@ -244,20 +252,66 @@ __global__ __launch_bounds__(256) void cross_cov_mean_kernel(BatchView v, const 
     for (int a = 0; a < 8; ++a) macc[c][a] = 0.;
   double* Kz = Ks ? Ks + (size_t)z * MP * ld : nullptr;
   const int ntj = v.NP / 64;
+  // prefetch registers and the (tile-independent) LDS slot of each: element e = t + 256 q of a [64][D] row block goes to [d][row]
+  double px[NPF > 0 ? NPF : 1], pa[NPA];
+  int loff[NPF > 0 ? NPF : 1];
+  const int cnt = 64 * D;
+  if (NPF > 0) {
+#pragma unroll
+    for (int q = 0; q < NPF; ++q) {
+      const int e = t + 256 * q, r = e / D;
+      loff[q] = (e - r * D) * 64 + r;
+    }
+  }
+  auto fetch = [&](int j0) {
+    const int avail = max(0, min(64, n - j0)) * D;
+    const double* src = Xtr + (size_t)j0 * D;
+#pragma unroll
+    for (int q = 0; q < NPF; ++q) {
+      const int e = t + 256 * q;
+      px[q] = (e < avail) ? src[e] : 0.0;
+    }
+#pragma unroll
+    for (int q = 0; q < NPA; ++q) {
+      const int e = t + 256 * q, c = e >> 6, jj = e & 63;
+      const double* srca = (c == 0) ? alpha0 : Zr + (size_t)c * ld;
+      pa[q] = (e < R * 64 && j0 + jj < n) ? srca[j0 + jj] : 0.0;
+    }
+  };
+  auto deposit = [&](int buf) {
+#pragma unroll
+    for (int q = 0; q < NPF; ++q)
+      if (t + 256 * q < cnt) sj[buf * cnt + loff[q]] = px[q];
+#pragma unroll
+    for (int q = 0; q < NPA; ++q)
+      if (t + 256 * q < R * 64) sa[buf * RMAX * 64 + t + 256 * q] = pa[q];
+  };
+  if (NPF > 0) {
+    fetch(0);
+    deposit(0);
+  }
   for (int tj = 0; tj < ntj; ++tj) {
     const int j0 = tj * 64;
+    const int cur = NPF > 0 ? (tj & 1) : 0;
+    const double* sjc = sj + cur * cnt;
+    const double* sac = sa + cur * RMAX * 64;
     __syncthreads();
-    if (j0 < n) {
-      stage_rows(v.X + (size_t)emu * v.XS, n, D, j0, sj);
-      for (int e = threadIdx.x; e < R * 64; e += 256) {
-        const int c = e >> 6, jj = e & 63;
-        const double* src = (c == 0) ? alpha0 : Zr + (size_t)c * ld;
-        sa[e] = (j0 + jj < n) ? src[j0 + jj] : 0.0;
+    if (NPF == 0) {
+      if (j0 < n) {
+        stage_rows(Xtr, n, D, j0, sj);
+        for (int e = t; e < R * 64; e += 256) {
+          const int c = e >> 6, jj = e & 63;
+          const double* src = (c == 0) ? alpha0 : Zr + (size_t)c * ld;
+          sa[e] = (j0 + jj < n) ? src[j0 + jj] : 0.0;
+        }
       }
+      __syncthreads();
+    } else if (j0 + 64 < n) {
+      fetch(j0 + 64);
     }
-    __syncthreads();
     double kv[8][2];
-    if (j0 < n) micro_k<KT, 8, 2>(si, sj, P, D, ty, tx, kv, etab);
+    if (j0 < n) micro_k<KT, 8, 2>(si, sjc, P, D, ty, tx, kv, etab);
+    double* Kt = Kz + (size_t)(i0 + 8 * ty) * ld + j0 + 2 * tx;
 #pragma unroll
     for (int a = 0; a < 8; ++a) {
       const int i = i0 + 8 * ty + a;
@@ -271,11 +325,13 @@ __global__ __launch_bounds__(256) void cross_cov_mean_kernel(BatchView v, const 
         if (j0 < n) {
 #pragma unroll
           for (int c = 0; c < RB; ++c)
-            if (c < R) macc[c][a] = __builtin_fma(x, sa[c * 64 + 2 * tx + b], macc[c][a]);
+            if (c < R) macc[c][a] = __builtin_fma(x, sac[c * 64 + 2 * tx + b], macc[c][a]);
         }
       }
-      if (Kz) *reinterpret_cast<double2*>(Kz + (size_t)i * ld + j0 + 2 * tx) = make_double2(out[0], out[1]);
+      if (Kz) *reinterpret_cast<double2*>(Kt + (size_t)a * ld) = make_double2(out[0], out[1]);
     }
+    // (the other buffer was last read in the previous iteration, which every wave left through the barrier above)
+    if (NPF > 0 && j0 + 64 < n) deposit(cur ^ 1);
   }
 #pragma unroll
   for (int c = 0; c < RB; ++c) {
@@ -284,10 +340,10 @@ __global__ __launch_bounds__(256) void cross_cov_mean_kernel(BatchView v, const 
 #pragma unroll
       for (int a = 0; a < 8; ++a) red[(8 * ty + a) * 33 + tx] = macc[c][a];
       __syncthreads();
-      if (threadIdx.x < 64) {
+      if (t < 64) {
         double s = 0.;
-        for (int q = 0; q < 32; ++q) s += red[threadIdx.x * 33 + q];
-        const int i = i0 + threadIdx.x;
+        for (int q = 0; q < 32; ++q) s += red[t * 33 + q];
+        const int i = i0 + t;
         if (i < m) mean[((size_t)z * R + c) * mean_ld + i] = s;
       }
     }
@@ -649,15 +705,28 @@ void launch_cov_full(const BatchView& v, int emu, double* out, hipStream_t s) {
 }
 
 void launch_cross_cov_mean(const BatchView& v, const double* Xs, int m, int MP, double* Ks, double* mean, int mean_ld, hipStream_t s) {
-  const size_t sm = (size_t)(128 * v.D + RMAX * 64 + 64 * 33) * sizeof(double);
+  // prefetch registers per thread for the next training tile: 64 D values over 256 threads (0 = the synchronous form)
+  const int npf = v.D <= 16 ? 4 : (v.D <= 32 ? 8 : 0);
+  const int nbuf = npf ? 2 : 1;
+  const size_t sm = (size_t)(64 * v.D + nbuf * (64 * v.D + RMAX * 64) + 64 * 33) * sizeof(double);
   prof_begin("cross_cov", s);
-#define CALL(K)                                                                                                                      \
-  do {                                                                                                                               \
-    if (v.R == 1) hipLaunchKernelGGL((cross_cov_mean_kernel<K, 1>), dim3(MP / 64, v.nb), dim3(256), sm, s, v, Xs, m, MP, Ks, mean, mean_ld);   \
-    else hipLaunchKernelGGL((cross_cov_mean_kernel<K, RMAX>), dim3(MP / 64, v.nb), dim3(256), sm, s, v, Xs, m, MP, Ks, mean, mean_ld);       \
+#define LAUNCH(K, RBV, NPFV) \
+  hipLaunchKernelGGL((cross_cov_mean_kernel<K, RBV, NPFV>), dim3(MP / 64, v.nb), dim3(256), sm, s, v, Xs, m, MP, Ks, mean, mean_ld)
+#define CALL(K)                                                        \
+  do {                                                                 \
+    if (v.R == 1) {                                                    \
+      if (npf == 4) LAUNCH(K, 1, 4);                                   \
+      else if (npf == 8) LAUNCH(K, 1, 8);                              \
+      else LAUNCH(K, 1, 0);                                            \
+    } else {                                                           \
+      if (npf == 4) LAUNCH(K, RMAX, 4);                                \
+      else if (npf == 8) LAUNCH(K, RMAX, 8);                           \
+      else LAUNCH(K, RMAX, 0);                                         \
+    }                                                                  \
   } while (0)
   KT_DISPATCH(v.kernel_type, CALL);
 #undef CALL
+#undef LAUNCH
   prof_end("cross_cov", s, 0., (double)v.nb * (8.0 * (double)m * (double)v.n + 8.0 * ((double)m + v.n) * v.D));      // algorithmic m x n entries, not the padded MP x NP
 }
 

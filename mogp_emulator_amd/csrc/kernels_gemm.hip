@@ -545,6 +545,7 @@ __global__ __launch_bounds__(512, 4) void update_tri8_kernel(BatchView v, int c0
 // (Round 5: the soft lock-step of a super-tile's workgroups -- MOGP_PV_SYNC, persistent workgroups that waited for each other every 8
 // k-steps: 3.4 x less L2-miss traffic, 1 - 7 % slower -- and the downward walk of the short row tile, MOGP_PV_DESC, are gone; their
 // measurements are in HISTORY.md.)
+constexpr bool PV_SWZ = true;      // swizzled ds_read_b128 fragments (mainloop_w<.., SWZ>; round 5: 65.2 -> 66.5 TFLOP/s, profiles/r05_predict_swz_ab.txt)
 template <int WR, int WC, bool TRI>
 __global__ __launch_bounds__(64 * WR * WC, (WR * WC >= 8 ? 4 : 2)) void predict_var_w_kernel(
     BatchView v, const double* __restrict__ Ks, int MP, int nti, int ntj, double* __restrict__ partial, int lgc, int single) {
@@ -578,7 +579,7 @@ __global__ __launch_bounds__(64 * WR * WC, (WR * WC >= 8 ? 4 : 2)) void predict_
     v4d acc[C::TI][C::TJ];
     // L^-1 is lower triangular and its rows >= n are padding: TRI skips the structurally zero steps (mainloop_w)
     const int nk = TRI ? min(i0 + 128, (v.n + 15) & ~15) / BK : (i0 + 128) / BK;
-    mainloop_w<128, 128, WR, WC, TRI>(Li + (size_t)i0 * ld, ld, K + (size_t)j0 * ld, ld, nk, acc, smem, i0 / BK, v.n - i0);
+    mainloop_w<128, 128, WR, WC, TRI, true, PV_SWZ>(Li + (size_t)i0 * ld, ld, K + (size_t)j0 * ld, ld, nk, acc, smem, i0 / BK, v.n - i0);
     // column sums of squares over the tile's 128 rows: red[wr][128]
     double* red = smem;
 #pragma unroll

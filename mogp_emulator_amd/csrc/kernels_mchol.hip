@@ -51,31 +51,20 @@ constexpr int MC_ABORT = 0, MC_TIMEOUTS = 1;      // ctrl[0], ctrl[1]
 constexpr int MC_HEADS = MC_LINE;                 // queue head q at ctrl[MC_HEADS + q * MC_LINE]
 constexpr int MC_CU0 = MC_LINE * 9;               // per-CU "a diagonal block is being factored here" words, index xcc * 256 + HW_ID[15:8]
 constexpr int MC_EMU0 = MC_CU0 + 8 * 256;         // per-emulator blocks start here
-constexpr int MC_PD = 4;                          // k-steps the global loads of a GEMM task run ahead (gemm_dev.h, mainloop_pf)
+constexpr int MC_PD = 4;                          // 16-column pieces a GEMM task consumes per call of its main loop (and the steps its global loads run ahead)
 constexpr int MC_LDS_HDR = 4;                     // doubles in front of the operand buffers: [task / ok words]
 
 __device__ __forceinline__ unsigned ldu(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void stu(unsigned* p, unsigned x) { __hip_atomic_store(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
-#ifndef MOGP_MC_Q_ORDER
-#define MOGP_MC_Q_ORDER 0
-#endif
-// the GEMM main loop of the tasks: -DMOGP_MC_LOOP_PF keeps mainloop_pf (rounds 3 - 4), the default is mainloop_q (round 5, gemm_dev.h)
+// the GEMM main loop of the tasks (gemm_dev.h): mainloop_q, two global-load steps ahead of its three LDS stages
 template <int BM, int BN>
 __device__ __forceinline__ void MC_GEMM(const double* __restrict__ Ag, int lda, const double* __restrict__ Bg, int ldb, int nk, v4d (&acc)[BM / 32][BN / 32],
                                         double* smem, const unsigned* park, int* park_lds, int park_spins, int kmask) {
-#ifdef MOGP_MC_LOOP_PF
-  mainloop_pf<BM, BN, 2, 2, MC_PD>(Ag, lda, Bg, ldb, nk, acc, smem, park, park_lds, park_spins, kmask);
-#else
-  mainloop_q<BM, BN, 2, 2, 2, MOGP_MC_Q_ORDER>(Ag, lda, Bg, ldb, nk, acc, smem, park, park_lds, park_spins, kmask);
-#endif
+  mainloop_q<BM, BN, 2, 2, 2>(Ag, lda, Bg, ldb, nk, acc, smem, park, park_lds, park_spins, kmask);
 }
-#ifdef MOGP_MC_LOOP_PF
-constexpr size_t MC_GEMM_LDS = WCfg<64, 128, 2, 2>::SMEM_DOUBLES;
-#else
 constexpr size_t MC_GEMM_LDS = QCfg<64, 128>::SMEM_DOUBLES;
-#endif
 
 struct McCtx {
   unsigned* ctrl;
@@ -255,11 +244,14 @@ __global__ __launch_bounds__(256, SOLO ? 1 : 2) void mchol_kernel(BatchView v, u
         const int ti = r > 0 ? 1 : 0, tj = r > 1 ? 1 : 0;
         const int gi0 = c0 + 64 * ti, gj0 = c0 + 64 * tj;
         __builtin_amdgcn_s_setprio(2);
-        v4d acc[2][2];
+        v4d acc[2][2];              // (SOLO: starts as -C, see the T tasks)
+        double* pcG = A + (size_t)(gi0 + (t >> 7) * 32 + ((t & 63) >> 4)) * ld + (gj0 + ((t >> 6) & 1) * 32 + (t & 15));
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-          for (int j = 0; j < 2; ++j) acc[i][j] = (v4d){0., 0., 0., 0.};
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[i][j][q] = SOLO ? -pcG[(size_t)(i * 16 + 4 * q) * ld + j * 16] : 0.0;
         const int kend = c - 1;
         int kb = 0;
         while (kb < kend) {
@@ -275,21 +267,22 @@ __global__ __launch_bounds__(256, SOLO ? 1 : 2) void mchol_kernel(BatchView v, u
         draw_next();
         {
           double cv[2][2][4];
-          const int lane = t & 63, wave = t >> 6, wr = wave >> 1, wc = wave & 1;
-          double* pc0 = A + (size_t)(gi0 + wr * 32 + (lane >> 4)) * ld + (gj0 + wc * 32 + (lane & 15));
+          if (!SOLO) {
 #pragma unroll
-          for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+              for (int j = 0; j < 2; ++j)
 #pragma unroll
-              for (int q = 0; q < 4; ++q) cv[i][j][q] = pc0[(size_t)(i * 16 + 4 * q) * ld + j * 16];
+                for (int q = 0; q < 4; ++q) cv[i][j][q] = pcG[(size_t)(i * 16 + 4 * q) * ld + j * 16];
+          }
 #pragma unroll
           for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
               for (int q = 0; q < 4; ++q)      // read by D(c) on another CU: write-through
-                __hip_atomic_store(pc0 + (size_t)(i * 16 + 4 * q) * ld + j * 16, cv[i][j][q] - acc[i][j][q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(pcG + (size_t)(i * 16 + 4 * q) * ld + j * 16, SOLO ? -acc[i][j][q] : cv[i][j][q] - acc[i][j][q], __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
         }
         drain_stores();
         mc_stamp<TRACE>(tr, 4);
@@ -308,11 +301,41 @@ __global__ __launch_bounds__(256, SOLO ? 1 : 2) void mchol_kernel(BatchView v, u
       if (urgent) __builtin_amdgcn_s_setprio(2);
       const int kend = c;
       if (kend > 0) {
+        // SOLO (chain-bound launches, one workgroup per CU): acc starts as -C -- the tile's covariance entries are requested with the first
+        // operands instead of after the GEMM, where their latency sits on the dependent chain (one n = 2000 matrix: mchol 0.471 -> 0.454 ms);
+        // the solve then takes x = -acc.  Throughput-bound launches read C after the GEMM as before: there the early read costs 1 % (its
+        // latency is covered by the CU partner anyway, and the first MFMAs wait for it).  Round 5, profiles/r05_negc_ab.txt.
         v4d acc[2][4];
+        const double* pcT = A + (size_t)(r0 + (t >> 7) * 32 + ((t & 63) >> 4)) * ld + (c0 + ((t >> 6) & 1) * 64 + (t & 15));
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-          for (int j = 0; j < 4; ++j) acc[i][j] = (v4d){0., 0., 0., 0.};
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[i][j][q] = SOLO ? -pcT[(size_t)(i * 16 + 4 * q) * ld + j * 16] : 0.0;
+        // x = C - (sum of products), whichever way acc started
+        auto finish_x = [&]() {
+          if (SOLO) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+              for (int j = 0; j < 4; ++j) acc[i][j] = -acc[i][j];
+          } else {
+            double cv[2][4][4];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+              for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) cv[i][j][q] = pcT[(size_t)(i * 16 + 4 * q) * ld + j * 16];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+              for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[i][j][q] = cv[i][j][q] - acc[i][j][q];
+          }
+        };
         {
           // The k range is consumed in 16-column PIECES as they become visible (rowprog counts them: whole block columns of finished
           // tiles plus what a chain task has published of the tile it is solving), MC_PD pieces at a time.  Why: every tile of block
@@ -340,21 +363,7 @@ __global__ __launch_bounds__(256, SOLO ? 1 : 2) void mchol_kernel(BatchView v, u
           if (mc_wait_min3(cx, ddone + c, ddone + c, ddone + c, 8u, tr) < 0) return;       // (a formality for a bulk task)
           TrsmSlabPre SP;
           trsm128_slab_request(pk, SP);
-          const int lane = t & 63, wave = t >> 6, wr = wave >> 1, wc = wave & 1;
-          const double* pc0 = A + (size_t)(r0 + wr * 32 + (lane >> 4)) * ld + (c0 + wc * 64 + (lane & 15));
-          double cv[2][4][4];
-#pragma unroll
-          for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-              for (int q = 0; q < 4; ++q) cv[i][j][q] = pc0[(size_t)(i * 16 + 4 * q) * ld + j * 16];
-#pragma unroll
-          for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-              for (int q = 0; q < 4; ++q) acc[i][j][q] = cv[i][j][q] - acc[i][j][q];
+          finish_x();
           mc_stamp<TRACE>(tr, 4);
           mc_stamp<TRACE>(tr, 8);
           __builtin_amdgcn_s_setprio(1);
@@ -373,23 +382,7 @@ __global__ __launch_bounds__(256, SOLO ? 1 : 2) void mchol_kernel(BatchView v, u
         {
           // chain task, round 4: x = C - acc stays in registers and is re-dealt to the solving waves through LDS (trsm128_tile2_chain_dev)
           // instead of being written back and re-read by the pipelined solve
-          {
-            const int lane = t & 63, wave = t >> 6, wr = wave >> 1, wc = wave & 1;
-            const double* pc0 = A + (size_t)(r0 + wr * 32 + (lane >> 4)) * ld + (c0 + wc * 64 + (lane & 15));
-            double cv[2][4][4];
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-              for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) cv[i][j][q] = pc0[(size_t)(i * 16 + 4 * q) * ld + j * 16];
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-              for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) acc[i][j][q] = cv[i][j][q] - acc[i][j][q];
-          }
+          finish_x();
           mc_stamp<TRACE>(tr, 4);
           bool first = true;
           auto wait = [&](int b) {

@@ -14,8 +14,8 @@ using namespace mogp;
 
 constexpr int LD = 2048;
 
-// V = 0: mainloop_pf<64,128,2,2,4> (round 3-4); V = 1: mainloop_q<64,128,2,2,2>; V = 2: mainloop_q G = 4; V = 3 / 4: G = 2 / 4 with the barrier in
-// the middle of the step (ORDER 1); V = 5: mainloop_pf with PD = 2
+// V = 0: mainloop_pf<64,128,2,2,4> (rounds 3-4); V = 1: mainloop_q<64,128,2,2,2> (round 5, the kernel's); V = 2: mainloop_q with G = 4; V = 3: mainloop_pf
+// with PD = 2.  (The barrier-in-mid-step form of mainloop_q measured here in round 5 was level with V = 1 and is gone: profiles/r05_loop_probe_ab.txt.)
 template <int V, int WGS>
 __global__ __launch_bounds__(256, WGS) void loop_kernel(const double* __restrict__ M, int nk, int reps, double* __restrict__ out, int write_tile) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -28,10 +28,8 @@ __global__ __launch_bounds__(256, WGS) void loop_kernel(const double* __restrict
   for (int rep = 0; rep < reps; ++rep) {
     const double *Ap = M + (size_t)r0 * LD, *Bp = M + (size_t)c0 * LD;
     if (V == 0) mainloop_pf<64, 128, 2, 2, 4>(Ap, LD, Bp, LD, nk, acc, smem);
-    else if (V == 1) mainloop_q<64, 128, 2, 2, 2, 0>(Ap, LD, Bp, LD, nk, acc, smem);
-    else if (V == 2) mainloop_q<64, 128, 2, 2, 4, 0>(Ap, LD, Bp, LD, nk, acc, smem);
-    else if (V == 3) mainloop_q<64, 128, 2, 2, 2, 1>(Ap, LD, Bp, LD, nk, acc, smem);
-    else if (V == 4) mainloop_q<64, 128, 2, 2, 4, 1>(Ap, LD, Bp, LD, nk, acc, smem);
+    else if (V == 1) mainloop_q<64, 128, 2, 2, 2>(Ap, LD, Bp, LD, nk, acc, smem);
+    else if (V == 2) mainloop_q<64, 128, 2, 2, 4>(Ap, LD, Bp, LD, nk, acc, smem);
     else mainloop_pf<64, 128, 2, 2, 2>(Ap, LD, Bp, LD, nk, acc, smem);
     __syncthreads();
   }
@@ -64,16 +62,14 @@ static double run(const double* dM, int nk, int reps, double* dOut, int grid, si
   return best;
 }
 
-constexpr int NV = 6;
+constexpr int NV = 4;
 template <int WGS>
 static double run_v(int v, const double* dM, int nk, int reps, double* dOut, int grid, size_t lds, int write_tile) {
   switch (v) {
     case 0: return run<0, WGS>(dM, nk, reps, dOut, grid, lds, write_tile);
     case 1: return run<1, WGS>(dM, nk, reps, dOut, grid, lds, write_tile);
     case 2: return run<2, WGS>(dM, nk, reps, dOut, grid, lds, write_tile);
-    case 3: return run<3, WGS>(dM, nk, reps, dOut, grid, lds, write_tile);
-    case 4: return run<4, WGS>(dM, nk, reps, dOut, grid, lds, write_tile);
-    default: return run<5, WGS>(dM, nk, reps, dOut, grid, lds, write_tile);
+    default: return run<3, WGS>(dM, nk, reps, dOut, grid, lds, write_tile);
   }
 }
 
@@ -102,7 +98,7 @@ int main(int argc, char** argv) {
         }
     }
     for (int v = 0; v < NV; ++v) {
-      run_v<2>(v, dM, nk, 1, dOut, 8, v == 0 || v == 5 ? lds_pf : lds_q, 1);
+      run_v<2>(v, dM, nk, 1, dOut, 8, v == 0 || v == 3 ? lds_pf : lds_q, 1);
       CK(hipMemcpy(got.data(), dOut, got.size() * 8, hipMemcpyDeviceToHost));
       double err = 0., mx = 0.;
       for (size_t e = 0; e < ref.size(); ++e) { err = std::fmax(err, std::fabs(got[e] - ref[e])); mx = std::fmax(mx, std::fabs(ref[e])); }
@@ -114,10 +110,10 @@ int main(int argc, char** argv) {
     const int grid = ncu * wgs;
     double ms[NV];
     for (int v = 0; v < NV; ++v) {
-      const size_t lds = wgs == 1 ? solo : (v == 0 || v == 5 ? lds_pf : lds_q);
+      const size_t lds = wgs == 1 ? solo : (v == 0 || v == 3 ? lds_pf : lds_q);
       ms[v] = wgs == 1 ? run_v<1>(v, dM, nk, reps, dOut, grid, lds, 0) : run_v<2>(v, dM, nk, reps, dOut, grid, lds, 0);
     }
-    const char* names[NV] = {"mainloop_pf<..,4>    ", "mainloop_q<..,2,0>   ", "mainloop_q<..,4,0>   ", "mainloop_q<..,2,1>   ", "mainloop_q<..,4,1>   ", "mainloop_pf<..,2>    "};
+    const char* names[NV] = {"mainloop_pf<..,4>", "mainloop_q<..,2> ", "mainloop_q<..,4> ", "mainloop_pf<..,2>"};
     for (int v = 0; v < NV; ++v) {
       const double us = ms[v] * 1e3 / steps;
       const double tf = (double)grid * steps * 64. * 128. * 16. * 2. / (ms[v] * 1e-3) * 1e-12;
