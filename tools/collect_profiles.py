@@ -1,10 +1,11 @@
-"""File the outputs of tools/jobs/r4_final.sh (gpurun_out/final_<commit>/) under profiles/r04_<commit>_* with explanatory headers and derive
-profiles/r04_traffic.json (what bench.py reports as roofline.traffic).  usage: collect_profiles.py <commit>
+"""File the outputs of tools/jobs/r5_final.sh (gpurun_out/final_<commit>/) under profiles/<round>_<commit>_* (round: env ROUND, default r05) with explanatory
+headers and derive profiles/<round>_traffic.json (what bench.py reports as roofline.traffic).  usage: collect_profiles.py <commit>
 REFUSES when the library that ran the job was not built from <commit> (mogp_emulator_amd/libmogp_hip.build, written by the Makefile), or when HEAD differs
 from <commit> in anything the job executed (library, package, bench.py, tools)."""
 import json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1]
+RND = os.environ.get("ROUND", "r05")
 src = os.path.join(ROOT, "gpurun_out", "final_" + tag)
 dst = os.path.join(ROOT, "profiles")
 head = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short=7", "HEAD"], capture_output=True, text=True).stdout.strip()
@@ -24,7 +25,7 @@ def rd(name):
 
 
 def wr(name, text):
-    with open(os.path.join(dst, "r04_%s_%s" % (tag, name)), "w") as fh:
+    with open(os.path.join(dst, "%s_%s_%s" % (RND, tag, name)), "w") as fh:
         fh.write(text)
 
 
@@ -61,10 +62,10 @@ for suffix, what in (("", "64 x n=2000 x d=10, m=10000"), ("_S8", "the 8-emulato
            "#   two fit+gradient evaluations and two predictions; bash tools/pmc_fetch.sh).  gfx950: FETCH_SIZE reports half of the bytes of wide coalesced\n"
            "#   reads (MI355X_MICROARCH.md, HBM section) -> HBM-side bytes = 2 x FETCH_SIZE + WRITE_SIZE:\n" % (tag, what)) + "".join(lines)
     wr("pmc_fetch_write_kb%s.txt" % suffix, hdr + txt)
-with open(os.path.join(dst, "r04_traffic.json"), "w") as fh:
+with open(os.path.join(dst, RND + "_traffic.json"), "w") as fh:
     json.dump({"predict_var": {"traffic_bytes_per_launch": per_launch,
-                               "source": "profiles/r04_%s_pmc_fetch_write_kb.txt: (2 x FETCH_SIZE + WRITE_SIZE) KB x 1024 / launches, separate --pmc passes "
-                                         "(bash tools/pmc_fetch.sh), gfx950 FETCH_SIZE x2 correction" % tag,
+                               "source": "profiles/%s_%s_pmc_fetch_write_kb.txt: (2 x FETCH_SIZE + WRITE_SIZE) KB x 1024 / launches, separate --pmc passes "
+                                         "(bash tools/pmc_fetch.sh), gfx950 FETCH_SIZE x2 correction" % (RND, tag),
                                "config": "64 outputs n=2000 d=10 m=10000, one launch of 10112 padded points per predict (MOGP_KS_BUDGET_GB=12)"}}, fh)
 # SQ
 for B in (64, 8, 1):
@@ -88,4 +89,9 @@ for B in (64, 8, 1):
             hdr += "#   %-48s %.3f\n" % (k[:48], v)
     wr("pmc_sq_B%d.txt" % B, hdr + txt)
 wr("pmc_tcc.txt", "# commit %s, 64 x n=2000: rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum -- python tools/pmc_step.py (own pass): L2 hit rate = HIT / (HIT + MISS)\n" % tag + rd("pmc_tcc.txt"))
-print("profiles/r04_%s_* written; predict_var traffic %.1f GB per launch" % (tag, per_launch / 1e9))
+if os.path.exists(os.path.join(src, "pmc_sq_valu_B64.txt")):
+    wr("pmc_sq_valu_B64.txt", "# commit %s, 64 x n=2000 x d=10, m=10000: rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE\n"
+       "#   -- python tools/pmc_step.py (own pass): vector-ALU instructions per kernel (sums over two fit+gradient evaluations and two predictions)\n" % tag + rd("pmc_sq_valu_B64.txt"))
+if os.path.exists(os.path.join(src, "gemm_loop_probe.txt")):
+    wr("gemm_loop_probe.txt", "# commit %s: tools/gemm_loop_probe.bin 64 40 (the GEMM main loops of the Cholesky tasks alone)\n" % tag + rd("gemm_loop_probe.txt"))
+print("profiles/%s_%s_* written; predict_var traffic %.1f GB per launch" % (RND, tag, per_launch / 1e9))
