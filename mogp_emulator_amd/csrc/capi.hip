@@ -300,8 +300,7 @@ int mogp_densegp_predict_deriv(mogp_densegp* h, const double* testing, int m, in
       throw std::runtime_error("predict_deriv: the result buffer passed was the wrong shape to hold the result");
     check_batch(h, m, D, m, "");
     std::vector<int> ids{h->idx};
-    std::vector<double> mean(m);
-    h->eng->predict(ids, testing, m, false, mean.data(), nullptr, m, false, out);
+    h->eng->predict(ids, testing, m, false, nullptr, nullptr, m, false, out);        // derivatives only: no cross covariance
   });
 }
 int mogp_densegp_predict_full_cov(mogp_densegp* h, const double* testing, int m, int D, double* mean_out, double* cov_out) {
@@ -483,12 +482,12 @@ static void mogp_predict_common(mogp_mogp* h, const double* testing, int m, int 
   std::vector<int> ids = fitted_ids(h);
   if (ids.empty()) return;
   const size_t nf = ids.size();
-  if ((int)nf == e->B && means) {    // every emulator fitted: results go straight into the caller's arrays
+  if ((int)nf == e->B) {             // every emulator fitted: results go straight into the caller's arrays (means == null: derivatives only)
     e->predict(ids, testing, m, false, means, vars, m, false, derivs);
     return;
   }
-  std::vector<double> mm(nf * m), vv(vars ? nf * m : 0), dd(derivs ? nf * m * D : 0);
-  e->predict(ids, testing, m, false, mm.data(), vars ? vv.data() : nullptr, m, false, derivs ? dd.data() : nullptr);
+  std::vector<double> mm(means ? nf * m : 0), vv(vars ? nf * m : 0), dd(derivs ? nf * m * D : 0);
+  e->predict(ids, testing, m, false, means ? mm.data() : nullptr, vars ? vv.data() : nullptr, m, false, derivs ? dd.data() : nullptr);
   for (size_t k = 0; k < nf; ++k) {
     if (means) std::memcpy(means + (size_t)ids[k] * m, mm.data() + k * m, m * sizeof(double));
     if (vars) std::memcpy(vars + (size_t)ids[k] * m, vv.data() + k * m, m * sizeof(double));
@@ -624,6 +623,14 @@ int mogp_mchol_task_table(int n_plus_rhs, int* out, int capacity) {
   // host-only: the per-emulator task order of the one-launch Cholesky for a matrix of NP = roundup(n_plus_rhs, 128) rows
   const int NP = (n_plus_rhs + TILE - 1) / TILE * TILE;
   const std::vector<int> tb = mchol_task_table(NP);
+  if (out)
+    for (int i = 0; i < (int)tb.size() && i < capacity; ++i) out[i] = tb[i];
+  return (int)tb.size();
+}
+int mogp_mchol_task_table_wide(int n_plus_rhs, int* out, int capacity) {
+  // the table of throughput-bound launches: type 1 with 3 in the row field = GW(c), the tiles (1,0), (1,1) of diagonal block c as one task
+  const int NP = (n_plus_rhs + TILE - 1) / TILE * TILE;
+  const std::vector<int> tb = mchol_task_table(NP, true);
   if (out)
     for (int i = 0; i < (int)tb.size() && i < capacity; ++i) out[i] = tb[i];
   return (int)tb.size();

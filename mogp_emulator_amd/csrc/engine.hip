@@ -225,7 +225,7 @@ Engine::~Engine() {
     if (p) hipFree(p);
   if (hRes) hipHostFree(hRes);
   if (dBsFlags) hipFree(dBsFlags);
-  for (void* p : {(void*)dMcTable, (void*)dMcCtrl, (void*)dMcPacks})
+  for (void* p : {(void*)dMcTable[0], (void*)dMcTable[1], (void*)dMcCtrl, (void*)dMcPacks})
     if (p) hipFree(p);
   if (sigU1) hipFree(sigU1);
   for (auto& kv : w2) hipFree(kv.second);
@@ -488,11 +488,12 @@ void Engine::factorize_blocked(const std::vector<int>& ids, std::vector<int>& in
   mc_used = schedule == 4;
   if (schedule == 4) {
     // ONE LAUNCH: persistent workgroups take the tasks of all block columns from a dependency-ordered queue (kernels_mchol.hip)
-    if (!dMcTable) {
-      const std::vector<int> tb = mchol_task_table(NP);
-      mc_ntasks = (int)tb.size();
-      dMcTable = dalloc<int>(tb.size());
-      HIPCK(hipMemcpy(dMcTable, tb.data(), tb.size() * sizeof(int), hipMemcpyHostToDevice));
+    const int wg = mchol_wide_g(nb, NP) ? 1 : 0;            // which task table (kernels_mchol.hip: GW tasks for throughput-bound launches)
+    if (!dMcTable[wg]) {
+      const std::vector<int> tb = mchol_task_table(NP, wg != 0);
+      mc_ntasks[wg] = (int)tb.size();
+      dMcTable[wg] = dalloc<int>(tb.size());
+      HIPCK(hipMemcpy(dMcTable[wg], tb.data(), tb.size() * sizeof(int), hipMemcpyHostToDevice));
     }
     if (nb > mc_slots) {
       // control rows and packs are per batch SLOT of a launch, sized for the largest launch seen so far -- not for the engine's B: a
@@ -510,7 +511,7 @@ void Engine::factorize_blocked(const std::vector<int>& ids, std::vector<int>& in
     }
     HIPCK(hipMemsetAsync(dInfo, 0, B * sizeof(int), stream));
     build_cov(v);
-    launch_mchol(v, dMcCtrl, mchol_ctrl_ints(NP, nb), dMcTable, mc_ntasks, dMcPacks, dInfo, n_cu, stream);
+    launch_mchol(v, dMcCtrl, mchol_ctrl_ints(NP, nb), dMcTable[wg], mc_ntasks[wg], dMcPacks, dInfo, n_cu, stream);
     if (!defer_info) {
       read_info(info, false);
       unsigned aborted = 0;
@@ -1127,7 +1128,9 @@ void Engine::predict(const std::vector<int>& ids, const double* Xs, int m, bool 
   double* fv = vars;
   double* fd = derivs;
   long ld = out_ld;
-  if (!out_on_device) {
+  const bool want_mean = means != nullptr;       // derivatives only (mogp_*_predict_deriv): no cross covariance, no mean
+  if (!want_mean && vars) throw std::runtime_error("predict: variances without means");
+  if (!out_on_device && want_mean) {
     grow(dMeanFin, capMeanFin, (size_t)nb * m);
     fm = dMeanFin;
     ld = m;
@@ -1135,14 +1138,14 @@ void Engine::predict(const std::vector<int>& ids, const double* Xs, int m, bool 
       grow(dVar, capVar, (size_t)nb * m);
       fv = dVar;
     }
-    if (derivs) {
-      grow(dDeriv, capDeriv, (size_t)nb * m * D);
-      fd = dDeriv;
-    }
+  }
+  if (!out_on_device && derivs) {
+    grow(dDeriv, capDeriv, (size_t)nb * m * D);
+    fd = dDeriv;
   }
   double* dots = fm;
   long dots_ld = ld;
-  if (R > 1) {
+  if (R > 1 && want_mean) {
     grow(dMean, capMean, (size_t)nb * R * m);
     dots = dMean;
     dots_ld = m;
@@ -1159,7 +1162,7 @@ void Engine::predict(const std::vector<int>& ids, const double* Xs, int m, bool 
   long MC = (long)(cap / ((double)nb * LD * 8.0)) / 128 * 128;
   MC = std::max<long>(128, std::min<long>(MC, MPtot));
   if (vars) ensure_predict_scratch(nb, (int)MC);
-  for (int c0 = 0; c0 < m; c0 += (int)MC) {
+  for (int c0 = 0; want_mean && c0 < m; c0 += (int)MC) {
     const int mc = std::min<int>((int)MC, m - c0);
     const int MPc = roundup(mc, 128);
     launch_cross_cov_mean(v, dXsrc + (size_t)c0 * D, mc, MPc, vars ? dKs : nullptr, dots + c0, (int)dots_ld, stream);
@@ -1215,7 +1218,8 @@ void Engine::predict(const std::vector<int>& ids, const double* Xs, int m, bool 
     HIPCK(hipStreamSynchronize(stream));      // `st` is the source of an asynchronous copy
   }
   if (!out_on_device) {
-    if (out_ld == m) {               // contiguous result arrays: one transfer each instead of one per emulator
+    if (!want_mean) {
+    } else if (out_ld == m) {        // contiguous result arrays: one transfer each instead of one per emulator
       HIPCK(hipMemcpyAsync(means, fm, (size_t)nb * m * sizeof(double), hipMemcpyDeviceToHost, stream));
       if (vars) HIPCK(hipMemcpyAsync(vars, fv, (size_t)nb * m * sizeof(double), hipMemcpyDeviceToHost, stream));
     } else {

@@ -732,9 +732,13 @@ void launch_cross_cov_mean(const BatchView& v, const double* Xs, int m, int MP, 
 
 void launch_predict_deriv(const BatchView& v, const double* Xs, int m, double* deriv, long deriv_stride, hipStream_t s) {
   const size_t sm = (size_t)(128 * v.D + 64 * 65 + 64 * v.D) * sizeof(double);
+  // (round 5: the next-tile prefetch of the cross covariance was built here too and changed nothing -- 6.2 ms per 64 x 10^4 points either
+  // way: this kernel is bound by its arithmetic and the G tile's trip through LDS, not by the staging loads)
+  prof_begin("predict_deriv", s);
 #define CALL(K) hipLaunchKernelGGL((predict_deriv_kernel<K>), dim3((m + 63) / 64, v.nb), dim3(256), sm, s, v, Xs, m, deriv, deriv_stride)
   KT_DISPATCH(v.kernel_type, CALL);
 #undef CALL
+  prof_end("predict_deriv", s, 0., (double)v.nb * 8.0 * (double)m * v.D);      // algorithmic bytes: the (m, D) derivatives written
 }
 
 int grad_num_tiles(int n) {
