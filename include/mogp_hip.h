@@ -229,9 +229,6 @@ int mogp_profile_get(const char* kernel_tag, double* total_ms, long long* launch
    `capacity` entries, returns the number of tasks.  Host-only (no device needed): the CPU suite checks that the order is
    topological, which is what the kernel's forward-progress argument rests on. */
 int mogp_mchol_task_table(int n_plus_rhs, int* out, int capacity);
-/* The same for throughput-bound launches (rho >= 2: 32+ matrices of n = 2000, one n = 16000 matrix ...): the tiles (1,0) and (1,1) of diagonal
-   block c are listed as ONE entry of type 1 with 3 in the row field, GW(c): a 64 x 128 task; all other entries as above. */
-int mogp_mchol_task_table_wide(int n_plus_rhs, int* out, int capacity);
 /* process-wide diagnostic counters: "backsolve_timeouts" = back substitutions that were repeated with the multi-launch
    path because a wait of the one-launch chain timed out (0 in normal operation); "mchol_aborts" = factorisations the
    one-launch Cholesky gave up on and a multi-launch schedule repeated (0 in normal operation); "objective_evals" / "gradient_evals" =

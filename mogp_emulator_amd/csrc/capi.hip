@@ -627,14 +627,6 @@ int mogp_mchol_task_table(int n_plus_rhs, int* out, int capacity) {
     for (int i = 0; i < (int)tb.size() && i < capacity; ++i) out[i] = tb[i];
   return (int)tb.size();
 }
-int mogp_mchol_task_table_wide(int n_plus_rhs, int* out, int capacity) {
-  // the table of throughput-bound launches: type 1 with 3 in the row field = GW(c), the tiles (1,0), (1,1) of diagonal block c as one task
-  const int NP = (n_plus_rhs + TILE - 1) / TILE * TILE;
-  const std::vector<int> tb = mchol_task_table(NP, true);
-  if (out)
-    for (int i = 0; i < (int)tb.size() && i < capacity; ++i) out[i] = tb[i];
-  return (int)tb.size();
-}
 int mogp_profile_counter(const char* name, long long* out) {
   const long long v = prof_counter(name);
   if (v < 0 || !out) {

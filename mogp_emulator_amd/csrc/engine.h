@@ -139,8 +139,8 @@ class Engine {
   bool can_waitval = false;      // hipDeviceAttributeCanUseStreamWaitValue of the engine's device
   int device = 0;                // HIP device the engine was created on
   // one-launch Cholesky (kernels_mchol.hip): task table, control words, per-column packs
-  int* dMcTable[2] = {nullptr, nullptr};     // the task order of one emulator (mchol_task_table): [0] three 64 x 64 G tasks per diagonal block, [1] wide G tasks
-  int mc_ntasks[2] = {0, 0};
+  int* dMcTable = nullptr;       // the task order of one emulator (mchol_task_table)
+  int mc_ntasks = 0;
   unsigned* dMcCtrl = nullptr;
   size_t mc_ctrl_ints = 0;
   int mc_slots = 0;              // batch slots dMcCtrl / dMcPacks are sized for (grown to the largest one-launch batch seen)

@@ -225,7 +225,7 @@ Engine::~Engine() {
     if (p) hipFree(p);
   if (hRes) hipHostFree(hRes);
   if (dBsFlags) hipFree(dBsFlags);
-  for (void* p : {(void*)dMcTable[0], (void*)dMcTable[1], (void*)dMcCtrl, (void*)dMcPacks})
+  for (void* p : {(void*)dMcTable, (void*)dMcCtrl, (void*)dMcPacks})
     if (p) hipFree(p);
   if (sigU1) hipFree(sigU1);
   for (auto& kv : w2) hipFree(kv.second);
@@ -488,12 +488,11 @@ void Engine::factorize_blocked(const std::vector<int>& ids, std::vector<int>& in
   mc_used = schedule == 4;
   if (schedule == 4) {
     // ONE LAUNCH: persistent workgroups take the tasks of all block columns from a dependency-ordered queue (kernels_mchol.hip)
-    const int wg = mchol_wide_g(nb, NP) ? 1 : 0;            // which task table (kernels_mchol.hip: GW tasks for throughput-bound launches)
-    if (!dMcTable[wg]) {
-      const std::vector<int> tb = mchol_task_table(NP, wg != 0);
-      mc_ntasks[wg] = (int)tb.size();
-      dMcTable[wg] = dalloc<int>(tb.size());
-      HIPCK(hipMemcpy(dMcTable[wg], tb.data(), tb.size() * sizeof(int), hipMemcpyHostToDevice));
+    if (!dMcTable) {
+      const std::vector<int> tb = mchol_task_table(NP);
+      mc_ntasks = (int)tb.size();
+      dMcTable = dalloc<int>(tb.size());
+      HIPCK(hipMemcpy(dMcTable, tb.data(), tb.size() * sizeof(int), hipMemcpyHostToDevice));
     }
     if (nb > mc_slots) {
       // control rows and packs are per batch SLOT of a launch, sized for the largest launch seen so far -- not for the engine's B: a
@@ -511,7 +510,7 @@ void Engine::factorize_blocked(const std::vector<int>& ids, std::vector<int>& in
     }
     HIPCK(hipMemsetAsync(dInfo, 0, B * sizeof(int), stream));
     build_cov(v);
-    launch_mchol(v, dMcCtrl, mchol_ctrl_ints(NP, nb), dMcTable[wg], mc_ntasks[wg], dMcPacks, dInfo, n_cu, stream);
+    launch_mchol(v, dMcCtrl, mchol_ctrl_ints(NP, nb), dMcTable, mc_ntasks, dMcPacks, dInfo, n_cu, stream);
     if (!defer_info) {
       read_info(info, false);
       unsigned aborted = 0;

@@ -236,12 +236,7 @@ __global__ __launch_bounds__(256, SOLO ? 1 : 2) void mchol_kernel(BatchView v, u
         mc_stamp<TRACE>(tr, 5);
         continue;
       }
-      // GW(c) (type 1, s = 3; throughput-bound launches only, mchol_task_table(.., wide_g)): the tiles (1,0) and (1,1) of the diagonal block as ONE
-      // 64 x 128 task -- the GEMM of a T task over the panels 0 .. c-2, then the store of a G task.  Two 64 x 64 G tasks took 2 x 72 us of a
-      // workgroup for what a 64 x 128 tile does in ~90 (16 instead of 32 MFMAs per wave and k-step behind the same loads and barrier); where
-      // the diagonal blocks have slack (64 emulators: they wait 12 us on average anyway) that is 2.5 % of the launch's workgroup time.
-      const bool gwide = type == 1 && r == 3;
-      if (type == 1 && !gwide) {
+      if (type == 1) {
         // ---- G(s, c): lower 64 x 64 tile s = (0,0), (1,0), (1,1) of the diagonal block receives the panels 0 .. c-2 -----------
         // (three 64 x 64 tasks rather than two 64 x 128 ones: no work on the upper-right quarter, and half the length per task -- a
         // 64 x 128 task of a late block column needed ~7 c us of a whole CU, more than one block-column period, and the diagonal
@@ -298,14 +293,13 @@ __global__ __launch_bounds__(256, SOLO ? 1 : 2) void mchol_kernel(BatchView v, u
         continue;
       }
       // ---- T: 64 rows x 128 columns receive the panels 0 .. c-1 -----------------------------------------------------
-      const int rt = gwide ? 2 * c + 1 : r;               // row tile (GW: the second row tile of the diagonal block itself)
-      const int r0 = 64 * rt;
+      const int r0 = 64 * r;
       // tasks of the dependent chain (diagonal tiles, the two row blocks of the next diagonal block) issue ahead of the
       // workgroup they share the CU with
       // (tile_solve bits 8, 9: 4 + 2 x rows below the diagonal block are chain tasks -- chain-bound launches take three pairs)
-      const bool urgent = !gwide && r < 2 * c + 4 + 2 * ((tile_solve >> 8) & 3);
-      if (urgent || gwide) __builtin_amdgcn_s_setprio(2);
-      const int kend = gwide ? c - 1 : c;                 // (panel c-1 of the diagonal block is applied inside D(c))
+      const bool urgent = r < 2 * c + 4 + 2 * ((tile_solve >> 8) & 3);
+      if (urgent) __builtin_amdgcn_s_setprio(2);
+      const int kend = c;
       if (kend > 0) {
         // SOLO (chain-bound launches, one workgroup per CU): acc starts as -C -- the tile's covariance entries are requested with the first
         // operands instead of after the GEMM, where their latency sits on the dependent chain (one n = 2000 matrix: mchol 0.471 -> 0.454 ms);
@@ -352,7 +346,7 @@ __global__ __launch_bounds__(256, SOLO ? 1 : 2) void mchol_kernel(BatchView v, u
           const int kse = 8 * kend;
           while (ks < kse) {
             mc_stamp<TRACE>(tr, 1);
-            int have = mc_wait_min3(cx, rowprog + rt, rowprog + 2 * c, rowprog + 2 * c + 1, (unsigned)(ks + MC_PD), tr);
+            int have = mc_wait_min3(cx, rowprog + r, rowprog + 2 * c, rowprog + 2 * c + 1, (unsigned)(ks + MC_PD), tr);
             if (have < 0) return;
             mc_stamp<TRACE>(tr, 2);
             have = (have < kse ? have : kse) & ~(MC_PD - 1);
@@ -363,25 +357,6 @@ __global__ __launch_bounds__(256, SOLO ? 1 : 2) void mchol_kernel(BatchView v, u
         }
         mc_stamp<TRACE>(tr, 3);
         draw_next();
-        if (gwide) {
-          // the tile leaves as a G task's does: write-through (D(c) reads it on another CU), drained, then the diagonal block's counter
-          finish_x();
-          double* pcw = A + (size_t)(r0 + (t >> 7) * 32 + ((t & 63) >> 4)) * ld + (c0 + ((t >> 6) & 1) * 64 + (t & 15));
-#pragma unroll
-          for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-              for (int q = 0; q < 4; ++q)
-                __hip_atomic_store(pcw + (size_t)(i * 16 + 4 * q) * ld + j * 16, acc[i][j][q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          drain_stores();
-          mc_stamp<TRACE>(tr, 4);
-          __syncthreads();
-          if (t == 0) __hip_atomic_fetch_add(diagcnt + c, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          mc_stamp<TRACE>(tr, 5);
-          __builtin_amdgcn_s_setprio(0);
-          continue;
-        }
         if (!urgent) {
           // bulk task, round 4: the tile is re-dealt to the solving waves through LDS BEFORE the solve (trsm128_tile2_dev); the first
           // pack images are requested before the C tile is read
@@ -494,8 +469,7 @@ __global__ __launch_bounds__(256, SOLO ? 1 : 2) void mchol_kernel(BatchView v, u
 //   for c = 0, 1, ...:  D(c+1);  T(2c+4, c+1), T(2c+5, c+1);  G(0..2, c+2);  T(2c+6, c), T(2c+7, c);  T(2c+6, c+1), T(2c+7, c+1);
 //                       T(r, c) for r >= 2c+8
 // (a workgroup that draws a chain task early does its GEMM and then waits: at most a handful of waiting workgroups per emulator).
-// wide_g: the tiles (1,0), (1,1) of a diagonal block as ONE 64 x 128 task GW(c) (type 1, s = 3) instead of G(1, c), G(2, c) -- throughput-bound launches
-std::vector<int> mchol_task_table(int NP, bool wide_g) {
+std::vector<int> mchol_task_table(int NP) {
   const int K = NP / 128, K2 = NP / 64;
   auto word = [](int type, int c, int r) { return (int)(((unsigned)type << 30) | ((unsigned)c << 15) | (unsigned)r); };
   std::vector<int> tb;
@@ -511,14 +485,10 @@ std::vector<int> mchol_task_table(int NP, bool wide_g) {
     if (c + 1 < K) tb.push_back(word(0, c + 1, 0));
     T(2 * c + 4, c + 1);
     T(2 * c + 5, c + 1);
-    if (c + 2 < K) {
-      tb.push_back(word(1, c + 2, 0));
-      if (wide_g) tb.push_back(word(1, c + 2, 3));
-      else {
-        tb.push_back(word(1, c + 2, 1));
-        tb.push_back(word(1, c + 2, 2));
-      }
-    }
+    // (three 64 x 64 G tasks per diagonal block; round 5 measured the tiles (1,0), (1,1) as ONE 64 x 128 task for throughput-bound launches:
+    // level and bit-identical, profiles/r05_wide_g_ab.txt -- not kept)
+    if (c + 2 < K)
+      for (int sub = 0; sub < 3; ++sub) tb.push_back(word(1, c + 2, sub));
     T(2 * c + 6, c);
     T(2 * c + 7, c);
     T(2 * c + 6, c + 1);
@@ -532,17 +502,10 @@ int mchol_emu_stride(int NP) { return (2 * (NP / 64) + 2 * (NP / 128) + MC_LINE 
 size_t mchol_ctrl_ints(int NP, int B) { return MC_EMU0 + (size_t)B * mchol_emu_stride(NP); }
 size_t mchol_pack_doubles(int NP, int B) { return (size_t)B * (NP / 128) * PACK128_STRIDE; }
 
-// the wide G tasks where the diagonal blocks have slack: rho >= 2 (32+ emulators of n = 2000, 4+ of n = 5000, one n = 16000 matrix)
-bool mchol_wide_g(int nb, int NP);
 // rho = (time the matrix cores need at ~45 TFLOP/s) / (length of the dependent chain, ~55 us per block column)
 static double mchol_rho(int nb, int NP) {
   const double npd = NP;
   return ((double)nb * npd * npd * npd / 3.0 / 45e12) / ((npd / 128.0) * 55e-6);
-}
-
-bool mchol_wide_g(int nb, int NP) {
-  static const int force = [] { const char* e = getenv("MOGP_MC_WIDEG"); return e ? atoi(e) : -1; }();
-  return force >= 0 ? force != 0 : mchol_rho(nb, NP) >= 2.0;
 }
 
 void launch_mchol(const BatchView& v, unsigned* ctrl, size_t ctrl_ints, const int* table, int ntasks, double* packs, int* info, int n_cu,

@@ -101,9 +101,7 @@ void launch_update_trailing(const BatchView& v, int c0, int k0, int k1, hipStrea
 // != 0 afterwards = a wait timed out and the factors are unusable: factorise again with a multi-launch schedule); packs:
 // mchol_pack_doubles(NP, B) doubles (one diagonal-block pack per emulator and block column); info as launch_panel128.
 // The matrix of one emulator must be smaller than 4 GB (write-through stores go through a buffer descriptor).
-std::vector<int> mchol_task_table(int NP, bool wide_g = false);
-// throughput-bound launches list the tiles (1,0), (1,1) of every diagonal block as one 64 x 128 task (the wide_g table)
-bool mchol_wide_g(int nb, int NP);
+std::vector<int> mchol_task_table(int NP);
 size_t mchol_ctrl_ints(int NP, int B);
 size_t mchol_pack_doubles(int NP, int B);
 void launch_mchol(const BatchView& v, unsigned* ctrl, size_t ctrl_ints, const int* table, int ntasks, double* packs, int* info, int n_cu,

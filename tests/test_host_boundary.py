@@ -285,20 +285,18 @@ def test_native_meanpriors_prior_dists_and_sample():
     assert len(pri.sample()) == 2 + 1 + 1                               # mean parameters first (gppriors.hpp:458-471)
 
 
-@pytest.mark.parametrize("wide", [False, True])
 @pytest.mark.parametrize("n", [1, 100, 128, 129, 300, 640, 2000, 5000, 16000])
-def test_one_launch_cholesky_task_order_is_topological(n, wide):
+def test_one_launch_cholesky_task_order_is_topological(n):
     """The forward-progress argument of the one-launch Cholesky (csrc/kernels_mchol.hip) rests on ONE property of its task table:
     every task only depends on tasks with a smaller number.  Replay the dependency rules of the kernel against the tables the
     library builds (host-only entry points, no device needed):
       D(c)     needs G(0, c), G(1, c), G(2, c) (c >= 2) and the row tiles 2c, 2c+1 of column c-1 (c >= 1)
       G(s, c)  (lower 64 x 64 tile (ti, tj) = (0,0), (1,0), (1,1) of the diagonal block) needs the row tiles 2c+ti, 2c+tj of every column k <= c-2
-      GW(c)    (wide table: tiles (1,0) and (1,1) as one task, s = 3) needs the row tiles 2c, 2c+1 of every column k <= c-2
       T(r, c)  needs D(c) and the row tiles r, 2c, 2c+1 of every column k <= c-1
     and check that every tile of the lower block triangle is produced exactly once."""
     import ctypes
     lib = _capi.load()
-    fn = lib.mogp_mchol_task_table_wide if wide else lib.mogp_mchol_task_table
+    fn = lib.mogp_mchol_task_table
     cnt = fn(n + 1, None, 0)
     buf = (ctypes.c_int * cnt)()
     assert fn(n + 1, buf, cnt) == cnt
@@ -318,19 +316,18 @@ def test_one_launch_cholesky_task_order_is_topological(n, wide):
             tile[(r, c)] = p
     assert sorted(c for (t, c, r) in pos if t == 0) == list(range(K))
     assert sorted(tile) == sorted((r, c) for c in range(K) for r in range(2 * c + 2, K2))
-    assert sorted((r, c) for (t, c, r) in pos if t == 1) == sorted((sub, c) for c in range(2, K) for sub in ((0, 3) if wide else (0, 1, 2)))
+    assert sorted((r, c) for (t, c, r) in pos if t == 1) == sorted((sub, c) for c in range(2, K) for sub in range(3))
     for (t, c, r), p in pos.items():
         need_tiles, deps = [], []
         if t == 0:
             if c >= 2:
-                deps += [(1, c, 0), (1, c, 3)] if wide else [(1, c, 0), (1, c, 1), (1, c, 2)]
+                deps += [(1, c, 0), (1, c, 1), (1, c, 2)]
             if c >= 1:
                 need_tiles += [(2 * c, c - 1), (2 * c + 1, c - 1)]
         elif t == 1:
             ti, tj = (1 if r > 0 else 0), (1 if r > 1 else 0)
-            rows = {2 * c, 2 * c + 1} if r == 3 else {2 * c + ti, 2 * c + tj}
             for k in range(c - 1):
-                need_tiles += [(rr, k) for rr in rows]
+                need_tiles += [(rr, k) for rr in {2 * c + ti, 2 * c + tj}]
         else:
             rows = {r, 2 * c, 2 * c + 1}
             for k in range(c):
