@@ -139,33 +139,40 @@ SIGNATURES = {
 
 
 def elf_dynamic(path):
-    """(DT_SONAME or None, [DT_NEEDED ...]) of a little-endian ELF64 shared object, read with struct -- no external tool."""
+    """(DT_SONAME or None, [DT_NEEDED ...]) of a little-endian ELF64 shared object, read with struct -- no external tool.  Only the
+    headers, the dynamic section and the strings it points at are read (a HIP runtime is tens of megabytes)."""
     import struct
     with open(path, "rb") as f:
-        data = f.read()
-    if data[:6] != b"\x7fELF\x02\x01":
-        raise OSError("%s is not a little-endian ELF64 file" % path)
-    e_phoff, = struct.unpack_from("<Q", data, 0x20)
-    e_phentsize, e_phnum = struct.unpack_from("<HH", data, 0x36)
-    loads, dyn = [], None
-    for k in range(e_phnum):
-        p_type, _, p_offset, p_vaddr, _, p_filesz = struct.unpack_from("<IIQQQQ", data, e_phoff + k * e_phentsize)
-        if p_type == 1:
-            loads.append((p_vaddr, p_offset, p_filesz))
-        elif p_type == 2:
-            dyn = (p_offset, p_filesz)
-    if dyn is None:
-        return None, []
-    entries = [struct.unpack_from("<qQ", data, dyn[0] + 16 * k) for k in range(dyn[1] // 16)]
-    strtab = next((v for t, v in entries if t == 5), None)
-    if strtab is None:
-        return None, []
-    stroff = next((off + strtab - va for va, off, sz in loads if va <= strtab < va + sz), strtab)
+        def at(off, size):
+            f.seek(off)
+            return f.read(size)
+        ident = at(0, 64)
+        if ident[:6] != b"\x7fELF\x02\x01":
+            raise OSError("%s is not a little-endian ELF64 file" % path)
+        e_phoff, = struct.unpack_from("<Q", ident, 0x20)
+        e_phentsize, e_phnum = struct.unpack_from("<HH", ident, 0x36)
+        ph = at(e_phoff, e_phentsize * e_phnum)
+        loads, dyn = [], None
+        for k in range(e_phnum):
+            p_type, _, p_offset, p_vaddr, _, p_filesz = struct.unpack_from("<IIQQQQ", ph, k * e_phentsize)
+            if p_type == 1:
+                loads.append((p_vaddr, p_offset, p_filesz))
+            elif p_type == 2:
+                dyn = (p_offset, p_filesz)
+        if dyn is None:
+            return None, []
+        dsec = at(*dyn)
+        entries = [struct.unpack_from("<qQ", dsec, 16 * k) for k in range(len(dsec) // 16)]
+        strtab = next((v for t, v in entries if t == 5), None)
+        if strtab is None:
+            return None, []
+        stroff = next((off + strtab - va for va, off, sz in loads if va <= strtab < va + sz), strtab)
 
-    def name(o):
-        return data[stroff + o:data.index(b"\0", stroff + o)].decode()
-    soname = next((name(v) for t, v in entries if t == 14), None)
-    return soname, [name(v) for t, v in entries if t == 1]
+        def name(o):
+            raw = at(stroff + o, 256)
+            return raw[:raw.index(b"\0")].decode()
+        soname = next((name(v) for t, v in entries if t == 14), None)
+        return soname, [name(v) for t, v in entries if t == 1]
 
 
 def _bundled_runtime_to_preload(lib_path):

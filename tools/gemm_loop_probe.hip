@@ -14,7 +14,7 @@ using namespace mogp;
 
 constexpr int LD = 2048;
 
-// V = 0: mainloop_pf<64,128,2,2,4> (rounds 3-4); V = 1: mainloop_q<64,128,2,2,2> (round 5, the kernel's); V = 2: mainloop_q with G = 4; V = 3: mainloop_pf
+// V = 0: mainloop_pf<64,128,2,2,4> (rounds 3-4); V = 1: mainloop_q<64,128,2,2,2> (round 5, the kernel's); V = 2: mainloop_q with the barrier pinned behind the step's last MFMAs; V = 3: mainloop_pf
 // with PD = 2.  (The barrier-in-mid-step form of mainloop_q measured here in round 5 was level with V = 1 and is gone: profiles/r05_loop_probe_ab.txt.)
 template <int V, int WGS>
 __global__ __launch_bounds__(256, WGS) void loop_kernel(const double* __restrict__ M, int nk, int reps, double* __restrict__ out, int write_tile) {
@@ -29,7 +29,7 @@ __global__ __launch_bounds__(256, WGS) void loop_kernel(const double* __restrict
     const double *Ap = M + (size_t)r0 * LD, *Bp = M + (size_t)c0 * LD;
     if (V == 0) mainloop_pf<64, 128, 2, 2, 4>(Ap, LD, Bp, LD, nk, acc, smem);
     else if (V == 1) mainloop_q<64, 128, 2, 2, 2>(Ap, LD, Bp, LD, nk, acc, smem);
-    else if (V == 2) mainloop_q<64, 128, 2, 2, 4>(Ap, LD, Bp, LD, nk, acc, smem);
+    else if (V == 2) mainloop_q<64, 128, 2, 2, 2, true>(Ap, LD, Bp, LD, nk, acc, smem);
     else mainloop_pf<64, 128, 2, 2, 2>(Ap, LD, Bp, LD, nk, acc, smem);
     __syncthreads();
   }
@@ -113,7 +113,7 @@ int main(int argc, char** argv) {
       const size_t lds = wgs == 1 ? solo : (v == 0 || v == 3 ? lds_pf : lds_q);
       ms[v] = wgs == 1 ? run_v<1>(v, dM, nk, reps, dOut, grid, lds, 0) : run_v<2>(v, dM, nk, reps, dOut, grid, lds, 0);
     }
-    const char* names[NV] = {"mainloop_pf<..,4>", "mainloop_q<..,2> ", "mainloop_q<..,4> ", "mainloop_pf<..,2>"};
+    const char* names[NV] = {"mainloop_pf<..,4>", "mainloop_q<..,2> ", "mainloop_q<..,2,PIN>", "mainloop_pf<..,2>"};
     for (int v = 0; v < NV; ++v) {
       const double us = ms[v] * 1e3 / steps;
       const double tf = (double)grid * steps * 64. * 128. * 16. * 2. / (ms[v] * 1e-3) * 1e-12;
