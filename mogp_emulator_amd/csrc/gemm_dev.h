@@ -294,7 +294,7 @@ struct QCfg {
 };
 
 // park / park_lds / park_spins and kmask: as in mainloop_pf.
-template <int BM, int BN, int WR, int WC, int G>
+template <int BM, int BN, int WR, int WC, int G, bool PIN = false>
 __device__ __forceinline__ void mainloop_q(const double* __restrict__ Ag, int lda, const double* __restrict__ Bg, int ldb, int nk,
                                            v4d (&acc)[WCfg<BM, BN, WR, WC>::TI][WCfg<BM, BN, WR, WC>::TJ], double* smem,
                                            const unsigned* park = nullptr, int* park_lds = nullptr, int park_spins = 0, int kmask = -1) {
@@ -385,6 +385,7 @@ __device__ __forceinline__ void mainloop_q(const double* __restrict__ Ag, int ld
       load(u, min(kt + 2 + G, last));
       frag(0, smem + nxt * STAGE, 0);                      // written during step kt - 1: visible since the barrier that ended it
       mfmas(1);
+      if (PIN) __builtin_amdgcn_sched_barrier(0);          // (the scheduler otherwise lifts the barrier -- and its wait for the reads just requested -- above these MFMAs)
       __syncthreads();
       // (tried: the barrier in the MIDDLE of the step, so that every LDS operation in flight at it was issued half a step earlier -- the
       // same times, tools/gemm_loop_probe.hip round 5)
