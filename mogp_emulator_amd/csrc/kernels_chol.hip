@@ -243,17 +243,15 @@ __device__ __forceinline__ void st_agent(double* p, double x) { __hip_atomic_sto
 // first) is folded while its producer still solves the upper half.  A lane that gives up takes 0.0 (never the pattern, which an fma
 // would propagate into its own results and make every chunk behind it time out too) and the emulator is re-solved by the engine.
 template <bool SENT>
-__global__ __launch_bounds__(256, 2) void backsolve_chain_kernel(BatchView v, int* __restrict__ flags, int epoch, int nch, int* __restrict__ status, int spin_limit, int egrp) {
+__global__ __launch_bounds__(256, 2) void backsolve_chain_kernel(BatchView v, int* __restrict__ flags, int epoch, int nch, int* __restrict__ status, int spin_limit) {
   __shared__ double Ld[2][64 * 65];        // the two diagonal blocks of this chunk: [row][column], row stride 65
   __shared__ double w[128], xs[128];
   __shared__ v2d part[3][64];
   __shared__ int timed_out;
-  // dispatch order: groups of egrp emulators, inside a group every emulator's rightmost chunk first.  With more workgroups than the GPU holds
-  // (64 x 16 on 512 slots) one group over all emulators made the LEFTMOST chunks -- the ones with the most rows of L to stream, none of
-  // which depends on alpha -- the last to become resident
-  const int gsz = egrp * nch, grp = blockIdx.x / gsz, rem = blockIdx.x - grp * gsz;
-  const int gcur = min(egrp, v.nb - grp * egrp);
-  const int cp = rem / gcur, z = grp * egrp + rem - cp * gcur;
+  // (dispatch order: every emulator's rightmost chunk first.  Round 5 measured groups of 32 / 16 / 8 / 4 / 1 emulators, each with all its chunks
+  // before the next group's, for launches with more workgroups than the GPU holds -- 64 x 16 on 512 slots, where the leftmost chunks,
+  // which stream the most rows of L, become resident last: level, profiles/r05_backsolve_order_ab.txt)
+  const int cp = blockIdx.x / v.nb, z = blockIdx.x % v.nb;
   const int c = nch - 1 - cp;              // rightmost chunk first in dispatch order
   const int emu = slot_emu(v.idx, z);
   const int ld = v.LD, n = v.n;
@@ -686,12 +684,9 @@ void launch_backsolve_chain(const BatchView& v, int* flags, int epoch, int* stat
   // which is how the GPU suite exercises the fallback
   static const int spin_limit = [] { const char* e = getenv("MOGP_BS_SPIN"); return e ? atoi(e) : (1 << 20); }();
   static const int sent = [] { const char* e = getenv("MOGP_BS_SENTINEL"); return e ? atoi(e) : 1; }();
-  // MOGP_BS_GROUP: emulators per dispatch group (0: all in one, the order of rounds 2 - 4)
-  static const int grp_env = [] { const char* e = getenv("MOGP_BS_GROUP"); return e ? atoi(e) : -1; }();
-  const int egrp = grp_env > 0 ? std::min(grp_env, v.nb) : v.nb;
   prof_begin("backsolve", s);
-  if (sent) hipLaunchKernelGGL(backsolve_chain_kernel<true>, dim3(v.nb * nch), dim3(256), 0, s, v, flags, epoch, nch, status, spin_limit, egrp);
-  else hipLaunchKernelGGL(backsolve_chain_kernel<false>, dim3(v.nb * nch), dim3(256), 0, s, v, flags, epoch, nch, status, spin_limit, egrp);
+  if (sent) hipLaunchKernelGGL(backsolve_chain_kernel<true>, dim3(v.nb * nch), dim3(256), 0, s, v, flags, epoch, nch, status, spin_limit);
+  else hipLaunchKernelGGL(backsolve_chain_kernel<false>, dim3(v.nb * nch), dim3(256), 0, s, v, flags, epoch, nch, status, spin_limit);
   prof_end("backsolve", s, 0., (double)v.nb * 4.0 * (double)v.n * (double)v.n);      // algorithmic: the lower triangle of L read once
 }
 

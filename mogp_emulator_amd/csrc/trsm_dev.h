@@ -187,10 +187,16 @@ struct TrsmSlabPre {
 __device__ __forceinline__ void trsm128_slab_request(const double* __restrict__ pk, TrsmSlabPre& P) {
   const int t = mogp_tid();
   const double* LT = pk + PACK128_LT;
-  // step 0 needs inv(L_00) only; step 1 the 16 pieces of row block 1 (128 chunks: q = 0, t < 128) and inv(L_11)
-  if (t < 128) P.pr[1][0] = *reinterpret_cast<const v2d_p*>(LT + (size_t)(t >> 3) * 128 + 16 + (t & 7) * 2);
-  if (t < 128) P.pinv[0] = *reinterpret_cast<const v2d_p*>(pk + PACK128_INV + 2 * t);
-  if (t < 128) P.pinv[1] = *reinterpret_cast<const v2d_p*>(pk + PACK128_INV + 256 + 2 * t);
+  // the images of block steps 0 and 1 (trsm128_tile2_dev: column block b of L below its diagonal sub-block, and inv(L_bb))
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int ch = t + 256 * q;
+      if (ch < 128 * (7 - b)) P.pr[b][q] = *reinterpret_cast<const v2d_p*>(LT + (size_t)(16 * b + ((ch >> 3) & 15)) * 128 + 16 * (b + 1 + (ch >> 7)) + (ch & 7) * 2);
+    }
+    if (t < 128) P.pinv[b] = *reinterpret_cast<const v2d_p*>(pk + PACK128_INV + b * 256 + 2 * t);
+  }
 }
 
 // Round 4 (default for bulk tasks): the tile is RE-DEALT to the solving waves before the solve.  All four waves put their 32 x 64 piece of
@@ -223,12 +229,15 @@ __device__ __forceinline__ void trsm128_tile2_dev(const BatchView& v, int c0, in
   double* ts = lds + 2 * TL_PK + wave * TL_TS;           // (after the re-deal: this wave's private 16 x 18 stage for the way out)
   const double* LT = pk + PACK128_LT;
   const int sr0 = lane >> 3, sp = (lane & 7) * 2;
+  // image of block step b: [0, 256) inv(L_bb) as in the pack; [(16 c + k) * 16 + i], c = b+1 .. 7: L[16 c + i][16 b + k] -- column block b
+  // of L below its diagonal sub-block (rows 16 b .. 16 b + 15 of the pack's transposed copy), the A operands of the updates of step b
   auto pack_request = [&](int b) {
     const int u = b & 1;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int ch = t + 256 * q;
-      if (ch < 128 * b) P.pr[u][q] = *reinterpret_cast<const v2d_p*>(LT + (size_t)(ch >> 3) * 128 + 16 * b + (ch & 7) * 2);
+      if (ch < 128 * (7 - b))
+        P.pr[u][q] = *reinterpret_cast<const v2d_p*>(LT + (size_t)(16 * b + ((ch >> 3) & 15)) * 128 + 16 * (b + 1 + (ch >> 7)) + (ch & 7) * 2);
     }
     if (t < 128) P.pinv[u] = *reinterpret_cast<const v2d_p*>(pk + PACK128_INV + b * 256 + 2 * t);
   };
@@ -237,9 +246,9 @@ __device__ __forceinline__ void trsm128_tile2_dev(const BatchView& v, int c0, in
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int ch = t + 256 * q;
-      if (ch < 128 * b) *reinterpret_cast<v2d_p*>(img + (ch >> 3) * 16 + (ch & 7) * 2) = P.pr[u][q];
+      if (ch < 128 * (7 - b)) *reinterpret_cast<v2d_p*>(img + ((b + 1 + (ch >> 7)) * 16 + ((ch >> 3) & 15)) * 16 + (ch & 7) * 2) = P.pr[u][q];
     }
-    if (t < 128) *reinterpret_cast<v2d_p*>(img + 112 * 16 + 2 * t) = P.pinv[u];
+    if (t < 128) *reinterpret_cast<v2d_p*>(img + 2 * t) = P.pinv[u];
   };
   // whole-tile stage over ALL of lds: [slab 2 wr + ii][block 4 wc + j][16 x 17]
 #pragma unroll
@@ -263,15 +272,17 @@ __device__ __forceinline__ void trsm128_tile2_dev(const BatchView& v, int c0, in
   for (int b = 0; b < 8; ++b) {
     const double* img = pkb[b & 1];
     if (b + 2 < 8) pack_request(b + 2);
-    v4d_t Tb = T[b];
-#pragma unroll
-    for (int a = 0; a < b; ++a)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) Tb = __builtin_amdgcn_mfma_f64_16x16x4f64(-img[(16 * a + g + 4 * r) * 16 + i], X[a][r], Tb, 0, 0, 0);
-    const double* inv = img + 112 * 16;
+    // RIGHT-LOOKING (round 5): x_b = inv(L_bb) t_b, then every later block takes its update t_c -= L_cb x_b at once.  The left-looking order of
+    // rounds 3 - 4 (t_b collects the updates of all earlier blocks in step b) made the solve ONE chain of 144 dependent MFMAs; here a step's
+    // chain is its 4 + 4 (x_b, then t_{b+1}) and the other 4 (6 - b) MFMAs are independent of it.  Every t_c still receives its updates in the
+    // order b = 0, 1, .. with the same operands: bit-identical to the left-looking forms (trsm128_lds_dev, the chain tasks).
     X[b] = (v4d_t){0., 0., 0., 0.};
 #pragma unroll
-    for (int r = 0; r < 4; ++r) X[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(inv[(g + 4 * r) * 16 + i], Tb[r], X[b], 0, 0, 0);
+    for (int r = 0; r < 4; ++r) X[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(img[(g + 4 * r) * 16 + i], T[b][r], X[b], 0, 0, 0);
+#pragma unroll
+    for (int c = b + 1; c < 8; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) T[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(-img[(16 * c + g + 4 * r) * 16 + i], X[b][r], T[c], 0, 0, 0);
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int r = 0; r < 4; ++r) ts[i * 18 + g + 4 * r] = X[b][r];

@@ -32,7 +32,7 @@ for it in range(reps):
     tf += t1 - t0; tg += t2 - t1; tp += t3 - t2
 lib.mogp_profile_enable(0)
 print("%s: fit %.3f ms  fit+grad %.3f ms  predict %.3f ms" % (os.environ.get("MOGP_LIB_PATH", "in-tree"), tf / reps * 1e3, tg / reps * 1e3, tp / reps * 1e3))
-for tag in ("mchol", "chol_update", "chol_diag128", "chol_trsm128", "syrk_trailing", "trtri_merge", "kinv", "grad_reduce", "cov_build", "cross_cov", "predict_var", "predict_deriv"):
+for tag in ("mchol", "chol_update", "chol_diag128", "chol_trsm128", "syrk_trailing", "trtri_merge", "kinv", "grad_reduce", "cov_build", "backsolve", "cross_cov", "predict_var", "predict_deriv"):
     ms, cnt, fl, by = ctypes.c_double(), ctypes.c_longlong(), ctypes.c_double(), ctypes.c_double()
     if lib.mogp_profile_get(tag.encode(), ctypes.byref(ms), ctypes.byref(cnt), ctypes.byref(fl), ctypes.byref(by)) == 0 and cnt.value:
         print("   %-14s %5d launches  %9.4f ms avg  %8.2f TFLOP/s  %8.1f GB/s" % (tag, cnt.value, ms.value / cnt.value, fl.value / ms.value * 1e-9, by.value / ms.value * 1e-6))
