@@ -471,14 +471,11 @@ __global__ __launch_bounds__(256, SOLO ? 1 : 2) void mchol_kernel(BatchView v, u
 //   for c = 0, 1, ...:  D(c+1);  T(2c+4, c+1), T(2c+5, c+1);  G(0..2, c+2);  T(2c+6, c), T(2c+7, c);  T(2c+6, c+1), T(2c+7, c+1);
 //                       T(r, c) for r >= 2c+8
 // (a workgroup that draws a chain task early does its GEMM and then waits: at most a handful of waiting workgroups per emulator).
+// Round 5 measured other orders for the LAST block columns, where a launch has fewer tasks than workgroups and ends on the row band 2c+6, 2c+7
+// (per-task stamps: the last tickets of 64 x n=2000 are drawn at 3.5 ms of 3.7): that band at the front of its iteration, or directly behind
+// the chain pair: level; the G tasks in front of D(c+1): 2 % slower (profiles/r05_task_order_ab.txt).
 std::vector<int> mchol_task_table(int NP) {
   const int K = NP / 128, K2 = NP / 64;
-  // MOGP_MC_ORDER (experiment, read per call): the order inside the LAST MOGP_MC_ORDER_FROM (default 4) iterations, where a launch has fewer
-  // tasks than workgroups and the row band 2c+6, 2c+7 is the path the launch ends on.  bit 0: T(2c+6, c), T(2c+7, c) lead the iteration;
-  // bit 1: T(2c+6, c+1), T(2c+7, c+1) follow the chain pair directly (implies bit 0); bit 2: G(., c+2) in front of D(c+1)
-  const char* oe = getenv("MOGP_MC_ORDER");
-  const char* fe = getenv("MOGP_MC_ORDER_FROM");
-  const int order = oe ? atoi(oe) : 0, from = K - (fe ? atoi(fe) : 4);
   auto word = [](int type, int c, int r) { return (int)(((unsigned)type << 30) | ((unsigned)c << 15) | (unsigned)r); };
   std::vector<int> tb;
   auto T = [&](int r, int c) {
@@ -490,35 +487,17 @@ std::vector<int> mchol_task_table(int NP) {
   T(4, 0);
   T(5, 0);
   for (int c = 0; c < K; ++c) {
-    const int o = c >= from ? order : 0;
-    const bool band_first = (o & 3) != 0, band2_early = (o & 2) != 0, g_first = (o & 4) != 0;
-    auto G = [&]() {
-      // (three 64 x 64 G tasks per diagonal block; round 5 measured the tiles (1,0), (1,1) as ONE 64 x 128 task for throughput-bound launches:
-      // level and bit-identical, profiles/r05_wide_g_ab.txt -- not kept)
-      if (c + 2 < K)
-        for (int sub = 0; sub < 3; ++sub) tb.push_back(word(1, c + 2, sub));
-    };
-    if (band_first) {
-      T(2 * c + 6, c);
-      T(2 * c + 7, c);
-    }
-    if (g_first) G();
     if (c + 1 < K) tb.push_back(word(0, c + 1, 0));
     T(2 * c + 4, c + 1);
     T(2 * c + 5, c + 1);
-    if (band2_early) {
-      T(2 * c + 6, c + 1);
-      T(2 * c + 7, c + 1);
-    }
-    if (!g_first) G();
-    if (!band_first) {
-      T(2 * c + 6, c);
-      T(2 * c + 7, c);
-    }
-    if (!band2_early) {
-      T(2 * c + 6, c + 1);
-      T(2 * c + 7, c + 1);
-    }
+    // (three 64 x 64 G tasks per diagonal block; round 5 measured the tiles (1,0), (1,1) as ONE 64 x 128 task for throughput-bound launches:
+    // level and bit-identical, profiles/r05_wide_g_ab.txt -- not kept)
+    if (c + 2 < K)
+      for (int sub = 0; sub < 3; ++sub) tb.push_back(word(1, c + 2, sub));
+    T(2 * c + 6, c);
+    T(2 * c + 7, c);
+    T(2 * c + 6, c + 1);
+    T(2 * c + 7, c + 1);
     for (int r = 2 * c + 8; r < K2; ++r) T(r, c);
   }
   return tb;
