@@ -22,13 +22,24 @@ SECS = float(sys.argv[1]) if len(sys.argv) > 1 else 4.0
 
 
 def hwmon_files():
-    out = {}
-    for h in glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*"):
-        for key, names in (("sclk_hz", ("freq1_input",)), ("power_uw", ("power1_average", "power1_input")), ("mclk_hz", ("freq2_input",))):
-            for nm in names:
-                p = os.path.join(h, nm)
-                if os.path.exists(p) and key not in out:
-                    out[key] = p
+    """hwmon directory of the GPU this process computes on (a box shows every GPU of its host in sysfs): matched by PCI address"""
+    import torch
+    pr = torch.cuda.get_device_properties(0)
+    want = "%04x:%02x:%02x" % (getattr(pr, "pci_domain_id", 0), getattr(pr, "pci_bus_id", -1), getattr(pr, "pci_device_id", 0))
+    out = {"pci": want}
+    for card in glob.glob("/sys/class/drm/card*"):
+        try:
+            slot = [l.split("=", 1)[1].strip() for l in open(os.path.join(card, "device", "uevent")) if l.startswith("PCI_SLOT_NAME")][0]
+        except Exception:
+            continue
+        if not slot.lower().startswith(want):
+            continue
+        for h in glob.glob(os.path.join(card, "device", "hwmon", "hwmon*")):
+            for key, names in (("sclk_hz", ("freq1_input",)), ("power_uw", ("power1_average", "power1_input")), ("mclk_hz", ("freq2_input",))):
+                for nm in names:
+                    p = os.path.join(h, nm)
+                    if os.path.exists(p) and key not in out:
+                        out[key] = p
     return out
 
 
@@ -38,6 +49,8 @@ FILES = hwmon_files()
 def sample():
     s = {}
     for k, p in FILES.items():
+        if k == "pci":
+            continue
         try:
             s[k] = float(open(p).read().strip())
         except Exception:
