@@ -259,7 +259,7 @@ __device__ __forceinline__ void c128_column_groups(c128_v4d& Dn, c128_v4d& Xn, c
 // already without asking.  The update then runs in step with the panel solve that produces X (trsm128_lds_dev<.., PUB>) and is
 // complete ~2 us after the solve instead of 14 us after it.  Pieces that are known to be there are requested two steps ahead as
 // before; a piece that has to be waited for is requested after the arithmetic of the current one.  after_pre() is called by all
-// threads when the update is done (the one-launch Cholesky parks the workgroup it shares the CU with from there on).
+// threads when the update is done (the one-launch Cholesky stamps its trace there).
 struct C128NoWait {
   __device__ __forceinline__ bool known(int) const { return true; }
   __device__ __forceinline__ bool operator()(int) { return true; }

@@ -180,14 +180,11 @@ __device__ __forceinline__ void mainloop_w(const double* __restrict__ Ag, int ld
 // workgroup has published them write-through, i.e. from HBM / the infinity cache, and with the one-step prefetch of
 // mainloop_w every one of its 8 steps exposed a full memory latency (25-35 us for 8 steps, per-task stamps of
 // tools/mchol_trace.py); four steps ahead the latency is paid about twice.  nk must be a multiple of PD.
-// park != nullptr: a word that is non-zero while a latency-bound task (the diagonal block of the one-launch Cholesky) runs
-// on THIS CU in the co-resident workgroup; this workgroup then leaves the CU's matrix pipes to it: every step lane 0
-// publishes the word's value (loaded asynchronously a step earlier) through park_lds[0 / 1], and while it is set all waves
-// sleep at a barrier until lane 0 sees it cleared (bounded by park_spins polls).
+// (Rounds 2 - 4 let a GEMM task PARK -- sleep at a barrier while a diagonal-block task ran in the co-resident workgroup of its CU; on the
+// round-5 kernels parking never wins, profiles/r05_regime_sweep.txt, and is gone.)
 template <int BM, int BN, int WR, int WC, int PD>
 __device__ __forceinline__ void mainloop_pf(const double* __restrict__ Ag, int lda, const double* __restrict__ Bg, int ldb, int nk,
-                                            v4d (&acc)[WCfg<BM, BN, WR, WC>::TI][WCfg<BM, BN, WR, WC>::TJ], double* smem,
-                                            const unsigned* park = nullptr, int* park_lds = nullptr, int park_spins = 0, int kmask = -1) {
+                                            v4d (&acc)[WCfg<BM, BN, WR, WC>::TI][WCfg<BM, BN, WR, WC>::TJ], double* smem, int kmask = -1) {
   // kmask (measurement only, MOGP_MC_NOTRAFFIC): k-step kt reads the operand columns of step kt & kmask -- with kmask = 3 every task
   // re-reads its first 64 columns from the caches: the same instruction stream without the memory traffic (results are garbage)
   using C = WCfg<BM, BN, WR, WC>;
@@ -224,27 +221,10 @@ __device__ __forceinline__ void mainloop_pf(const double* __restrict__ Ag, int l
   for (int u = 0; u < PD; ++u) load(u, u);
   store(0, smem, smem + C::OPA);
   __syncthreads();
-  unsigned pword = 0;
   for (int kt0 = 0; kt0 < nk; kt0 += PD) {
 #pragma unroll
     for (int u = 0; u < PD; ++u) {
       const int kt = kt0 + u;
-      if (park) {
-        // slot kt & 1 was written during step kt - 1, before the barrier that ended it: every thread reads the same value
-        // (two slots, so that lane 0's next write cannot overtake a slower wave's read)
-        if (kt > 0 && park_lds[kt & 1] != 0) {
-          if (t == 0) {
-            int spins = 0;
-            while (__hip_atomic_load(park, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u && ++spins < park_spins) __builtin_amdgcn_s_sleep(16);
-            pword = 0;
-          }
-          __syncthreads();
-        }
-        if (t == 0) {
-          park_lds[(kt + 1) & 1] = (int)pword;                  // value loaded a step ago; everybody reads it after this step's barrier
-          pword = __hip_atomic_load(park, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-      }
       const double* sA = smem + (kt & 1) * (C::OPA + C::OPB);
       const double* sB = sA + C::OPA;
       if (kt + PD < nk) load(u, kt + PD);                 // register set u held step kt, which is in LDS already
@@ -293,11 +273,10 @@ struct QCfg {
   static constexpr int SMEM_DOUBLES = 3 * STAGE;
 };
 
-// park / park_lds / park_spins and kmask: as in mainloop_pf.
+// kmask: as in mainloop_pf.
 template <int BM, int BN, int WR, int WC, int G, bool PIN = false>
 __device__ __forceinline__ void mainloop_q(const double* __restrict__ Ag, int lda, const double* __restrict__ Bg, int ldb, int nk,
-                                           v4d (&acc)[WCfg<BM, BN, WR, WC>::TI][WCfg<BM, BN, WR, WC>::TJ], double* smem,
-                                           const unsigned* park = nullptr, int* park_lds = nullptr, int park_spins = 0, int kmask = -1) {
+                                           v4d (&acc)[WCfg<BM, BN, WR, WC>::TI][WCfg<BM, BN, WR, WC>::TJ], double* smem, int kmask = -1) {
   using C = WCfg<BM, BN, WR, WC>;
   constexpr int STAGE = QCfg<BM, BN>::STAGE;
   const int t = mogp_tid(), lane = t & 63, wave = t >> 6;
@@ -356,26 +335,10 @@ __device__ __forceinline__ void mainloop_q(const double* __restrict__ Ag, int ld
   __syncthreads();
   frag(0, smem, 0);
   int cur = 0;                                            // stage of step kt
-  unsigned pword = 0;
   for (int kt0 = 0; kt0 < nk; kt0 += G) {
 #pragma unroll
     for (int u = 0; u < G; ++u) {
       const int kt = kt0 + u;
-      if (park) {
-        // slot kt & 1 was written during step kt - 1, before the barrier that ended it: every thread reads the same value
-        if (kt > 0 && park_lds[kt & 1] != 0) {
-          if (t == 0) {
-            int spins = 0;
-            while (__hip_atomic_load(park, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u && ++spins < park_spins) __builtin_amdgcn_s_sleep(16);
-            pword = 0;
-          }
-          __syncthreads();
-        }
-        if (t == 0) {
-          park_lds[(kt + 1) & 1] = (int)pword;            // value loaded a step ago; everybody reads it after this step's barrier
-          pword = __hip_atomic_load(park, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-      }
       const double* st = smem + cur * STAGE;
       const int nxt = cur == 2 ? 0 : cur + 1, wrt = nxt == 2 ? 0 : nxt + 1;
       frag(1, st, 1);

@@ -49,8 +49,7 @@ namespace {
 constexpr int MC_LINE = 32;                       // ints per 128-byte line
 constexpr int MC_ABORT = 0, MC_TIMEOUTS = 1;      // ctrl[0], ctrl[1]
 constexpr int MC_HEADS = MC_LINE;                 // queue head q at ctrl[MC_HEADS + q * MC_LINE]
-constexpr int MC_CU0 = MC_LINE * 9;               // per-CU "a diagonal block is being factored here" words, index xcc * 256 + HW_ID[15:8]
-constexpr int MC_EMU0 = MC_CU0 + 8 * 256;         // per-emulator blocks start here
+constexpr int MC_EMU0 = MC_LINE * 9;              // per-emulator blocks start here
 constexpr int MC_PD = 4;                          // 16-column pieces a GEMM task consumes per call of its main loop (and the steps its global loads run ahead)
 constexpr int MC_LDS_HDR = 4;                     // doubles in front of the operand buffers: [task / ok words]
 
@@ -63,15 +62,15 @@ __device__ __forceinline__ void drain_stores() { asm volatile("s_waitcnt vmcnt(0
 // level elsewhere; profiles/r05_loop_pin_ab.txt)
 template <int BM, int BN>
 __device__ __forceinline__ void MC_GEMM(const double* __restrict__ Ag, int lda, const double* __restrict__ Bg, int ldb, int nk, v4d (&acc)[BM / 32][BN / 32],
-                                        double* smem, const unsigned* park, int* park_lds, int park_spins, int kmask) {
-  mainloop_q<BM, BN, 2, 2, 2, true>(Ag, lda, Bg, ldb, nk, acc, smem, park, park_lds, park_spins, kmask);
+                                        double* smem, int kmask) {
+  mainloop_q<BM, BN, 2, 2, 2, true>(Ag, lda, Bg, ldb, nk, acc, smem, kmask);
 }
 constexpr size_t MC_GEMM_LDS = QCfg<64, 128>::SMEM_DOUBLES;
 
 struct McCtx {
   unsigned* ctrl;
   int spin_limit;
-  int* shi;          // LDS: [0] task number, [1] result of a wait, [2], [3] park words of the GEMM main loop
+  int* shi;          // LDS: [0] task number, [1] result of a wait
 };
 
 // optional per-task time stamps (tools/mchol_trace.py; MOGP_MC_TRACE=<file>): MC_TRW 64-bit words per task,
@@ -158,7 +157,7 @@ struct PieceWait {
 template <bool TRACE, bool SOLO = false>
 __global__ __launch_bounds__(256, SOLO ? 1 : 2) void mchol_kernel(BatchView v, unsigned* __restrict__ ctrl, const int* __restrict__ table, int ntasks,
                                                        int emu_stride, double* __restrict__ packs, int* __restrict__ info, int nq, int spin_limit,
-                                                       int park_on, unsigned long long* __restrict__ trace, int tile_solve) {
+                                                       unsigned long long* __restrict__ trace, int tile_solve) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   int* shi = reinterpret_cast<int*>(smem);
   double* lds = smem + MC_LDS_HDR;
@@ -167,10 +166,6 @@ __global__ __launch_bounds__(256, SOLO ? 1 : 2) void mchol_kernel(BatchView v, u
   const int ld = v.LD;
   const int K = v.NP / 128, K2 = v.NP / 64;
   const int home = (int)blockIdx.x & (nq - 1);          // observed: block b runs on XCD b % 8 (for speed only)
-  // this workgroup's CU: XCC_ID and HW_ID[15:8] (CU / SH / SE); only used to keep the co-resident workgroup off the matrix
-  // pipes while a diagonal block is factored here -- a wrong or shared index costs speed, never correctness
-  unsigned* cuword = ctrl + MC_CU0 + (__builtin_amdgcn_s_getreg(6164) & 7u) * 256u + (__builtin_amdgcn_s_getreg(((8 - 1) << 11) | (8 << 6) | 4) & 255u);
-  const bool use_park = park_on != 0;
   const int emus_q = v.nb / nq;
   const int total = ntasks * emus_q;
   for (int qi = 0; qi < nq; ++qi) {
@@ -217,20 +212,16 @@ __global__ __launch_bounds__(256, SOLO ? 1 : 2) void mchol_kernel(BatchView v, u
         // the panels 0 .. c-2 arrive through the two G tasks (c >= 2), panel c-1 is applied here, straight from the two
         // panel-solve tasks that produced it
         if (c > 1 && mc_wait_min3(cx, diagcnt + c, diagcnt + c, diagcnt + c, 3u, tr) < 0) return;
-        auto park = [&]() {
-          mc_stamp<TRACE>(tr, 2);
-          if (use_park && t == 0) __hip_atomic_fetch_add(cuword, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        };
+        auto inputs_seen = [&]() { mc_stamp<TRACE>(tr, 2); };
         // (ddone[c] counts the block steps whose pack entries are visible: 8 = the whole pack)
         if (c > 0) {
           // panel c-1 is consumed in 16-column pieces while the two panel-solve tasks still produce it (rowprog)
           PieceWait pw{cx, rowprog + 2 * c, rowprog + 2 * c + 1, 8u * (unsigned)(c - 1), 0, tr};
-          if (!chol128_dev<true, true, true>(A + (size_t)c0 * ld + c0, ld, pk, info + emu, c0, lds, ddone + c, pw, park)) return;
+          if (!chol128_dev<true, true, true>(A + (size_t)c0 * ld + c0, ld, pk, info + emu, c0, lds, ddone + c, pw, inputs_seen)) return;
         } else {
-          park();
+          inputs_seen();
           chol128_dev<true, false, true>(A + (size_t)c0 * ld + c0, ld, pk, info + emu, c0, lds, ddone + c);
         }
-        if (use_park && t == 0) __hip_atomic_fetch_sub(cuword, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __builtin_amdgcn_s_setprio(0);
         drain_stores();
         __syncthreads();
@@ -262,7 +253,7 @@ __global__ __launch_bounds__(256, SOLO ? 1 : 2) void mchol_kernel(BatchView v, u
           if (m < 0) return;
           mc_stamp<TRACE>(tr, 2);
           m = m < kend ? m : kend;
-          MC_GEMM<64, 64>(A + (size_t)gi0 * ld + 128 * kb, ld, A + (size_t)gj0 * ld + 128 * kb, ld, 8 * (m - kb), acc, lds, nullptr, nullptr, 0, -1);
+          MC_GEMM<64, 64>(A + (size_t)gi0 * ld + 128 * kb, ld, A + (size_t)gj0 * ld + 128 * kb, ld, 8 * (m - kb), acc, lds, -1);
           kb = m;
         }
         mc_stamp<TRACE>(tr, 3);
@@ -353,7 +344,7 @@ __global__ __launch_bounds__(256, SOLO ? 1 : 2) void mchol_kernel(BatchView v, u
             mc_stamp<TRACE>(tr, 2);
             have = (have < kse ? have : kse) & ~(MC_PD - 1);
             MC_GEMM<64, 128>(A + (size_t)r0 * ld + 16 * ks, ld, A + (size_t)c0 * ld + 16 * ks, ld, have - ks, acc, lds,
-                             (use_park && !urgent) ? cuword : nullptr, shi + 2, 1 << 14, (tile_solve & 2) ? 3 : -1);
+                             (tile_solve & 2) ? 3 : -1);
             ks = have;
           }
         }
@@ -517,17 +508,15 @@ void launch_mchol(const BatchView& v, unsigned* ctrl, size_t ctrl_ints, const in
                   hipStream_t s) {
   // MOGP_MC_SPIN: polls before a wait gives up (default 2^22: seconds)
   static const int spin_limit = [] { const char* e = getenv("MOGP_MC_SPIN"); return e ? atoi(e) : (1 << 22); }();
-  // Workgroups per CU and parking, by regime.  rho = (time the matrix cores need at ~45 TFLOP/s) / (length of the dependent
-  // chain, ~55 us per block column).  Chain-bound batches (rho < 1: 8 x n=2000, 2 x n=5000) run ONE workgroup per CU, so that
-  // a diagonal-block task never shares its CU's matrix pipes (measured 1.15 vs 1.25 ms at 8 x n=2000, 2.91 vs 3.01 at
-  // 2 x n=5000); beyond that two per CU (16 x n=2000: 1.62 vs 1.71 ms; n=16000: 26.3 vs 27.9), and up to rho = 2 the
-  // workgroup that shares a CU with a diagonal-block task parks (mainloop_pf) -- with more work than that the diagonal
-  // blocks have slack and a parked workgroup is only lost capacity.  MOGP_MC_WGS = 1 / 2 and MOGP_MC_PARK = 0 / 1 force either.
+  // Workgroups per CU by regime.  rho = (time the matrix cores need at ~45 TFLOP/s) / (length of the dependent chain, ~55 us per block
+  // column).  Chain-bound batches (rho < 1: up to 12 x n=2000, 2 x n=5000) run ONE workgroup per CU, so that a diagonal-block task never
+  // shares its CU's matrix pipes; beyond that two per CU.  Round-5 kernels, mchol ms one / two per CU (profiles/r05_regime_sweep.txt):
+  // 4 x n=2000 0.48 / 0.58, 8 x 0.71 / 0.73, 12 x 0.92 / 0.91 - 0.93, 16 x 1.17 / 1.15, 24 x 1.68 / 1.56, 32 x 2.13 / 1.97, 2 x n=5000 2.10 / 2.14,
+  // 4 x n=5000 3.73 / 3.61.  MOGP_MC_WGS = 1 / 2 forces either.  (Rounds 2 - 4: for 1 <= rho < 2 the workgroup sharing a CU with a
+  // diagonal-block task PARKED, MOGP_MC_PARK; on the round-5 kernels parking is level to 2 % slower in every regime and is gone.)
   static const int force_wgs = [] { const char* e = getenv("MOGP_MC_WGS"); return e ? std::max(1, atoi(e)) : 0; }();
-  static const int force_park = [] { const char* e = getenv("MOGP_MC_PARK"); return e ? atoi(e) : -1; }();
   const double rho = mchol_rho(v.nb, v.NP);
   const int per_cu = force_wgs ? force_wgs : (rho < 1.0 ? 1 : 2);
-  const int park_on = force_park >= 0 ? force_park : ((per_cu > 1 && rho < 2.0) ? 1 : 0);
   // bit 1: MOGP_MC_NOTRAFFIC=1 (measurement only, garbage results): the bulk GEMM tasks re-read their first 64 operand columns -- the traffic A/B;
   // bit 5: MOGP_MC_LATE=0: chain tasks always solve in the pipelined form, also when their diagonal block has already finished
   static const int tile_solve = [] {
@@ -559,7 +548,7 @@ void launch_mchol(const BatchView& v, unsigned* ctrl, size_t ctrl_ints, const in
   if (trace_file && dtr) {
     (void)hipMemsetAsync(dtr, 0, words * 8, s);
     hipLaunchKernelGGL(mchol_kernel<true>, dim3(grid), dim3(256), lds_doubles * sizeof(double), s, v, ctrl, table, ntasks, mchol_emu_stride(v.NP), packs,
-                       info, nq, spin_limit, park_on, dtr, ts);
+                       info, nq, spin_limit, dtr, ts);
     std::vector<unsigned long long> h(words);
     (void)hipStreamSynchronize(s);
     (void)hipMemcpy(h.data(), dtr, words * 8, hipMemcpyDeviceToHost);
@@ -576,10 +565,10 @@ void launch_mchol(const BatchView& v, unsigned* ctrl, size_t ctrl_ints, const in
   static const int solo_ok = [] { const char* e = getenv("MOGP_MC_SOLO"); return e ? atoi(e) : 1; }();
   if (per_cu == 1 && solo_ok)
     hipLaunchKernelGGL((mchol_kernel<false, true>), dim3(grid), dim3(256), lds_doubles * sizeof(double), s, v, ctrl, table, ntasks, mchol_emu_stride(v.NP), packs,
-                     info, nq, spin_limit, park_on, (unsigned long long*)nullptr, ts);
+                     info, nq, spin_limit, (unsigned long long*)nullptr, ts);
   else
     hipLaunchKernelGGL(mchol_kernel<false>, dim3(grid), dim3(256), lds_doubles * sizeof(double), s, v, ctrl, table, ntasks, mchol_emu_stride(v.NP), packs,
-                     info, nq, spin_limit, park_on, (unsigned long long*)nullptr, ts);
+                     info, nq, spin_limit, (unsigned long long*)nullptr, ts);
   const double n = v.n;                 // ALGORITHMIC work (n^3 / 3 per emulator), not the padded NP the tiles cover
   prof_end("mchol", s, (double)v.nb * n * n * n / 3.0, (double)v.nb * 8.0 * n * n);
 }

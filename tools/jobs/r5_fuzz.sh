@@ -7,4 +7,4 @@ for seed in ${SEEDS:-411 412}; do
   timeout 1500 python tests/tools/fuzz_parity.py 1500 $seed 2>&1 | tail -12 > $O/fuzz_$seed.txt; tail -3 $O/fuzz_$seed.txt
 done
 timeout 1500 python tests/tools/fuzz_parity.py 300 ${LSEED:-413} large 2>&1 | tail -12 > $O/fuzz_large.txt; tail -3 $O/fuzz_large.txt
-MOGP_MC_WGS=2 MOGP_MC_PARK=1 timeout 900 python tests/tools/fuzz_parity.py 150 ${LSEED2:-414} large 2>&1 | tail -12 > $O/fuzz_large_wgs2.txt; tail -3 $O/fuzz_large_wgs2.txt
+MOGP_MC_WGS=2 timeout 900 python tests/tools/fuzz_parity.py 150 ${LSEED2:-414} large 2>&1 | tail -12 > $O/fuzz_large_wgs2.txt; tail -3 $O/fuzz_large_wgs2.txt

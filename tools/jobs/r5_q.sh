@@ -16,3 +16,6 @@ for shp in ${SHAPES:-64,2000,10 32,2000,10 16,2000,10 8,2000,10 1,2000,10 16,500
   done
 done
 } 2>&1 | grep -v "^$\|amdgpu.ids" | tee $O/ab.txt
+if [ -n "$SUITE" ]; then
+  timeout 2700 python -m pytest tests -m gpu -q --durations=8 2>&1 | tail -40 > $O/gpu_tests.txt; tail -15 $O/gpu_tests.txt
+fi
