@@ -731,7 +731,7 @@ void Engine::eval(const std::vector<int>& ids, const std::vector<const double*>&
             if (!z_armed[i]) HIPCK(hipMemsetAsync(dAlpha + (size_t)i * RA * LD, 0xFF, (size_t)LD * sizeof(double), stream));
             z_armed[i] = 0;                                  // consumed by this solve
           }
-          launch_backsolve_chain(v, dBsFlags, ++bs_epoch, dBsFlags + nfl, stream);
+          launch_backsolve_chain(v, dBsFlags, ++bs_epoch, dBsFlags + nfl, n_cu, stream);
           chained = true;
         } else {
           launch_backsolve(v, stream);

@@ -242,8 +242,10 @@ __device__ __forceinline__ void st_agent(double* p, double x) { __hip_atomic_sto
 // barrier + flag store and the consumer's payload load behind its flag poll (~2.5 of 7 us), and the lower half of a chunk (solved
 // first) is folded while its producer still solves the upper half.  A lane that gives up takes 0.0 (never the pattern, which an fma
 // would propagate into its own results and make every chunk behind it time out too) and the emulator is re-solved by the engine.
-template <bool SENT>
-__global__ __launch_bounds__(256, 2) void backsolve_chain_kernel(BatchView v, int* __restrict__ flags, int epoch, int nch, int* __restrict__ status, int spin_limit) {
+// HOIST (launches with at most one workgroup per CU -- the chain-bound ones; needs SENT): see preload_diag below; the one-per-CU build has the
+// registers for it (with two per CU the 128 extra live registers spilled into the solve they were meant to shorten).
+template <bool SENT, bool HOIST = false>
+__global__ __launch_bounds__(256, HOIST ? 1 : 2) void backsolve_chain_kernel(BatchView v, int* __restrict__ flags, int epoch, int nch, int* __restrict__ status, int spin_limit) {
   __shared__ double Ld[2][64 * 65];        // the two diagonal blocks of this chunk: [row][column], row stride 65
   __shared__ double w[128], xs[128];
   __shared__ v2d part[3][64];
@@ -306,26 +308,35 @@ __global__ __launch_bounds__(256, 2) void backsolve_chain_kernel(BatchView v, in
     }
     __syncthreads();
   };
+  // SENT: the lane's 64 scaled column entries of a diagonal block, -L[j][lane] / L_ll, in REGISTERS, held by the wave that solves the block: wave 0
+  // the lower block (rows j0+64.., solved first), wave 1 the upper one.  HOIST (round 5): fetched at the START of the kernel, before the chunk's
+  // dependencies arrive (they depend on L only); otherwise inside each solve -- 64 LDS reads + 64 multiplies in front of the 64-step substitution,
+  // ~1 of the 2.3 us of a block, twice per step of the launch's dependent chain.
+  double Lc[64], rdgw = 0.0;
+  const int myblk = rg == 0 ? 1 : 0;           // (waves 2, 3: unused)
+  auto preload_diag = [&]() {
+    if (SENT && rg < 2) {
+      const double* Lb = Ld[myblk];
+      const double dg = Lb[lane * 65 + lane];
+      rdgw = (j0 + 64 * myblk + lane < n) ? 1.0 / dg : 0.0;
+#pragma unroll
+      for (int j = 0; j < 64; ++j) Lc[j] = Lb[j * 65 + lane];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < 64; ++j) Lc[j] *= -rdgw;
+    }
+  };
   // x = L_kk^-T w[woff .. woff+64) for diagonal block blk (one wave; lane t holds column t of the block), into xs and alpha
   auto solve_diag = [&](int blk) {
     const int k0 = j0 + 64 * blk;
-    if (rg == 0) {
+    if (SENT ? rg == (blk ? 0 : 1) : rg == 0) {
       const double* Lb = Ld[blk];
-      const double dg = Lb[lane * 65 + lane];
-      const double rdg = (k0 + lane < n) ? 1.0 / dg : 0.0;
       double xout = 0.0;
       if (SENT) {
+        if (!HOIST) preload_diag();
         // the lane carries b / L_ll instead of b: per step readlane -> fma (the multiply by 1 / L_ll left the chain; the scaled column
         // entries L[j][lane] / L_ll do not depend on the right-hand side)
-        // ... and the lane's 64 scaled column entries are in REGISTERS before the chain starts: read inside the loop (as the compiler
-        // scheduled it) every second step waited for an LDS round trip -- 1.7 of the 2.3 us of a 64-entry substitution
-        double Lc[64];
-#pragma unroll
-        for (int j = 0; j < 64; ++j) Lc[j] = Lb[j * 65 + lane];
-        double bs = w[64 * blk + lane] * rdg;
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int j = 0; j < 64; ++j) Lc[j] *= -rdg;
+        double bs = w[64 * blk + lane] * rdgw;
         __builtin_amdgcn_sched_barrier(0);
         int xlo = 0, xhi = 0;
 #pragma unroll
@@ -339,6 +350,8 @@ __global__ __launch_bounds__(256, 2) void backsolve_chain_kernel(BatchView v, in
         }
         xout = __hiloint2double(xhi, xlo);
       } else {
+      const double dg = Lb[lane * 65 + lane];
+      const double rdg = (k0 + lane < n) ? 1.0 / dg : 0.0;
       double b = w[64 * blk + lane];
 #pragma unroll
       for (int j = 63; j >= 0; --j) {
@@ -372,6 +385,7 @@ __global__ __launch_bounds__(256, 2) void backsolve_chain_kernel(BatchView v, in
     __syncthreads();
   };
   __syncthreads();
+  if (HOIST) preload_diag();
   // blocks below the chunk, from the bottom up: chunk cc' = nch-1 .. c+1, each with two 64-row blocks
   if (nch - 1 > c) {
     load_tile(tA, 128 * (nch - 1) + 64);
@@ -678,14 +692,18 @@ void launch_combine_rows(const BatchView& v, const double* M, hipStream_t s) {
   hipLaunchKernelGGL(combine_rows_kernel, dim3((v.LD + 255) / 256, v.nb), dim3(256), 0, s, v, M);
 }
 
-void launch_backsolve_chain(const BatchView& v, int* flags, int epoch, int* status, hipStream_t s) {
+void launch_backsolve_chain(const BatchView& v, int* flags, int epoch, int* status, int n_cu, hipStream_t s) {
   const int nch = (v.n + 127) / 128;
   // MOGP_BS_SPIN: polls before a wait gives up (default 2^20, about a second); 0 makes every unsatisfied wait a timeout,
   // which is how the GPU suite exercises the fallback
   static const int spin_limit = [] { const char* e = getenv("MOGP_BS_SPIN"); return e ? atoi(e) : (1 << 20); }();
   static const int sent = [] { const char* e = getenv("MOGP_BS_SENTINEL"); return e ? atoi(e) : 1; }();
   prof_begin("backsolve", s);
-  if (sent) hipLaunchKernelGGL(backsolve_chain_kernel<true>, dim3(v.nb * nch), dim3(256), 0, s, v, flags, epoch, nch, status, spin_limit);
+  // MOGP_BS_HOIST=0: the chain-bound launches (at most one workgroup per CU) also run the two-per-CU build
+  static const int hoist = [] { const char* e = getenv("MOGP_BS_HOIST"); return e ? atoi(e) : 1; }();
+  if (sent && hoist && v.nb * nch <= n_cu)
+    hipLaunchKernelGGL((backsolve_chain_kernel<true, true>), dim3(v.nb * nch), dim3(256), 0, s, v, flags, epoch, nch, status, spin_limit);
+  else if (sent) hipLaunchKernelGGL(backsolve_chain_kernel<true>, dim3(v.nb * nch), dim3(256), 0, s, v, flags, epoch, nch, status, spin_limit);
   else hipLaunchKernelGGL(backsolve_chain_kernel<false>, dim3(v.nb * nch), dim3(256), 0, s, v, flags, epoch, nch, status, spin_limit);
   prof_end("backsolve", s, 0., (double)v.nb * 4.0 * (double)v.n * (double)v.n);      // algorithmic: the lower triangle of L read once
 }
