@@ -1,18 +1,31 @@
-"""Print the kernel timeline of ONE evaluation from a rocprofv3 --kernel-trace results.db: start (us, relative), duration,
-stream / queue, grid, kernel name.  Usage: timeline.py results.db [index of the cov_build launch to start from] [count]"""
-import sqlite3, sys
-con = sqlite3.connect(sys.argv[1])
-rows = con.execute("select start, end, queue_id, stream_id, grid_x, grid_y, name from kernels order by start").fetchall()
-starts = [i for i, r in enumerate(rows) if "cov_build" in r[6]]
-k = int(sys.argv[2]) if len(sys.argv) > 2 else len(starts) // 2
-cnt = int(sys.argv[3]) if len(sys.argv) > 3 else 200
-i0 = starts[k]
-i1 = starts[k + 1] if k + 1 < len(starts) else len(rows)
-t0 = rows[i0][0]
-busy_end = t0
-for r in rows[i0:min(i1, i0 + cnt)]:
-    gap = (r[0] - busy_end) / 1e3
-    busy_end = max(busy_end, r[1])
-    print("%9.1f us  +%7.1f us  gap %6.1f  q%-3s s%-3s grid %6d x %-4d %s" % ((r[0] - t0) / 1e3, (r[1] - r[0]) / 1e3, gap, r[2], r[3], r[4], r[5],
-                                                                      r[6].replace("mogp::", "").replace("void ", "")[:60]))
-print("evaluation wall (first start to last end): %.1f us" % ((max(r[1] for r in rows[i0:i1]) - t0) / 1e3))
+"""Timeline of one evaluation from a rocprofv3 trace: every kernel and memory copy of the LAST evaluation with its start (relative, us), duration and
+the gap to the previous command.   usage: python tools/timeline.py <dir with *_kernel_trace.csv [and *_memory_copy_trace.csv]> [first kernel name part]"""
+import csv
+import glob
+import os
+import sys
+
+d = sys.argv[1]
+first = sys.argv[2] if len(sys.argv) > 2 else "cov_build"
+rows = []
+for f in glob.glob(os.path.join(d, "**", "*_kernel_trace.csv"), recursive=True):
+    for r in csv.DictReader(open(f)):
+        rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"][:70]))
+for f in glob.glob(os.path.join(d, "**", "*_memory_copy_trace.csv"), recursive=True):
+    for r in csv.DictReader(open(f)):
+        rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), "copy " + r.get("Direction", r.get("Name", ""))))
+rows.sort()
+starts = [i for i, r in enumerate(rows) if first in r[2]]
+if len(starts) < 3:
+    print("no evaluations found", len(rows)); sys.exit(1)
+a, b = starts[-2], starts[-1]
+# commands of the last-but-one evaluation: from shortly before its first kernel to the next evaluation's first kernel
+lo = a
+while lo > 0 and rows[a][0] - rows[lo - 1][1] < 60000:      # commands within 60 us in front of the K build belong to this evaluation
+    lo -= 1
+t0, prev_end = rows[lo][0], None
+for s, e, name in rows[lo:b]:
+    gap = (s - prev_end) / 1e3 if prev_end is not None else 0.0
+    print("%9.1f us  +%7.1f dur  gap %6.1f  %s" % ((s - t0) / 1e3, (e - s) / 1e3, gap, name))
+    prev_end = e
+print("evaluation period (first kernel to first kernel): %.1f us" % ((rows[b][0] - rows[a][0]) / 1e3))
