@@ -128,7 +128,7 @@ class Engine {
   void ensure_linv(const std::vector<int>& ids);
   void ensure_kinv(const std::vector<int>& ids, bool for_gradient = false);
   BatchView view(int nb) const;
-  void build_cov(const BatchView& v);
+  void build_cov(const BatchView& v, const ZeroRanges& zero = ZeroRanges());
   std::vector<char> z_armed;     // per emulator: its solution row holds the sentinel pattern of the one-launch back substitution
   void set_theta(int i, const double* theta);
   void ensure_predict_scratch(int nb, int MC);

@@ -247,8 +247,8 @@ double Engine::nugget_size(int i) const {
 // K build of the slots in dIdx.  With one right-hand side it also presets the solution rows to the all-ones pattern the one-launch
 // back substitution polls for (backsolve_chain_kernel<SENT>); `z_armed` records that, so that a chain launched on a row that has
 // not been preset since its last solve arms it itself instead of reading stale values as "already there".
-void Engine::build_cov(const BatchView& v) {
-  launch_cov_build(v, stream);
+void Engine::build_cov(const BatchView& v, const ZeroRanges& zero) {
+  launch_cov_build(v, stream, zero);
   if (z_armed.size() != (size_t)B) z_armed.assign(B, 0);
   for (int i : idx_on_device) z_armed[i] = (R == 1 && v.Z != nullptr) ? 1 : 0;
 }
@@ -508,9 +508,12 @@ void Engine::factorize_blocked(const std::vector<int>& ids, std::vector<int>& in
       dMcCtrl = dalloc<unsigned>(mc_ctrl_ints);
       dMcPacks = dalloc<double>(mchol_pack_doubles(NP, mc_slots));
     }
-    HIPCK(hipMemsetAsync(dInfo, 0, B * sizeof(int), stream));
-    build_cov(v);
-    launch_mchol(v, dMcCtrl, mchol_ctrl_ints(NP, nb), dMcTable, mc_ntasks, dMcPacks, dInfo, n_cu, stream);
+    // (the info words and the kernel's control words are cleared by the K build: two memset commands less in front of a small fit)
+    ZeroRanges zr;
+    zr.p[0] = reinterpret_cast<unsigned*>(dInfo); zr.n[0] = (unsigned)B;
+    zr.p[1] = dMcCtrl; zr.n[1] = (unsigned)mchol_ctrl_ints(NP, nb);
+    build_cov(v, zr);
+    launch_mchol(v, dMcCtrl, mchol_ctrl_ints(NP, nb), dMcTable, mc_ntasks, dMcPacks, dInfo, n_cu, stream, true);
     if (!defer_info) {
       read_info(info, false);
       unsigned aborted = 0;

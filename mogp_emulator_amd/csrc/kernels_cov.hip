@@ -127,7 +127,9 @@ __device__ __forceinline__ void micro_k(const double* si, const double* sj, cons
 // fused on the diagonal, the targets laid into row n and identity padding beyond.
 // ---------------------------------------------------------------------------------------------
 template <int KT>
-__global__ __launch_bounds__(256) void cov_build_kernel(BatchView v) {
+__global__ __launch_bounds__(256) void cov_build_kernel(BatchView v, ZeroRanges zero) {
+  if (blockIdx.y == 0 && blockIdx.x < 2 && zero.p[blockIdx.x])          // (workgroups (0, 0) and (1, 0): one range each; NP >= 128 gives three tiles)
+    for (unsigned e = threadIdx.x; e < zero.n[blockIdx.x]; e += 256) zero.p[blockIdx.x][e] = 0u;
   extern __shared__ __attribute__((aligned(16))) double sm[];
   __shared__ double etab[256];
   stage_exp_tab(etab);
@@ -668,12 +670,12 @@ __global__ __launch_bounds__(256) void kernel_object_kernel(const double* __rest
     if ((kt) == 0) { CALL(0); } else if ((kt) == 1) { CALL(1); } else { CALL(2); } \
   } while (0)
 
-void launch_cov_build(const BatchView& v, hipStream_t s) {
+void launch_cov_build(const BatchView& v, hipStream_t s, const ZeroRanges& zero) {
   const int nt = v.NP / 64;
   const int ntiles = nt * (nt + 1) / 2;
   const size_t sm = (size_t)128 * v.D * sizeof(double);
   prof_begin("cov_build", s);
-#define CALL(K) hipLaunchKernelGGL((cov_build_kernel<K>), dim3(ntiles, v.nb), dim3(256), sm, s, v)
+#define CALL(K) hipLaunchKernelGGL((cov_build_kernel<K>), dim3(ntiles, v.nb), dim3(256), sm, s, v, zero)
   KT_DISPATCH(v.kernel_type, CALL);
 #undef CALL
   // algorithmic bytes: lower triangle written once (4 n^2) + X read once per emulator

@@ -505,7 +505,7 @@ static double mchol_rho(int nb, int NP) {
 }
 
 void launch_mchol(const BatchView& v, unsigned* ctrl, size_t ctrl_ints, const int* table, int ntasks, double* packs, int* info, int n_cu,
-                  hipStream_t s) {
+                  hipStream_t s, bool ctrl_zeroed) {
   // MOGP_MC_SPIN: polls before a wait gives up (default 2^22: seconds)
   static const int spin_limit = [] { const char* e = getenv("MOGP_MC_SPIN"); return e ? atoi(e) : (1 << 22); }();
   // Workgroups per CU by regime.  rho = (time the matrix cores need at ~45 TFLOP/s) / (length of the dependent chain, ~55 us per block
@@ -527,7 +527,7 @@ void launch_mchol(const BatchView& v, unsigned* ctrl, size_t ctrl_ints, const in
   // MOGP_MC_URG = 0 / 1 / 2: two, four or six row tiles below the diagonal block are chain tasks (pipelined solve, pieces published)
   static const int force_urg = [] { const char* e = getenv("MOGP_MC_URG"); return e ? atoi(e) & 3 : -1; }();
 
-  (void)hipMemsetAsync(ctrl, 0, ctrl_ints * sizeof(unsigned), s);
+  if (!ctrl_zeroed) (void)hipMemsetAsync(ctrl, 0, ctrl_ints * sizeof(unsigned), s);
   const int nq = (v.nb % 8 == 0) ? 8 : 1;
   // one workgroup per CU is enforced through the LDS request: more than half of the 160 KB
   const size_t lds_need = MC_LDS_HDR + std::max<size_t>({(size_t)MC_GEMM_LDS, (size_t)TRSM128L_LDS, (size_t)C128_LDS_PRE_DOUBLES, (size_t)TRSM128T_LDS});

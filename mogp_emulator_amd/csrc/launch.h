@@ -63,7 +63,13 @@ struct BatchView {
 };
 
 // --- covariance build ---------------------------------------------------------------------
-void launch_cov_build(const BatchView& v, hipStream_t s);
+// zero: up to two int ranges the launch also clears (the factorisation's info words, the one-launch Cholesky's control words) -- each was a
+// memset command of its own in front of the kernel that needs it, 9 - 10 us per command on the path of a small fit
+struct ZeroRanges {
+  unsigned* p[2] = {nullptr, nullptr};
+  unsigned n[2] = {0, 0};
+};
+void launch_cov_build(const BatchView& v, hipStream_t s, const ZeroRanges& zero = ZeroRanges());
 // full symmetric K (no nugget) for get_K: out (n,n) for one emulator
 void launch_cov_full(const BatchView& v, int emu, double* out, hipStream_t s);
 // stand-alone kernel objects (bindings.cu:340-361): device buffers x1 (n1, D), x2 (n2, D), P = [exp(theta_d) (D), sigma^2];
@@ -104,8 +110,9 @@ void launch_update_trailing(const BatchView& v, int c0, int k0, int k1, hipStrea
 std::vector<int> mchol_task_table(int NP);
 size_t mchol_ctrl_ints(int NP, int B);
 size_t mchol_pack_doubles(int NP, int B);
+// ctrl_zeroed: the caller has cleared ctrl[0 .. ctrl_ints) on the stream already (launch_cov_build's ZeroRanges)
 void launch_mchol(const BatchView& v, unsigned* ctrl, size_t ctrl_ints, const int* table, int ntasks, double* packs, int* info, int n_cu,
-                  hipStream_t s);
+                  hipStream_t s, bool ctrl_zeroed = false);
 constexpr int MCHOL_ABORTED = -3;     // status reported by launch_logdet for every emulator when ctrl[0] != 0
 
 // res (indexed by emulator, RES_STRIDE doubles each): [0] = 2 sum_{i<n} log L_ii, [1] = info[emu] -- or BACKSOLVE_TIMEOUT when the
