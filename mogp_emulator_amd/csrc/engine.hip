@@ -709,7 +709,7 @@ void Engine::eval(const std::vector<int>& ids, const std::vector<const double*>&
     for (int pass = 0; pass < 2 && !todo.empty(); ++pass) {
       upload_idx(todo);
       BatchView v = view((int)todo.size());
-      bool chained = false;
+      bool chained = false, res_done = false;
       if (want_grad) {
         // gradient path: L^-1 is needed anyway, so K^-1 [t, H] = L^-T Y is one fully parallel gemv with it
         ensure_linv(todo);
@@ -734,14 +734,14 @@ void Engine::eval(const std::vector<int>& ids, const std::vector<const double*>&
             if (!z_armed[i]) HIPCK(hipMemsetAsync(dAlpha + (size_t)i * RA * LD, 0xFF, (size_t)LD * sizeof(double), stream));
             z_armed[i] = 0;                                  // consumed by this solve
           }
-          launch_backsolve_chain(v, dBsFlags, ++bs_epoch, dBsFlags + nfl, n_cu, stream);
+          res_done = launch_backsolve_chain(v, dBsFlags, ++bs_epoch, dBsFlags + nfl, n_cu, stream, dInfo, dRes, mc_used ? dMcCtrl : nullptr);
           chained = true;
         } else {
           launch_backsolve(v, stream);
         }
       }
       // (after the solves: it also collects the status words)
-      launch_logdet(v, dInfo, dRes, stream, chained ? dBsFlags + (size_t)B * ((n + 127) / 128) : nullptr, bs_epoch, mc_used ? dMcCtrl : nullptr);
+      if (!res_done) launch_logdet(v, dInfo, dRes, stream, chained ? dBsFlags + (size_t)B * ((n + 127) / 128) : nullptr, bs_epoch, mc_used ? dMcCtrl : nullptr);
       // status words, log-determinants and Gram matrices come back in ONE copy into pinned host memory
       HIPCK(hipMemcpyAsync(hRes, dRes, (size_t)B * RES_STRIDE * sizeof(double), hipMemcpyDeviceToHost, stream));
       HIPCK(hipStreamSynchronize(stream));

@@ -20,23 +20,24 @@ __device__ __forceinline__ int slot_emu(const int* idx, int z) { return idx ? id
 // everything the host needs after a factorisation in ONE device-to-host copy (three separate copies cost ~20 us each).
 // A back substitution that gave up waiting (backsolve_chain_kernel) is reported as status BACKSOLVE_TIMEOUT -- a code of its
 // own, never confused with a failed factorisation (> 0): the engine repeats the solve of that emulator with the multi-launch path.
-__global__ __launch_bounds__(256) void logdet_kernel(BatchView v, const int* __restrict__ info, double* __restrict__ res,
-                                                     const int* __restrict__ bs_status, int bs_epoch, const unsigned* __restrict__ mc_abort) {
-  __shared__ double red[256];
-  const int emu = slot_emu(v.idx, blockIdx.x);
+// The sums of one emulator by one 256-thread workgroup: res[0] and the Gram matrix (everything but the status word).  Also called by the
+// leftmost chunk of the one-launch back substitution (round 5), which has nothing to do until the chain reaches it: same code, same bits.
+// (RM: right-hand-side rows handled -- RMAX in logdet_kernel, 1 in the back substitution, whose launches have one; an entry's sum does not depend on RM)
+template <int RM>
+__device__ __forceinline__ void logdet_gram_dev(const BatchView& v, int emu, double* __restrict__ res, double* red) {
   const int ld = v.LD, R = v.R;
   const double* A = v.A + (size_t)emu * v.MS;
   double s = 0.;
-  double acc[RMAX * (RMAX + 1) / 2];
+  double acc[RM * (RM + 1) / 2];
 #pragma unroll
-  for (int e = 0; e < RMAX * (RMAX + 1) / 2; ++e) acc[e] = 0.;
+  for (int e = 0; e < RM * (RM + 1) / 2; ++e) acc[e] = 0.;
   for (int i = threadIdx.x; i < v.n; i += 256) {
     s += log(A[(size_t)i * ld + i]);
-    double y[RMAX];
+    double y[RM];
 #pragma unroll
-    for (int r = 0; r < RMAX; ++r) y[r] = (r < R) ? A[(size_t)(v.n + r) * ld + i] : 0.0;
+    for (int r = 0; r < RM; ++r) y[r] = (r < R) ? A[(size_t)(v.n + r) * ld + i] : 0.0;
 #pragma unroll
-    for (int r = 0; r < RMAX; ++r)
+    for (int r = 0; r < RM; ++r)
 #pragma unroll
       for (int c = 0; c <= r; ++c) acc[r * (r + 1) / 2 + c] = __builtin_fma(y[r], y[c], acc[r * (r + 1) / 2 + c]);
   }
@@ -53,15 +54,9 @@ __global__ __launch_bounds__(256) void logdet_kernel(BatchView v, const int* __r
   };
   const double ls = block_sum(s);
   double* out = res + (size_t)emu * RES_STRIDE;
-  if (threadIdx.x == 0) {
-    out[0] = 2.0 * ls;
-    const int st = info[emu];
-    int rep = (st == 0 && bs_status && bs_status[emu] == bs_epoch) ? BACKSOLVE_TIMEOUT : st;
-    if (mc_abort && *mc_abort != 0u) rep = MCHOL_ABORTED;       // the one-launch Cholesky gave up: nothing in A is usable
-    out[1] = (double)rep;
-  }
+  if (threadIdx.x == 0) out[0] = 2.0 * ls;
 #pragma unroll
-  for (int r = 0; r < RMAX; ++r)
+  for (int r = 0; r < RM; ++r)
 #pragma unroll
     for (int c = 0; c <= r; ++c) {
       if (r < R) {                    // uniform
@@ -72,6 +67,19 @@ __global__ __launch_bounds__(256) void logdet_kernel(BatchView v, const int* __r
         }
       }
     }
+}
+
+__global__ __launch_bounds__(256) void logdet_kernel(BatchView v, const int* __restrict__ info, double* __restrict__ res,
+                                                     const int* __restrict__ bs_status, int bs_epoch, const unsigned* __restrict__ mc_abort) {
+  __shared__ double red[256];
+  const int emu = slot_emu(v.idx, blockIdx.x);
+  logdet_gram_dev<RMAX>(v, emu, res, red);
+  if (threadIdx.x == 0) {
+    const int st = info[emu];
+    int rep = (st == 0 && bs_status && bs_status[emu] == bs_epoch) ? BACKSOLVE_TIMEOUT : st;
+    if (mc_abort && *mc_abort != 0u) rep = MCHOL_ABORTED;       // the one-launch Cholesky gave up: nothing in A is usable
+    res[(size_t)emu * RES_STRIDE + 1] = (double)rep;
+  }
 }
 
 // Multi-launch back substitution alpha = L^-T y (several right-hand sides, and the fall-back of the one-launch chain below):
@@ -245,11 +253,13 @@ __device__ __forceinline__ void st_agent(double* p, double x) { __hip_atomic_sto
 // HOIST (launches with at most one workgroup per CU -- the chain-bound ones; needs SENT): see preload_diag below; the one-per-CU build has the
 // registers for it (with two per CU the 128 extra live registers spilled into the solve they were meant to shorten).
 template <bool SENT, bool HOIST = false>
-__global__ __launch_bounds__(256, HOIST ? 1 : 2) void backsolve_chain_kernel(BatchView v, int* __restrict__ flags, int epoch, int nch, int* __restrict__ status, int spin_limit) {
+__global__ __launch_bounds__(256, HOIST ? 1 : 2) void backsolve_chain_kernel(BatchView v, int* __restrict__ flags, int epoch, int nch, int* __restrict__ status, int spin_limit,
+                                                                 const int* __restrict__ info, double* __restrict__ res, const unsigned* __restrict__ mc_abort) {
   __shared__ double Ld[2][64 * 65];        // the two diagonal blocks of this chunk: [row][column], row stride 65
   __shared__ double w[128], xs[128];
   __shared__ v2d part[3][64];
   __shared__ int timed_out;
+  __shared__ double red[256];
   // (dispatch order: every emulator's rightmost chunk first.  Round 5 measured groups of 32 / 16 / 8 / 4 / 1 emulators, each with all its chunks
   // before the next group's, for launches with more workgroups than the GPU holds -- 64 x 16 on 512 slots, where the leftmost chunks,
   // which stream the most rows of L, become resident last: level, profiles/r05_backsolve_order_ab.txt)
@@ -361,6 +371,7 @@ __global__ __launch_bounds__(256, HOIST ? 1 : 2) void backsolve_chain_kernel(Bat
       }
       }
       xs[64 * blk + lane] = xout;
+      if (SENT && xout != xout) timed_out = 1;                                       // (a timed-out chunk to the right, or garbage)
       if (SENT && __double_as_longlong(xout) == -1ll) xout = __builtin_nan("");      // (only garbage can be the "not there yet" pattern)
       st_agent(alpha + k0 + lane, xout);
     }
@@ -378,7 +389,7 @@ __global__ __launch_bounds__(256, HOIST ? 1 : 2) void backsolve_chain_kernel(Bat
       }
       if (__double_as_longlong(x) == -1ll) {
         timed_out = 1;
-        x = 0.0;
+        x = __builtin_nan("");             // (not the pattern; poisons every chunk to the left, so that the leftmost one -- which reports -- sees it)
       }
       xs[t] = x;
     }
@@ -386,6 +397,9 @@ __global__ __launch_bounds__(256, HOIST ? 1 : 2) void backsolve_chain_kernel(Bat
   };
   __syncthreads();
   if (HOIST) preload_diag();
+  // res != nullptr (round 5): the leftmost chunk -- last in the chain, idle until it is reached -- also forms the emulator's log-determinant and
+  // Gram entry (the work of logdet_kernel: one launch and its 6 us gap less per evaluation) and, at its end, the status word
+  if (SENT && res && c == 0) logdet_gram_dev<1>(v, emu, res, red);
   // blocks below the chunk, from the bottom up: chunk cc' = nch-1 .. c+1, each with two 64-row blocks
   if (nch - 1 > c) {
     load_tile(tA, 128 * (nch - 1) + 64);
@@ -425,6 +439,13 @@ __global__ __launch_bounds__(256, HOIST ? 1 : 2) void backsolve_chain_kernel(Bat
   solve_diag(0);
   if (SENT) {                                  // (the stores of solve_diag are the publication)
     if (t == 0 && timed_out) __hip_atomic_store(status + emu, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (res && c == 0 && t == 0) {
+      // every chunk's result enters this one's: a wait that gave up anywhere in the chain has arrived here as NaN
+      const int st = info[emu];
+      int rep = (st == 0 && timed_out) ? BACKSOLVE_TIMEOUT : st;
+      if (mc_abort && *mc_abort != 0u) rep = MCHOL_ABORTED;
+      res[(size_t)emu * RES_STRIDE + 1] = (double)rep;
+    }
     return;
   }
   // publish: payload drained, then the flag
@@ -692,7 +713,7 @@ void launch_combine_rows(const BatchView& v, const double* M, hipStream_t s) {
   hipLaunchKernelGGL(combine_rows_kernel, dim3((v.LD + 255) / 256, v.nb), dim3(256), 0, s, v, M);
 }
 
-void launch_backsolve_chain(const BatchView& v, int* flags, int epoch, int* status, int n_cu, hipStream_t s) {
+bool launch_backsolve_chain(const BatchView& v, int* flags, int epoch, int* status, int n_cu, hipStream_t s, const int* info, double* res, const unsigned* mc_abort) {
   const int nch = (v.n + 127) / 128;
   // MOGP_BS_SPIN: polls before a wait gives up (default 2^20, about a second); 0 makes every unsatisfied wait a timeout,
   // which is how the GPU suite exercises the fallback
@@ -701,11 +722,16 @@ void launch_backsolve_chain(const BatchView& v, int* flags, int epoch, int* stat
   prof_begin("backsolve", s);
   // MOGP_BS_HOIST=0: the chain-bound launches (at most one workgroup per CU) also run the two-per-CU build
   static const int hoist = [] { const char* e = getenv("MOGP_BS_HOIST"); return e ? atoi(e) : 1; }();
+  // MOGP_BS_LOGDET=0: log-determinant and status by logdet_kernel behind the chain, as before round 5
+  static const int fuse = [] { const char* e = getenv("MOGP_BS_LOGDET"); return e ? atoi(e) : 1; }();
+  // (chain-bound launches only: with more workgroups than CUs the leftmost chunks, which stream the most rows of L, are the launch's stragglers)
+  double* r = (sent && fuse && v.R == 1 && v.nb * nch <= n_cu) ? res : nullptr;
   if (sent && hoist && v.nb * nch <= n_cu)
-    hipLaunchKernelGGL((backsolve_chain_kernel<true, true>), dim3(v.nb * nch), dim3(256), 0, s, v, flags, epoch, nch, status, spin_limit);
-  else if (sent) hipLaunchKernelGGL(backsolve_chain_kernel<true>, dim3(v.nb * nch), dim3(256), 0, s, v, flags, epoch, nch, status, spin_limit);
-  else hipLaunchKernelGGL(backsolve_chain_kernel<false>, dim3(v.nb * nch), dim3(256), 0, s, v, flags, epoch, nch, status, spin_limit);
+    hipLaunchKernelGGL((backsolve_chain_kernel<true, true>), dim3(v.nb * nch), dim3(256), 0, s, v, flags, epoch, nch, status, spin_limit, info, r, mc_abort);
+  else if (sent) hipLaunchKernelGGL(backsolve_chain_kernel<true>, dim3(v.nb * nch), dim3(256), 0, s, v, flags, epoch, nch, status, spin_limit, info, r, mc_abort);
+  else hipLaunchKernelGGL(backsolve_chain_kernel<false>, dim3(v.nb * nch), dim3(256), 0, s, v, flags, epoch, nch, status, spin_limit, info, r, mc_abort);
   prof_end("backsolve", s, 0., (double)v.nb * 4.0 * (double)v.n * (double)v.n);      // algorithmic: the lower triangle of L read once
+  return r != nullptr;
 }
 
 void launch_backsolve(const BatchView& v, hipStream_t s) {

@@ -128,7 +128,10 @@ void launch_combine_rows(const BatchView& v, const double* M, hipStream_t s);
 void launch_backsolve(const BatchView& v, hipStream_t s);
 // the same in one launch (R == 1): flags = B * ceil(n/128) ints indexed by emulator, all != epoch on entry; status[emu] = epoch
 // when a wait of that emulator's chain timed out (alpha is then unusable: repeat with launch_backsolve)
-void launch_backsolve_chain(const BatchView& v, int* flags, int epoch, int* status, int n_cu, hipStream_t s);
+// info / res / mc_abort: as launch_logdet's -- the chain's leftmost chunk then writes res (log-determinant, Gram entry, status word) itself;
+// returns whether it does (single right-hand side, sentinel form): the caller launches launch_logdet otherwise.
+bool launch_backsolve_chain(const BatchView& v, int* flags, int epoch, int* status, int n_cu, hipStream_t s, const int* info = nullptr,
+                            double* res = nullptr, const unsigned* mc_abort = nullptr);
 // Pivoted Cholesky with LAPACK dpstrf semantics (nugget="pivot", linalg/cholesky.py:284-327), see kernels_pivot.hip.
 // A (K without nugget, and the right-hand-side rows) is factored in place with symmetric row/column interchanges:
 //   begin -> { panel(k0, 64 columns) -> rank-64 update of everything to its right } ... -> tail -> end
