@@ -229,6 +229,10 @@ int mogp_profile_get(const char* kernel_tag, double* total_ms, long long* launch
    `capacity` entries, returns the number of tasks.  Host-only (no device needed): the CPU suite checks that the order is
    topological, which is what the kernel's forward-progress argument rests on. */
 int mogp_mchol_task_table(int n_plus_rhs, int* out, int capacity);
+/* The order launches with enough workgroups per queue use (kernels_mchol.hip, mchol_task_table): the same tasks, the band tasks of an
+   iteration -- entries with bit 29 set; the block column is bits 15..28 -- listed directly in front of the diagonal block they wait for, at
+   most 6 places ahead of it with only such entries in between.  The CPU suite checks exactly that bound. */
+int mogp_mchol_task_table_ahead(int n_plus_rhs, int* out, int capacity);
 /* process-wide diagnostic counters: "backsolve_timeouts" = back substitutions that were repeated with the multi-launch
    path because a wait of the one-launch chain timed out (0 in normal operation); "mchol_aborts" = factorisations the
    one-launch Cholesky gave up on and a multi-launch schedule repeated (0 in normal operation); "objective_evals" / "gradient_evals" =

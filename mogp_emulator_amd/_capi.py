@@ -130,6 +130,7 @@ SIGNATURES = {
     "mogp_profile_get": (c_int, [c_char_p, c_double_p, POINTER(c_longlong), c_double_p, c_double_p]),
     "mogp_profile_counter": (c_int, [c_char_p, POINTER(c_longlong)]),
     "mogp_mchol_task_table": (c_int, [c_int, c_int_p, c_int]),
+    "mogp_mchol_task_table_ahead": (c_int, [c_int, c_int_p, c_int]),
     "mogp_dev_malloc": (c_void_p, [c_ulonglong]),
     "mogp_dev_free": (c_int, [c_void_p]),
     "mogp_dev_upload": (c_int, [c_void_p, c_void_p, c_ulonglong]),

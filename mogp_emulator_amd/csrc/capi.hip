@@ -619,14 +619,16 @@ int mogp_profile_schedule(int schedule, int single_stream) {
   schedule_override().single_stream = single_stream != 0;
   return 0;
 }
-int mogp_mchol_task_table(int n_plus_rhs, int* out, int capacity) {
+static int task_table_out(int n_plus_rhs, bool ahead, int* out, int capacity) {
   // host-only: the per-emulator task order of the one-launch Cholesky for a matrix of NP = roundup(n_plus_rhs, 128) rows
   const int NP = (n_plus_rhs + TILE - 1) / TILE * TILE;
-  const std::vector<int> tb = mchol_task_table(NP);
+  const std::vector<int> tb = mchol_task_table(NP, ahead);
   if (out)
     for (int i = 0; i < (int)tb.size() && i < capacity; ++i) out[i] = tb[i];
   return (int)tb.size();
 }
+int mogp_mchol_task_table(int n_plus_rhs, int* out, int capacity) { return task_table_out(n_plus_rhs, false, out, capacity); }
+int mogp_mchol_task_table_ahead(int n_plus_rhs, int* out, int capacity) { return task_table_out(n_plus_rhs, true, out, capacity); }
 int mogp_profile_counter(const char* name, long long* out) {
   const long long v = prof_counter(name);
   if (v < 0 || !out) {

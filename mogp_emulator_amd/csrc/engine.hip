@@ -489,8 +489,10 @@ void Engine::factorize_blocked(const std::vector<int>& ids, std::vector<int>& in
   if (schedule == 4) {
     // ONE LAUNCH: persistent workgroups take the tasks of all block columns from a dependency-ordered queue (kernels_mchol.hip)
     if (!dMcTable) {
-      const std::vector<int> tb = mchol_task_table(NP);
+      std::vector<int> tb = mchol_task_table(NP);
+      const std::vector<int> ta = mchol_task_table(NP, true);
       mc_ntasks = (int)tb.size();
+      tb.insert(tb.end(), ta.begin(), ta.end());              // [in-order | band-ahead]: launch_mchol picks
       dMcTable = dalloc<int>(tb.size());
       HIPCK(hipMemcpy(dMcTable, tb.data(), tb.size() * sizeof(int), hipMemcpyHostToDevice));
     }

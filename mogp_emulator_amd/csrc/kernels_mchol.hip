@@ -35,6 +35,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <utility>
 #include <vector>
 #define MOGP_OPAQUE_TID 1
 #include "launch.h"
@@ -50,6 +51,7 @@ constexpr int MC_LINE = 32;                       // ints per 128-byte line
 constexpr int MC_ABORT = 0, MC_TIMEOUTS = 1;      // ctrl[0], ctrl[1]
 constexpr int MC_HEADS = MC_LINE;                 // queue head q at ctrl[MC_HEADS + q * MC_LINE]
 constexpr int MC_EMU0 = MC_LINE * 9;              // per-emulator blocks start here
+constexpr int MC_AHEAD_BIT = 1 << 29;              // task word: listed in front of the diagonal block it waits for (mchol_task_table)
 constexpr int MC_PD = 4;                          // 16-column pieces a GEMM task consumes per call of its main loop (and the steps its global loads run ahead)
 constexpr int MC_LDS_HDR = 4;                     // doubles in front of the operand buffers: [task / ok words]
 
@@ -192,7 +194,8 @@ __global__ __launch_bounds__(256, SOLO ? 1 : 2) void mchol_kernel(BatchView v, u
       const int z = zl * nq + q;
       const int emu = __builtin_amdgcn_readfirstlane(v.idx ? v.idx[z] : z);
       const int word = table[p];
-      const int type = (word >> 30) & 3, c = (word >> 15) & 0x7fff, r = word & 0x7fff;
+      const int type = (word >> 30) & 3, c = (word >> 15) & 0x3fff, r = word & 0x7fff;
+      const bool listed_ahead = (word & MC_AHEAD_BIT) != 0;     // (stands in front of the D it waits for: draws no ticket while it waits)
       double* A = v.A + (size_t)emu * v.MS;
       unsigned* rowdone = ctrl + MC_EMU0 + (size_t)z * emu_stride;      // control rows and packs belong to the batch SLOT z of this launch
       unsigned* diagcnt = rowdone + K2;
@@ -349,7 +352,7 @@ __global__ __launch_bounds__(256, SOLO ? 1 : 2) void mchol_kernel(BatchView v, u
           }
         }
         mc_stamp<TRACE>(tr, 3);
-        draw_next();
+        if (!listed_ahead) draw_next();
         if (!urgent) {
           // bulk task, round 4: the tile is re-dealt to the solving waves through LDS BEFORE the solve (trsm128_tile2_dev); the first
           // pack images are requested before the C tile is read
@@ -465,32 +468,53 @@ __global__ __launch_bounds__(256, SOLO ? 1 : 2) void mchol_kernel(BatchView v, u
 // Round 5 measured other orders for the LAST block columns, where a launch has fewer tasks than workgroups and ends on the row band 2c+6, 2c+7
 // (per-task stamps: the last tickets of 64 x n=2000 are drawn at 3.5 ms of 3.7): that band at the front of its iteration, or directly behind
 // the chain pair: level; the G tasks in front of D(c+1): 2 % slower (profiles/r05_task_order_ab.txt).
-std::vector<int> mchol_task_table(int NP) {
+// ahead (round 5): the BAND tasks of an iteration -- the chain pair T(2c+4, c+1), T(2c+5, c+1), the pair below it T(2c+6, c+1), T(2c+7, c+1) and
+// that pair's tasks of the column before, T(2c+6, c), T(2c+7, c) -- are listed at the END of iteration c-1, directly IN FRONT of the diagonal
+// block D(c+1) four of them wait for, and carry MC_AHEAD_BIT.  Drawn a few tickets earlier, they have more of their long-K GEMM behind them
+// when that block finishes (8 x n=2000 0.689 -> 0.670 ms, 16 x 1.126 -> 1.078, one matrix 0.451 -> 0.445).  This is a BOUNDED exception to
+// "every task only depends on smaller numbers": a flagged task may wait for the D listed at most 6 places behind it, with only flagged tasks
+// in between.  Forward progress then needs (a) that a flagged task holds no drawn-ahead ticket while it waits (the kernel draws its next
+// number only when it is done: that ticket could be the very D it waits for), and (b) more workgroups per queue than the 7 tickets per
+// emulator that can be waiting in front of one D: launch_mchol uses the in-order table otherwise.
+std::vector<int> mchol_task_table(int NP, bool ahead) {
   const int K = NP / 128, K2 = NP / 64;
   auto word = [](int type, int c, int r) { return (int)(((unsigned)type << 30) | ((unsigned)c << 15) | (unsigned)r); };
-  std::vector<int> tb;
-  auto T = [&](int r, int c) {
-    if (c < K && r < K2 && r >= 2 * c + 2) tb.push_back(word(2, c, r));
+  std::vector<std::pair<long, int>> keyed;
+  const long M = 4L * K2 + 64;                       // keys per iteration
+  long slot = 0;
+  int iter = -1;
+  auto put = [&](int w, bool band) {
+    const bool moved = band && ahead && iter >= 1;
+    keyed.push_back({(long)((moved ? iter - 1 : iter) + 1) * M + (moved ? M / 2 : 0) + slot, moved ? (w | MC_AHEAD_BIT) : w});
+    ++slot;
   };
-  tb.push_back(word(0, 0, 0));
-  T(2, 0);
-  T(3, 0);
-  T(4, 0);
-  T(5, 0);
+  auto T = [&](int r, int c, bool band) {
+    if (c < K && r < K2 && r >= 2 * c + 2) put(word(2, c, r), band);
+  };
+  put(word(0, 0, 0), false);
+  T(2, 0, false);
+  T(3, 0, false);
+  T(4, 0, false);
+  T(5, 0, false);
   for (int c = 0; c < K; ++c) {
-    if (c + 1 < K) tb.push_back(word(0, c + 1, 0));
-    T(2 * c + 4, c + 1);
-    T(2 * c + 5, c + 1);
+    iter = c;
+    slot = 0;
+    if (c + 1 < K) put(word(0, c + 1, 0), false);
+    T(2 * c + 4, c + 1, true);
+    T(2 * c + 5, c + 1, true);
     // (three 64 x 64 G tasks per diagonal block; round 5 measured the tiles (1,0), (1,1) as ONE 64 x 128 task for throughput-bound launches:
     // level and bit-identical, profiles/r05_wide_g_ab.txt -- not kept)
     if (c + 2 < K)
-      for (int sub = 0; sub < 3; ++sub) tb.push_back(word(1, c + 2, sub));
-    T(2 * c + 6, c);
-    T(2 * c + 7, c);
-    T(2 * c + 6, c + 1);
-    T(2 * c + 7, c + 1);
-    for (int r = 2 * c + 8; r < K2; ++r) T(r, c);
+      for (int sub = 0; sub < 3; ++sub) put(word(1, c + 2, sub), false);
+    T(2 * c + 6, c, true);
+    T(2 * c + 7, c, true);
+    T(2 * c + 6, c + 1, true);
+    T(2 * c + 7, c + 1, true);
+    for (int r = 2 * c + 8; r < K2; ++r) T(r, c, false);
   }
+  std::stable_sort(keyed.begin(), keyed.end(), [](const std::pair<long, int>& a, const std::pair<long, int>& b) { return a.first < b.first; });
+  std::vector<int> tb;
+  for (auto& kw : keyed) tb.push_back(kw.second);
   return tb;
 }
 
@@ -504,7 +528,7 @@ static double mchol_rho(int nb, int NP) {
   return ((double)nb * npd * npd * npd / 3.0 / 45e12) / ((npd / 128.0) * 55e-6);
 }
 
-void launch_mchol(const BatchView& v, unsigned* ctrl, size_t ctrl_ints, const int* table, int ntasks, double* packs, int* info, int n_cu,
+void launch_mchol(const BatchView& v, unsigned* ctrl, size_t ctrl_ints, const int* tables, int ntasks, double* packs, int* info, int n_cu,
                   hipStream_t s, bool ctrl_zeroed) {
   // MOGP_MC_SPIN: polls before a wait gives up (default 2^22: seconds)
   static const int spin_limit = [] { const char* e = getenv("MOGP_MC_SPIN"); return e ? atoi(e) : (1 << 22); }();
@@ -534,6 +558,13 @@ void launch_mchol(const BatchView& v, unsigned* ctrl, size_t ctrl_ints, const in
   const size_t lds_doubles = per_cu == 1 ? std::max<size_t>(lds_need, 10 * 1024 + 64) : lds_need;
   const int total = ntasks * v.nb;
   const int grid = std::min(per_cu * n_cu, total);
+  // the band-ahead order (mchol_task_table) needs more workgroups per queue than tickets that can wait in front of one diagonal block;
+  // MOGP_MC_AHEAD=0: always the in-order table
+  static const bool ahead_on = [] { const char* e = getenv("MOGP_MC_AHEAD"); return !e || atoi(e) != 0; }();
+  // (measured, mchol ms in-order / band-ahead: 4 x n=2000 0.485 / 0.477, 8 x 0.700 / 0.676, 12 x 0.923 / 0.905, 16 x 1.122 / 1.106, 24 x 1.556 / 1.534,
+  // 32 x level, 64 x 3.69 / 3.77, one matrix 0.460 / 0.463, n=5000 and n=16000 level: profiles/r05_band_ahead_ab.txt -- so: 0.2 <= rho < 2)
+  const bool ahead = ahead_on && rho >= 0.2 && rho < 2.0 && 8 * (v.nb / nq) <= grid / nq;
+  const int* table = tables + (ahead ? ntasks : 0);
   // MOGP_MC_TRACE=<file>: per-task time stamps of EVERY launch are appended to the file (analysis only: synchronises)
   static const char* trace_file = getenv("MOGP_MC_TRACE");
   const size_t words = (size_t)total * MC_TRW;

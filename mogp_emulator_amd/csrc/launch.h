@@ -107,11 +107,12 @@ void launch_update_trailing(const BatchView& v, int c0, int k0, int k1, hipStrea
 // != 0 afterwards = a wait timed out and the factors are unusable: factorise again with a multi-launch schedule); packs:
 // mchol_pack_doubles(NP, B) doubles (one diagonal-block pack per emulator and block column); info as launch_panel128.
 // The matrix of one emulator must be smaller than 4 GB (write-through stores go through a buffer descriptor).
-std::vector<int> mchol_task_table(int NP);
+std::vector<int> mchol_task_table(int NP, bool ahead = false);
 size_t mchol_ctrl_ints(int NP, int B);
 size_t mchol_pack_doubles(int NP, int B);
 // ctrl_zeroed: the caller has cleared ctrl[0 .. ctrl_ints) on the stream already (launch_cov_build's ZeroRanges)
-void launch_mchol(const BatchView& v, unsigned* ctrl, size_t ctrl_ints, const int* table, int ntasks, double* packs, int* info, int n_cu,
+// tables: the in-order table, then the band-ahead one (mchol_task_table(NP, true)), ntasks entries each
+void launch_mchol(const BatchView& v, unsigned* ctrl, size_t ctrl_ints, const int* tables, int ntasks, double* packs, int* info, int n_cu,
                   hipStream_t s, bool ctrl_zeroed = false);
 constexpr int MCHOL_ABORTED = -3;     // status reported by launch_logdet for every emulator when ctrl[0] != 0
 

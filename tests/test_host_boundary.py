@@ -285,28 +285,36 @@ def test_native_meanpriors_prior_dists_and_sample():
     assert len(pri.sample()) == 2 + 1 + 1                               # mean parameters first (gppriors.hpp:458-471)
 
 
+@pytest.mark.parametrize("ahead", [False, True], ids=["in-order", "band-ahead"])
 @pytest.mark.parametrize("n", [1, 100, 128, 129, 300, 640, 2000, 5000, 16000])
-def test_one_launch_cholesky_task_order_is_topological(n):
+def test_one_launch_cholesky_task_order_is_topological(n, ahead):
     """The forward-progress argument of the one-launch Cholesky (csrc/kernels_mchol.hip) rests on ONE property of its task table:
     every task only depends on tasks with a smaller number.  Replay the dependency rules of the kernel against the tables the
     library builds (host-only entry points, no device needed):
       D(c)     needs G(0, c), G(1, c), G(2, c) (c >= 2) and the row tiles 2c, 2c+1 of column c-1 (c >= 1)
       G(s, c)  (lower 64 x 64 tile (ti, tj) = (0,0), (1,0), (1,1) of the diagonal block) needs the row tiles 2c+ti, 2c+tj of every column k <= c-2
       T(r, c)  needs D(c) and the row tiles r, 2c, 2c+1 of every column k <= c-1
-    and check that every tile of the lower block triangle is produced exactly once."""
+    and check that every tile of the lower block triangle is produced exactly once.
+    The band-ahead table (round 5) has ONE bounded exception, and only for entries that carry bit 29: such a T task may stand in front of
+    its D(c) -- at most 6 places, with nothing but flagged entries in between (the launcher's condition for using the table, more
+    workgroups per queue than 7 tickets per emulator, and the kernel's "a flagged task draws no ticket while it waits" rest on this)."""
     import ctypes
     lib = _capi.load()
-    fn = lib.mogp_mchol_task_table
+    fn = lib.mogp_mchol_task_table_ahead if ahead else lib.mogp_mchol_task_table
     cnt = fn(n + 1, None, 0)
     buf = (ctypes.c_int * cnt)()
     assert fn(n + 1, buf, cnt) == cnt
     NP = (n + 1 + 127) // 128 * 128
     K, K2 = NP // 128, NP // 64
     pos = {}
+    flagged = set()
     tile = {}                                   # (row tile, column) -> position of the task that produces it
     for p, w in enumerate(buf):
         w &= 0xffffffff
-        t, c, r = (w >> 30) & 3, (w >> 15) & 0x7fff, w & 0x7fff
+        t, c, r = (w >> 30) & 3, (w >> 15) & 0x3fff, w & 0x7fff
+        if (w >> 29) & 1:
+            assert ahead and t == 2
+            flagged.add(p)
         key = (t, c, r if t else 0)
         assert key not in pos, "task listed twice: %r" % (key,)
         pos[key] = p
@@ -334,6 +342,9 @@ def test_one_launch_cholesky_task_order_is_topological(n):
                 need_tiles += [(rr, k) for rr in rows]
             deps.append((0, c, 0))
         for d in deps:
+            if t == 2 and p in flagged and d in pos and pos[d] > p:
+                assert pos[d] - p <= 6 and all(q in flagged for q in range(p + 1, pos[d])), "flagged task %r at %d, its D at %d" % ((t, c, r), p, pos[d])
+                continue
             assert d in pos and pos[d] < p, "task %r (position %d) depends on %r (position %s)" % ((t, c, r), p, d, pos.get(d))
         for d in need_tiles:
             assert d in tile and tile[d] < p, "task %r (position %d) needs tile %r (position %s)" % ((t, c, r), p, d, tile.get(d))

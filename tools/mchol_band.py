@@ -13,7 +13,7 @@ j0, j1 = (int(sys.argv[3]) if len(sys.argv) > 3 else 6), (int(sys.argv[4]) if le
 t0 = int(tr[:, :, 0][tr[:, :, 0] > 0].min())
 us = lambda x: (int(x) - t0) / 100.0 if x else -1.0
 w = tr[0, :, 7] & 0xffffffff
-typ, col, row = (w >> 30) & 3, (w >> 15) & 0x7fff, w & 0x7fff
+typ, col, row = (w >> 30) & 3, (w >> 15) & 0x3fff, w & 0x7fff
 pos = {(int(typ[p]), int(col[p]), int(row[p]) if typ[p] else 0): p for p in range(ntasks)}
 K = NP // 128
 for j in range(j0, j1 + 1):

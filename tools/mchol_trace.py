@@ -23,7 +23,7 @@ us = lambda x: (int(x) - t0) / 100.0          # 100 MHz
 total_us = (tend - t0) / 100.0
 print("# %d launches in file; launch %d: nb=%d NP=%d tasks/emulator=%d grid=%d; kernel %.1f us" % (len(launches), which, nb, NP, ntasks, grid, total_us))
 w = tr[0, :, 7] & 0xffffffff
-typ, col, row = (w >> 30) & 3, (w >> 15) & 0x7fff, w & 0x7fff
+typ, col, row = (w >> 30) & 3, (w >> 15) & 0x3fff, w & 0x7fff
 tasks = {}
 for p in range(ntasks):
     tasks[(int(typ[p]), int(col[p]), int(row[p]) if typ[p] else 0)] = tr[slot, p]
