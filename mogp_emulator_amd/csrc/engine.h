@@ -162,7 +162,7 @@ class Engine {
   std::map<int, double*> w2;     // emulator -> (n - rank) x LD rows of L^-1 of the skipped pivots (gradient path)
   void drop_w2(int i);
   std::vector<double> hH;        // q x n design-matrix columns      // packed transposed diagonal block + reciprocal diagonal (potf2 -> trsm)
-  std::vector<double> hP;
+  double* hP = nullptr;          // pinned host copy of the parameter blocks (B * PS doubles)
   // predict scratch
   double *dXs = nullptr, *dKs = nullptr, *dMean = nullptr, *dVar = nullptr, *dVarPartial = nullptr, *dDeriv = nullptr;
   size_t capXs = 0, capKs = 0, capMean = 0, capVar = 0, capVarPartial = 0, capDeriv = 0;

@@ -207,7 +207,9 @@ Engine::Engine(const double* X, int n_, int D_, const double* targets, int B_, u
   dInfo = dalloc<int>(B);
   dIdx = dalloc<int>(B);
   dLpack = dalloc<double>((size_t)B * lpack128_doubles_per_emulator());
-  hP.assign((size_t)B * PS, 0.);
+  // (pinned: the parameter block goes up in front of every evaluation, and an asynchronous copy from pageable memory is staged by the runtime)
+  HIPCK(hipHostMalloc(reinterpret_cast<void**>(&hP), (size_t)B * PS * sizeof(double), hipHostMallocDefault));
+  std::fill(hP, hP + (size_t)B * PS, 0.);
   HIPCK(hipMemcpy(dX, hX.data(), hX.size() * sizeof(double), hipMemcpyHostToDevice));
   // residual targets for parameter-free means are fixed once
   std::vector<double> res(hT);
@@ -224,6 +226,7 @@ Engine::~Engine() {
                   (void*)dPerm, (void*)dRank, (void*)dMeanFin, (void*)dMeanAux})
     if (p) hipFree(p);
   if (hRes) hipHostFree(hRes);
+  if (hP) hipHostFree(hP);
   if (dBsFlags) hipFree(dBsFlags);
   for (void* p : {(void*)dMcTable, (void*)dMcCtrl, (void*)dMcPacks})
     if (p) hipFree(p);
@@ -305,12 +308,12 @@ void Engine::set_theta(int i, const double* theta) {
 void Engine::upload_params(const std::vector<int>& ids) {
   for (int i : ids) {
     const GPState& g = gp[i];
-    double* p = hP.data() + (size_t)i * PS;
+    double* p = hP + (size_t)i * PS;
     for (int d = 0; d < D; ++d) p[d] = std::exp(g.data[uniform() ? 0 : d]);
     p[D] = std::exp(g.data[NC]);
     p[D + 1] = g.nugget_used;
   }
-  HIPCK(hipMemcpyAsync(dP, hP.data(), hP.size() * sizeof(double), hipMemcpyHostToDevice, stream));
+  HIPCK(hipMemcpyAsync(dP, hP, (size_t)B * PS * sizeof(double), hipMemcpyHostToDevice, stream));
 }
 
 // Blocked right-looking Cholesky of K + nugget I for the emulators in `ids` (one batched sequence).
