@@ -273,8 +273,32 @@ struct QCfg {
   static constexpr int SMEM_DOUBLES = 3 * STAGE;
 };
 
-// kmask: as in mainloop_pf.
-template <int BM, int BN, int WR, int WC, int G, bool PIN = false>
+// Instruction order of a step for the scheduler (SCHED = 2): one memory operation behind each of the first MFMAs of a half step, so that
+// LDS reads / writes and global loads ISSUE while the matrix pipe works -- left alone the compiler puts the step's 12 reads and 6 writes in
+// front of its first MFMA and waits for all of them there (one wave per SIMD: nobody else fills the pipe meanwhile).
+template <int MASK, int SIZE>
+__device__ __forceinline__ void sched_group() { __builtin_amdgcn_sched_group_barrier(MASK, SIZE, 0); }
+template <int K, int HI, int NR, int NW>
+__device__ __forceinline__ void sched_ops() {        // memory operations K .. HI-1 of a half step: NR LDS reads, NW LDS writes, then global loads
+  if constexpr (K < HI) {
+    if constexpr (K < NR) sched_group<0x100, 1>();
+    else if constexpr (K < NR + NW) sched_group<0x200, 1>();
+    else sched_group<0x020, 1>();
+    sched_ops<K + 1, HI, NR, NW>();
+  }
+}
+template <int M, int NM, int NR, int NW, int NL>
+__device__ __forceinline__ void sched_half() {       // MFMA M of NM, then its share of the NR + NW + NL memory operations
+  if constexpr (M < NM) {
+    sched_group<0x008, 1>();
+    constexpr int TOT = NR + NW + NL;
+    sched_ops<M * TOT / NM, (M + 1) * TOT / NM, NR, NW>();
+    sched_half<M + 1, NM, NR, NW, NL>();
+  }
+}
+
+// kmask: as in mainloop_pf.  SCHED: 0 the compiler's order, 1 the barrier pinned behind the step's last MFMAs, 2 also the interleave above.
+template <int BM, int BN, int WR, int WC, int G, int SCHED = 0>
 __device__ __forceinline__ void mainloop_q(const double* __restrict__ Ag, int lda, const double* __restrict__ Bg, int ldb, int nk,
                                            v4d (&acc)[WCfg<BM, BN, WR, WC>::TI][WCfg<BM, BN, WR, WC>::TJ], double* smem, int kmask = -1) {
   using C = WCfg<BM, BN, WR, WC>;
@@ -348,7 +372,12 @@ __device__ __forceinline__ void mainloop_q(const double* __restrict__ Ag, int ld
       load(u, min(kt + 2 + G, last));
       frag(0, smem + nxt * STAGE, 0);                      // written during step kt - 1: visible since the barrier that ended it
       mfmas(1);
-      if (PIN) __builtin_amdgcn_sched_barrier(0);          // (the scheduler otherwise lifts the barrier -- and its wait for the reads just requested -- above these MFMAs)
+      if (SCHED >= 2) {
+        constexpr int NM = 2 * C::TI * C::TJ, NR = C::TI + C::TJ, NW = C::CHA + C::CHB;
+        sched_half<0, NM, NR, NW, NW>();                   // first half step: frag(1) reads, the stage's writes, the next global loads
+        sched_half<0, NM, NR, 0, 0>();                     // second: the first fragments of the next step
+      }
+      if (SCHED >= 1) __builtin_amdgcn_sched_barrier(0);   // (the scheduler otherwise lifts the barrier -- and its wait for the reads just requested -- above these MFMAs)
       __syncthreads();
       // (tried: the barrier in the MIDDLE of the step, so that every LDS operation in flight at it was issued half a step earlier -- the
       // same times, tools/gemm_loop_probe.hip round 5)

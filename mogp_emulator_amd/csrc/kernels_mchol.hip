@@ -59,13 +59,17 @@ __device__ __forceinline__ unsigned ldu(const unsigned* p) { return __hip_atomic
 __device__ __forceinline__ void stu(unsigned* p, unsigned x) { __hip_atomic_store(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
+#ifndef MOGP_MC_SCHED
+#define MOGP_MC_SCHED 2
+#endif
+constexpr int MC_SCHED = MOGP_MC_SCHED;
 // the GEMM main loop of the tasks (gemm_dev.h): mainloop_q, two global-load steps ahead of its three LDS stages
 // (PIN: the step's barrier stays behind its last MFMAs -- probe 2.13 -> 2.08 us per k-step with two workgroups per CU, 8 x n=2000 0.707 -> 0.693 ms,
 // level elsewhere; profiles/r05_loop_pin_ab.txt)
 template <int BM, int BN>
 __device__ __forceinline__ void MC_GEMM(const double* __restrict__ Ag, int lda, const double* __restrict__ Bg, int ldb, int nk, v4d (&acc)[BM / 32][BN / 32],
                                         double* smem, int kmask) {
-  mainloop_q<BM, BN, 2, 2, 2, true>(Ag, lda, Bg, ldb, nk, acc, smem, kmask);
+  mainloop_q<BM, BN, 2, 2, 2, MC_SCHED>(Ag, lda, Bg, ldb, nk, acc, smem, kmask);
 }
 constexpr size_t MC_GEMM_LDS = QCfg<64, 128>::SMEM_DOUBLES;
 
