@@ -386,6 +386,120 @@ __device__ __forceinline__ void mainloop_q(const double* __restrict__ Ag, int ld
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// mainloop_qt (round 5, the predictive variance): the k-step of mainloop_q -- three swizzled LDS stages, fragments of the next half step requested
+// before the barrier, global loads two steps ahead of their stage, the step's instruction order prescribed (SCHED = 2) -- for a row tile of a
+// LOWER-TRIANGULAR A operand (TRIA of mainloop_w: sub-tile a = i * WR + wr, structurally zero (sub-tile, step) pairs of the diagonal block and
+// padding sub-tiles skipped through consecutive loops with fixed active sets [S, E)).  acc starts at zero.  LDS: QCfg<BM, BN>::SMEM_DOUBLES.
+// ---------------------------------------------------------------------------------------------
+template <int BM, int BN, int WR, int WC>
+__device__ __forceinline__ void mainloop_qt(const double* __restrict__ Ag, int lda, const double* __restrict__ Bg, int ldb, int nk,
+                                            v4d (&acc)[WCfg<BM, BN, WR, WC>::TI][WCfg<BM, BN, WR, WC>::TJ], double* smem, int nk_full, int a_rows) {
+  using C = WCfg<BM, BN, WR, WC>;
+  constexpr int STAGE = QCfg<BM, BN>::STAGE;
+  static_assert(C::TI == 4, "the phase dispatch below is written for four sub-tiles per wave");
+  const int t = mogp_tid(), lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wr = wave / WC, wc = wave % WC;
+  const int fr = lane & 15, fk = lane >> 4;
+#pragma unroll
+  for (int i = 0; i < C::TI; ++i)
+#pragma unroll
+    for (int j = 0; j < C::TJ; ++j) acc[i][j] = (v4d){0., 0., 0., 0.};
+  if (nk <= 0) return;
+  v2d ra[1][C::CHA], rb[1][C::CHB];
+  const unsigned offA = (unsigned)(((t >> 3) * lda + (t & 7) * 2) * (int)sizeof(double));
+  const unsigned offB = (unsigned)(((t >> 3) * ldb + (t & 7) * 2) * (int)sizeof(double));
+  auto load = [&](auto U_, int kt) {
+    constexpr int u = decltype(U_)::value;
+#pragma unroll
+    for (int q = 0; q < C::CHA; ++q)
+      ra[u][q] = *reinterpret_cast<const v2d*>(reinterpret_cast<const char*>(Ag + (size_t)q * (C::NT / 8) * lda + (size_t)kt * BK) + offA);
+#pragma unroll
+    for (int q = 0; q < C::CHB; ++q)
+      rb[u][q] = *reinterpret_cast<const v2d*>(reinterpret_cast<const char*>(Bg + (size_t)q * (C::NT / 8) * ldb + (size_t)kt * BK) + offB);
+  };
+  const int st_off = (t >> 3) * BK + (((t & 7) ^ q_swz((t >> 3) & 15)) << 1);
+  auto store = [&](auto U_, double* st) {
+    constexpr int u = decltype(U_)::value;
+#pragma unroll
+    for (int q = 0; q < C::CHA; ++q) *reinterpret_cast<v2d*>(st + st_off + q * (C::NT / 8) * BK) = ra[u][q];
+#pragma unroll
+    for (int q = 0; q < C::CHB; ++q) *reinterpret_cast<v2d*>(st + BM * BK + st_off + q * (C::NT / 8) * BK) = rb[u][q];
+  };
+  const int fo0 = fr * BK + (((2 * fk) ^ q_swz(fr)) << 1);
+  v2d fa[2][C::TI], fb[2][C::TJ];
+  auto frag = [&](auto SET_, const double* st, int h) {
+    constexpr int set = decltype(SET_)::value;
+    const int fo = fo0 ^ (h << 1);
+#pragma unroll
+    for (int i = 0; i < C::TI; ++i) fa[set][i] = *reinterpret_cast<const v2d*>(st + (i * WR + wr) * 16 * BK + fo);
+#pragma unroll
+    for (int j = 0; j < C::TJ; ++j) fb[set][j] = *reinterpret_cast<const v2d*>(st + BM * BK + (wc * C::TJ + j) * 16 * BK + fo);
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  const int last = nk - 1;
+  load(I0(), 0);
+  store(I0(), smem);
+  load(I0(), min(1, last));
+  store(I0(), smem + STAGE);
+  load(I0(), min(2, last));
+  __syncthreads();
+  frag(I0(), smem, 0);
+  int cur = 0;
+  // one k-step with the sub-tiles [S, E) of this wave; the ONE staging register set holds step kt + 2 (requested a step ago -- with two sets,
+  // two steps ahead as in mainloop_q, the 22 step bodies of the phase dispatch spilled 120 dwords into their loops)
+  auto step = [&](int kt, auto S_, auto E_) {
+    constexpr int S = decltype(S_)::value, E = decltype(E_)::value;
+    const double* st = smem + cur * STAGE;
+    const int nxt = cur == 2 ? 0 : cur + 1, wrt = nxt == 2 ? 0 : nxt + 1;
+    frag(I1(), st, 1);
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+#pragma unroll
+      for (int i = S; i < E; ++i)
+#pragma unroll
+        for (int j = 0; j < C::TJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[0][i][e], fb[0][j][e], acc[i][j], 0, 0, 0);
+    store(I0(), smem + wrt * STAGE);
+    load(I0(), min(kt + 3, last));
+    frag(I0(), smem + nxt * STAGE, 0);
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+#pragma unroll
+      for (int i = S; i < E; ++i)
+#pragma unroll
+        for (int j = 0; j < C::TJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[1][i][e], fb[1][j][e], acc[i][j], 0, 0, 0);
+    if constexpr (E > S) {
+      constexpr int NM = 2 * (E - S) * C::TJ, NR = C::TI + C::TJ, NW = C::CHA + C::CHB;
+      sched_half<0, NM, NR, NW, NW>();
+      sched_half<0, NM, NR, 0, 0>();
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
+    cur = nxt;
+  };
+  int kt = 0;
+  auto run = [&](int end, auto S_, auto E_) {
+    for (; kt < end; ++kt) step(kt, S_, E_);
+  };
+  auto phases = [&](auto E_) {
+    constexpr int E = decltype(E_)::value;
+    if (E > 0) run(min(nk, nk_full + 0 * WR + wr + 1), std::integral_constant<int, 0>(), E_);
+    if (E > 1) run(min(nk, nk_full + 1 * WR + wr + 1), std::integral_constant<int, 1>(), E_);
+    if (E > 2) run(min(nk, nk_full + 2 * WR + wr + 1), std::integral_constant<int, 2>(), E_);
+    if (E > 3) run(min(nk, nk_full + 3 * WR + wr + 1), std::integral_constant<int, 3>(), E_);
+  };
+  int n_act = 0;     // sub-tiles of this wave that contain real rows
+#pragma unroll
+  for (int i = 0; i < C::TI; ++i) n_act += ((i * WR + wr) * 16 < a_rows) ? 1 : 0;
+  if (n_act == 4) phases(std::integral_constant<int, 4>());
+  else if (n_act == 3) phases(std::integral_constant<int, 3>());
+  else if (n_act == 2) phases(std::integral_constant<int, 2>());
+  else if (n_act == 1) phases(std::integral_constant<int, 1>());
+  run(nk, I0(), I0());               // (what is left only moves the wave's share of the operand tiles)
+}
+
 // f(row_in_tile, col_in_tile, value) over the accumulator fragment of mainloop_w
 template <int WC, int TI, int TJ, typename F>
 __device__ __forceinline__ void for_each_acc_w(v4d (&acc)[TI][TJ], F f) {

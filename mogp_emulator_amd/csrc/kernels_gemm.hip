@@ -729,6 +729,60 @@ void launch_trtri_merges(const BatchView& v, hipStream_t s) {
   }
 }
 
+// predict_var_q_kernel (round 5): the same task -- a pair of 128-row tiles of L^-1 against one column tile of K*, column sums of squares -- on
+// the k-step of the one-launch Cholesky's GEMM tasks (mainloop_qt: three swizzled LDS stages, the next fragments requested before the barrier,
+// the step's instruction order prescribed).  256 threads (2 x 2 waves) per 128 x 64 tile, two workgroups per CU: alone in the probe that loop
+// reaches 0.91 of the fp64 MFMA peak with two waves per SIMD, where the 8-wave 128 x 128 form above (four waves per SIMD, 128 registers, two
+// stages, fragments read in front of the MFMAs that need them) stands at 0.83 - 0.85.  Column tiles are 64 points wide: K* is read as often as
+// before (half as wide a panel, twice as many of them), L^-1 twice as often.
+template <bool TRI>
+__global__ __launch_bounds__(256, 2) void predict_var_q_kernel(BatchView v, const double* __restrict__ Ks, int MP, int nti, int ntj,
+                                                               double* __restrict__ partial, int lgc, int single) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  using C = WCfg<128, 64, 2, 2>;
+  const int npairs = single ? nti : (nti + 1) / 2;
+  const int SC = 1 << lgc, SR = 64 >> lgc;           // super-tile = SR pairs x SC column tiles
+  const int nsr = (npairs + SR - 1) / SR, nsc = (ntj + SC - 1) / SC;
+  const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wr = wave / 2, wc = wave % 2;
+  int z, tile;
+  decode_block(v.nb, nsr * nsc * 64, z, tile);
+  if (z >= v.nb) return;
+  const int st = tile >> 6, w = tile & 63;
+  const int pr = (st / nsc) * SR + (w >> lgc), tj = (st % nsc) * SC + (w & (SC - 1));
+  if (pr >= npairs || tj >= ntj) return;
+  const int emu = slot_to_emu(v.idx, z);
+  const int ld = v.LD;
+  const double* Li = v.Linv + (size_t)emu * v.MS;
+  const double* K = Ks + (size_t)z * MP * ld;
+  const int j0 = tj * 64;
+  const int ti_long = nti - 1 - pr, ti_short = single ? ti_long : pr;
+  for (int pass = 0; pass < 2; ++pass) {
+    if (pass == 1 && ti_short == ti_long) break;
+    const int ti = pass == 0 ? ti_long : ti_short;
+    const int i0 = ti * 128;
+    v4d acc[C::TI][C::TJ];
+    const int nk = min(i0 + 128, (v.n + 15) & ~15) / BK;
+    mainloop_qt<128, 64, 2, 2>(Li + (size_t)i0 * ld, ld, K + (size_t)j0 * ld, ld, nk, acc, smem, TRI ? i0 / BK : nk, TRI ? v.n - i0 : 128);
+    // column sums of squares over the tile's 128 rows: red[wr][64]
+    double* red = smem;
+#pragma unroll
+    for (int j = 0; j < C::TJ; ++j) {
+      double s = 0.;
+#pragma unroll
+      for (int i = 0; i < C::TI; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s += acc[i][j][r] * acc[i][j][r];
+      s += __shfl_xor(s, 16);
+      s += __shfl_xor(s, 32);
+      if (lane < 16) red[wr * 64 + wc * 16 * C::TJ + j * 16 + lane] = s;
+    }
+    __syncthreads();
+    if (t < 64) partial[((size_t)z * nti + ti) * MP + j0 + t] = red[t] + red[64 + t];
+    __syncthreads();                 // red aliases the operand buffers of the next pass
+  }
+}
+
 void launch_kinv(const BatchView& v, int n_cu, hipStream_t s) {
   const int kend = ((v.n + 15) / 16) * 16;
   const int nt = (v.n + 127) / 128;      // tiles that contain real rows
@@ -753,7 +807,8 @@ void launch_predict_var(const BatchView& v, const double* Ks, int m, int MP, dou
   // super-tile = 2^lgc column tiles x 64/2^lgc row-tile pairs.  Measured at nti = 16 (8 pairs), m = 5632, L2-miss bytes per launch /
   // TFLOP/s: 8x8 37 GB / 62.3, 4 pairs x 16 44 GB / 61.9, 2 x 32 53 GB / 60.4, 1 x 64 54 GB / 60.4; without the XCD-aware
   // block decode (workgroups of a super-tile spread over all eight L2s) 47 GB but only 52.1 TFLOP/s
-  static const int lgc = [] { const char* e = getenv("MOGP_PV_LGC"); return e ? atoi(e) : 3; }();
+  static const int lgc_env = [] { const char* e = getenv("MOGP_PV_LGC"); return e ? atoi(e) : -1; }();
+  const int lgc = lgc_env >= 0 ? lgc_env : 3;
   // MOGP_PV_SINGLE = 0 / 1 forces pairs / single row tiles; default: single row tiles when the pair tasks fill the device fewer than twice.
   // Measured (predict incl. host copies, m = 10^4, ms, pairs / single): 1 x n=2000 1.080 / 1.031, 2 x 1.82 / 1.84, 3 x 2.44 / 2.50, 4 x 3.05 /
   // 3.27, 1 x n=5000 5.36 / 4.86, 1 x n=700 (m = 3000) 0.213 / 0.187; bit-identical
@@ -763,7 +818,23 @@ void launch_predict_var(const BatchView& v, const double* Ks, int m, int MP, dou
     const int nst = (((nti + 1) / 2 + SR - 1) / SR) * ((ntj + SC - 1) / SC);
     const long pair_tasks = (long)v.nb * ((nti + 1) / 2) * ntj;
     const bool single = force_single >= 0 ? force_single != 0 : pair_tasks < 2L * 2 * n_cu;
-    if (single) {
+    // predict_var_q_kernel for launches of single row tiles (one n = 2000 matrix, 10^4 points: 0.82 -> 0.70 ms); MOGP_PV_Q = 0 / 1 forces either
+    // kernel.  For full launches the two are level -- 64 x n=2000 66.5 / 66.4 TFLOP/s, n=16000 68.2 / 68.2, 16 x n=5000 66.3 / 65.3 -- two kernels
+    // that share nothing but the MFMA instruction end at the same rate: the part is at its power limit there (1.31 kW, 2.28 - 2.30 GHz under
+    // either; profiles/r05_predict_q_ab.txt)
+    static const int force_q = [] { const char* e = getenv("MOGP_PV_Q"); return e ? atoi(e) : -1; }();
+    const bool use_q = force_q >= 0 ? force_q != 0 : single;
+    if (use_q) {
+      // (64-point column tiles: sixteen of them per super-tile -- the 1024 points of eight 128-point tiles -- for single row tiles: one matrix
+      // 52.5 -> 57.1 TFLOP/s; full launches are fastest with eight)
+      const int lgq = lgc_env >= 0 ? lgc_env : (single ? 4 : 3);
+      const int SC = 1 << lgq, SR = 64 >> lgq;
+      const int ntq = MP / 64;
+      constexpr size_t lds_q = (size_t)QCfg<128, 64>::SMEM_DOUBLES * sizeof(double);
+      const int nsq = ((((single ? nti : (nti + 1) / 2)) + SR - 1) / SR) * ((ntq + SC - 1) / SC);
+      hipLaunchKernelGGL((predict_var_q_kernel<true>), dim3(padded_grid(v.nb, nsq * 64)), dim3(256), lds_q, s, v, Ks, MP,
+                         nti, ntq, partial, lgq, single ? 1 : 0);
+    } else if (single) {
       const int nst1 = ((nti + SR - 1) / SR) * ((ntj + SC - 1) / SC);
       hipLaunchKernelGGL((predict_var_w_kernel<2, 4, true>), dim3(padded_grid(v.nb, nst1 * 64)), dim3(512), smem_bytes<4>(), s, v, Ks, MP, nti, ntj, partial, lgc, 1);
     } else
