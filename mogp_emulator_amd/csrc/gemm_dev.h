@@ -372,10 +372,16 @@ __device__ __forceinline__ void mainloop_q(const double* __restrict__ Ag, int ld
       load(u, min(kt + 2 + G, last));
       frag(0, smem + nxt * STAGE, 0);                      // written during step kt - 1: visible since the barrier that ended it
       mfmas(1);
-      if (SCHED >= 2) {
+      if (SCHED == 2) {
         constexpr int NM = 2 * C::TI * C::TJ, NR = C::TI + C::TJ, NW = C::CHA + C::CHB;
         sched_half<0, NM, NR, NW, NW>();                   // first half step: frag(1) reads, the stage's writes, the next global loads
         sched_half<0, NM, NR, 0, 0>();                     // second: the first fragments of the next step
+      }
+      if (SCHED == 3) {                                    // (probe: the next step's fragments early in the second half, two behind each MFMA)
+        constexpr int NM = 2 * C::TI * C::TJ, NR = C::TI + C::TJ, NW = C::CHA + C::CHB;
+        sched_half<0, NM, NR, NW, NW>();
+        sched_half<0, NR / 2, NR, 0, 0>();
+        sched_group<0x008, NM - NR / 2>();
       }
       if (SCHED >= 1) __builtin_amdgcn_sched_barrier(0);   // (the scheduler otherwise lifts the barrier -- and its wait for the reads just requested -- above these MFMAs)
       __syncthreads();

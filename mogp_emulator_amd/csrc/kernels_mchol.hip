@@ -33,6 +33,7 @@
 // of view), so no cache can hold a stale copy and no acquire invalidation is needed; tiles and packs are 128-byte aligned,
 // so no line is shared between tasks.
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <utility>
@@ -60,7 +61,7 @@ __device__ __forceinline__ void stu(unsigned* p, unsigned x) { __hip_atomic_stor
 __device__ __forceinline__ void drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 #ifndef MOGP_MC_SCHED
-#define MOGP_MC_SCHED 2
+#define MOGP_MC_SCHED 3
 #endif
 constexpr int MC_SCHED = MOGP_MC_SCHED;
 // the GEMM main loop of the tasks (gemm_dev.h): mainloop_q, two global-load steps ahead of its three LDS stages
@@ -537,14 +538,19 @@ void launch_mchol(const BatchView& v, unsigned* ctrl, size_t ctrl_ints, const in
   // MOGP_MC_SPIN: polls before a wait gives up (default 2^22: seconds)
   static const int spin_limit = [] { const char* e = getenv("MOGP_MC_SPIN"); return e ? atoi(e) : (1 << 22); }();
   // Workgroups per CU by regime.  rho = (time the matrix cores need at ~45 TFLOP/s) / (length of the dependent chain, ~55 us per block
-  // column).  Chain-bound batches (rho < 1: up to 12 x n=2000, 2 x n=5000) run ONE workgroup per CU, so that a diagonal-block task never
-  // shares its CU's matrix pipes; beyond that two per CU.  Round-5 kernels, mchol ms one / two per CU (profiles/r05_regime_sweep.txt):
-  // 4 x n=2000 0.48 / 0.58, 8 x 0.71 / 0.73, 12 x 0.92 / 0.91 - 0.93, 16 x 1.17 / 1.15, 24 x 1.68 / 1.56, 32 x 2.13 / 1.97, 2 x n=5000 2.10 / 2.14,
-  // 4 x n=5000 3.73 / 3.61.  MOGP_MC_WGS = 1 / 2 forces either.  (Rounds 2 - 4: for 1 <= rho < 2 the workgroup sharing a CU with a
+  // column).  Chain-bound batches run ONE workgroup per CU, so that a diagonal-block task never shares its CU's matrix pipes; beyond that two
+  // per CU.  Before the interleaved k-step the crossover was rho = 1 (mchol ms one / two per CU, profiles/r05_regime_sweep.txt: 4 x n=2000
+  // 0.48 / 0.58, 8 x 0.71 / 0.73, 12 x 0.92 / 0.91 - 0.93, 16 x 1.17 / 1.15, 24 x 1.68 / 1.56, 32 x 2.13 / 1.97, 2 x n=5000 2.10 / 2.14, 4 x n=5000
+  // 3.73 / 3.61); now see below (profiles/r05_regime_sweep2.txt).  MOGP_MC_WGS = 1 / 2 forces either.  (Rounds 2 - 4: for 1 <= rho < 2 the workgroup sharing a CU with a
   // diagonal-block task PARKED, MOGP_MC_PARK; on the round-5 kernels parking is level to 2 % slower in every regime and is gone.)
   static const int force_wgs = [] { const char* e = getenv("MOGP_MC_WGS"); return e ? std::max(1, atoi(e)) : 0; }();
   const double rho = mchol_rho(v.nb, v.NP);
-  const int per_cu = force_wgs ? force_wgs : (rho < 1.0 ? 1 : 2);
+  // (with the interleaved k-step a lone workgroup's GEMM runs at 0.974 us per step, a pair at 1.873 for two: one per CU gives up 4 % of GEMM
+  // throughput and keeps the chain free -- it now wins up to 14 x n=2000 (equal at 16; 20 x 1.34 / 1.29, 32 x 2.04 / 1.94, 64 x 3.96 / 3.66),
+  // up to 4 x n=5000 (3 x 2.65 / 2.86, 4 x 3.43 / 3.58; equal at 6 - 8; 16 x 12.95 / 12.76) and for one n=16000 matrix (24.39 / 24.80): the
+  // threshold grows with the depth of the matrix, whose share of GEMM work it follows)
+  const double K16 = std::max(1.0, (v.NP / 128) / 16.0);
+  const int per_cu = force_wgs ? force_wgs : (rho < 1.2 * std::pow(K16, 0.7) ? 1 : 2);
   // bit 1: MOGP_MC_NOTRAFFIC=1 (measurement only, garbage results): the bulk GEMM tasks re-read their first 64 operand columns -- the traffic A/B;
   // bit 5: MOGP_MC_LATE=0: chain tasks always solve in the pipelined form, also when their diagonal block has already finished
   static const int tile_solve = [] {

@@ -31,6 +31,7 @@ __global__ __launch_bounds__(256, WGS) void loop_kernel(const double* __restrict
     else if (V == 1) mainloop_q<64, 128, 2, 2, 2>(Ap, LD, Bp, LD, nk, acc, smem);
     else if (V == 2) mainloop_q<64, 128, 2, 2, 2, 1>(Ap, LD, Bp, LD, nk, acc, smem);
     else if (V == 4) mainloop_q<64, 128, 2, 2, 2, 2>(Ap, LD, Bp, LD, nk, acc, smem);
+    else if (V == 5) mainloop_q<64, 128, 2, 2, 2, 3>(Ap, LD, Bp, LD, nk, acc, smem);
     else mainloop_pf<64, 128, 2, 2, 2>(Ap, LD, Bp, LD, nk, acc, smem);
     __syncthreads();
   }
@@ -63,7 +64,7 @@ static double run(const double* dM, int nk, int reps, double* dOut, int grid, si
   return best;
 }
 
-constexpr int NV = 5;
+constexpr int NV = 6;
 template <int WGS>
 static double run_v(int v, const double* dM, int nk, int reps, double* dOut, int grid, size_t lds, int write_tile) {
   switch (v) {
@@ -71,6 +72,7 @@ static double run_v(int v, const double* dM, int nk, int reps, double* dOut, int
     case 1: return run<1, WGS>(dM, nk, reps, dOut, grid, lds, write_tile);
     case 2: return run<2, WGS>(dM, nk, reps, dOut, grid, lds, write_tile);
     case 4: return run<4, WGS>(dM, nk, reps, dOut, grid, lds, write_tile);
+    case 5: return run<5, WGS>(dM, nk, reps, dOut, grid, lds, write_tile);
     default: return run<3, WGS>(dM, nk, reps, dOut, grid, lds, write_tile);
   }
 }
@@ -115,7 +117,7 @@ int main(int argc, char** argv) {
       const size_t lds = wgs == 1 ? solo : (v == 0 || v == 3 ? lds_pf : lds_q);
       ms[v] = wgs == 1 ? run_v<1>(v, dM, nk, reps, dOut, grid, lds, 0) : run_v<2>(v, dM, nk, reps, dOut, grid, lds, 0);
     }
-    const char* names[NV] = {"mainloop_pf<..,4>", "mainloop_q<..,2> ", "mainloop_q<..,2,PIN>", "mainloop_pf<..,2>", "mainloop_q<..,2,PIN+interleave>"};
+    const char* names[NV] = {"mainloop_pf<..,4>", "mainloop_q<..,2> ", "mainloop_q<..,2,PIN>", "mainloop_pf<..,2>", "mainloop_q<..,2,PIN+interleave>", "mainloop_q<..,2,interleave, next fragments early>"};
     for (int v = 0; v < NV; ++v) {
       const double us = ms[v] * 1e3 / steps;
       const double tf = (double)grid * steps * 64. * 128. * 16. * 2. / (ms[v] * 1e-3) * 1e-12;
