@@ -386,11 +386,29 @@ __device__ __forceinline__ bool trsm128_tile2_chain_dev(const BatchView& v, int 
     // waited for, on an image requested during block step b - 1 (behind that step's wait); only inv(L_bb) -- fetched straight
     // into the MFMA operand layout, no LDS image, no barrier -- is read behind the wait for piece b.  (Before: the whole image
     // of step b was requested behind the wait: per block step one exposed round trip plus the deposit plus up to 28 MFMAs.)
+    // (round 5: every MFMA of the step is chained on Tb and takes its A operand from an LDS read of its own; left alone the compiler issues
+    // each read in front of its MFMA and waits for it there -- ~100 cycles of LDS latency on top of the MFMA's 64, and a chain task is alone
+    // on its CU's pipes in the launches where it matters.  The four operands of the NEXT quad are now requested before the MFMAs of this one,
+    // pinned by scheduling barriers; X holds -x from here on (the sign on the four values of x_a, not on every operand): same products.)
     v4d_t Tb = T[b];
+    if (b > 0) {
+      double an[4], ac[4];
 #pragma unroll
-    for (int a = 0; a < b; ++a)
+      for (int r = 0; r < 4; ++r) an[r] = img[(g + 4 * r) * 16 + i];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) Tb = __builtin_amdgcn_mfma_f64_16x16x4f64(-img[(16 * a + g + 4 * r) * 16 + i], X[a][r], Tb, 0, 0, 0);
+      for (int a = 0; a < b; ++a) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ac[r] = an[r];
+        if (a + 1 < b) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) an[r] = img[(16 * (a + 1) + g + 4 * r) * 16 + i];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Tb = __builtin_amdgcn_mfma_f64_16x16x4f64(ac[r], X[a][r], Tb, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
     double invr[4];
     if (LATE) {
       const double* inv = img + 112 * 16;
@@ -408,6 +426,7 @@ __device__ __forceinline__ bool trsm128_tile2_chain_dev(const BatchView& v, int 
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int r = 0; r < 4; ++r) ts[i * 18 + g + 4 * r] = X[b][r];
+    X[b] = -X[b];                          // (only an operand of the later steps from here on)
     __builtin_amdgcn_wave_barrier();
     {
       const v2d_p o0 = *reinterpret_cast<const v2d_p*>(ts + sr0 * 18 + sp);
