@@ -360,11 +360,21 @@ __device__ __forceinline__ bool chol128_dev(double* __restrict__ A, int ld, doub
       }
 #pragma unroll
       for (int s = 0; s < 4; ++s) Dn = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[s], a0[s], Dn, 0, 0, 0);
+      // (round 5: the four operands of sub-block row k + 1 are requested before the MFMAs of row k -- the wave-uniform branches below cut the
+      // loop into basic blocks, and inside one the compiler reads, waits, multiplies: the image's latency stood in front of every quad)
+      double an[4];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) an[s] = S[cl * C128_LD + rg + 4 * s];
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
         double ak[4];
 #pragma unroll
-        for (int s = 0; s < 4; ++s) ak[s] = S[(16 * k + cl) * C128_LD + rg + 4 * s];
+        for (int s = 0; s < 4; ++s) ak[s] = an[s];
+        if (k + 1 < 8) {
+#pragma unroll
+          for (int s = 0; s < 4; ++s) an[s] = S[(16 * (k + 1) + cl) * C128_LD + rg + 4 * s];
+        }
+        __builtin_amdgcn_sched_barrier(0);
         // (sub-blocks the wave does not own, k > r, are skipped with wave-uniform branches: 40 instead of 52 MFMAs per chunk)
         if (k < 4 && k <= r1 && r1 > 0) {
 #pragma unroll
