@@ -96,6 +96,14 @@ def watch(name, fn):
 
 
 print("hwmon files:", FILES or "none (rocm-smi)")
+for nm in ("power1_cap", "power1_cap_default", "power1_cap_max"):
+    if "power_uw" in FILES:
+        pth = os.path.join(os.path.dirname(FILES["power_uw"]), nm)
+        if os.path.exists(pth):
+            try:
+                print("%s = %.0f W" % (nm, float(open(pth).read().strip()) * 1e-6))
+            except Exception:
+                pass
 B, n, d, m = 64, 2000, 10, 10000
 X, T, Xs = synth(2, n, d, B, m)
 gp = M.MultiOutputGP_GPU(X, T, nugget=1e-6, priors=GPPriors(n_corr=d, nugget_type="fixed"))
