@@ -175,6 +175,7 @@ __global__ __launch_bounds__(256, SOLO ? 1 : 2) void mchol_kernel(BatchView v, u
   const int home = (int)blockIdx.x & (nq - 1);          // observed: block b runs on XCD b % 8 (for speed only)
   const int emus_q = v.nb / nq;
   const int total = ntasks * emus_q;
+  const int gs = ((tile_solve >> 12) & 0xff) ? ((tile_solve >> 12) & 0xff) : emus_q;
   for (int qi = 0; qi < nq; ++qi) {
     const int q = (home + qi) & (nq - 1);                 // own queue first, then help the others
     unsigned* head = ctrl + MC_HEADS + q * MC_LINE;
@@ -195,7 +196,9 @@ __global__ __launch_bounds__(256, SOLO ? 1 : 2) void mchol_kernel(BatchView v, u
       __syncthreads();
       if (tk >= total) break;
       next_tk = -1;
-      const int p = tk / emus_q, zl = tk - p * emus_q;
+      // tickets: groups of gs emulators of this queue, one group's tasks (interleaved over its emulators) before the next group's
+      const int per = ntasks * gs, grp = tk / per, rem = tk - grp * per;
+      const int p = rem / gs, zl = grp * gs + (rem - p * gs);
       const int z = zl * nq + q;
       const int emu = __builtin_amdgcn_readfirstlane(v.idx ? v.idx[z] : z);
       const int word = table[p];
@@ -579,7 +582,21 @@ void launch_mchol(const BatchView& v, unsigned* ctrl, size_t ctrl_ints, const in
   static const char* trace_file = getenv("MOGP_MC_TRACE");
   const size_t words = (size_t)total * MC_TRW;
   unsigned long long* dtr = nullptr;
-  const int ts = tile_solve | ((force_urg >= 0 ? force_urg : (rho < 1.0 ? 2 : 0)) << 8);
+  // Emulators per ticket GROUP inside a queue (round 5): a queue hands out the tasks of gs of its emulators, interleaved, before the next gs -- the
+  // next group starts in the tail of the one before, and fewer matrices are in flight per XCD.  The smallest divisor of the queue's emulators
+  // that still offers 1.25 x as many row tiles as the queue has workgroups.  mchol ms, all / groups: 64 x n=2000 (8 per queue) 3.54 / 3.47 in
+  // fours (twos 3.61, ones 3.98), 16 x n=5000 (2 per queue) 12.48 / 12.32 in ones; bit-identical.  MOGP_MC_EGRP: 0 = no groups, n = groups of n.
+  static const int egrp = [] { const char* e = getenv("MOGP_MC_EGRP"); return e ? atoi(e) : -1; }();
+  const int emus_q = v.nb / nq, wg_q = std::max(1, grid / nq);
+  int gsz = 0;
+  if (egrp > 0) gsz = (emus_q % egrp == 0) ? egrp : 0;
+  else if (egrp < 0)
+    for (int g = 1; g < emus_q; ++g)
+      if (emus_q % g == 0 && 4 * g * (v.NP / 64) >= 5 * wg_q) {
+        gsz = g;
+        break;
+      }
+  const int ts = tile_solve | ((force_urg >= 0 ? force_urg : (rho < 1.0 ? 2 : 0)) << 8) | (gsz << 12);
   if (trace_file) {
     if (hipMalloc(reinterpret_cast<void**>(&dtr), words * 8) != hipSuccess) {
       dtr = nullptr;                                        // no room for the stamps: factorise untraced, and say so
