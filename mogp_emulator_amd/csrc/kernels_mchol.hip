@@ -590,7 +590,8 @@ void launch_mchol(const BatchView& v, unsigned* ctrl, size_t ctrl_ints, const in
   const int emus_q = v.nb / nq, wg_q = std::max(1, grid / nq);
   int gsz = 0;
   if (egrp > 0) gsz = (emus_q % egrp == 0) ? egrp : 0;
-  else if (egrp < 0)
+  else if (egrp < 0 && v.NP >= 2048)           // (128 x n=1000, sixteen per queue: groups of eight 1.222 against 1.198 ms undivided -- short matrices stay undivided;
+                                               //  96 x n=2000 5.43 -> 5.20, 120 x 6.77 -> 6.40, 32 x n=5000 24.9 -> 24.5)
     for (int g = 1; g < emus_q; ++g)
       if (emus_q % g == 0 && 4 * g * (v.NP / 64) >= 5 * wg_q) {
         gsz = g;
