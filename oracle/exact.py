@@ -36,6 +36,26 @@ def loglike_longdouble(K, T, nb=64):
     return 0.5 * (np.sum(Y * Y, axis=0) + logdet + n * np.log(np.longdouble(2) * np.pi))
 
 
+def min_pivot_longdouble(K):
+    """Smallest pivot d_j = K_jj - sum_k L_jk^2 of the Cholesky factorisation of the fp64 matrix K carried out in 80-bit long double
+    (the pivots of K itself up to ~1e-19 relative: what ANY fp64 factorisation perturbs by its rounding).  Stops at the first
+    non-positive pivot and returns it: K is then not positive definite as a matrix of real numbers.  Used to classify the points of
+    the adaptive-nugget sweep (linalg/cholesky.py:234-281: plain dpotrf first, jitter only when it fails) into clearly definite,
+    clearly indefinite and the knife-edge band in between, where fp64 factorisations with different summation orders may decide
+    differently (tests/test_gpu_parity.py::test_adaptive_nugget_decision_sweep_across_the_knife_edge)."""
+    n = K.shape[0]
+    A = np.array(K, dtype=np.longdouble)
+    dmin = np.longdouble(np.inf)
+    for j in range(n):
+        d = A[j, j]
+        dmin = min(dmin, d)
+        if not d > 0:
+            return float(dmin)
+        A[j + 1:, j] /= np.sqrt(d)
+        A[j + 1:, j + 1:] -= np.outer(A[j + 1:, j], A[j + 1:, j])
+    return float(dmin)
+
+
 def cond_eps(K):
     """cond_2(K) * 2^-52 of a symmetric positive definite fp64 matrix."""
     w = np.linalg.eigvalsh(K)
