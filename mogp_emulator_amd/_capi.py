@@ -7,6 +7,7 @@ if the library cannot be loaded, ``load()`` raises, and every higher layer
 """
 import ctypes
 import os
+import struct
 from ctypes import POINTER, c_char_p, c_double, c_int, c_longlong, c_uint, c_ulonglong, c_void_p
 
 import numpy as np
@@ -142,7 +143,6 @@ SIGNATURES = {
 def elf_dynamic(path):
     """(DT_SONAME or None, [DT_NEEDED ...]) of a little-endian ELF64 shared object, read with struct -- no external tool.  Only the
     headers, the dynamic section and the strings it points at are read (a HIP runtime is tens of megabytes)."""
-    import struct
     with open(path, "rb") as f:
         def at(off, size):
             f.seek(off)
@@ -152,6 +152,8 @@ def elf_dynamic(path):
             raise OSError("%s is not a little-endian ELF64 file" % path)
         e_phoff, = struct.unpack_from("<Q", ident, 0x20)
         e_phentsize, e_phnum = struct.unpack_from("<HH", ident, 0x36)
+        if e_phentsize < 56:
+            raise OSError("%s: ELF64 program headers of %d bytes" % (path, e_phentsize))
         ph = at(e_phoff, e_phentsize * e_phnum)
         loads, dyn = [], None
         for k in range(e_phnum):
@@ -194,7 +196,7 @@ def _bundled_runtime_to_preload(lib_path):
     try:
         needed = [n for n in elf_dynamic(lib_path)[1] if n.startswith("libamdhip64.so")]
         soname = elf_dynamic(hip)[0]
-    except (OSError, ValueError, IndexError):
+    except (OSError, ValueError, IndexError, struct.error):      # a truncated / odd ELF degrades to the system runtime
         return []
     if not needed or soname != needed[0]:
         return []

@@ -541,39 +541,53 @@ static void mogp_predict_dev_common(mogp_mogp* h, const double* d_testing, int m
   Engine* e = h->eng.get();
   if (D != e->D) throw std::runtime_error("testing points must have D columns");
   if (m <= 0) return;
+  // the same contract whatever the fit status is: the test points are required, any of the three outputs may be null
+  // (Engine::predict: means == nullptr = derivatives only), but not all of them
+  if (!d_testing) throw std::runtime_error("device-resident predict: the test points pointer is null");
+  if (!d_means && !d_vars && !d_derivs) throw std::runtime_error("device-resident predict: no output buffer given");
   std::vector<int> ids = fitted_ids(h);
   if ((int)ids.size() == e->B) {
     e->predict(ids, d_testing, m, true, d_means, d_vars, m, true, d_derivs);
     return;
   }
-  // some emulators are not fit: the fitted ones are predicted into scratch rows and copied to their places, the others become NaN
+  // some emulators are not fit: the fitted ones are predicted into scratch rows and copied to their places, the others become NaN (the
+  // all-ones bit pattern is a quiet NaN: a memset on the engine's stream instead of one blocking host copy per row and array)
   const size_t nf = ids.size(), row = (size_t)m, drow = (size_t)m * D;
-  std::vector<double> nan_row(std::max(row, d_derivs ? drow : row), std::numeric_limits<double>::quiet_NaN());
+  hipStream_t st = e->stream;
   std::vector<char> fitted(e->B, 0);
   for (int i : ids) fitted[i] = 1;
   for (int i = 0; i < e->B; ++i) {
     if (fitted[i]) continue;
-    HIPCK(hipMemcpy(d_means + (size_t)i * row, nan_row.data(), row * sizeof(double), hipMemcpyHostToDevice));
-    if (d_vars) HIPCK(hipMemcpy(d_vars + (size_t)i * row, nan_row.data(), row * sizeof(double), hipMemcpyHostToDevice));
-    if (d_derivs) HIPCK(hipMemcpy(d_derivs + (size_t)i * drow, nan_row.data(), drow * sizeof(double), hipMemcpyHostToDevice));
+    if (d_means) HIPCK(hipMemsetAsync(d_means + (size_t)i * row, 0xFF, row * sizeof(double), st));
+    if (d_vars) HIPCK(hipMemsetAsync(d_vars + (size_t)i * row, 0xFF, row * sizeof(double), st));
+    if (d_derivs) HIPCK(hipMemsetAsync(d_derivs + (size_t)i * drow, 0xFF, drow * sizeof(double), st));
   }
-  if (nf == 0) return;
+  if (nf == 0) {
+    HIPCK(hipStreamSynchronize(st));
+    return;
+  }
   double *tm = nullptr, *tv = nullptr, *td = nullptr;
   auto release = [&] {
     for (double* p : {tm, tv, td})
       if (p) hipFree(p);
   };
   try {
-    HIPCK(hipMalloc((void**)&tm, nf * row * sizeof(double)));
+    if (d_means) HIPCK(hipMalloc((void**)&tm, nf * row * sizeof(double)));
     if (d_vars) HIPCK(hipMalloc((void**)&tv, nf * row * sizeof(double)));
     if (d_derivs) HIPCK(hipMalloc((void**)&td, nf * drow * sizeof(double)));
     e->predict(ids, d_testing, m, true, tm, tv, m, true, td);
-    for (size_t k = 0; k < nf; ++k) {
-      HIPCK(hipMemcpy(d_means + (size_t)ids[k] * row, tm + k * row, row * sizeof(double), hipMemcpyDeviceToDevice));
-      if (d_vars) HIPCK(hipMemcpy(d_vars + (size_t)ids[k] * row, tv + k * row, row * sizeof(double), hipMemcpyDeviceToDevice));
-      if (d_derivs) HIPCK(hipMemcpy(d_derivs + (size_t)ids[k] * drow, td + k * drow, drow * sizeof(double), hipMemcpyDeviceToDevice));
+    // runs of consecutive fitted emulators go in one copy each
+    for (size_t k = 0; k < nf;) {
+      size_t len = 1;
+      while (k + len < nf && ids[k + len] == ids[k] + (int)len) ++len;
+      if (d_means) HIPCK(hipMemcpyAsync(d_means + (size_t)ids[k] * row, tm + k * row, len * row * sizeof(double), hipMemcpyDeviceToDevice, st));
+      if (d_vars) HIPCK(hipMemcpyAsync(d_vars + (size_t)ids[k] * row, tv + k * row, len * row * sizeof(double), hipMemcpyDeviceToDevice, st));
+      if (d_derivs) HIPCK(hipMemcpyAsync(d_derivs + (size_t)ids[k] * drow, td + k * drow, len * drow * sizeof(double), hipMemcpyDeviceToDevice, st));
+      k += len;
     }
+    HIPCK(hipStreamSynchronize(st));
   } catch (...) {
+    hipStreamSynchronize(st);
     release();
     throw;
   }

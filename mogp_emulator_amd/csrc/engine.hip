@@ -1181,7 +1181,8 @@ void Engine::predict(const std::vector<int>& ids, const double* Xs, int m, bool 
     // definition of the basis, hostmath.h) from the test points -- read back when they were handed over in device memory
     std::vector<double> hx;
     const double* xs_h = Xs;
-    if (xs_on_device) {
+    const bool needs_x = mean.kind == 3 && !mean.dims.empty();      // (a constant / fixed mean has no basis column that depends on x*)
+    if (xs_on_device && needs_x) {
       hx.resize((size_t)m * D);
       HIPCK(hipMemcpyAsync(hx.data(), Xs, hx.size() * sizeof(double), hipMemcpyDeviceToHost, stream));
       HIPCK(hipStreamSynchronize(stream));
@@ -1212,11 +1213,13 @@ void Engine::predict(const std::vector<int>& ids, const double* Xs, int m, bool 
       else
         for (int t = 0; t < nbasis; ++t) c[t] = g.meanp[t];
     }
-    int* hi = reinterpret_cast<int*>(st.data() + o_int);
+    // (ints packed behind the doubles of the same staging block: copied in, not written through a punned pointer -- ADVICE r5)
+    std::vector<int> hi(2 * (size_t)nterm + 2, 0);
     for (int t = 0; t < nterm; ++t) {
       hi[t] = mean.dims[t];
       hi[nterm + t] = mean.powers[t];
     }
+    std::memcpy(st.data() + o_int, hi.data(), 2 * (size_t)nterm * sizeof(int));
     grow(dMeanAux, capMeanAux, total);
     HIPCK(hipMemcpyAsync(dMeanAux, st.data(), total * sizeof(double), hipMemcpyHostToDevice, stream));
     const int* di = reinterpret_cast<const int*>(dMeanAux + o_int);

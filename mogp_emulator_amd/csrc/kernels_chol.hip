@@ -248,8 +248,8 @@ __device__ __forceinline__ void st_agent(double* p, double x) { __hip_atomic_sto
 // preset to all-ones bit patterns by the K build, a chunk's entries are published by their own agent-scope stores, and a consumer's
 // lanes poll the 128 VALUES they need until they are no longer that pattern.  Per chain step this removes the producer's drain +
 // barrier + flag store and the consumer's payload load behind its flag poll (~2.5 of 7 us), and the lower half of a chunk (solved
-// first) is folded while its producer still solves the upper half.  A lane that gives up takes 0.0 (never the pattern, which an fma
-// would propagate into its own results and make every chunk behind it time out too) and the emulator is re-solved by the engine.
+// first) is folded while its producer still solves the upper half.  A lane that gives up stores the emulator's status word, takes 0.0 (never the
+// pattern, which an fma would propagate into its own results and make every chunk behind it time out too) and the emulator is re-solved by the engine.
 // HOIST (launches with at most one workgroup per CU -- the chain-bound ones; needs SENT): see preload_diag below; the one-per-CU build has the
 // registers for it (with two per CU the 128 extra live registers spilled into the solve they were meant to shorten).
 template <bool SENT, bool HOIST = false>
@@ -371,7 +371,6 @@ __global__ __launch_bounds__(256, HOIST ? 1 : 2) void backsolve_chain_kernel(Bat
       }
       }
       xs[64 * blk + lane] = xout;
-      if (SENT && xout != xout) timed_out = 1;                                       // (a timed-out chunk to the right, or garbage)
       if (SENT && __double_as_longlong(xout) == -1ll) xout = __builtin_nan("");      // (only garbage can be the "not there yet" pattern)
       st_agent(alpha + k0 + lane, xout);
     }
@@ -388,8 +387,15 @@ __global__ __launch_bounds__(256, HOIST ? 1 : 2) void backsolve_chain_kernel(Bat
         x = ld_agent(p);
       }
       if (__double_as_longlong(x) == -1ll) {
+        // Round 6: the time-out has a channel of its own -- the emulator's status word, stored and RELEASED here, before this
+        // workgroup publishes anything (its solves sit behind the barrier below), so that the leftmost chunk, which has polled every
+        // chunk's values when it reports, is certain to see it.  The lane takes 0.0 (never the pattern).  Round 5 poisoned the value with
+        // a NaN instead and let the leftmost chunk infer "timed out" from a NaN in its own result: a legitimately non-finite alpha
+        // (inf / NaN targets, overflowed hyper-parameters) was then reported as a time-out, counted and re-solved.
         timed_out = 1;
-        x = __builtin_nan("");             // (not the pattern; poisons every chunk to the left, so that the leftmost one -- which reports -- sees it)
+        __hip_atomic_store(status + emu, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        x = 0.0;
       }
       xs[t] = x;
     }
@@ -438,11 +444,13 @@ __global__ __launch_bounds__(256, HOIST ? 1 : 2) void backsolve_chain_kernel(Bat
   apply_tile(tA, 64, 64);
   solve_diag(0);
   if (SENT) {                                  // (the stores of solve_diag are the publication)
-    if (t == 0 && timed_out) __hip_atomic_store(status + emu, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (res && c == 0 && t == 0) {
-      // every chunk's result enters this one's: a wait that gave up anywhere in the chain has arrived here as NaN
+      // every chunk's values have been polled by this one: a wait that gave up anywhere in the chain stored the emulator's status word
+      // before that chunk published (poll_values), so it is visible here.  A NaN in the result is NOT a time-out: it surfaces with the
+      // factorisation's own status (non-finite log-posterior -> ok = 0) and is not re-solved.
       const int st = info[emu];
-      int rep = (st == 0 && timed_out) ? BACKSOLVE_TIMEOUT : st;
+      const bool gave_up = timed_out || __hip_atomic_load(status + emu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch;
+      int rep = (st == 0 && gave_up) ? BACKSOLVE_TIMEOUT : st;
       if (mc_abort && *mc_abort != 0u) rep = MCHOL_ABORTED;
       res[(size_t)emu * RES_STRIDE + 1] = (double)rep;
     }

@@ -247,9 +247,9 @@ class ShardedMultiOutputGP(object):
         assert testing.ndim == 2, "testing must be a 2D array"
         assert testing.shape[1] == self.D, "second dimension of testing must be the same as the number of input parameters"
         testing = np.ascontiguousarray(testing)
-        if not allow_not_fit and self._fit_known and not self.fit_ok.all():
-            # the same on every rank (fit_ok came out of the fit gather): nobody enters the collective
-            raise ValueError("Hyperparameters have not been fit for this Gaussian Process")
+        # Which emulators are not fit is read from the per-rank models NOW and travels in the gathered rows (flag column = 2), not from
+        # the outcome of the last fit gather: a caller may have refitted through `.local` since, and a ValueError raised on
+        # some ranks only, in front of the collective, would leave the others waiting in it.  Every rank enters the collective.
         m, D = testing.shape
         n_local = self.hi - self.lo
         # columns of one emulator's row in the single gather
@@ -258,14 +258,13 @@ class ShardedMultiOutputGP(object):
         o_flag = o_der + (m * D if deriv else 0)
         width = o_flag + 1
         error = None
+        nf_local = sorted(self.local.get_indices_not_fit()) if (self.local is not None and hasattr(self.local, "get_indices_not_fit")) else []
         if device is None and self._device_path():
             import torch
             dev = _collective_device(self.group)
             payload = torch.zeros((n_local, width), dtype=torch.float64, device=dev)
             try:
                 if self.local is not None:
-                    if not allow_not_fit and len(self.local.get_indices_not_fit()) > 0:
-                        raise ValueError("Hyperparameters have not been fit for this Gaussian Process")
                     d_x = torch.from_numpy(testing).to(dev)
                     d_mean = torch.empty((n_local, m), dtype=torch.float64, device=dev)
                     d_var = torch.empty((n_local, m), dtype=torch.float64, device=dev) if unc else None
@@ -279,6 +278,8 @@ class ShardedMultiOutputGP(object):
                         payload[:, o_unc:o_der] = torch.clamp_min(d_var, 0.)
                     if deriv:
                         payload[:, o_der:o_flag] = d_der
+                    if nf_local:               # (their rows came back as NaN from predict_dev)
+                        payload[nf_local, o_flag] = 2.
             except Exception as exc:           # noqa: BLE001
                 error = exc
                 payload.zero_()
@@ -288,28 +289,37 @@ class ShardedMultiOutputGP(object):
             payload = np.zeros((n_local, width))
             try:
                 if self.local is not None:
-                    res = self.local.predict(testing, unc=unc, deriv=deriv, include_nugget=include_nugget,
-                                             allow_not_fit=allow_not_fit)
+                    try:
+                        res = self.local.predict(testing, unc=unc, deriv=deriv, include_nugget=include_nugget,
+                                                 allow_not_fit=allow_not_fit or bool(nf_local))
+                    except TypeError:
+                        # a custom factory with the protocol of rounds 1-4: predict(testing, deriv=, include_nugget=) -> (mean, unc[, deriv])
+                        res = tuple(self.local.predict(testing, deriv=deriv, include_nugget=include_nugget)) + (None, None)
                     payload[:, :m] = res[0]
                     if unc and res[1] is not None:
                         payload[:, o_unc:o_der] = res[1]
                     if deriv and res[2] is not None:
                         payload[:, o_der:o_flag] = np.asarray(res[2]).reshape(n_local, m * D)
+                    if nf_local:
+                        payload[nf_local, o_flag] = 2.
             except Exception as exc:           # noqa: BLE001
                 error = exc
                 payload[:] = 0.
                 payload[:, o_flag] = 1.
             full = gather_rows(payload, self.n_emulators, device=device, group=self.group).cpu().numpy()
-        self._raise_if_failed(full[:, o_flag] > 0.5, error, "predict")
+        flag = full[:, o_flag]
+        self._raise_if_failed((flag > 0.5) & (flag < 1.5), error, "predict")
+        not_fit = flag > 1.5                   # the same array on every rank: it came out of the collective
+        if not_fit.any() and not allow_not_fit:
+            raise ValueError("Hyperparameters have not been fit for this Gaussian Process")
         means = full[:, :m].copy()
         uncs = full[:, o_unc:o_der].copy() if unc else np.zeros((self.n_emulators, m))
         derivs = full[:, o_der:o_flag].reshape(self.n_emulators, m, D).copy() if deriv else np.zeros((self.n_emulators, m, D))
-        if allow_not_fit and self._fit_known:
-            # emulators the fit gather reported as not fit: NaN rows on every rank, whatever the per-rank model returned
-            bad = ~self.fit_ok
-            means[bad] = np.nan
-            uncs[bad] = np.nan
-            derivs[bad] = np.nan
+        if not_fit.any():
+            # emulators their rank reported as not fit: NaN rows on every rank, whatever the per-rank model returned
+            means[not_fit] = np.nan
+            uncs[not_fit] = np.nan
+            derivs[not_fit] = np.nan
         return PredictResult(mean=means, unc=uncs, deriv=derivs)
 
     def __call__(self, testing, processes=None):

@@ -104,6 +104,22 @@ def _worker(rank, world, port, n_out, q):
             ok = ok and gp.theta_hat[k] is None and np.isnan(gp.logpost[k])
     g = gather_rows(np.arange(lo, hi, dtype=np.float64).reshape(-1, 1), n_out).numpy().ravel()
     ok = ok and np.array_equal(g, np.arange(n_out))
+    # the LAST rank's model changes behind the wrapper's back (a refit through `.local`): its first emulator stops being fit.
+    # The cached outcome of the fit gather is stale on every rank, and differently informative on each -- the not-fit state must travel
+    # in the predict gather: ValueError on EVERY rank (nobody left waiting in the collective), NaN rows with allow_not_fit.
+    last = world - 1 if n_out >= world else 0
+    if rank == last and gp.local is not None:
+        gp.local.t[0, 0] = -1.0
+    changed = shard_bounds(n_out, world, last)[0]
+    now_not_fit = sorted(set(not_fit) | {changed})
+    try:
+        gp.predict(Xs)
+        ok = False
+    except ValueError as exc:
+        ok = ok and "have not been fit" in str(exc)
+    m4, u4, d4 = gp.predict(Xs, allow_not_fit=True)
+    ok = ok and bool(np.isnan(m4[now_not_fit]).all()) and bool(np.isnan(u4[now_not_fit]).all()) and bool(np.isnan(d4[now_not_fit]).all())
+    ok = ok and bool(np.isfinite(np.delete(m4, now_not_fit, axis=0)).all())
     q.put((rank, bool(ok), (gp.lo, gp.hi)))
     dist.barrier()
     dist.destroy_process_group()

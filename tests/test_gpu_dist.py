@@ -196,22 +196,47 @@ def test_rccl_world1_gathers_the_real_payloads_on_device():
     assert all(res.values()), res
 
 
-def test_bench_gpus_flag_launches_that_many_ranks():
-    """`python bench.py --gpus 2` (no launcher around it) must start two ranks itself (VERDICT r3: --gpus was parsed and
-    ignored).  gloo + both ranks on device 0, as the one GPU of this box allows; the command shape is the driver's."""
+def _bench_line(gpus, extra):
     import json
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "MOGP_CHOL")}
     env["MOGP_BENCH_BACKEND"] = "gloo"
-    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
-                          "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=540)
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(gpus), "--steps", "1", "--warmup", "0"] + extra,
+                         env=env, capture_output=True, text=True, timeout=900)
     assert res.returncode == 0, res.stderr[-3000:]
     lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, res.stdout[-2000:]
-    out = json.loads(lines[0])
+    return json.loads(lines[0])
+
+
+def test_bench_gpus_flag_launches_that_many_ranks():
+    """`python bench.py --gpus 2` (no launcher around it) must start two ranks itself (VERDICT r3: --gpus was parsed and
+    ignored).  gloo + both ranks on device 0, as the one GPU of this box allows; the command shape is the driver's.  Round 6: an
+    N > 1 line carries `cpu_baseline` (rank 0, after the timed region) and, nested in `roofline`, the headline kernel's fraction with
+    the kernel times taken as maxima over the ranks; `traffic` is null and says why."""
+    out = _bench_line(2, [])
     assert out["n_gpus"] == 2 and out["rccl_ranks"] == 2 and out["collective_backend"] == "gloo"
     assert out["config"]["outputs_per_gpu"] == 32 and out["config"]["outputs_total"] == 64
     assert np.isfinite(out["value"]) and out["value"] > 0 and np.isfinite(out["predict_pts_per_s"])
     assert np.isfinite(out["logpost_checksum"])
+    rf = out["roofline"]
+    assert rf["traffic"] is None and "N > 1" in rf["traffic_source"]
+    assert rf["headline_kernel"]["kernel"] == "mchol" and 0. < rf["headline_kernel"]["frac"] < 1.
+    assert rf["kernels"]["mchol"]["avg_ms"] > 0. and "max over the 2 ranks" in out["kernels"]["mchol"]["note"]
+    assert out["kernels"]["mchol"]["ms_total"] >= out["kernels"]["mchol"]["ms_total_this_rank"]
+    assert rf["fit_phase"]["peak"] == 2 * 78.6
+    cb = out["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1 and cb["parity_in_bench"]["passed"] is True
+
+
+def test_bench_eight_ranks_control_flow_on_one_gpu():
+    """The driver's N = 8 line (8 emulators per rank: the chain-bound regime of the one-launch Cholesky), all eight ranks on the one
+    device of this box over gloo: shard bounds, the padded gather, the max-over-ranks reductions and the line's shape."""
+    out = _bench_line(8, ["--no-cpu-baseline", "--m", "2000"])
+    assert out["n_gpus"] == 8 and out["rccl_ranks"] == 8
+    assert out["config"]["outputs_per_gpu"] == 8 and out["config"]["outputs_total"] == 64 and out["scaling"] == "strong"
+    assert np.isfinite(out["value"]) and out["value"] > 0 and np.isfinite(out["logpost_checksum"])
+    assert out["roofline"]["headline_kernel"]["flops_per_launch"] == 8 * 2000. ** 3 / 3.
+    assert "cpu_baseline" not in out

@@ -912,6 +912,40 @@ def test_backsolve_chain_timeout_is_retried_not_reported_as_failure():
     assert int(out.stdout.split("BS-TIMEOUTS")[1].split()[0]) > 0, "the forced timeouts never happened: the test did not exercise the fallback"
 
 
+def test_non_finite_targets_are_not_reported_as_a_chain_timeout():
+    """a legitimately non-finite alpha (NaN / inf targets) used to look like a timed-out wait of the one-launch back
+    substitution (any NaN in the leftmost chunk's result set the time-out status): counted in `backsolve_timeouts`, re-solved by the
+    multi-launch path on every evaluation.  The time-out now has a channel of its own: such targets give a non-finite log-posterior, as
+    on the CPU (GaussianProcess.py:657-685 propagates them), and the counter stays where it was -- for 1, 9 and 70 emulators (one / two
+    workgroups per CU), the bad value in the first, a middle and the last chunk of the chain."""
+    import ctypes
+    lib = _capi.load()
+
+    def timeouts():
+        c = ctypes.c_longlong()
+        lib.mogp_profile_counter(b"backsolve_timeouts", ctypes.byref(c))
+        return c.value
+    for B, n in ((1, 700), (9, 700), (70, 400)):
+        X, T, _ = synth(5 + B, n, 3, B, 4)
+        bad = {0: (5, np.nan), B // 2: (n // 2, np.inf), B - 1: (n - 1, np.nan)}
+        for k, (i, val) in bad.items():
+            T[k, i] = val
+        mo = M.MultiOutputGP_GPU(X, T, nugget=1e-5, priors=weak(3, 1e-5))
+        theta = np.tile(np.array([1., 1., 1., 0.]), (B, 1))
+        t0 = timeouts()
+        for _ in range(3):
+            f, _, ok = mo._mogp_gpu.eval(theta, grad=False)
+        assert timeouts() == t0, "non-finite targets were re-solved as chain time-outs"
+        for k in range(B):
+            if k in bad:
+                assert not np.isfinite(f[k])
+            else:
+                assert ok[k] and np.isfinite(f[k])
+        good = [k for k in range(B) if k not in bad][:2]
+        for k in good:
+            assert_allclose(f[k], R.GPRef(X, T[k], nugget=1e-5).fit(theta[k]), rtol=1e-10)
+
+
 _STARTS_SCRIPT = r"""
 import sys, numpy as np
 sys.path.insert(0, %(root)r); sys.path.insert(0, %(tests)r)

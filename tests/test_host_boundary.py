@@ -436,6 +436,16 @@ def test_hip_runtime_preload_only_for_matching_soname(tmp_path, monkeypatch):
     assert _capi._bundled_runtime_to_preload(_capi.LIB_PATH) == []
     monkeypatch.setattr(importlib.util, "find_spec", lambda name: None)
     assert _capi._bundled_runtime_to_preload(_capi.LIB_PATH) == []
+    # a truncated / malformed bundled libamdhip64.so degrades to "nothing to preload" instead of failing the import
+    good = open(os.path.join(os.path.dirname(same.origin), "lib", "libamdhip64.so"), "rb").read()
+    for tag, blob in (("cut_phdr", good[:0x60]), ("cut_ident", good[:40]), ("small_phent", good[:0x36] + b"\x10\x00" + good[0x38:]), ("junk", b"\x7fELF\x02\x01" + b"\xff" * 80)):
+        root = tmp_path / tag / "torch"
+        (root / "lib").mkdir(parents=True)
+        (root / "__init__.py").write_text("")
+        (root / "lib" / "libamdhip64.so").write_bytes(blob)
+        broken = types.SimpleNamespace(origin=str(root / "__init__.py"))
+        monkeypatch.setattr(importlib.util, "find_spec", lambda name, b=broken: b)
+        assert _capi._bundled_runtime_to_preload(_capi.LIB_PATH) == [], tag
     monkeypatch.setenv("MOGP_HIP_RUNTIME", "system")
     monkeypatch.setattr(importlib.util, "find_spec", lambda name: same)
     assert _capi._one_hip_runtime_per_process() == []
