@@ -208,14 +208,17 @@ def time_fit_map(M, X, T, kernel, nugget, n_tries, max_iter):
     libgpgpu.set_fit_options(max_iter=max_iter, ftol=1e-9, gtol=1e-6, seed=1)
     gp = M.MultiOutputGP_GPU(X, T, kernel=kernel, nugget=nugget)              # default priors
     e0, g0 = counter("objective_evals"), counter("gradient_evals")
+    r0, sr0 = counter("pool_rounds"), counter("pool_slot_rounds")
     t0 = time.perf_counter()
     libgpgpu.fit_GP_MAP(gp._mogp_gpu, n_tries)
     dt = time.perf_counter() - t0
     evals = counter("objective_evals") - e0
+    rounds = counter("pool_rounds") - r0
     res = {"fit_GP_MAP_s": dt, "fit_GP_MAP_n_tries": n_tries, "fit_GP_MAP_max_iter": max_iter,
            "fit_GP_MAP_emulator_fits_per_s": B / dt, "fit_GP_MAP_all_fit": len(gp.get_indices_not_fit()) == 0,
            "fit_GP_MAP_objective_evals": evals, "fit_GP_MAP_gradient_evals": counter("gradient_evals") - g0,
            "fit_GP_MAP_objective_evals_per_s": evals / dt,
+           "fit_GP_MAP_pool_rounds": rounds, "fit_GP_MAP_mean_batch": (counter("pool_slot_rounds") - sr0) / max(rounds, 1),
            # n^3 / 3 per objective (Cholesky), n^3 with the gradient (+ L^-1, K^-1); the line search asks for the gradient of a
            # trial point only once its objective passed the sufficient-decrease test
            "fit_GP_MAP_TFLOPs": ((counter("gradient_evals") - g0) * 2.0 / 3.0 + evals / 3.0) * float(X.shape[0]) ** 3 / dt * 1e-12}
@@ -444,7 +447,9 @@ def main():
     ap.add_argument("--no-extras", action="store_true",
                     help="only the timed steps (+ the single-stream pass): none of the untimed extras (host-buffer predict, deriv, full_cov, "
                          "fit_GP_MAP, pivot, tsunami) -- for kernel traces whose per-kernel averages should be those of the timed steps")
-    args = ap.parse_args()
+    # (self-launched ranks get the command line through the environment: torch.distributed.run's own parser trips over script options
+    # that are prefixes of its own, e.g. --m)
+    args = ap.parse_args(json.loads(os.environ["MOGP_BENCH_ARGV"]) if "MOGP_BENCH_ARGV" in os.environ and "WORLD_SIZE" in os.environ else None)
 
     # `python bench.py --gpus N` outside a launcher: start the N ranks ourselves (one process per GPU, the launch line the
     # driver documents), rank 0 of the children prints the JSON line.  Under torch.distributed.run WORLD_SIZE is set and
@@ -454,7 +459,8 @@ def main():
             import socket
             s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
             cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
-                   "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+                   "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), "--gpus", str(args.gpus)]
+            os.environ["MOGP_BENCH_ARGV"] = json.dumps(sys.argv[1:])
             sys.stdout.flush()
             os.execv(sys.executable, cmd)
     elif int(os.environ["WORLD_SIZE"]) != args.gpus:

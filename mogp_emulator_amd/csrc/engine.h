@@ -5,6 +5,7 @@
 // ONE batched launch sequence over an index list of emulators.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <functional>
 #include <random>
 #include <string>
 #include <map>
@@ -100,10 +101,14 @@ class Engine {
   // pivot_cholesky(A) of linalg/cholesky.py:284-327 for an arbitrary symmetric matrix (host buffers, row-major)
   static void pivot_cholesky(const double* A, int n, double* L_out, int* P_out, int* rank_out);
 
-  // multi-start MAP fit of emulators `ids` in lock-step (fitting.hpp:61-128)
+  // multi-start MAP fit of emulators `ids` (fitting.hpp:61-128): all (emulator, start) runs through one slot pool
   void fit_map(const std::vector<int>& ids, int n_tries, const double* theta0, int theta0_len);
-  void run_starts(const std::vector<int>& ids, const std::vector<std::vector<double>>& x0, std::vector<double>& f_out,
-                  std::vector<std::vector<double>>& x_out);
+  // the optimiser runs as a slot pool on emulators `slots` of this engine: next(pos, x0, tag) hands slot `pos` its next run (false: none
+  // left), done(tag, f, x) receives a run's end point (f = +inf, x empty: failed)
+  void run_pool(const std::vector<int>& slots, const std::function<bool(int, std::vector<double>&, int&)>& next,
+                const std::function<void(int, double, const std::vector<double>&)>& done);
+  // slot `slot` of this (replica) engine takes targets, nugget type and priors of emulator i of `src`
+  void retarget(int slot, const Engine& src, int i);
 
   hipStream_t stream = nullptr;      // main stream: covariance build, trailing updates, everything else
   hipStream_t pstream = nullptr;     // look-ahead stream: panel factorisations

@@ -72,7 +72,7 @@ struct FlagGuard {
   ~FlagGuard() { b = false; }
 };
 static std::atomic<long long> g_bs_timeouts{0}, g_obj_evals{0}, g_grad_evals{0}, g_mc_aborts{0};
-static std::atomic<long long> g_lb_iters{0}, g_ls_short{0}, g_ls_long{0}, g_lb_runs{0};
+static std::atomic<long long> g_lb_iters{0}, g_ls_short{0}, g_ls_long{0}, g_lb_runs{0}, g_pool_rounds{0}, g_pool_slot_rounds{0};
 long long prof_counter(const char* name) {
   const std::string s(name ? name : "");
   if (s == "backsolve_timeouts") return g_bs_timeouts.load();
@@ -85,6 +85,9 @@ long long prof_counter(const char* name) {
   if (s == "lbfgs_iterations") return g_lb_iters.load();
   if (s == "linesearch_shortened") return g_ls_short.load();
   if (s == "linesearch_lengthened") return g_ls_long.load();
+  // slot pool of fit_GP_MAP: batched optimiser rounds, and the sum over rounds of the slots that took part (/ rounds = mean batch)
+  if (s == "pool_rounds") return g_pool_rounds.load();
+  if (s == "pool_slot_rounds") return g_pool_slot_rounds.load();
   return -1;
 }
 bool prof_is_on() { return g_prof_on; }
@@ -482,7 +485,11 @@ void Engine::factorize_blocked(const std::vector<int>& ids, std::vector<int>& in
   // matrices (2000 x n=100: 0.62 / 0.57, one task each) the two-group multi-launch schedule stays.
   const int legacy = tiles64 < 256 ? 1 : (tiles128 >= 1024 ? 0 : 3);
   static const bool mc_default = [] { const char* e = getenv("MOGP_MCHOL"); return !e || atoi(e) != 0; }();
-  const bool mc_regime = tiles128 < 2048 && (NP > TILE || nb <= 512);
+  // Round 6: re-measured on the round-5 kernels, the one-launch kernel wins at every batch size -- 128 / 256 / 512 x n=2000: 7.71 / 15.24 /
+  // 30.68 ms against 8.87 / 17.54 / 33.70 with the two-group schedule, 1024 x n=1000 11.19 / 11.73, 2048 x n=500 4.50 / 4.91, 4096 x n=250
+  // 2.34 / 2.75, 64 x n=5000 52.2 / 56.9 (profiles/r06_big_batch.txt) -- so the bound is now the pack memory alone (147 KB per emulator and
+  // block column: 16384 tiles = 2.4 GB); rounds 2-5 stopped at 2048 tiles (measured on the round-2 kernel: 240 x n=2000 17.3 / 16.8).
+  const bool mc_regime = tiles128 < 16384 && (NP > TILE || nb <= 512);
   int schedule = ovr.schedule >= 0 ? ovr.schedule : (forced >= 0 ? forced : ((mc_default && mc_regime) ? 4 : legacy));
   if (schedule == 5) schedule = legacy;            // (mogp_profile_schedule(5, ..): the multi-launch schedule of this regime)
   // the one-launch kernel addresses an emulator's matrix through a 32-bit buffer offset; after an abort the multi-launch
@@ -1486,11 +1493,10 @@ void Engine::get_chol(int i, double* out) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// Multi-start MAP fit, all emulators in lock-step (fitting.hpp:61-128, fitting.py:219-266).
-// Each optimiser "round" is ONE batched device evaluation (objective + gradient) of every
-// emulator that still needs one; every emulator runs its own L-BFGS (memory 10) with an
-// Armijo/curvature line search.  Optimiser trajectory parity with dlib / scipy is unpinned
-// (SURVEY.md section 8c); the end-point objective is what the tests compare.
+// Multi-start MAP fit (fitting.hpp:61-128, fitting.py:219-266).  Every optimiser "round" is ONE batched device evaluation
+// (objective + gradient) of every run that needs one; every run is its own L-BFGS (memory 10) with an Armijo/curvature
+// line search and advances independently of the others (slot pool, run_pool below).  Optimiser trajectory parity with
+// dlib / scipy is unpinned; the end-point objective is what the tests compare.
 // ---------------------------------------------------------------------------------------------
 namespace {
 struct Lbfgs {
@@ -1542,161 +1548,207 @@ struct Lbfgs {
 };
 }  // namespace
 
-// One L-BFGS run per listed emulator from the given starting points, all in lock-step (every round is one batched
-// objective + gradient evaluation of the emulators still active).  f_out[e] = +inf and x_out[e] empty for a failed run.
-void Engine::run_starts(const std::vector<int>& ids, const std::vector<std::vector<double>>& x0, std::vector<double>& f_out,
-                        std::vector<std::vector<double>>& x_out) {
+// The optimiser runs of a multi-start fit as a SLOT POOL (round 6).  `slots` are emulators of THIS engine; a slot
+// carries one L-BFGS run at a time.  Every round is ONE batched objective (+ gradient) evaluation of the slots whose run needs one; a run
+// that ends (converged, out of iterations, failed) hands its slot to the next pending run IN THE SAME ROUND -- `next(pos, x0, tag)` fills
+// the slot (and, on a replica engine, gives it the targets and priors of the run's emulator), `done(tag, f, x)` receives the end point
+// (f = +inf and x empty for a failed run) -- so every evaluation is full until the queue drains.  The reference runs one optimiser per
+// emulator with no coupling at all (mogp_gpu/src/fitting.hpp:122-127 OpenMP over emulators; fitting.py:333-335 Pool.starmap); rounds 1-5
+// ran fixed passes of starts in lock-step, each ending on its slowest run (64 x 15 starts: 71 % of the raw fit+gradient rate).
+// A run's trajectory depends on its own evaluations only, and those are bit-identical whatever the batch they are part of (one-launch
+// Cholesky), so the end points do not depend on the schedule.
+void Engine::run_pool(const std::vector<int>& slots, const std::function<bool(int, std::vector<double>&, int&)>& next,
+                      const std::function<void(int, double, const std::vector<double>&)>& done) {
   const FitOptions& opt = fit_options();
-  const int ne = (int)ids.size();
-  f_out.assign(ne, std::numeric_limits<double>::infinity());
-  x_out.assign(ne, {});
-  {
-    std::vector<Lbfgs> st(ne);
-    for (int e = 0; e < ne; ++e) {
-      Lbfgs& s = st[e];
-      s.np = n_theta(ids[e]);
-      s.g.resize(s.np); s.d.resize(s.np); s.gt.resize(s.np);
-      s.x = x0[e];
-      s.xt = s.x;
+  const int ns = (int)slots.size();
+  std::vector<Lbfgs> st(ns);
+  std::vector<int> tag(ns, -1), evals(ns, 0);
+  std::vector<char> live(ns, 0);
+  const int eval_cap = opt.max_iter * 25;
+  auto start_run = [&](int pos) {
+    std::vector<double> x0;
+    int t = -1;
+    if (!next(pos, x0, t)) {
+      live[pos] = 0;
+      return;
     }
-    g_lb_runs += ne;
-    for (int round = 0; round < opt.max_iter * 25; ++round) {
-      std::vector<int> act, actid;
-      std::vector<const double*> th;
-      for (int e = 0; e < ne; ++e)
-        if (st[e].state == Lbfgs::NEED_F0 || st[e].state == Lbfgs::LINESEARCH) {
-          act.push_back(e);
-          actid.push_back(ids[e]);
-          th.push_back(st[e].xt.data());
-        }
-      if (act.empty()) break;
-      int maxnp = 0;
-      for (int e : act) maxnp = std::max(maxnp, st[e].np);
-      std::vector<double> fv(act.size()), gv(act.size() * (size_t)maxnp);
-      std::vector<int> okv(act.size());
-      const double c1 = 1e-4, c2 = 0.9;      // Armijo / weak curvature
-      static const int lazy_env = [] { const char* e = getenv("MOGP_LAZY_GRAD"); return e ? atoi(e) : -1; }();
-      const bool lazy_grad = lazy_env < 0 ? n >= 512 : lazy_env != 0;
-      if (lazy_grad) {
-        // The objective of every active run first; the gradient (L^-1, K^-1, the fused reduction: 2/3 of an evaluation) only
-        // where the optimiser will look at it -- a trial point that fails the sufficient-decrease test is shortened without.
-        // 8 - 14 % of the trial points of the benchmark fits fail it: 64 emulators x 15 starts of n = 2000, 10 / 100
-        // iterations: 2.58 -> 2.34 s / 8.11 -> 7.42 s, same optima.  The second synchronisation per round costs small
-        // problems more than it saves (n = 200, 15 starts: 0.045 -> 0.051 s), so it is used from n = 512 (MOGP_LAZY_GRAD=0 / 1).
-        eval(actid, th, false, fv.data(), nullptr, 0, okv.data());
-        std::vector<int> gids, gpos;
-        for (size_t q = 0; q < act.size(); ++q) {
-          const Lbfgs& s = st[act[q]];
-          if (!okv[q]) continue;
-          if (s.state == Lbfgs::NEED_F0 || fv[q] <= s.f + c1 * s.step * s.slope) {
-            gids.push_back(actid[q]);
-            gpos.push_back((int)q);
-          }
-        }
-        if (!gids.empty()) {
-          g_grad_evals += (long long)gids.size();
-          std::vector<double> tmp(gids.size() * (size_t)maxnp);
-          grad_current(gids, tmp.data(), maxnp);
-          for (size_t k = 0; k < gids.size(); ++k) std::memcpy(gv.data() + (size_t)gpos[k] * maxnp, tmp.data() + k * maxnp, sizeof(double) * maxnp);
-        }
-      } else {
-        eval(actid, th, true, fv.data(), gv.data(), maxnp, okv.data());
+    Lbfgs s;
+    s.np = n_theta(slots[pos]);
+    if ((int)x0.size() != s.np) throw std::runtime_error("fit_map: starting point of the wrong length");
+    s.g.resize(s.np); s.d.resize(s.np); s.gt.resize(s.np);
+    s.x = x0;
+    s.xt = s.x;
+    st[pos] = std::move(s);
+    tag[pos] = t;
+    evals[pos] = 0;
+    live[pos] = 1;
+    g_lb_runs += 1;
+  };
+  auto finish_run = [&](int pos) {
+    const Lbfgs& s = st[pos];
+    const bool good = !(s.state == Lbfgs::FAILED || s.state == Lbfgs::NEED_F0) && std::isfinite(s.f);
+    done(tag[pos], good ? s.f : std::numeric_limits<double>::infinity(), good ? s.x : std::vector<double>());
+    start_run(pos);
+  };
+  for (int pos = 0; pos < ns; ++pos) start_run(pos);
+  const double c1 = 1e-4, c2 = 0.9;      // Armijo / weak curvature
+  static const int lazy_env = [] { const char* e = getenv("MOGP_LAZY_GRAD"); return e ? atoi(e) : -1; }();
+  const bool lazy_grad = lazy_env < 0 ? n >= 512 : lazy_env != 0;
+  for (;;) {
+    std::vector<int> act, actid;
+    std::vector<const double*> th;
+    for (int pos = 0; pos < ns; ++pos)
+      if (live[pos]) {
+        act.push_back(pos);
+        actid.push_back(slots[pos]);
+        th.push_back(st[pos].xt.data());
       }
+    if (act.empty()) break;
+    g_pool_rounds += 1;
+    g_pool_slot_rounds += (long long)act.size();
+    int maxnp = 0;
+    for (int pos : act) maxnp = std::max(maxnp, st[pos].np);
+    std::vector<double> fv(act.size()), gv(act.size() * (size_t)maxnp);
+    std::vector<int> okv(act.size());
+    if (lazy_grad) {
+      // The objective of every active run first; the gradient (L^-1, K^-1, the fused reduction: 2/3 of an evaluation) only
+      // where the optimiser will look at it -- a trial point that fails the sufficient-decrease test is shortened without.
+      // 8 - 14 % of the trial points of the benchmark fits fail it: 64 emulators x 15 starts of n = 2000, 10 / 100
+      // iterations: 2.58 -> 2.34 s / 8.11 -> 7.42 s, same optima.  The second synchronisation per round costs small
+      // problems more than it saves (n = 200, 15 starts: 0.045 -> 0.051 s), so it is used from n = 512 (MOGP_LAZY_GRAD=0 / 1).
+      eval(actid, th, false, fv.data(), nullptr, 0, okv.data());
+      std::vector<int> gids, gpos;
       for (size_t q = 0; q < act.size(); ++q) {
-        Lbfgs& s = st[act[q]];
-        const bool ok = okv[q] != 0;
-        const double* gq = gv.data() + q * maxnp;
-        bool gfinite = ok;
-        // (a trial point that fails the sufficient-decrease test is judged by its objective alone)
-        const bool armijo_fail = s.state == Lbfgs::LINESEARCH && ok && !(fv[q] <= s.f + c1 * s.step * s.slope);
-        if (ok && !armijo_fail) for (int k = 0; k < s.np; ++k) gfinite = gfinite && std::isfinite(gq[k]);
-        if (s.state == Lbfgs::NEED_F0) {
-          if (!gfinite) { s.state = Lbfgs::FAILED; continue; }
-          s.f = fv[q];
-          s.g.assign(gq, gq + s.np);
-          s.direction();
-          double gn = 0.;
-          for (int k = 0; k < s.np; ++k) gn += s.g[k] * s.g[k];
-          gn = std::sqrt(gn);
-          if (gn <= opt.gtol) { s.state = Lbfgs::DONE; continue; }
-          s.step = std::min(1.0, 1.0 / gn);
-          s.step_lo = 0.; s.step_hi = 0.; s.ls_iter = 0;
-          s.trial();
-          s.state = Lbfgs::LINESEARCH;
-          continue;
+        const Lbfgs& s = st[act[q]];
+        if (!okv[q]) continue;
+        if (s.state == Lbfgs::NEED_F0 || fv[q] <= s.f + c1 * s.step * s.slope) {
+          gids.push_back(actid[q]);
+          gpos.push_back((int)q);
         }
-        // line search step: Armijo (1e-4) + weak curvature (0.9) by bisection/expansion
-        bool accept = false;
-        if (!gfinite || !(fv[q] <= s.f + c1 * s.step * s.slope)) {
-          s.step_hi = s.step;
-          s.step = 0.5 * (s.step_lo + s.step_hi);
-          g_ls_short += 1;
-        } else {
-          double st_slope = 0.;
-          for (int k = 0; k < s.np; ++k) st_slope += gq[k] * s.d[k];
-          if (st_slope < c2 * s.slope && s.ls_iter < 10) {
-            s.step_lo = s.step;
-            s.step = (s.step_hi > 0.) ? 0.5 * (s.step_lo + s.step_hi) : 2.0 * s.step;
-            g_ls_long += 1;
-          } else {
-            accept = true;
-          }
-        }
-        s.ls_iter++;
-        if (!accept) {
-          if (s.ls_iter > 40 || s.step < 1e-20) {
-            // could not make progress along d: take what we have
-            s.state = Lbfgs::DONE;
-            continue;
-          }
-          s.trial();
-          continue;
-        }
-        // accept xt
-        std::vector<double> sv(s.np), yv(s.np);
-        double sy = 0., yy = 0.;
-        for (int k = 0; k < s.np; ++k) {
-          sv[k] = s.xt[k] - s.x[k];
-          yv[k] = gq[k] - s.g[k];
-          sy += sv[k] * yv[k];
-          yy += yv[k] * yv[k];
-        }
-        const double fold = s.f;
-        s.x = s.xt;
+      }
+      if (!gids.empty()) {
+        g_grad_evals += (long long)gids.size();
+        std::vector<double> tmp(gids.size() * (size_t)maxnp);
+        grad_current(gids, tmp.data(), maxnp);
+        for (size_t k = 0; k < gids.size(); ++k) std::memcpy(gv.data() + (size_t)gpos[k] * maxnp, tmp.data() + k * maxnp, sizeof(double) * maxnp);
+      }
+    } else {
+      eval(actid, th, true, fv.data(), gv.data(), maxnp, okv.data());
+    }
+    for (size_t q = 0; q < act.size(); ++q) {
+      const int pos = act[q];
+      Lbfgs& s = st[pos];
+      const bool ok = okv[q] != 0;
+      const double* gq = gv.data() + q * maxnp;
+      bool gfinite = ok;
+      evals[pos] += 1;
+      // (a trial point that fails the sufficient-decrease test is judged by its objective alone)
+      const bool armijo_fail = s.state == Lbfgs::LINESEARCH && ok && !(fv[q] <= s.f + c1 * s.step * s.slope);
+      if (ok && !armijo_fail) for (int k = 0; k < s.np; ++k) gfinite = gfinite && std::isfinite(gq[k]);
+      if (s.state == Lbfgs::NEED_F0) {
+        if (!gfinite) { s.state = Lbfgs::FAILED; finish_run(pos); continue; }
         s.f = fv[q];
         s.g.assign(gq, gq + s.np);
-        if (sy > 1e-10 * yy && yy > 0.) {
-          s.S.push_back(sv); s.Y.push_back(yv); s.rho.push_back(1.0 / sy);
-          if (s.S.size() > 10) { s.S.erase(s.S.begin()); s.Y.erase(s.Y.begin()); s.rho.erase(s.rho.begin()); }
+        s.direction();
+        double gn = 0.;
+        for (int k = 0; k < s.np; ++k) gn += s.g[k] * s.g[k];
+        gn = std::sqrt(gn);
+        if (gn <= opt.gtol) { s.state = Lbfgs::DONE; finish_run(pos); continue; }
+        s.step = std::min(1.0, 1.0 / gn);
+        s.step_lo = 0.; s.step_hi = 0.; s.ls_iter = 0;
+        s.trial();
+        s.state = Lbfgs::LINESEARCH;
+        continue;
+      }
+      // line search step: Armijo (1e-4) + weak curvature (0.9) by bisection/expansion
+      bool accept = false;
+      if (!gfinite || !(fv[q] <= s.f + c1 * s.step * s.slope)) {
+        s.step_hi = s.step;
+        s.step = 0.5 * (s.step_lo + s.step_hi);
+        g_ls_short += 1;
+      } else {
+        double st_slope = 0.;
+        for (int k = 0; k < s.np; ++k) st_slope += gq[k] * s.d[k];
+        if (st_slope < c2 * s.slope && s.ls_iter < 10) {
+          s.step_lo = s.step;
+          s.step = (s.step_hi > 0.) ? 0.5 * (s.step_lo + s.step_hi) : 2.0 * s.step;
+          g_ls_long += 1;
+        } else {
+          accept = true;
         }
-        s.iter++;
-        g_lb_iters += 1;
-        double gmax = 0.;
-        for (int k = 0; k < s.np; ++k) gmax = std::max(gmax, std::fabs(s.g[k]));
-        if (std::fabs(fold - s.f) <= opt.ftol * std::max(1.0, std::fabs(s.f)) || gmax <= opt.gtol || s.iter >= opt.max_iter) {
+      }
+      s.ls_iter++;
+      if (!accept) {
+        if (s.ls_iter > 40 || s.step < 1e-20 || evals[pos] >= eval_cap) {
+          // could not make progress along d: take what we have
           s.state = Lbfgs::DONE;
+          finish_run(pos);
           continue;
         }
-        s.direction();
-        s.step = 1.0; s.step_lo = 0.; s.step_hi = 0.; s.ls_iter = 0;
         s.trial();
+        continue;
       }
-    }
-    for (int e = 0; e < ne; ++e) {
-      const Lbfgs& s = st[e];
-      if (s.state == Lbfgs::FAILED || s.state == Lbfgs::NEED_F0) continue;
-      if (std::isfinite(s.f)) {
-        f_out[e] = s.f;
-        x_out[e] = s.x;
+      // accept xt
+      std::vector<double> sv(s.np), yv(s.np);
+      double sy = 0., yy = 0.;
+      for (int k = 0; k < s.np; ++k) {
+        sv[k] = s.xt[k] - s.x[k];
+        yv[k] = gq[k] - s.g[k];
+        sy += sv[k] * yv[k];
+        yy += yv[k] * yv[k];
       }
+      const double fold = s.f;
+      s.x = s.xt;
+      s.f = fv[q];
+      s.g.assign(gq, gq + s.np);
+      if (sy > 1e-10 * yy && yy > 0.) {
+        s.S.push_back(sv); s.Y.push_back(yv); s.rho.push_back(1.0 / sy);
+        if (s.S.size() > 10) { s.S.erase(s.S.begin()); s.Y.erase(s.Y.begin()); s.rho.erase(s.rho.begin()); }
+      }
+      s.iter++;
+      g_lb_iters += 1;
+      double gmax = 0.;
+      for (int k = 0; k < s.np; ++k) gmax = std::max(gmax, std::fabs(s.g[k]));
+      if (std::fabs(fold - s.f) <= opt.ftol * std::max(1.0, std::fabs(s.f)) || gmax <= opt.gtol || s.iter >= opt.max_iter || evals[pos] >= eval_cap) {
+        s.state = Lbfgs::DONE;
+        finish_run(pos);
+        continue;
+      }
+      s.direction();
+      s.step = 1.0; s.step_lo = 0.; s.step_hi = 0.; s.ls_iter = 0;
+      s.trial();
     }
   }
 }
 
+// Slot `slot` of this (replica) engine becomes a copy of emulator `i` of `src`: targets (host + device, with the fixed-mean
+// subtraction of the constructor), nugget type / size, hyper-parameter and mean priors; no hyper-parameters, no factor.
+void Engine::retarget(int slot, const Engine& src, int i) {
+  std::copy(src.hT.begin() + (size_t)i * n, src.hT.begin() + (size_t)(i + 1) * n, hT.begin() + (size_t)slot * n);
+  std::vector<double> res(hT.begin() + (size_t)slot * n, hT.begin() + (size_t)(slot + 1) * n);
+  if (!analytic && mean.n_params() == 0 && mean.kind == 1)
+    for (auto& x : res) x -= mean.value;
+  HIPCK(hipMemcpyAsync(dT + (size_t)slot * n, res.data(), (size_t)n * sizeof(double), hipMemcpyHostToDevice, stream));
+  HIPCK(hipStreamSynchronize(stream));          // `res` is a temporary
+  const GPState& s = src.gp[i];
+  GPState d;
+  d.nug_type = s.nug_type;
+  d.nug_size = s.nug_size;
+  d.pri = s.pri;
+  d.mp_b = s.mp_b; d.mp_Binv = s.mp_Binv; d.mp_Binvb = s.mp_Binvb; d.mp_logdetB = s.mp_logdetB;
+  d.data.assign(s.data.size(), 0.);
+  d.meanp.assign(n_mean(), 0.);
+  d.beta.assign(q, 0.);
+  drop_w2(slot);
+  gp[slot] = std::move(d);
+}
+
 // Multi-start MAP fit (fitting.hpp:61-128, fitting.py:219-266): n_tries L-BFGS runs per emulator, the best end point wins.
-// The starts of an emulator are independent, so as many of them as fit into device memory run CONCURRENTLY on a replica
-// engine (emulator e, start s -> replica e * chunk + s: same inputs, targets, priors): small problems, whose batches do
-// not fill the GPU, then cost about one start instead of n_tries (MOGP_PARALLEL_STARTS=0: one start after the other).
+// All (emulator, start) runs go through ONE slot pool (run_pool).  The runs are independent, so as many of them as pay run
+// CONCURRENTLY on a replica engine whose slots take the targets and priors of whatever run they are handed (retarget): small
+// problems, whose batches do not fill the GPU, then cost about one start instead of n_tries, and large ones keep every batched
+// evaluation full until the queue of runs drains.  MOGP_PARALLEL_STARTS=0: no replica engine -- the slots are this engine's own
+// emulators, each working through its own starts one after the other (still without waiting for its neighbours).
 void Engine::fit_map(const std::vector<int>& ids_in, int n_tries, const double* theta0, int theta0_len) {
   std::vector<int> ids(ids_in);
   if (ids.empty()) return;
@@ -1714,85 +1766,75 @@ void Engine::fit_map(const std::vector<int>& ids_in, int n_tries, const double* 
       else gp[ids[e]].pri.sample(rng, NC, gp[ids[e]].nug_type, x.data() + n_mean());
     }
   std::vector<double> best_f(ne, std::numeric_limits<double>::infinity());
+  std::vector<int> best_s(ne, -1);
   std::vector<std::vector<double>> best_x(ne);
-  auto keep_best = [&](int e, double f, const std::vector<double>& x) {
-    if (!x.empty() && std::isfinite(f) && f < best_f[e]) {
+  // run tag = s * ne + e; of equal end points the one of the earlier start wins, whatever order the runs finish in
+  auto done = [&](int tag, double f, const std::vector<double>& x) {
+    const int e = tag % ne, s = tag / ne;
+    if (!x.empty() && std::isfinite(f) && (f < best_f[e] || (f == best_f[e] && s < best_s[e]))) {
       best_f[e] = f;
+      best_s[e] = s;
       best_x[e] = x;
     }
   };
-  // how many starts fit beside this engine: A, L^-1, K^-1 per replica emulator plus the small per-emulator buffers
+  // how many replica slots: what fits beside this engine (A, L^-1, K^-1 per slot plus the small per-emulator buffers), what pays
+  // (replicas beyond what fills the device buy nothing and their buffers are fresh allocations: 64 x 15 starts of n = 2000 as ONE batch
+  // of 960 replicas took 3.7 - 5.8 s, capped at 256 2.44 s, 128: 2.52 s -- round 2), MOGP_START_REPLICAS overrides the cap
   static const bool parallel_starts = [] { const char* e = getenv("MOGP_PARALLEL_STARTS"); return !e || e[0] != '0'; }();
-  int chunk = 1;
+  const long total = (long)ne * n_tries;
+  long slots_n = ne;
   if (parallel_starts && n_tries > 1) {
     size_t free_b = 0, total_b = 0;
+    long fit = total;
     if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
       const double per_emu = 3.0 * (double)MS * sizeof(double) + 16.0 * LD * sizeof(double);
-      const double fit = 0.5 * (double)free_b / (per_emu * ne);
-      chunk = (int)std::max(1.0, std::min((double)n_tries, std::floor(fit)));
+      fit = (long)std::max(1.0, std::floor(0.5 * (double)free_b / per_emu));
     }
-    // Replicas beyond what fills the device buy nothing, and their buffers are fresh allocations: tens of GB of them cost
-    // seconds (constructing a 512-emulator engine of n = 2000 and its first evaluation: 1.2 s + 1.0 s against 93 ms for
-    // every later evaluation).  64 emulators x 15 starts of n = 2000 as ONE batch of 960 replicas took 3.7 - 5.8 s; capped
-    // at 256 replicas 2.44 s, 128: 2.52 s, one start at a time (no replicas) 2.48 s.  Cap: twice the batch up to which
-    // the one-launch Cholesky is used (nb * NP / 128 < 2048, factorize_blocked); the starts are dealt to equal passes
-    // (15 starts, at most 4 at a time -> 4 passes of 4, 4, 4, 3).  MOGP_START_REPLICAS overrides the cap.
     static const long replica_cap = [] { const char* e = getenv("MOGP_START_REPLICAS"); return e ? atol(e) : 0L; }();
-    const long cap = replica_cap > 0 ? replica_cap : std::max<long>(ne, 4095 / std::max(1, NP / TILE));
-    chunk = (int)std::max<long>(1, std::min<long>(chunk, cap / ne));
-    const int passes = (n_tries + chunk - 1) / chunk;
-    chunk = (n_tries + passes - 1) / passes;
+    const long cap = replica_cap > 0 ? replica_cap : std::max<long>(ne, 4095 / std::max(1, NP / TILE) + 1);
+    slots_n = std::min(total, std::min(fit, cap));
+    if (slots_n > 8) slots_n -= slots_n % 8;      // (batches that are multiples of 8 give every XCD whole emulators)
   }
-  if (chunk <= 1) {
-    std::vector<double> f;
-    std::vector<std::vector<double>> x;
-    for (int s = 0; s < n_tries; ++s) {
-      run_starts(ids, x0[s], f, x);
-      for (int e = 0; e < ne; ++e) keep_best(e, f[e], x[e]);
-    }
+  if (slots_n <= ne || !parallel_starts || n_tries == 1) {
+    // no replicas: slot e IS emulator ids[e] and works through its own starts
+    std::vector<int> nexts(ne, 0);
+    run_pool(ids,
+             [&](int pos, std::vector<double>& x, int& tag) {
+               if (nexts[pos] >= n_tries) return false;
+               const int s = nexts[pos]++;
+               x = x0[s][pos];
+               tag = s * ne + pos;
+               return true;
+             },
+             done);
   } else {
-    // ONE replica engine for all passes: `chunk` copies of every listed emulator (replica e * chunk + s = emulator e); a
-    // shorter last pass uses the first copies only.  (A fresh engine per pass paid for tens of GB of new allocations each time.)
-    std::unique_ptr<Engine> rep;
-    for (int s0 = 0; s0 < n_tries; s0 += chunk) {
-      const int c = std::min(chunk, n_tries - s0);
-      if (c == 1 && !rep) {
-        std::vector<double> f;
-        std::vector<std::vector<double>> x;
-        run_starts(ids, x0[s0], f, x);
-        for (int e = 0; e < ne; ++e) keep_best(e, f[e], x[e]);
-        continue;
-      }
-      if (!rep) {
-        std::vector<double> targets((size_t)ne * chunk * n);
-        for (int e = 0; e < ne; ++e)
-          for (int s = 0; s < chunk; ++s)
-            std::copy(hT.begin() + (size_t)ids[e] * n, hT.begin() + (size_t)(ids[e] + 1) * n, targets.begin() + ((size_t)e * chunk + s) * n);
-        rep.reset(new Engine(hX.data(), n, D, targets.data(), ne * chunk, testing_size, mean, kernel_type, gp[ids[0]].nug_type, gp[ids[0]].nug_size, analytic));
-        for (int e = 0; e < ne; ++e)
-          for (int s = 0; s < chunk; ++s) {
-            const GPState& src = gp[ids[e]];
-            GPState& dst = rep->gp[e * chunk + s];
-            dst.nug_type = src.nug_type;
-            dst.nug_size = src.nug_size;
-            dst.pri = src.pri;
-            dst.mp_b = src.mp_b; dst.mp_Binv = src.mp_Binv; dst.mp_Binvb = src.mp_Binvb; dst.mp_logdetB = src.mp_logdetB;
-            dst.data.assign(src.data.size(), 0.);
-          }
-      }
-      std::vector<int> rids;
-      std::vector<std::vector<double>> rx0;
-      for (int e = 0; e < ne; ++e)
-        for (int s = 0; s < c; ++s) {
-          rids.push_back(e * chunk + s);
-          rx0.push_back(x0[s0 + s][e]);
-        }
-      std::vector<double> f;
-      std::vector<std::vector<double>> x;
-      rep->run_starts(rids, rx0, f, x);
-      for (int e = 0; e < ne; ++e)
-        for (int s = 0; s < c; ++s) keep_best(e, f[e * c + s], x[e * c + s]);
+    // ONE replica engine of slots_n slots; the queue of runs in start-major order (all emulators' start 0 first)
+    std::vector<double> targets((size_t)slots_n * n);
+    for (long k = 0; k < slots_n; ++k) {
+      const int e = (int)(k % ne);
+      std::copy(hT.begin() + (size_t)ids[e] * n, hT.begin() + (size_t)(ids[e] + 1) * n, targets.begin() + (size_t)k * n);
     }
+    std::unique_ptr<Engine> rep(new Engine(hX.data(), n, D, targets.data(), (int)slots_n, testing_size, mean, kernel_type, gp[ids[0]].nug_type,
+                                           gp[ids[0]].nug_size, analytic));
+    std::vector<int> holds(slots_n, -1);          // which emulator (index into ids) a slot's targets and priors belong to
+    std::vector<int> rslots(slots_n);
+    for (long k = 0; k < slots_n; ++k) rslots[k] = (int)k;
+    long next_run = 0;
+    Engine* self = this;
+    rep->run_pool(rslots,
+                  [&](int pos, std::vector<double>& x, int& tag) {
+                    if (next_run >= total) return false;
+                    const long r = next_run++;
+                    const int s = (int)(r / ne), e = (int)(r % ne);
+                    if (holds[pos] != e) {
+                      rep->retarget(pos, *self, ids[e]);
+                      holds[pos] = e;
+                    }
+                    x = x0[s][e];
+                    tag = (int)r;
+                    return true;
+                  },
+                  done);
   }
   // refit at the best point of every emulator (fitting.hpp:115-117); failures -> "not fit" (:111-113)
   std::vector<int> fin;

@@ -1,7 +1,7 @@
 """
 ``fit_GP_MAP`` for the GPU classes -- mirror of the GPU branches of mogp_emulator/fitting.py:16-217.
-The optimisation itself is one native call (``LibGPGPU.fit_GP_MAP``): multi-start L-BFGS with every
-emulator of a MultiOutputGP_GPU advancing in lock-step through batched device evaluations.
+The optimisation itself is one native call (``LibGPGPU.fit_GP_MAP``): multi-start L-BFGS, every (emulator, start) run
+advancing independently through batched device evaluations (a slot pool: a run that ends hands its slot to the next one).
 """
 import numpy as np
 
