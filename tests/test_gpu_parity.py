@@ -943,7 +943,7 @@ def test_non_finite_targets_are_not_reported_as_a_chain_timeout():
                 assert ok[k] and np.isfinite(f[k])
         good = [k for k in range(B) if k not in bad][:2]
         for k in good:
-            assert_allclose(f[k], R.GPRef(X, T[k], nugget=1e-5).fit(theta[k]), rtol=1e-10)
+            assert_allclose(f[k], R.GPRef(X, T[k], nugget=1e-5).fit(theta[k]), rtol=1e-8)      # (d = 3, unit length scales, nugget 1e-5: cond(K) ~ 1e8)
 
 
 _STARTS_SCRIPT = r"""
