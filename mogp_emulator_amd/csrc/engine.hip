@@ -326,10 +326,9 @@ void Engine::upload_params(const std::vector<int>& ids) {
 // read-modify-write of C (256 KB per tile), which it does not at K = 128 (measured on C5: 256 -> 45.7 ms, 512 -> 41.7 ms).
 // One 128-wide block column [c, c+128), rows [c, NP), K = [k0, k1).  With few 128 x 128 tiles in the launch (a single
 // large matrix: (NP - c)/128 <= 125 workgroups on 256 CUs) the 64 x 64 tiling gives 4x the workgroups and the launch
-// takes one short tile instead of one long one; MOGP_COLTILE=128 restores the wide tiles everywhere.
+// takes one short tile instead of one long one.
 static void update_column_block(const BatchView& v, int c, int k0, int k1, hipStream_t st) {
-  static const long few = [] { const char* e = getenv("MOGP_COLTILE"); return (e && atoi(e) == 128) ? 0L : 512L; }();
-  if ((long)v.nb * ((v.NP - c) / TILE) < few) launch_update_narrow_pair(v, c, k0, k1, st);
+  if ((long)v.nb * ((v.NP - c) / TILE) < 512L) launch_update_narrow_pair(v, c, k0, k1, st);
   else launch_update_wide(v, c, k0, k1, st);
 }
 
@@ -559,7 +558,7 @@ void Engine::factorize_blocked(const std::vector<int>& ids, std::vector<int>& in
       evPanel.push_back(a);
       evUpd.push_back(b);
     }
-    static const long tail_threshold = [] { const char* e = getenv("MOGP_TAIL"); return e ? atol(e) : 1100L; }();
+    constexpr long tail_threshold = 1100L;
     auto long_update = [&](int o, int k1, hipStream_t st) {
       // 64 x 64 tiles unless the launch has several rounds of 128 x 128 ones (measured 7.6 vs 8.3 ms at 64 x n=2000)
       if ((long)nb * ((NP - o) / TILE) >= tail_threshold) launch_update_wide(v, o, 0, k1, st);
@@ -576,9 +575,8 @@ void Engine::factorize_blocked(const std::vector<int>& ids, std::vector<int>& in
     // at 8 x n=2000, 2.05 -> 1.94 at 16, 3.05 -> 2.94 at 32, 1.19 -> 1.14 at 64 x n=1000.  A waiter that really has to wait is
     // served later by the poll than by the event (n = 5000: 7.7 -> 8.0 ms at 4 emulators; the right-looking schedule, whose
     // waits are all of that kind: 5.2 -> 5.5 ms at 2 x n=5000, 34.3 -> 35.3 at n=16000; the other direction, panel -> U1, too),
-    // so it is used up to NP = 3072 (MOGP_WAITVAL=0 / 1 forces events / memory operations).
-    static const int waitval = [] { const char* e = getenv("MOGP_WAITVAL"); return e ? atoi(e) : -1; }();
-    const bool wv = can_waitval && !ovr.single_stream && (waitval < 0 ? NP <= 3072 : waitval != 0);
+    // so it is used up to NP = 3072.
+    const bool wv = can_waitval && !ovr.single_stream && NP <= 3072;
     if (wv && !sigU1) {
       HIPCK(hipExtMallocWithFlags(reinterpret_cast<void**>(&sigU1), 8, hipMallocSignalMemory));
       HIPCK(hipMemset(sigU1, 0, 8));
@@ -614,13 +612,12 @@ void Engine::factorize_blocked(const std::vector<int>& ids, std::vector<int>& in
     return;
   }
   if (schedule == 0) {
-    // Two independent emulator groups on separate streams (MOGP_GROUPS, default 2): while one group runs its
+    // Two independent emulator groups on separate streams: while one group runs its
     // latency-bound panel kernels (diagonal block / panel solve: few workgroups) the other group's MFMA update fills the
     // machine.  More than two streams collapse (round 1, 64 x n=2000: 1 group 6.58 ms, 2 groups 6.23 ms, 3 groups 8.3 ms,
     // 4 groups 14.2 ms -- the same when replayed from a captured hipGraph, so it is not host launch overhead).
-    static const long tail_threshold = [] { const char* e = getenv("MOGP_TAIL"); return e ? atol(e) : 1100L; }();
-    static const int want_groups = [] { const char* e = getenv("MOGP_GROUPS"); return e ? std::max(1, atoi(e)) : 2; }();
-    const int G = ovr.single_stream ? 1 : std::min(want_groups, std::max(1, nb / 8));
+    constexpr long tail_threshold = 1100L;
+    const int G = ovr.single_stream ? 1 : std::min(2, std::max(1, nb / 8));
     while ((int)gstreams.size() < G - 1) {
       hipStream_t st;
       HIPCK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
@@ -663,8 +660,8 @@ void Engine::factorize_blocked(const std::vector<int>& ids, std::vector<int>& in
   HIPCK(hipMemsetAsync(dInfo, 0, B * sizeof(int), stream));
   build_cov(v);
   std::vector<int> starts;
-  // outer block = K depth of the trailing update (MOGP_OUTER: 256 / 512 / 1024 -> C5 fit 45.7 / 41.7 / 44.3 ms)
-  static const int OUTERW = [] { const char* e = getenv("MOGP_OUTER"); const int w = e ? atoi(e) : 512; return (w == 128 || w == 256 || w == 512 || w == 1024) ? w : 512; }();
+  // outer block = K depth of the trailing update (256 / 512 / 1024 -> C5 fit 45.7 / 41.7 / 44.3 ms, round 1)
+  constexpr int OUTERW = 512;
   for (int o = 0; o < n + R; o += OUTERW) starts.push_back(o);
   const int K = (int)starts.size();
   while ((int)evPanel.size() < K + 1) {

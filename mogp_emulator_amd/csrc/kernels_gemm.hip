@@ -162,11 +162,11 @@ __device__ __forceinline__ void decode_block(int nb, int ntiles, int& z, int& ti
 }
 
 // ---------------------------------------------------------------------------------------------
-// Trailing / narrow symmetric update on A:  C[i,j] -= sum_{k in [k0,k1)} A[i,k] A[j,k]
-//   TRI = true : lower-triangular tile set over rows/cols [c0, NP)  (WT = 4)
-//   TRI = false: single tile column [c0, c0+BM), rows [c0, NP)     (WT = 2, "narrow" update)
+// Narrow symmetric update on A:  C[i,j] -= sum_{k in [k0,k1)} A[i,k] A[j,k] for a tile column [c0, c0+BM) (or the pair of 64-wide tile
+// columns of a 128-wide block column), rows [c0, NP).  (The lower-triangular tile set of the trailing update is update_tri8_kernel; the
+// 2 x 2-wave form of it that lived here behind MOGP_TRI_WAVES=4 went in round 6.)
 // ---------------------------------------------------------------------------------------------
-template <int WT, bool TRI>
+template <int WT>
 __global__ __launch_bounds__(256, 2) void update_kernel(BatchView v, int c0, int k0, int k1, int nt, int ntiles) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   using C = Cfg<WT>;
@@ -174,13 +174,7 @@ __global__ __launch_bounds__(256, 2) void update_kernel(BatchView v, int c0, int
   decode_block(v.nb, ntiles, z, tile);
   if (z >= v.nb) return;
   int ti, tj;
-  if (TRI) {
-    // tile = ti*(ti+1)/2 + tj, tj <= ti
-    ti = (int)((sqrt(8.0 * tile + 1.0) - 1.0) * 0.5);
-    while (ti * (ti + 1) / 2 > tile) --ti;
-    while ((ti + 1) * (ti + 2) / 2 <= tile) ++ti;
-    tj = tile - ti * (ti + 1) / 2;
-  } else if (ntiles == nt) {
+  if (ntiles == nt) {
     ti = tile;
     tj = 0;
   } else {
@@ -655,7 +649,7 @@ static int padded_grid(int nb, int ntiles) { return ((nb & 7) == 0) ? nb * ntile
 void launch_update_narrow(const BatchView& v, int c0, int k0, int k1, hipStream_t s) {
   const int nt = (v.NP - c0) / 64;
   if (nt <= 0) return;
-  hipLaunchKernelGGL((update_kernel<2, false>), dim3(padded_grid(v.nb, nt)), dim3(256), smem_bytes<2>(), s, v, c0, k0, k1, nt, nt);
+  hipLaunchKernelGGL((update_kernel<2>), dim3(padded_grid(v.nb, nt)), dim3(256), smem_bytes<2>(), s, v, c0, k0, k1, nt, nt);
 }
 
 // two adjacent 64-wide block columns [c0, c0+128) in ONE launch (2 nt - 1 lower tiles): twice the workgroups per
@@ -666,7 +660,7 @@ void launch_update_narrow_pair(const BatchView& v, int c0, int k0, int k1, hipSt
   const int ntiles = std::max(1, 2 * nt - 1);
   const double m = (double)(v.NP - c0);
   prof_begin("chol_update", s);
-  hipLaunchKernelGGL((update_kernel<2, false>), dim3(padded_grid(v.nb, ntiles)), dim3(256), smem_bytes<2>(), s, v, c0, k0, k1, nt, ntiles);
+  hipLaunchKernelGGL((update_kernel<2>), dim3(padded_grid(v.nb, ntiles)), dim3(256), smem_bytes<2>(), s, v, c0, k0, k1, nt, ntiles);
   // algorithmic flops: the lower part of the m x 128 block column, 2 flops per multiply-add
   prof_end("chol_update", s, (double)v.nb * (m * 128.0 - 128.0 * 128.0 / 2.0) * 2.0 * (k1 - k0), (double)v.nb * (16.0 * m * 128.0 + 8.0 * (m + 128.0) * (k1 - k0)));
 }
@@ -677,7 +671,7 @@ void launch_update_wide(const BatchView& v, int c0, int k0, int k1, hipStream_t 
   if (nt <= 0) return;
   const double m = (double)(v.NP - c0);
   prof_begin("chol_update", s);
-  hipLaunchKernelGGL((update_kernel<4, false>), dim3(padded_grid(v.nb, nt)), dim3(256), smem_bytes<4>(), s, v, c0, k0, k1, nt, nt);
+  hipLaunchKernelGGL((update_kernel<4>), dim3(padded_grid(v.nb, nt)), dim3(256), smem_bytes<4>(), s, v, c0, k0, k1, nt, nt);
   // algorithmic flops of the block-column update (lower part): (m*128 - 128*128/2) * 2 * K / 2 ... count m*128*K*2 minus the upper half of the diagonal tile
   prof_end("chol_update", s, (double)v.nb * (m * 128.0 - 128.0 * 128.0 / 2.0) * 2.0 * (k1 - k0), (double)v.nb * (16.0 * m * 128.0 + 8.0 * (m + 128.0) * (k1 - k0)));
 }
@@ -688,10 +682,7 @@ void launch_update_trailing(const BatchView& v, int c0, int k0, int k1, hipStrea
   const int ntiles = nt * (nt + 1) / 2;
   const double m = (double)(v.NP - c0);
   prof_begin("syrk_trailing", s);
-  static const bool w8 = [] { const char* e = getenv("MOGP_TRI_WAVES"); return !e || atoi(e) != 4; }();   // 4: 2 x 2-wave kernel
-  if (w8) hipLaunchKernelGGL(update_tri8_kernel, dim3(padded_grid(v.nb, ntiles)), dim3(512), smem_bytes<4>(), s, v, c0, k0, k1, ntiles);
-  else
-    hipLaunchKernelGGL((update_kernel<4, true>), dim3(padded_grid(v.nb, ntiles)), dim3(256), smem_bytes<4>(), s, v, c0, k0, k1, nt, ntiles);
+  hipLaunchKernelGGL(update_tri8_kernel, dim3(padded_grid(v.nb, ntiles)), dim3(512), smem_bytes<4>(), s, v, c0, k0, k1, ntiles);
   // algorithmic: lower half of an m x m rank-(k1-k0) update = m^2 (k1-k0) flops; bytes: read+write C lower half + panel
   prof_end("syrk_trailing", s, (double)v.nb * m * m * (k1 - k0), (double)v.nb * (8.0 * m * m + 8.0 * m * (k1 - k0)));
 }

@@ -400,7 +400,7 @@ __global__ __launch_bounds__(256, SOLO ? 1 : 2) void mchol_kernel(BatchView v, u
           };
           const int prog = mc_wait_min3(cx, ddone + c, ddone + c, ddone + c, 0u);
           if (prog < 0) return;
-          if (prog >= 8 && (tile_solve & 32)) {
+          if (prog >= 8) {
             mc_stamp<TRACE>(tr, 8);
             trsm128_tile2_chain_dev<true, true>(v, c0, r0, pk, emu, lds, acc, TrsmNoWait(), pub);
           } else if (!trsm128_tile2_chain_dev<true, false>(v, c0, r0, pk, emu, lds, acc, wait, pub)) return;
@@ -435,7 +435,7 @@ __global__ __launch_bounds__(256, SOLO ? 1 : 2) void mchol_kernel(BatchView v, u
         // memory round trip per block step: 15 us per solve against 8 - 9 with the images requested two steps ahead.
         const int prog = mc_wait_min3(cx, ddone + c, ddone + c, ddone + c, 0u);
         if (prog < 0) return;
-        if (prog >= 8 && (tile_solve & 32)) {
+        if (prog >= 8) {
           mc_stamp<TRACE>(tr, 8);
           trsm128_lds_dev<true, true, false>(v, c0, r0, pk, emu, 0, lds, TrsmNoWait(), pub);
         } else if (!trsm128_lds_dev<true, false, true>(v, c0, r0, pk, emu, 0, lds, wait, pub)) return;
@@ -554,12 +554,10 @@ void launch_mchol(const BatchView& v, unsigned* ctrl, size_t ctrl_ints, const in
   // threshold grows with the depth of the matrix, whose share of GEMM work it follows)
   const double K16 = std::max(1.0, (v.NP / 128) / 16.0);
   const int per_cu = force_wgs ? force_wgs : (rho < 1.2 * std::pow(K16, 0.7) ? 1 : 2);
-  // bit 1: MOGP_MC_NOTRAFFIC=1 (measurement only, garbage results): the bulk GEMM tasks re-read their first 64 operand columns -- the traffic A/B;
-  // bit 5: MOGP_MC_LATE=0: chain tasks always solve in the pipelined form, also when their diagonal block has already finished
+  // bit 1: MOGP_MC_NOTRAFFIC=1 (measurement only, garbage results): the bulk GEMM tasks re-read their first 64 operand columns -- the traffic A/B
   static const int tile_solve = [] {
     const char* f = getenv("MOGP_MC_NOTRAFFIC");
-    const char* l = getenv("MOGP_MC_LATE");
-    return ((f && atoi(f)) ? 2 : 0) | ((!l || atoi(l)) ? 32 : 0);
+    return (f && atoi(f)) ? 2 : 0;
   }();
   // MOGP_MC_URG = 0 / 1 / 2: two, four or six row tiles below the diagonal block are chain tasks (pipelined solve, pieces published)
   static const int force_urg = [] { const char* e = getenv("MOGP_MC_URG"); return e ? atoi(e) & 3 : -1; }();

@@ -668,11 +668,10 @@ print("SWITCH-OK", repr(float(f[0])))
 
 @pytest.mark.parametrize("env", [{"MOGP_CHOL": "mchol"}, {"MOGP_CHOL": "mchol", "MOGP_MC_WGS": "2"}, {"MOGP_MCHOL": "0"}, {"MOGP_CHOL": "mchol", "MOGP_MC_SOLO": "0"},
                                  {"MOGP_TRTRI_WT4_FROM": "128"}, {"MOGP_TRTRI_WT4_FROM": "100000"}, {"MOGP_KINV_WT": "2"}, {"MOGP_KINV_WT": "4"},
-                                 {"MOGP_CHOL": "mchol", "MOGP_MC_LATE": "0"}, {"MOGP_CHOL": "mchol", "MOGP_MC_AHEAD": "0"}, {"MOGP_CHOL": "mchol", "MOGP_MC_EGRP": "0"}, {"MOGP_CHOL": "mchol", "MOGP_MC_EGRP": "1", "MOGP_MC_WGS": "2"}, {"MOGP_BS_HOIST": "0"}, {"MOGP_BS_LOGDET": "0"},
+                                 {"MOGP_CHOL": "mchol", "MOGP_MC_AHEAD": "0"}, {"MOGP_CHOL": "mchol", "MOGP_MC_EGRP": "0"}, {"MOGP_CHOL": "mchol", "MOGP_MC_EGRP": "1", "MOGP_MC_WGS": "2"}, {"MOGP_BS_HOIST": "0"}, {"MOGP_BS_LOGDET": "0"},
                                  {"MOGP_CHOL": "mchol", "MOGP_MC_URG": "0"}, {"MOGP_CHOL": "mchol", "MOGP_MC_URG": "1", "MOGP_MC_WGS": "2"}, {"MOGP_PV_SINGLE": "1"}, {"MOGP_PV_SINGLE": "0"}, {"MOGP_PV_Q": "0"}, {"MOGP_PV_Q": "1", "MOGP_PV_SINGLE": "0"},
-                                 {"MOGP_CHOL": "la"}, {"MOGP_CHOL": "left"}, {"MOGP_CHOL": "left", "MOGP_GROUPS": "1"},
-                                 {"MOGP_CHOL": "right"}, {"MOGP_CHOL": "right", "MOGP_OUTER": "128"}, {"MOGP_TAIL": "0"},
-                                 {"MOGP_BACKSOLVE": "1"}, {"MOGP_BS_SENTINEL": "0"}, {"MOGP_WAITVAL": "0"}, {"MOGP_CHOL": "la", "MOGP_WAITVAL": "1"}, {"MOGP_KS_BUDGET_GB": "0.05"}],
+                                 {"MOGP_CHOL": "la"}, {"MOGP_CHOL": "left"}, {"MOGP_CHOL": "right"},
+                                 {"MOGP_BACKSOLVE": "1"}, {"MOGP_BS_SENTINEL": "0"}, {"MOGP_KS_BUDGET_GB": "0.05"}],
                          ids=lambda e: ",".join(k + "=" + v for k, v in e.items()))
 def test_cholesky_schedules_and_switches(env):
     """Every A/B switch libmogp_hip.so still reads (HISTORY.md section 5) goes through the C2 full-size parity check in its own

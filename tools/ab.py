@@ -1,7 +1,7 @@
 """A/B driver for library switches: every configuration (a set of MOGP_* variables) runs in its own process on the same
 workload; prints fit / fit+grad / predict times and the largest differences of the results against the first configuration.
 
-    python tools/ab.py "" "MOGP_WAITVAL=0" "MOGP_CHOL=la MOGP_GROUPS=1"
+    python tools/ab.py "" "MOGP_MC_EGRP=0" "MOGP_CHOL=la"
     env: B (64), N (2000), D (10), M (10000), REPS (10), WHAT (fit,grad,predict)
 """
 import json, os, subprocess, sys, time
