@@ -28,14 +28,18 @@ __device__ __forceinline__ double kern_dr2(double r2, const double* tab) {
   return -(5.0 / 6.0) * (1.0 + s) * lean_exp_neg<false>(s, tab);
 }
 
-// stage rows [r0, r0+64) of Xg (nrows, D) into sx[d*64 + r]; rows >= nrows are zero filled
-__device__ __forceinline__ void stage_rows(const double* __restrict__ Xg, int nrows, int D, int r0, double* sx) {
+// stage rows [r0, r0+64) of Xg (nrows, D) into sx[d*64 + r]; rows >= nrows are zero filled.  SC: multiplied by sqrt(P[d]) on the way
+// (micro_r2<.., SC>; equal inputs stay equal, so r2 of repeated points is still exactly 0)
+template <bool SC = false>
+__device__ __forceinline__ void stage_rows(const double* __restrict__ Xg, int nrows, int D, int r0, double* sx, const double* __restrict__ P = nullptr) {
   const int cnt = 64 * D;
   const int avail = max(0, min(64, nrows - r0)) * D;
   const double* src = Xg + (size_t)r0 * D;
   for (int e = threadIdx.x; e < cnt; e += 256) {
     const int r = e / D, d = e - r * D;
-    sx[d * 64 + r] = (e < avail) ? src[e] : 0.0;
+    double x = (e < avail) ? src[e] : 0.0;
+    if (SC) x *= sqrt(P[d]);
+    sx[d * 64 + r] = x;
   }
 }
 

@@ -3,6 +3,7 @@
 #include <algorithm>
 #include <memory>
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -72,7 +73,7 @@ struct FlagGuard {
   ~FlagGuard() { b = false; }
 };
 static std::atomic<long long> g_bs_timeouts{0}, g_obj_evals{0}, g_grad_evals{0}, g_mc_aborts{0};
-static std::atomic<long long> g_lb_iters{0}, g_ls_short{0}, g_ls_long{0}, g_lb_runs{0}, g_pool_rounds{0}, g_pool_slot_rounds{0};
+static std::atomic<long long> g_lb_iters{0}, g_ls_short{0}, g_ls_long{0}, g_lb_runs{0}, g_pool_rounds{0}, g_pool_slot_rounds{0}, g_rep_build_us{0};
 long long prof_counter(const char* name) {
   const std::string s(name ? name : "");
   if (s == "backsolve_timeouts") return g_bs_timeouts.load();
@@ -88,6 +89,7 @@ long long prof_counter(const char* name) {
   // slot pool of fit_GP_MAP: batched optimiser rounds, and the sum over rounds of the slots that took part (/ rounds = mean batch)
   if (s == "pool_rounds") return g_pool_rounds.load();
   if (s == "pool_slot_rounds") return g_pool_slot_rounds.load();
+  if (s == "replica_engine_build_us") return g_rep_build_us.load();      // host time spent constructing replica engines (allocations)
   return -1;
 }
 bool prof_is_on() { return g_prof_on; }
@@ -1811,8 +1813,10 @@ void Engine::fit_map(const std::vector<int>& ids_in, int n_tries, const double* 
       const int e = (int)(k % ne);
       std::copy(hT.begin() + (size_t)ids[e] * n, hT.begin() + (size_t)(ids[e] + 1) * n, targets.begin() + (size_t)k * n);
     }
+    const auto tc0 = std::chrono::steady_clock::now();
     std::unique_ptr<Engine> rep(new Engine(hX.data(), n, D, targets.data(), (int)slots_n, testing_size, mean, kernel_type, gp[ids[0]].nug_type,
                                            gp[ids[0]].nug_size, analytic));
+    g_rep_build_us += std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - tc0).count();
     std::vector<int> holds(slots_n, -1);          // which emulator (index into ids) a slot's targets and priors belong to
     std::vector<int> rslots(slots_n);
     for (long k = 0; k < slots_n; ++k) rslots[k] = (int)k;

@@ -23,11 +23,21 @@ namespace mogp {
 
 typedef double v2d __attribute__((ext_vector_type(2)));
 
+// K build and cross covariance of the squared-exponential / Matern-5/2 kernels on inputs scaled by sqrt(e_d) at staging (micro_r2<.., SC>).
+// Round 6, device time unscaled / scaled (profiles/r06_cov_scaled_ab.txt): cross covariance 64 x n=2000 x 10^4 points, d = 10: 2.89 -> 2.45 ms
+// (4.2 TB/s of written bytes); C4 (16 x n=5000, Matern-5/2, d = 20) 3.87 -> 3.07 ms; K build C4 0.79 -> 0.75 ms, headline 0.28 -> 0.27 (it
+// sits on its write floor); K entries agree to the last digit printed, log-posteriors to 2e-12 (cond 2e9) / 3e-15 (C4).
+constexpr bool COV_SCALED = true;
+
 __device__ __forceinline__ int slot_emu2(const int* idx, int z) { return idx ? idx[z] : z; }
 
 // r2 for the thread's RA x CB micro tile (rows RA*ty.., cols CB*tx..): 4 x 4 with (ty, tx) = (t >> 4, t & 15), or 8 x 2 with
 // (t >> 5, t & 31) -- the latter makes a wave's store instruction two whole 512-byte rows of the 64-column tile
-template <int RA, int CB>
+// SC (round 6): the staged coordinates are already multiplied by sqrt(e_d) (stage_rows<true>): r2 = sum_d (u_id - u_jd)^2, two vector
+// instructions per pair and dimension instead of three.  The difference form is kept -- r2 stays RELATIVELY accurate (a few ulp), which is
+// what the parity bars on ill-conditioned K rest on; the Gram form a_i + a_j - 2 b_ij through the matrix cores would
+// carry an ABSOLUTE error eps max a_i into every r2, i.e. a relative error ~1e-14 into K where the difference form has ~1e-16.
+template <int RA, int CB, bool SC = false>
 __device__ __forceinline__ void micro_r2(const double* si, const double* sj, const double* __restrict__ P, int D, int ty, int tx,
                                          double (&r2)[RA][CB]) {
 #pragma unroll
@@ -46,7 +56,7 @@ __device__ __forceinline__ void micro_r2(const double* si, const double* sj, con
 #pragma unroll
       for (int b = 0; b < CB; ++b) {
         const double df = xi[a] - xj[b];
-        r2[a][b] = __builtin_fma(e * df, df, r2[a][b]);
+        r2[a][b] = SC ? __builtin_fma(df, df, r2[a][b]) : __builtin_fma(e * df, df, r2[a][b]);
       }
   }
 }
@@ -72,12 +82,12 @@ __device__ __forceinline__ void group_fence(double (&t)[RA][CB], int g) {
 }
 
 // kernel values (without sigma^2) of the thread's micro tile
-template <int KT, int RA, int CB>
+template <int KT, int RA, int CB, bool SC = false>
 __device__ __forceinline__ void micro_k(const double* si, const double* sj, const double* __restrict__ P, int D, int ty, int tx,
                                         double (&k)[RA][CB], const double* etab) {
   double* kf = &k[0][0];
   if (KT < 2) {
-    micro_r2<RA, CB>(si, sj, P, D, ty, tx, k);
+    micro_r2<RA, CB, SC>(si, sj, P, D, ty, tx, k);
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
 #pragma unroll
@@ -147,15 +157,16 @@ __global__ __launch_bounds__(256) void cov_build_kernel(BatchView v, ZeroRanges 
   const double* T = v.T + (size_t)emu * n;
   double* si = sm;
   double* sj = sm + 64 * D;
-  stage_rows(v.X + (size_t)emu * v.XS, n, D, i0, si);
-  stage_rows(v.X + (size_t)emu * v.XS, n, D, j0, sj);
+  constexpr bool SC = COV_SCALED && KT < 2;
+  stage_rows<SC>(v.X + (size_t)emu * v.XS, n, D, i0, si, P);
+  stage_rows<SC>(v.X + (size_t)emu * v.XS, n, D, j0, sj, P);
   __syncthreads();
   // 8 x 2 micro tile: thread (ty, tx) = (t >> 5, t & 31) owns rows 8 ty .. 8 ty + 7 and columns 2 tx, 2 tx + 1, so that one store
   // instruction of a wave is two whole 512-byte rows of the tile (with 4 x 4 micro tiles it was sixteen 16-byte pieces per row pair
   // at a 32-byte stride: every 128-byte line written by two instructions, half each)
   const int ty = threadIdx.x >> 5, tx = threadIdx.x & 31;
   double kv[8][2];
-  micro_k<KT, 8, 2>(si, sj, P, D, ty, tx, kv, etab);
+  micro_k<KT, 8, 2, SC>(si, sj, P, D, ty, tx, kv, etab);
   const double sig2 = P[D], nug = P[D + 1];
   // INTERIOR: a tile strictly below the diagonal whose rows are all training points (15 of 16 tiles at n = 2000): every entry is
   // sigma^2 k -- no nugget, no target row, no padding
@@ -243,7 +254,8 @@ __global__ __launch_bounds__(256) void cross_cov_mean_kernel(BatchView v, const 
   double* sj = sm + 64 * D;           // NB x [D][64]
   double* sa = sj + NB * 64 * D;      // NB x [R][64] operand tile
   double* red = sa + NB * RMAX * 64;  // 64 x 33
-  stage_rows(Xs, m, D, i0, si);
+  constexpr bool SC = COV_SCALED && KT < 2;
+  stage_rows<SC>(Xs, m, D, i0, si, P);
   // 8 x 2 micro tile (see cov_build_kernel): a wave's store instruction is two whole 512-byte rows of the K* tile
   const int t = threadIdx.x, ty = t >> 5, tx = t & 31;
   const double sig2 = P[D];
@@ -256,6 +268,7 @@ __global__ __launch_bounds__(256) void cross_cov_mean_kernel(BatchView v, const 
   const int ntj = v.NP / 64;
   // prefetch registers and the (tile-independent) LDS slot of each: element e = t + 256 q of a [64][D] row block goes to [d][row]
   double px[NPF > 0 ? NPF : 1], pa[NPA];
+  double psc[NPF > 0 ? NPF : 1];                              // SC: sqrt(e_d) of the coordinate a prefetch register carries
   int loff[NPF > 0 ? NPF : 1];
   const int cnt = 64 * D;
   if (NPF > 0) {
@@ -263,6 +276,7 @@ __global__ __launch_bounds__(256) void cross_cov_mean_kernel(BatchView v, const 
     for (int q = 0; q < NPF; ++q) {
       const int e = t + 256 * q, r = e / D;
       loff[q] = (e - r * D) * 64 + r;
+      psc[q] = (SC && e < cnt) ? sqrt(P[e - r * D]) : 1.0;
     }
   }
   auto fetch = [&](int j0) {
@@ -283,7 +297,7 @@ __global__ __launch_bounds__(256) void cross_cov_mean_kernel(BatchView v, const 
   auto deposit = [&](int buf) {
 #pragma unroll
     for (int q = 0; q < NPF; ++q)
-      if (t + 256 * q < cnt) sj[buf * cnt + loff[q]] = px[q];
+      if (t + 256 * q < cnt) sj[buf * cnt + loff[q]] = SC ? px[q] * psc[q] : px[q];
 #pragma unroll
     for (int q = 0; q < NPA; ++q)
       if (t + 256 * q < R * 64) sa[buf * RMAX * 64 + t + 256 * q] = pa[q];
@@ -300,7 +314,7 @@ __global__ __launch_bounds__(256) void cross_cov_mean_kernel(BatchView v, const 
     __syncthreads();
     if (NPF == 0) {
       if (j0 < n) {
-        stage_rows(Xtr, n, D, j0, sj);
+        stage_rows<SC>(Xtr, n, D, j0, sj, P);
         for (int e = t; e < R * 64; e += 256) {
           const int c = e >> 6, jj = e & 63;
           const double* src = (c == 0) ? alpha0 : Zr + (size_t)c * ld;
@@ -312,7 +326,7 @@ __global__ __launch_bounds__(256) void cross_cov_mean_kernel(BatchView v, const 
       fetch(j0 + 64);
     }
     double kv[8][2];
-    if (j0 < n) micro_k<KT, 8, 2>(si, sjc, P, D, ty, tx, kv, etab);
+    if (j0 < n) micro_k<KT, 8, 2, SC>(si, sjc, P, D, ty, tx, kv, etab);
     double* Kt = Kz + (size_t)(i0 + 8 * ty) * ld + j0 + 2 * tx;
 #pragma unroll
     for (int a = 0; a < 8; ++a) {

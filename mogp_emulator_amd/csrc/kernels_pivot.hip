@@ -254,8 +254,9 @@ __device__ __forceinline__ double cov_pair_global(const BatchView& v, const doub
   if (v.kernel_type < 2) {
     double r2 = 0.0;
     for (int d = 0; d < D; ++d) {
-      const double df = xa[d] - xb[d];
-      r2 = __builtin_fma(P[d] * df, df, r2);
+      const double sc = sqrt(P[d]);          // (the K build stages its inputs multiplied by sqrt(e_d): stage_rows<true>, micro_r2<.., true>)
+      const double df = xa[d] * sc - xb[d] * sc;
+      r2 = __builtin_fma(df, df, r2);
     }
     return P[D] * (v.kernel_type == 0 ? kern_val<0>(r2, EXP_TAB_G) : kern_val<1>(r2, EXP_TAB_G));
   }
