@@ -486,10 +486,14 @@ def main():
     dev_index = local_rank % ndev if backend != "nccl" else local_rank
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # (rank 0 times the CPU baseline after the timed region while the other ranks wait in the final barrier: minutes at most, but
+        # beyond the watchdog's default patience when the host is busy)
+        import datetime
+        patience = datetime.timedelta(minutes=45)
         if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index))
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index), timeout=patience)
         else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+            dist.init_process_group(backend, rank=rank, world_size=world, timeout=patience)
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     coll_dev = dev if backend == "nccl" else torch.device("cpu")
