@@ -205,16 +205,24 @@ def time_fit_map(M, X, T, kernel, nugget, n_tries, max_iter):
     i.e. it works in the full-batch regime of the Cholesky, not in the 8-matrix regime of a single fit(theta)."""
     from mogp_emulator_amd import libgpgpu
     B = T.shape[0]
-    libgpgpu.set_fit_options(max_iter=max_iter, ftol=1e-9, gtol=1e-6, seed=1)
-    gp = M.MultiOutputGP_GPU(X, T, kernel=kernel, nugget=nugget)              # default priors (SURVEY 8d)
-    e0, g0 = counter("objective_evals"), counter("gradient_evals")
-    r0, sr0 = counter("pool_rounds"), counter("pool_slot_rounds")
-    t0 = time.perf_counter()
-    libgpgpu.fit_GP_MAP(gp._mogp_gpu, n_tries)
-    dt = time.perf_counter() - t0
+    # Twice (same seed, same starts, same evaluations): the first call of a process that needs more device memory than the process has
+    # touched before pays for the fresh allocations of its replica slots -- 0 to 1.5 s for 25 GB depending on the box (round 6,
+    # tools/fitmap_context.py) --, the second one runs on memory the runtime already holds.  `fit_GP_MAP_s` is the second call,
+    # `fit_GP_MAP_first_call_s` the first.
+    first = None
+    for rep in range(2):
+        libgpgpu.set_fit_options(max_iter=max_iter, ftol=1e-9, gtol=1e-6, seed=1)
+        gp = M.MultiOutputGP_GPU(X, T, kernel=kernel, nugget=nugget)              # default priors (SURVEY 8d)
+        e0, g0 = counter("objective_evals"), counter("gradient_evals")
+        r0, sr0 = counter("pool_rounds"), counter("pool_slot_rounds")
+        t0 = time.perf_counter()
+        libgpgpu.fit_GP_MAP(gp._mogp_gpu, n_tries)
+        dt = time.perf_counter() - t0
+        if first is None:
+            first = dt
     evals = counter("objective_evals") - e0
     rounds = counter("pool_rounds") - r0
-    res = {"fit_GP_MAP_s": dt, "fit_GP_MAP_n_tries": n_tries, "fit_GP_MAP_max_iter": max_iter,
+    res = {"fit_GP_MAP_s": dt, "fit_GP_MAP_first_call_s": first, "fit_GP_MAP_n_tries": n_tries, "fit_GP_MAP_max_iter": max_iter,
            "fit_GP_MAP_emulator_fits_per_s": B / dt, "fit_GP_MAP_all_fit": len(gp.get_indices_not_fit()) == 0,
            "fit_GP_MAP_objective_evals": evals, "fit_GP_MAP_gradient_evals": counter("gradient_evals") - g0,
            "fit_GP_MAP_objective_evals_per_s": evals / dt,
@@ -420,7 +428,8 @@ def nest_summaries(out, n, total_emus, world):
     fm = out.get("fit_GP_MAP_15_starts_64_emulators")
     if fm:
         fg = (out.get("fit_roofline") or {}).get("fit_grad_achieved")
-        rf["fit_GP_MAP"] = {"workload": "%d emulators x 15 starts, max_iter 10" % total_emus, "s": round(fm["fit_GP_MAP_s"], 4), "TFLOPs": round(fm["fit_GP_MAP_TFLOPs"], 2),
+        rf["fit_GP_MAP"] = {"workload": "%d emulators x 15 starts, max_iter 10" % total_emus, "s": round(fm["fit_GP_MAP_s"], 4),
+                            "first_call_s": round(fm["fit_GP_MAP_first_call_s"], 4), "TFLOPs": round(fm["fit_GP_MAP_TFLOPs"], 2),
                             "objective_evals": fm["fit_GP_MAP_objective_evals"], "gradient_evals": fm["fit_GP_MAP_gradient_evals"],
                             "over_fit_grad_phase": round(fm["fit_GP_MAP_TFLOPs"] / fg, 3) if fg else None}
     if "cpu_baseline" in out and "parity_in_bench" in out:

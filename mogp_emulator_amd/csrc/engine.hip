@@ -73,7 +73,7 @@ struct FlagGuard {
   ~FlagGuard() { b = false; }
 };
 static std::atomic<long long> g_bs_timeouts{0}, g_obj_evals{0}, g_grad_evals{0}, g_mc_aborts{0};
-static std::atomic<long long> g_lb_iters{0}, g_ls_short{0}, g_ls_long{0}, g_lb_runs{0}, g_pool_rounds{0}, g_pool_slot_rounds{0}, g_rep_build_us{0};
+static std::atomic<long long> g_lb_iters{0}, g_ls_short{0}, g_ls_long{0}, g_lb_runs{0}, g_pool_rounds{0}, g_pool_slot_rounds{0}, g_rep_build_us{0}, g_rep_pool_us{0};
 long long prof_counter(const char* name) {
   const std::string s(name ? name : "");
   if (s == "backsolve_timeouts") return g_bs_timeouts.load();
@@ -90,6 +90,7 @@ long long prof_counter(const char* name) {
   if (s == "pool_rounds") return g_pool_rounds.load();
   if (s == "pool_slot_rounds") return g_pool_slot_rounds.load();
   if (s == "replica_engine_build_us") return g_rep_build_us.load();      // host time spent constructing replica engines (allocations)
+  if (s == "replica_pool_us") return g_rep_pool_us.load();               // ... from there to the end of fit_map's replica block (pool + its destruction excluded)
   return -1;
 }
 bool prof_is_on() { return g_prof_on; }
@@ -721,35 +722,51 @@ void Engine::eval(const std::vector<int>& ids, const std::vector<const double*>&
       upload_idx(todo);
       BatchView v = view((int)todo.size());
       bool chained = false, res_done = false;
-      if (want_grad) {
-        // gradient path: L^-1 is needed anyway, so K^-1 [t, H] = L^-T Y is one fully parallel gemv with it
-        ensure_linv(todo);
-        upload_idx(todo);
-        v = view((int)todo.size());
-        launch_alpha_from_linv(v, stream);
-      } else {
-        // single right-hand side: the one-launch chain (MOGP_BACKSOLVE=1: per-block launches, the path a timed-out chain falls back to)
-        static const bool chain = [] { const char* e = getenv("MOGP_BACKSOLVE"); return !e; }();
-        if (chain && R == 1 && pass == 0) {
-          const size_t nfl = (size_t)B * ((n + 127) / 128);
-          if (!dBsFlags) {
-            dBsFlags = dalloc<int>(nfl + B);                 // flags, then one status word per emulator
-            HIPCK(hipMemsetAsync(dBsFlags, 0, (nfl + B) * sizeof(int), stream));
-          }
-          if (bs_epoch > 0x7FFFFF00) {                       // flags and status are compared with the epoch: start over before it wraps
-            HIPCK(hipMemsetAsync(dBsFlags, 0, (nfl + B) * sizeof(int), stream));
-            bs_epoch = 0;
-          }
-          if (z_armed.size() != (size_t)B) z_armed.assign(B, 0);
-          for (int i : todo) {
-            if (!z_armed[i]) HIPCK(hipMemsetAsync(dAlpha + (size_t)i * RA * LD, 0xFF, (size_t)LD * sizeof(double), stream));
-            z_armed[i] = 0;                                  // consumed by this solve
-          }
-          res_done = launch_backsolve_chain(v, dBsFlags, ++bs_epoch, dBsFlags + nfl, n_cu, stream, dInfo, dRes, mc_used ? dMcCtrl : nullptr);
-          chained = true;
-        } else {
-          launch_backsolve(v, stream);
+      // single right-hand side: the one-launch chain (MOGP_BACKSOLVE=1: per-block launches, the path a timed-out chain falls back to)
+      static const bool chain = [] { const char* e = getenv("MOGP_BACKSOLVE"); return !e; }();
+      const bool use_chain = chain && R == 1 && pass == 0;
+      // the chain on stream `st` (flags and sentinel rows prepared on the same stream, in front of it)
+      auto launch_chain = [&](hipStream_t st) {
+        const size_t nfl = (size_t)B * ((n + 127) / 128);
+        if (!dBsFlags) {
+          dBsFlags = dalloc<int>(nfl + B);                 // flags, then one status word per emulator
+          HIPCK(hipMemsetAsync(dBsFlags, 0, (nfl + B) * sizeof(int), st));
         }
+        if (bs_epoch > 0x7FFFFF00) {                       // flags and status are compared with the epoch: start over before it wraps
+          HIPCK(hipMemsetAsync(dBsFlags, 0, (nfl + B) * sizeof(int), st));
+          bs_epoch = 0;
+        }
+        if (z_armed.size() != (size_t)B) z_armed.assign(B, 0);
+        for (int i : todo) {
+          if (!z_armed[i]) HIPCK(hipMemsetAsync(dAlpha + (size_t)i * RA * LD, 0xFF, (size_t)LD * sizeof(double), st));
+          z_armed[i] = 0;                                  // consumed by this solve
+        }
+        res_done = launch_backsolve_chain(v, dBsFlags, ++bs_epoch, dBsFlags + nfl, n_cu, st, dInfo, dRes, mc_used ? dMcCtrl : nullptr);
+        chained = true;
+      };
+      if (want_grad) {
+        if (use_chain) {
+          // Round 6: alpha by the SAME one-launch back substitution as a plain fit -- on the panel stream, UNDER the triangular inversion
+          // (both only read the factor): the gemv with L^-1 that used to follow the inversion (0.25 ms for 64 x n=2000, HBM-bound) and the
+          // logdet launch leave the path, and eval(grad=True) returns bit for bit the alpha, log-determinant and log-posterior of eval(grad=False).
+          // fit + gradient, gemv behind the inversion / chain under it: 64 x n=2000 10.87 -> 10.81 ms, 8 x 1.751 -> 1.711, one matrix 0.918 -> 0.889.
+          HIPCK(hipEventRecord(evReady, stream));            // the factor and the index list are in place
+          HIPCK(hipStreamWaitEvent(pstream, evReady, 0));
+          launch_chain(pstream);
+          HIPCK(hipEventRecord(evGroup[14], pstream));
+          ensure_linv(todo);                                 // (fresh factors: every listed emulator needs it, so the index list on the device stays as it is)
+          HIPCK(hipStreamWaitEvent(stream, evGroup[14], 0));
+        } else {
+          // L^-1 is needed anyway, so K^-1 [t, H] = L^-T Y is one fully parallel gemv with it
+          ensure_linv(todo);
+          upload_idx(todo);
+          v = view((int)todo.size());
+          launch_alpha_from_linv(v, stream);
+        }
+      } else if (use_chain) {
+        launch_chain(stream);
+      } else {
+        launch_backsolve(v, stream);
       }
       // (after the solves: it also collects the status words)
       if (!res_done) launch_logdet(v, dInfo, dRes, stream, chained ? dBsFlags + (size_t)B * ((n + 127) / 128) : nullptr, bs_epoch, mc_used ? dMcCtrl : nullptr);
@@ -1822,6 +1839,11 @@ void Engine::fit_map(const std::vector<int>& ids_in, int n_tries, const double* 
     for (long k = 0; k < slots_n; ++k) rslots[k] = (int)k;
     long next_run = 0;
     Engine* self = this;
+    const auto tp0 = std::chrono::steady_clock::now();
+    struct PoolTimer {
+      std::chrono::steady_clock::time_point t0;
+      ~PoolTimer() { g_rep_pool_us += std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count(); }
+    } pool_timer{tp0};
     rep->run_pool(rslots,
                   [&](int pos, std::vector<double>& x, int& tag) {
                     if (next_run >= total) return false;

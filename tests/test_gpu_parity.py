@@ -911,6 +911,30 @@ def test_backsolve_chain_timeout_is_retried_not_reported_as_failure():
     assert int(out.stdout.split("BS-TIMEOUTS")[1].split()[0]) > 0, "the forced timeouts never happened: the test did not exercise the fallback"
 
 
+def test_objective_with_and_without_gradient_is_the_same_number():
+    """Round 6: eval(grad=True) takes alpha from the same one-launch back substitution as eval(grad=False) (it runs under the triangular
+    inversion on a second stream) instead of from a product with L^-1: log-posterior and K^-1 t agree BIT FOR BIT between the two calls --
+    what the line search of fit_GP_MAP compares (objective of a trial point first, its gradient later) is one number.  1, 9 and 64 emulators."""
+    for B, n in ((1, 900), (9, 700), (64, 300)):
+        X, T, _ = synth(31 + B, n, 4, B, 4)
+        mo = M.MultiOutputGP_GPU(X, T, nugget=1e-6, priors=weak(4, 1e-6))
+        theta = np.tile(np.array([1.5, 2., 1., 2.5, 0.3]), (B, 1)) + 0.01 * np.arange(B)[:, None]
+        f0, _, ok0 = mo._mogp_gpu.eval(theta, grad=False)
+        mo.fit(theta)
+        a0 = [mo.emulators[k].Kinv_t.copy() for k in (0, B - 1)]
+        f1, g1, ok1 = mo._mogp_gpu.eval(theta, grad=True)
+        assert ok0.all() and ok1.all() and np.all(np.isfinite(g1))
+        assert np.array_equal(f0, f1), np.abs(f0 - f1).max()
+        mo2 = M.MultiOutputGP_GPU(X, T, nugget=1e-6, priors=weak(4, 1e-6))
+        mo2._mogp_gpu.eval(theta, grad=True)
+        for k, a in zip((0, B - 1), a0):
+            b = np.zeros(n); mo2._mogp_gpu.emulator(k).get_invQt(b)
+            assert np.array_equal(a, b)
+        ref = R.GPRef(X, T[0], nugget=1e-6)
+        assert_allclose(f1[0], ref.fit(theta[0]), rtol=1e-9)
+        assert_allclose(g1[0], ref.logpost_deriv(theta[0]), rtol=1e-6, atol=1e-7)
+
+
 def test_non_finite_targets_are_not_reported_as_a_chain_timeout():
     """a legitimately non-finite alpha (NaN / inf targets) used to look like a timed-out wait of the one-launch back
     substitution (any NaN in the leftmost chunk's result set the time-out status): counted in `backsolve_timeouts`, re-solved by the

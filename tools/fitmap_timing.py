@@ -9,6 +9,10 @@ from mogp_emulator_amd import libgpgpu, _capi
 from bench import synth, counter
 B, n, d, tries, mi = (int(os.environ.get(k, v)) for k, v in (("B", 64), ("N", 2000), ("D", 10), ("TRIES", 15), ("MAXITER", 10)))
 nug = os.environ.get("NUGGET", "adaptive")
+try:
+    nug = float(nug)
+except ValueError:
+    pass
 lib = _capi.load()
 X, T, _ = synth(2, n, d, B, 8)
 libgpgpu.set_fit_options(max_iter=mi, ftol=1e-9, gtol=1e-6, seed=1)
