@@ -15,7 +15,7 @@ LARGE = len(sys.argv) > 3 and sys.argv[3] == "large"       # several block colum
 KERNELS = ["SquaredExponential", "Matern52", "ProductMat52", "UniformSqExp", "UniformMat52"]
 bad = 0
 with_repeats = 0
-adaptive_seen = ladder_seen = 0
+adaptive_seen = ladder_seen = edge_seen = 0
 ONLY = set(int(x) for x in os.environ["FUZZ_ONLY"].split(",")) if os.environ.get("FUZZ_ONLY") else None
 
 
@@ -136,8 +136,18 @@ for case in range(cases):
             adaptive_seen += 1
             dev_nug = float(mo._nuggets()[k])
             if abs(dev_nug - ref.nugget) > 1e-13 * abs(ref.nugget):
+                # the decisions differ: legitimate only inside the knife-edge band -- the smallest pivot of K in 80-bit
+                # long double within one unit n eps max K_ii of zero, where two fp64 factorisations with different summation orders may
+                # decide differently (tests/test_gpu_parity.py::test_adaptive_nugget_decision_sweep_across_the_knife_edge)
+                from oracle import exact
+                Kx = ref.get_K_matrix()
+                dmin = exact.min_pivot_longdouble(Kx) / (n * 2. ** -52 * Kx.diagonal().max())
+                if abs(dmin) < 1.:
+                    edge_seen += 1
+                    print("knife-edge   device nugget %r oracle %r  d_min %.3f units  %s" % (dev_nug, ref.nugget, dmin, ctx), flush=True)
+                    continue
                 bad += 1
-                print("MISMATCH nugget   device %r oracle %r  %s" % (dev_nug, ref.nugget, ctx), flush=True)
+                print("MISMATCH nugget   device %r oracle %r  d_min %.3f units  %s" % (dev_nug, ref.nugget, dmin, ctx), flush=True)
             if ref.nugget > 0:
                 ladder_seen += 1
                 continue
@@ -182,5 +192,5 @@ for case in range(cases):
         if cov is not None:
             close("fullcov", cov[k], ref.predict(Xs[:min(m, 9)], full_cov=True)[1], 1e-5 * amp, 1e-8 * amp, c2)
 print("%d cases, %d mismatches" % (cases, bad))
-print("(%d of them with repeated design points; %d adaptive-nugget emulators compared on the nugget, %d of them with the ladder engaged)" % (with_repeats, adaptive_seen, ladder_seen))
+print("(%d of them with repeated design points; %d adaptive-nugget emulators compared on the nugget, %d of them with the ladder engaged, %d decided differently inside the knife-edge band)" % (with_repeats, adaptive_seen, ladder_seen, edge_seen))
 sys.exit(1 if bad else 0)
