@@ -73,7 +73,7 @@ struct FlagGuard {
   ~FlagGuard() { b = false; }
 };
 static std::atomic<long long> g_bs_timeouts{0}, g_obj_evals{0}, g_grad_evals{0}, g_mc_aborts{0};
-static std::atomic<long long> g_lb_iters{0}, g_ls_short{0}, g_ls_long{0}, g_lb_runs{0}, g_pool_rounds{0}, g_pool_slot_rounds{0}, g_rep_build_us{0}, g_rep_pool_us{0};
+static std::atomic<long long> g_lb_iters{0}, g_ls_short{0}, g_ls_long{0}, g_lb_runs{0}, g_pool_rounds{0}, g_pool_slot_rounds{0}, g_rep_build_us{0}, g_rep_pool_us{0}, g_retarget_us{0}, g_retargets{0}, g_rep_reused{0};
 long long prof_counter(const char* name) {
   const std::string s(name ? name : "");
   if (s == "backsolve_timeouts") return g_bs_timeouts.load();
@@ -90,6 +90,9 @@ long long prof_counter(const char* name) {
   if (s == "pool_rounds") return g_pool_rounds.load();
   if (s == "pool_slot_rounds") return g_pool_slot_rounds.load();
   if (s == "replica_engine_build_us") return g_rep_build_us.load();      // host time spent constructing replica engines (allocations)
+  if (s == "retarget_us") return g_retarget_us.load();                   // host time inside Engine::retarget (slot takes another emulator's targets)
+  if (s == "retargets") return g_retargets.load();
+  if (s == "replica_engines_reused") return g_rep_reused.load();          // multi-start fits that took the cached replica engine
   if (s == "replica_pool_us") return g_rep_pool_us.load();               // ... from there to the end of fit_map's replica block (pool + its destruction excluded)
   return -1;
 }
@@ -1564,6 +1567,16 @@ struct Lbfgs {
 };
 }  // namespace
 
+// the process-wide replica engine kept between multi-start fits (never destroyed at exit: the HIP runtime may be gone by then)
+static std::unique_ptr<Engine>& replica_cache() {
+  static std::unique_ptr<Engine>* p = new std::unique_ptr<Engine>();
+  return *p;
+}
+static std::mutex& replica_cache_mutex() {
+  static std::mutex* m = new std::mutex();
+  return *m;
+}
+
 // The optimiser runs of a multi-start fit as a SLOT POOL (round 6).  `slots` are emulators of THIS engine; a slot
 // carries one L-BFGS run at a time.  Every round is ONE batched objective (+ gradient) evaluation of the slots whose run needs one; a run
 // that ends (converged, out of iterations, failed) hands its slot to the next pending run IN THE SAME ROUND -- `next(pos, x0, tag)` fills
@@ -1831,8 +1844,42 @@ void Engine::fit_map(const std::vector<int>& ids_in, int n_tries, const double* 
       std::copy(hT.begin() + (size_t)ids[e] * n, hT.begin() + (size_t)(ids[e] + 1) * n, targets.begin() + (size_t)k * n);
     }
     const auto tc0 = std::chrono::steady_clock::now();
-    std::unique_ptr<Engine> rep(new Engine(hX.data(), n, D, targets.data(), (int)slots_n, testing_size, mean, kernel_type, gp[ids[0]].nug_type,
-                                           gp[ids[0]].nug_size, analytic));
+    // The replica engine of the LAST multi-start fit of the process is kept (one engine, process-wide) and taken again when the next fit
+    // has the same shape (n, D, slots, kernel, mean function, device): its 3 x slots matrices are tens of GB, and on SOME boxes fresh
+    // allocations of that size cost 0.9 - 1.5 s per fit (bench.py run behind the GPU test suite on the same box: fit_GP_MAP 3.1 instead of
+    // 2.15 s, every call with 256 slots; on a fresh box 2.13 s from the first call; writing 200 GB from another process beforehand did not
+    // reproduce it -- profiles/r06_fitmap_context_and_grad_chain.txt).  A fit of another shape frees it.  MOGP_REPLICA_CACHE=0: every fit
+    // builds and frees its own.
+    static const bool cache_on = [] { const char* e = getenv("MOGP_REPLICA_CACHE"); return !e || atoi(e) != 0; }();
+    std::unique_ptr<Engine> rep;
+    {
+      std::lock_guard<std::mutex> lk(replica_cache_mutex());
+      std::unique_ptr<Engine>& slot = replica_cache();
+      int dev = -1;
+      (void)hipGetDevice(&dev);
+      if (slot && cache_on && slot->n == n && slot->D == D && slot->B == (int)slots_n && slot->kernel_type == kernel_type && slot->analytic == analytic &&
+          slot->testing_size == testing_size && slot->device == dev && slot->mean.kind == mean.kind && slot->mean.value == mean.value &&
+          slot->mean.dims == mean.dims && slot->mean.powers == mean.powers) {
+        rep = std::move(slot);
+        rep->hX = hX;
+        HIPCK(hipMemcpy(rep->dX, hX.data(), hX.size() * sizeof(double), hipMemcpyHostToDevice));
+        g_rep_reused += 1;
+      } else {
+        slot.reset();                                   // (frees the old one BEFORE the new one is allocated)
+      }
+    }
+    if (!rep)
+      rep.reset(new Engine(hX.data(), n, D, targets.data(), (int)slots_n, testing_size, mean, kernel_type, gp[ids[0]].nug_type, gp[ids[0]].nug_size, analytic));
+    // hand the engine back to the cache when this block is left normally (an exception destroys it)
+    struct Keep {
+      std::unique_ptr<Engine>& rep;
+      bool on;
+      ~Keep() {
+        if (!on || !rep || std::uncaught_exceptions() > 0) return;
+        std::lock_guard<std::mutex> lk(replica_cache_mutex());
+        replica_cache() = std::move(rep);
+      }
+    } keep{rep, cache_on};
     g_rep_build_us += std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - tc0).count();
     std::vector<int> holds(slots_n, -1);          // which emulator (index into ids) a slot's targets and priors belong to
     std::vector<int> rslots(slots_n);
@@ -1850,7 +1897,10 @@ void Engine::fit_map(const std::vector<int>& ids_in, int n_tries, const double* 
                     const long r = next_run++;
                     const int s = (int)(r / ne), e = (int)(r % ne);
                     if (holds[pos] != e) {
+                      const auto tr0 = std::chrono::steady_clock::now();
                       rep->retarget(pos, *self, ids[e]);
+                      g_retarget_us += std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - tr0).count();
+                      g_retargets += 1;
                       holds[pos] = e;
                     }
                     x = x0[s][e];

@@ -9,12 +9,12 @@ O=$R/gpurun_out/final_$TAG
 rm -rf $O; mkdir -p $O
 cd $R
 cp mogp_emulator_amd/libmogp_hip.build $O/build_commit.txt; cat $O/build_commit.txt        # written by the Makefile next to the library
-# 1. the GPU suite + smoke
+# 1. the bench line the driver will also produce (first: on the fresh box, as the driver runs it)
+python bench.py > $O/bench.json 2> $O/bench.err
+# 2. the GPU suite + smoke
 timeout 2400 python -m pytest tests -m gpu -x -q --durations=10 2>&1 | tail -22 > $O/gpu_tests.txt
 tail -3 $O/gpu_tests.txt
 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1 >> $O/gpu_tests.txt
-# 2. the bench line the driver will also produce
-python bench.py > $O/bench.json 2> $O/bench.err
 # 3. kernel stats of the default bench workload: ONLY the timed steps (+ the single-stream pass), no extras
 cd /tmp
 CMD="python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-shard-sweep --no-other-configs --no-extras"
