@@ -976,9 +976,19 @@ import mogp_emulator_amd as M
 from mogp_emulator_amd import libgpgpu
 from test_gpu_parity import synth
 X, T, _ = synth(4242, 300, 4, 6, 8)
+# a multi-start fit of ANOTHER problem of the same shape first: the replica engine it leaves behind (Engine::fit_map keeps one per process,
+# MOGP_REPLICA_CACHE) is taken again by the fit that is checked -- with other inputs, targets and priors in every slot
+X0, T0, _ = synth(99, 300, 4, 6, 8)
+libgpgpu.set_fit_options(max_iter=5, ftol=1e-9, gtol=1e-6, seed=3)
+M.fit_GP_MAP(M.MultiOutputGP_GPU(X0, T0, nugget="fit"), n_tries=5)
 libgpgpu.set_fit_options(max_iter=40, ftol=1e-9, gtol=1e-6, seed=11)
 mo = M.fit_GP_MAP(M.MultiOutputGP_GPU(X, T, nugget="fit"), n_tries=5)
 assert mo.get_indices_not_fit() == []
+import ctypes
+from mogp_emulator_amd import _capi
+c = ctypes.c_longlong()
+_capi.load().mogp_profile_counter(b"replica_engines_reused", ctypes.byref(c))
+print("REUSED", c.value)
 print("STARTS-OK", " ".join(repr(float(em.current_logpost)) for em in mo.emulators))
 """
 
@@ -990,13 +1000,18 @@ def test_fit_GP_MAP_is_independent_of_how_the_starts_are_scheduled():
     import subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     script = _STARTS_SCRIPT % {"root": root, "tests": os.path.join(root, "tests")}
-    res = []
-    for env in ({}, {"MOGP_START_REPLICAS": "12"}, {"MOGP_PARALLEL_STARTS": "0"}, {"MOGP_LAZY_GRAD": "1"}):
+    res, reused = [], []
+    for env in ({}, {"MOGP_START_REPLICAS": "12"}, {"MOGP_PARALLEL_STARTS": "0"}, {"MOGP_LAZY_GRAD": "1"}, {"MOGP_REPLICA_CACHE": "0"}):
         out = subprocess.run([sys.executable, "-c", script], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
         assert out.returncode == 0 and "STARTS-OK" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
         res.append(np.array([float(x) for x in out.stdout.split("STARTS-OK")[1].split()]))
+        reused.append(int(out.stdout.split("REUSED")[1].split()[0]))
     assert_allclose(res[1], res[0], rtol=1e-9)
     assert_allclose(res[2], res[0], rtol=1e-9)
+    # round 6: the second fit of the process ran on the replica engine the first one left behind (same shape) -- and ends where a fit on a
+    # fresh engine ends (MOGP_REPLICA_CACHE=0), bit for bit
+    assert reused[0] == 1 and reused[1] == 1 and reused[2] == 0 and reused[4] == 0, reused
+    assert np.array_equal(res[4], res[0])
     # gradient only for trial points that pass the sufficient-decrease test (the default from n = 512): the same decisions,
     # alpha by back substitution instead of the product with L^-1 -- the optima agree to the optimiser's tolerance
     assert_allclose(res[3], res[0], rtol=1e-6)
