@@ -238,7 +238,11 @@ int mogp_mchol_task_table_ahead(int n_plus_rhs, int* out, int capacity);
    one-launch Cholesky gave up on and a multi-launch schedule repeated (0 in normal operation); "objective_evals" / "gradient_evals" =
    emulator objective evaluations so far (all / with gradient), e.g. to turn a fit_GP_MAP wall time into evaluations/s;
    "lbfgs_runs" / "lbfgs_iterations" / "linesearch_shortened" / "linesearch_lengthened" = optimiser runs started by fit_GP_MAP,
-   their accepted steps, and the line-search trial points that failed the sufficient-decrease / the curvature test */
+   their accepted steps, and the line-search trial points that failed the sufficient-decrease / the curvature test;
+   round 6, the slot pool of fit_GP_MAP: "pool_rounds" = batched optimiser rounds, "pool_slot_rounds" = sum over them of the runs that took
+   part (/ rounds = mean batch), "retargets" / "retarget_us" = replica slots handed to another emulator and the host time that took,
+   "replica_engine_build_us" / "replica_pool_us" = host time constructing (or re-taking) the replica engine / inside the pool,
+   "replica_engines_reused" = multi-start fits that ran on the replica engine the previous one left behind (MOGP_REPLICA_CACHE) */
 int mogp_profile_counter(const char* name, long long* out);
 /* device memory helpers so a host program can hand device-resident buffers to the *_dev calls */
 void* mogp_dev_malloc(unsigned long long bytes);
