@@ -1203,38 +1203,22 @@ void Engine::predict(const std::vector<int>& ids, const double* Xs, int m, bool 
   }
   if (derivs) launch_predict_deriv(v, dXsrc, m, fd, (long)m * D, stream);
   if (mean.kind != 0 || R > 1) {
-    // mean-function terms, on the device (predict_mean_finish_kernel): the basis columns are evaluated here on the host (the one
-    // definition of the basis, hostmath.h) from the test points -- read back when they were handed over in device memory
-    std::vector<double> hx;
-    const double* xs_h = Xs;
-    const bool needs_x = mean.kind == 3 && !mean.dims.empty();      // (a constant / fixed mean has no basis column that depends on x*)
-    if (xs_on_device && needs_x) {
-      hx.resize((size_t)m * D);
-      HIPCK(hipMemcpyAsync(hx.data(), Xs, hx.size() * sizeof(double), hipMemcpyDeviceToHost, stream));
-      HIPCK(hipStreamSynchronize(stream));
-      xs_h = hx.data();
-    }
+    // mean-function terms, on the device: the basis columns from the device-resident test points (mean_basis_kernel; round 6 -- the host used to
+    // evaluate them, with a read-back of the points when they were handed over in device memory), then predict_mean_finish_kernel
     const int nterm = (mean.kind == 3) ? (int)mean.dims.size() : 0;
     const int nbasis = 1 + nterm;
     const int qq = R - 1;
     if (R > 1 && qq != nbasis) throw std::runtime_error("predict: analytic mean with an unexpected number of columns");
-    // one staging block: basis | dbasis | coef | LA | (ints) ddims, dpowers
+    // device block: basis | dbasis | coef | LA | (ints) dims, powers -- the first two filled on the device, the rest staged from the host
     const size_t o_basis = 0, o_dbasis = o_basis + (size_t)nbasis * m, o_coef = o_dbasis + (size_t)nterm * m,
                  o_la = o_coef + (size_t)nb * nbasis, o_int = o_la + (size_t)nb * qq * qq, total = o_int + (size_t)nterm + 1;
-    std::vector<double> st(total, 0.);
-    for (int j = 0; j < m; ++j) st[o_basis + j] = 1.;
-    for (int t = 0; t < nterm; ++t)
-      for (int j = 0; j < m; ++j) {
-        const double x = xs_h[(size_t)j * D + mean.dims[t]];
-        st[o_basis + (size_t)(t + 1) * m + j] = std::pow(x, mean.powers[t]);
-        st[o_dbasis + (size_t)t * m + j] = std::pow(x, mean.powers[t] - 1);
-      }
+    std::vector<double> st(total - o_coef, 0.);
     for (int k = 0; k < nb; ++k) {
       const GPState& g = gp[ids[k]];
-      double* c = st.data() + o_coef + (size_t)k * nbasis;
+      double* c = st.data() + (size_t)k * nbasis;
       if (R > 1) {
         for (int t = 0; t < qq; ++t) c[t] = g.beta[t];
-        for (int e = 0; e < qq * qq; ++e) st[o_la + (size_t)k * qq * qq + e] = g.LA[e];
+        for (int e = 0; e < qq * qq; ++e) st[(o_la - o_coef) + (size_t)k * qq * qq + e] = g.LA[e];
       } else if (mean.kind == 1) c[0] = mean.value;
       else
         for (int t = 0; t < nbasis; ++t) c[t] = g.meanp[t];
@@ -1245,10 +1229,11 @@ void Engine::predict(const std::vector<int>& ids, const double* Xs, int m, bool 
       hi[t] = mean.dims[t];
       hi[nterm + t] = mean.powers[t];
     }
-    std::memcpy(st.data() + o_int, hi.data(), 2 * (size_t)nterm * sizeof(int));
+    std::memcpy(st.data() + (o_int - o_coef), hi.data(), 2 * (size_t)nterm * sizeof(int));
     grow(dMeanAux, capMeanAux, total);
-    HIPCK(hipMemcpyAsync(dMeanAux, st.data(), total * sizeof(double), hipMemcpyHostToDevice, stream));
+    HIPCK(hipMemcpyAsync(dMeanAux + o_coef, st.data(), st.size() * sizeof(double), hipMemcpyHostToDevice, stream));
     const int* di = reinterpret_cast<const int*>(dMeanAux + o_int);
+    launch_mean_basis(dXsrc, m, D, nterm, di, di + nterm, dMeanAux + o_basis, dMeanAux + o_dbasis, stream);
     launch_predict_mean_finish(nb, m, D, R, nbasis, dMeanAux + o_basis, dMeanAux + o_coef, R > 1 ? dots : nullptr, dMeanAux + o_la, fm,
                                (R > 1 && vars) ? fv : nullptr, ld, derivs ? nterm : 0, dMeanAux + o_dbasis, di, di + nterm, fd, stream);
     HIPCK(hipStreamSynchronize(stream));      // `st` is the source of an asynchronous copy

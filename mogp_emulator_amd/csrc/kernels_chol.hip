@@ -771,6 +771,31 @@ void launch_implausibility(int nb, const double* mean, const double* var, int ld
   hipLaunchKernelGGL(implausibility_kernel, dim3((m + 255) / 256), dim3(256), 0, s, nb, mean, var, ld, m, prm, rank, out);
 }
 
+// basis (1 + nterm, m) and dbasis (nterm, m) of a polynomial mean function at device-resident test points (round 6, ADVICE r5: the host used to
+// evaluate them -- a read-back of the test points, std::pow over m x nterm and a staged upload on the device-resident predict path):
+// basis[0] = 1, basis[t + 1][j] = x_j[dims[t]] ^ powers[t], dbasis[t][j] = x_j[dims[t]] ^ (powers[t] - 1)  (hostmath.h MeanFunc).  Powers 0, 1, 2
+// are formed exactly (what a correctly rounded pow returns); others through pow.
+__device__ __forceinline__ double int_pow(double x, int p) {
+  if (p == 0) return 1.0;
+  if (p == 1) return x;
+  if (p == 2) return x * x;
+  return pow(x, (double)p);
+}
+__global__ __launch_bounds__(256) void mean_basis_kernel(const double* __restrict__ Xs, int m, int D, int nterm, const int* __restrict__ dims,
+                                                         const int* __restrict__ powers, double* __restrict__ basis, double* __restrict__ dbasis) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= m) return;
+  basis[j] = 1.0;
+  for (int t = 0; t < nterm; ++t) {
+    const double x = Xs[(size_t)j * D + dims[t]];
+    basis[(size_t)(t + 1) * m + j] = int_pow(x, powers[t]);
+    dbasis[(size_t)t * m + j] = int_pow(x, powers[t] - 1);
+  }
+}
+void launch_mean_basis(const double* Xs, int m, int D, int nterm, const int* dims, const int* powers, double* basis, double* dbasis, hipStream_t s) {
+  hipLaunchKernelGGL(mean_basis_kernel, dim3((m + 255) / 256), dim3(256), 0, s, Xs, m, D, nterm, dims, powers, basis, dbasis);
+}
+
 void launch_predict_mean_finish(int nb, int m, int D, int R, int nbasis, const double* basis, const double* coef, const double* dots,
                                 const double* LA, double* mean, double* var, long ld, int nterm, const double* dbasis, const int* ddims,
                                 const int* dpowers, double* deriv, hipStream_t s) {

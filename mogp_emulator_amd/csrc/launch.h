@@ -175,6 +175,8 @@ void launch_predict_deriv(const BatchView& v, const double* Xs, int m, double* d
 // mean-function terms of a batched prediction on device buffers (kernels_chol.hip predict_mean_finish_kernel): basis (nbasis, m),
 // coef (nb, nbasis), R > 1: dots (nb, R, m) and LA (nb, q, q); mean / var (nb rows of stride ld; either may be null); derivative terms
 // dbasis (nterm, m), ddims / dpowers (nterm) into deriv (nb, m, D) or null
+// basis (1 + nterm, m) / dbasis (nterm, m) of a polynomial mean at device-resident points Xs (m, D); dims / powers: device ints
+void launch_mean_basis(const double* Xs, int m, int D, int nterm, const int* dims, const int* powers, double* basis, double* dbasis, hipStream_t s);
 void launch_predict_mean_finish(int nb, int m, int D, int R, int nbasis, const double* basis, const double* coef, const double* dots,
                                 const double* LA, double* mean, double* var, long ld, int nterm, const double* dbasis, const int* ddims,
                                 const int* dpowers, double* deriv, hipStream_t s);

@@ -56,6 +56,28 @@ def min_pivot_longdouble(K):
     return float(dmin)
 
 
+def knife_edge_class(K, c=8.0):
+    """Classify an fp64 matrix for the adaptive-nugget decision (linalg/cholesky.py:234-281: jitter only when the plain factorisation fails) by
+    the pivots of its Cholesky factorisation in 80-bit long double: tau = c * max(n, 32) * eps * max K_ii is what the rounding of ANY fp64
+    factorisation (LAPACK's blocked dpotrf, the device's 4-column groups with explicit 4 x 4 inverses) may move a pivot by, and once a pivot
+    is below tau the following ones are amplified rounding noise in every implementation.  So the FIRST exact pivot below tau decides:
+      none                    -> ("definite", smallest pivot / tau): every correct implementation factors without jitter;
+      first one <= -tau       -> ("indefinite", that pivot / tau):   every correct implementation must jitter;
+      first one in (-tau, tau)-> ("band", that pivot / tau):         either decision is a correct execution of the reference's algorithm."""
+    n = K.shape[0]
+    A = np.array(K, dtype=np.longdouble)
+    tau = np.longdouble(c * max(n, 32) * 2.0 ** -52) * np.longdouble(np.max(np.diag(K)))
+    dmin = np.longdouble(np.inf)
+    for j in range(n):
+        d = A[j, j]
+        if d < tau:
+            return ("indefinite" if d <= -tau else "band"), float(d / tau)
+        dmin = min(dmin, d)
+        A[j + 1:, j] /= np.sqrt(d)
+        A[j + 1:, j + 1:] -= np.outer(A[j + 1:, j], A[j + 1:, j])
+    return "definite", float(dmin / tau)
+
+
 def cond_eps(K):
     """cond_2(K) * 2^-52 of a symmetric positive definite fp64 matrix."""
     w = np.linalg.eigvalsh(K)

@@ -135,9 +135,10 @@ def test_medium_configs_vs_reference(tag, kern, mode):
 def adaptive_sweep_case():
     """C1's inputs, SquaredExponential, sigma^2 = 1, one shared log inverse squared length scale swept from -0.5 (cond 3e13) to -3.0 (K
     indefinite in fp64) in steps of 1/8: the adaptive nugget's knife-edge (linalg/cholesky.py:234-281).  Every point is classified by the
-    smallest pivot d_min of K's Cholesky factorisation in 80-bit long double (oracle/exact.py), in units of n eps max K_ii:
-    >= 1 clearly definite, <= -1 clearly indefinite, in between the band where two fp64 factorisations with different summation orders
-    may decide differently (the reference's LAPACK succeeds down to d_min = 0.08 units and fails from 0.04 units on)."""
+    pivots of K's Cholesky factorisation in 80-bit long double (oracle/exact.py knife_edge_class): with tau = 8 max(n, 32) eps max K_ii,
+    "definite" when no exact pivot is below tau, "indefinite" when the first one below it is <= -tau, "band" otherwise -- where two fp64
+    factorisations with different summation orders may decide differently (the reference's LAPACK succeeds down to a smallest pivot of
+    0.01 tau and fails from 0.005 tau on)."""
     g = load_golden("c1_n200_d4.npz")
     X, t = g["X"], g["T"][0]
     ths = np.arange(-0.5, -3.01, -0.125)
@@ -159,25 +160,24 @@ def adaptive_sweep_check(X, t, thetas, verbose=False):
         ref = R.GPRef(X, t, nugget="adaptive")
         lp = ref.fit(thetas[k])
         K = ref.get_K_matrix()
-        unit = n * 2. ** -52 * K.diagonal().max()
-        dmin = exact.min_pivot_longdouble(K) / unit
+        cls, dmin = exact.knife_edge_class(K)
         rung0 = 1e-6 * K.diagonal().mean()
         ladder = [0.0] + [rung0 * 10. ** j for j in range(5)]
         solo = make_gp(X, t, nugget="adaptive"); solo.fit(thetas[k])
         if verbose:
-            print("theta %.3f  d_min %8.3f units  oracle nugget %g  device nugget %g (alone %g)  logpost oracle %.9g device %.9g" %
-                  (thetas[k][0], dmin, ref.nugget, nug[k], solo.nugget, lp, f[k]), flush=True)
+            print("theta %.3f  %-10s pivot %9.4f tau  oracle nugget %g  device nugget %g (alone %g)  logpost oracle %.9g device %.9g" %
+                  (thetas[k][0], cls, dmin, ref.nugget, nug[k], solo.nugget, lp, f[k]), flush=True)
         assert solo.nugget == nug[k], "the decision depends on the batch"            # and with it everything else
         assert solo.current_logpost == mo.emulators[k].current_logpost or not (os.environ.get("MOGP_CHOL"))
         assert any(abs(nug[k] - r) <= 1e-13 * r for r in ladder), (nug[k], ladder)   # zero or a rung of the reference's ladder
-        if dmin >= 1.:
+        if cls == "definite":
             stats["definite"] += 1
             assert ref.nugget == 0.0 and nug[k] == 0.0, (thetas[k][0], dmin, ref.nugget, nug[k])
             w = np.linalg.eigvalsh(K)
             condeps = float(w[-1] / w[0]) * 2. ** -52 if w[0] > 0. else np.inf      # (eigvalsh itself is off by ~ n eps |K| at the small end)
-            if dmin >= 1e3 and condeps < 1e-2:
+            if dmin >= 100. and condeps < 1e-2:
                 assert_allclose(f[k], lp, rtol=max(1e-10, 0.05 * condeps))
-        elif dmin <= -1.:
+        elif cls == "indefinite":
             stats["indefinite"] += 1
             assert ref.nugget > 0. and abs(nug[k] - ref.nugget) <= 1e-13 * ref.nugget, (thetas[k][0], dmin, ref.nugget, nug[k])
             assert_allclose(f[k], lp, rtol=1e-5)
@@ -195,12 +195,15 @@ def adaptive_sweep_check(X, t, thetas, verbose=False):
 def test_adaptive_nugget_decision_sweep_across_the_knife_edge():
     """VERDICT r5 item 1.  Policy: the device tries the unjittered matrix first and walks the reference's ladder only
     when a pivot of ITS factorisation is not positive, exactly like jit_cholesky around dpotrf.  Outside the knife-edge band the decision
-    equals the reference's; inside it (|d_min| < n eps max K_ii in exact arithmetic) either outcome is a correct execution of the
-    reference's algorithm, the value of the nugget is zero or a ladder rung, and the decision is the same alone and in a batch."""
+    equals the reference's; inside it (the first exact pivot below tau = 8 max(n, 32) eps max K_ii lies within +-tau) either outcome is a
+    correct execution of the reference's algorithm, the value of the nugget is zero or a ladder rung, and the decision is the same alone and
+    in a batch."""
     X, t, thetas = adaptive_sweep_case()
     stats = adaptive_sweep_check(X, t, thetas, verbose=True)
     print(stats)
-    assert stats["definite"] >= 7 and stats["indefinite"] >= 1 and stats["band"] >= 8
+    # (no point of this sweep is "indefinite" in the strict sense -- a tiny positive pivot always comes before the first negative one; exactly
+    # singular designs, where every implementation must jitter, are test_adaptive_jitter_ladder_on_duplicated_inputs / ..._mixed_batch_...)
+    assert stats["definite"] >= 5 and stats["band"] >= 8 and stats["band_agree"] >= stats["band"] - 3
 
 
 _SWEEP_SCRIPT = r"""

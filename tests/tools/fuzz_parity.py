@@ -136,18 +136,18 @@ for case in range(cases):
             adaptive_seen += 1
             dev_nug = float(mo._nuggets()[k])
             if abs(dev_nug - ref.nugget) > 1e-13 * abs(ref.nugget):
-                # the decisions differ: legitimate only inside the knife-edge band -- the smallest pivot of K in 80-bit
-                # long double within one unit n eps max K_ii of zero, where two fp64 factorisations with different summation orders may
-                # decide differently (tests/test_gpu_parity.py::test_adaptive_nugget_decision_sweep_across_the_knife_edge)
+                # the decisions differ: legitimate only inside the knife-edge band (oracle/exact.py knife_edge_class) --
+                # the first pivot of K in 80-bit long double that is below tau = 8 max(n, 32) eps max K_ii lies within +-tau: from there on two
+                # fp64 factorisations with different summation orders may decide differently
+                # (tests/test_gpu_parity.py::test_adaptive_nugget_decision_sweep_across_the_knife_edge)
                 from oracle import exact
-                Kx = ref.get_K_matrix()
-                dmin = exact.min_pivot_longdouble(Kx) / (n * 2. ** -52 * Kx.diagonal().max())
-                if abs(dmin) < 1.:
+                cls, dmin = exact.knife_edge_class(ref.get_K_matrix())
+                if cls == "band":
                     edge_seen += 1
-                    print("knife-edge   device nugget %r oracle %r  d_min %.3f units  %s" % (dev_nug, ref.nugget, dmin, ctx), flush=True)
+                    print("knife-edge   device nugget %r oracle %r  first small pivot %.4f tau  %s" % (dev_nug, ref.nugget, dmin, ctx), flush=True)
                     continue
                 bad += 1
-                print("MISMATCH nugget   device %r oracle %r  d_min %.3f units  %s" % (dev_nug, ref.nugget, dmin, ctx), flush=True)
+                print("MISMATCH nugget   device %r oracle %r  %s, pivot %.4f tau  %s" % (dev_nug, ref.nugget, cls, dmin, ctx), flush=True)
             if ref.nugget > 0:
                 ladder_seen += 1
                 continue
