@@ -34,9 +34,10 @@ __device__ __forceinline__ int slot_emu2(const int* idx, int z) { return idx ? i
 // r2 for the thread's RA x CB micro tile (rows RA*ty.., cols CB*tx..): 4 x 4 with (ty, tx) = (t >> 4, t & 15), or 8 x 2 with
 // (t >> 5, t & 31) -- the latter makes a wave's store instruction two whole 512-byte rows of the 64-column tile
 // SC (round 6): the staged coordinates are already multiplied by sqrt(e_d) (stage_rows<true>): r2 = sum_d (u_id - u_jd)^2, two vector
-// instructions per pair and dimension instead of three.  The difference form is kept -- r2 stays RELATIVELY accurate (a few ulp), which is
-// what the parity bars on ill-conditioned K rest on; the Gram form a_i + a_j - 2 b_ij through the matrix cores would
-// carry an ABSOLUTE error eps max a_i into every r2, i.e. a relative error ~1e-14 into K where the difference form has ~1e-16.
+// instructions per pair and dimension instead of three.  The difference form is kept: r2 of REPEATED points is exactly 0 (identical rows of K:
+// what nugget="pivot" and the jitter ladder rest on) and of near-coincident points relatively accurate; the Gram form a_i + a_j - 2 b_ij
+// through the matrix cores carries an absolute error ~eps max a_i into every r2 -- harmless where all pairs are far apart
+// (the benchmark designs: profiles/r06_gram_form_accuracy.txt), but it gives repeated points r2 = +-1e-15.
 template <int RA, int CB, bool SC = false>
 __device__ __forceinline__ void micro_r2(const double* si, const double* sj, const double* __restrict__ P, int D, int ty, int tx,
                                          double (&r2)[RA][CB]) {
